@@ -1,0 +1,237 @@
+/*
+ * ttx.h -- C ABI of libttx.so: MI355X (gfx950) native TT-compressed EmbeddingBag.
+ *
+ * This header is the drop-in boundary for the hot path of
+ * facebookresearch/FBTT-Embedding.  Every entry point below replaces one of the
+ * eleven functions the reference exports from its native module `tt_embeddings`
+ * (reference tt_embeddings.cpp:131-161); the reference prototype each one
+ * replaces is cited next to it.  Signatures carry only plain pointers, sizes and
+ * scalars (no torch / ATen types): the Python shim
+ * fbtt-embedding_amd/tt_embeddings.py binds them with ctypes, and INTEGRATION.md
+ * shows the pybind11 stub a maintainer of the reference would write instead.
+ *
+ * Conventions
+ *  - All data pointers are DEVICE pointers (HBM) unless the name ends in _host.
+ *    `tt_cores`, `optimizer_state`, `d_tt_cores` are HOST arrays of T device
+ *    pointers (one per TT core).
+ *  - Index tensors are int64 (as in the reference), cores/outputs fp32, all
+ *    contiguous.  Core t has shape [num_tables, p[t], r[t]*q[t]*r[t+1]]; each
+ *    p-slice is row-major [r[t]][q[t]][r[t+1]] (reference tt_embeddings_ops.py
+ *    :513-530, :601-611).
+ *  - `stream` is a hipStream_t.  All work is enqueued on it; nothing
+ *    synchronises with the host except ttx_preprocess_indices_sync in the
+ *    cache-live case (exactly like the reference, tt_embeddings_cuda.cu:1481-1488)
+ *    and ttx_cache_populate (one 8-byte read-back to size the radix sort).
+ *  - `workspace` is caller-provided device scratch of at least the size the
+ *    matching *_workspace_bytes() query returns (256-byte aligned).  No entry
+ *    point allocates device memory.
+ *  - Return value: 0 on success, negative TTX_E* on error;
+ *    ttx_last_error() returns a thread-local message for the last failure.
+ *  - Strides L[t] = prod_{s>t} p[s] (reference tt_embeddings_ops.py:506-512) are
+ *    derived from `p` on the host; the reference's device tensor `L` is not read.
+ */
+#ifndef TTX_H_
+#define TTX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTX_MAX_CORES 4
+
+#define TTX_OK 0
+#define TTX_EINVAL (-1)    /* bad argument (mirrors the reference's TORCH_CHECKs) */
+#define TTX_EWORKSPACE (-2) /* workspace too small */
+#define TTX_EUNSUPPORTED (-3) /* geometry does not fit this build's LDS tiling */
+#define TTX_EHIP (-4)       /* a HIP runtime call failed */
+
+/* fused-optimizer selector of ttx_tt_backward (reference OPTIM_* enum,
+ * tt_embeddings_cuda.cu:31-35) */
+#define TTX_OPTIM_SGD 0
+#define TTX_OPTIM_ADAGRAD 1
+#define TTX_OPTIM_DENSE 2
+
+typedef void* ttx_stream_t; /* hipStream_t */
+
+/* TT geometry shared by all tables of one TableBatchedTTEmbeddingBag
+ * (reference tt_embeddings_ops.py:459-488). */
+typedef struct ttx_geom {
+  int32_t T;                    /* number of TT cores, 2..4 */
+  int32_t num_tables;           /* tt_cores[t].size(0) */
+  int32_t p[TTX_MAX_CORES];     /* tt_p_shapes */
+  int32_t q[TTX_MAX_CORES];     /* tt_q_shapes */
+  int32_t r[TTX_MAX_CORES + 1]; /* padded ranks [1, r1, .., 1] */
+} ttx_geom;
+
+const char* ttx_last_error(void);
+int ttx_version(void);
+
+/* ------------------------------------------------------------------ plan ---
+ * The lookup plan is this library's replacement for the reference's per-chunk
+ * pointer-array set-up kernels (init_batch_gemm_{forward,backward}_*T_kernel,
+ * tt_embeddings_cuda.cu:79-360, :754-918): index decode, a stable radix sort of
+ * the lookups by (table, i_t) for every core and the work-list of index groups
+ * that share a middle-core slice.  It depends only on (geometry, indices,
+ * tableidx); forward and backward of the same batch can share one plan.
+ * Passing plan == NULL to ttx_tt_forward / ttx_tt_backward builds it inside
+ * their workspace. */
+size_t ttx_plan_bytes(const ttx_geom* g, int64_t nnz);
+int ttx_plan_build(const ttx_geom* g, int64_t nnz, const int64_t* indices,
+                   const int64_t* tableidx, void* plan, size_t plan_bytes,
+                   ttx_stream_t stream);
+
+/* --------------------------------------------------------------- forward ---
+ * replaces tt_embeddings_forward_cuda (tt_embeddings.cpp:13-26,
+ * tt_embeddings_cuda.cu:964-1075).  output[num_tables,B,D] is overwritten with
+ * the bag sums of the first `nnz` lookups (zeros when nnz == 0).  D may be any
+ * positive value (the reference requires D % 4 == 0). */
+size_t ttx_tt_forward_workspace_bytes(const ttx_geom* g, int32_t B, int32_t D,
+                                      int64_t nnz);
+int ttx_tt_forward(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz,
+                   const int64_t* indices, const int64_t* rowidx,
+                   const int64_t* tableidx, const float* const* tt_cores,
+                   float* output, const void* plan, void* workspace,
+                   size_t workspace_bytes, ttx_stream_t stream);
+
+/* decompress rows: rows[n, :] = TT row of indices[n] in table tableidx[n]
+ * (tableidx == NULL -> table 0).  This is the contraction alone, the part of
+ * prefetch_cached_weights_cuda (tt_embeddings_cuda.cu:1156-1258) that fills
+ * cache_weight.  Same workspace size as ttx_tt_forward with B = 0. */
+int ttx_tt_rows(const ttx_geom* g, int32_t D, int64_t nnz,
+                const int64_t* indices, const int64_t* tableidx,
+                const float* const* tt_cores, float* rows, void* workspace,
+                size_t workspace_bytes, ttx_stream_t stream);
+
+/* -------------------------------------------------------------- backward ---
+ * replaces tt_embeddings_backward_{dense,sgd,adagrad}_cuda
+ * (tt_embeddings.cpp:28-72, tt_embeddings_cuda.cu:419-752).
+ *  optim == TTX_OPTIM_DENSE  : d_tt_cores[t] (full core shape) is overwritten
+ *                              with the gradient; cores untouched.
+ *  optim == TTX_OPTIM_SGD    : cores  -= lr * g              (every element)
+ *  optim == TTX_OPTIM_ADAGRAD: state += g*g;
+ *                              cores  -= lr * g / (sqrtf(state) + eps)
+ * Gradients of duplicate lookups are summed before the single optimizer step.
+ * Unlike the reference's apply kernels (tt_embeddings_cuda.cu:612-648, whose
+ * grid covers only part of each core when p[t] > r*q*r) every touched slice is
+ * updated; slices with no lookup have g == 0 and are left unchanged. */
+size_t ttx_tt_backward_workspace_bytes(const ttx_geom* g, int32_t B, int32_t D,
+                                       int64_t nnz);
+int ttx_tt_backward(const ttx_geom* g, int32_t optim, int32_t B, int32_t D,
+                    float learning_rate, float eps, int64_t nnz,
+                    const int64_t* indices, const int64_t* rowidx,
+                    const int64_t* tableidx, const float* d_output,
+                    float* const* tt_cores, float* const* optimizer_state,
+                    float* const* d_tt_cores, const void* plan, void* workspace,
+                    size_t workspace_bytes, ttx_stream_t stream);
+
+/* ------------------------------------------------------ software cache -----
+ * replaces update_cache_state_cuda (tt_embeddings.cpp:74,
+ * tt_embeddings_cuda.cu:1077-1113): cache_freq[slot(idx)] += 1 with at most 3
+ * linear probes of an open-addressing table keyed by a murmur3-style hash
+ * (hashtbl_cuda_utils.cuh:48-76, :102-133). */
+int ttx_update_cache_state(int64_t nnz, const int64_t* indices,
+                           int64_t hashtbl_size, int64_t* hashtbl,
+                           int64_t* cache_freq, ttx_stream_t stream);
+
+/* replaces preprocess_indices_sync_cuda (tt_embeddings.cpp:88-95,
+ * tt_embeddings_cuda.cu:1377-1496).
+ *  rowidx/tableidx[nnz] are always written (bag b covers
+ *  [offsets[b], offsets[b+1]); rowidx = b % B, tableidx = b / B).
+ *  If warmup != 0 or num_tables != 1 nothing else happens, *num_tt_host = nnz
+ *  and *partitioned_host = 0.  Otherwise every index is looked up in the
+ *  hash table; lookups whose slot has a cache row go to the REAR of
+ *  part_colidx / part_rowidx / part_cache_locations in reverse order, the rest
+ *  keep their order at the front (cub::DevicePartition::Flagged semantics), the
+ *  count of front entries is copied to *num_tt_host after a stream
+ *  synchronise, and *partitioned_host = 1.  part_cache_locations of front
+ *  entries is -1 (uninitialised in the reference). */
+size_t ttx_preprocess_workspace_bytes(int64_t nnz);
+int ttx_preprocess_indices_sync(int64_t nnz, const int64_t* colidx,
+                                int64_t num_bags_total, const int64_t* offsets,
+                                int32_t num_tables, int32_t warmup,
+                                int64_t hashtbl_size, const int64_t* hashtbl,
+                                const int32_t* cache_state, int64_t* rowidx,
+                                int64_t* tableidx, int64_t* part_colidx,
+                                int64_t* part_rowidx,
+                                int32_t* part_cache_locations,
+                                int32_t* num_tt_host, int32_t* partitioned_host,
+                                void* workspace, size_t workspace_bytes,
+                                ttx_stream_t stream);
+
+/* replaces cache_populate_cuda (tt_embeddings.cpp:76-86,
+ * tt_embeddings_cuda.cu:1260-1336): stable descending radix sort of the slots
+ * by frequency, the top cache_size keys get cache rows (cache_state[slot] =
+ * rank), the others are evicted from the table, and the cache rows are
+ * decompressed from the TT cores. */
+size_t ttx_cache_populate_workspace_bytes(const ttx_geom* g, int64_t hashtbl_size,
+                                          int64_t cache_size, int32_t D);
+int ttx_cache_populate(const ttx_geom* g, const float* const* tt_cores,
+                       int64_t hashtbl_size, int64_t* hashtbl,
+                       int64_t* cache_freq, int32_t* cache_state,
+                       int64_t cache_size, int32_t D, float* cache_weight,
+                       void* workspace, size_t workspace_bytes,
+                       ttx_stream_t stream);
+
+/* replaces cache_forward_cuda (tt_embeddings.cpp:97-103,
+ * tt_embeddings_cuda.cu:1498-1572): output[rowidx[n], :] += cache_weight[
+ * cache_locations[n], :], summed per run of equal rowidx. */
+int ttx_cache_forward(int32_t B, int64_t nnz, const int32_t* cache_locations,
+                      const int64_t* rowidx, int32_t D,
+                      const float* cache_weight, float* output,
+                      ttx_stream_t stream);
+
+/* replaces cache_backward_sgd_cuda (tt_embeddings.cpp:105-111,
+ * tt_embeddings_cuda.cu:1574-1657):
+ * cache_weight[loc[n], :] += -grad_output[rowidx[n], :] * lr. */
+int ttx_cache_backward_sgd(int64_t nnz, int32_t D, const float* grad_output,
+                           const int32_t* cache_locations, const int64_t* rowidx,
+                           float learning_rate, float* cache_weight,
+                           ttx_stream_t stream);
+
+/* replaces cache_backward_dense_cuda (tt_embeddings.cpp:113-119,
+ * tt_embeddings_cuda.cu:1659-1733): grad_cache_weight[cache_size, D] is
+ * overwritten with the scatter-sum of grad_output rows. */
+int ttx_cache_backward_dense(int64_t nnz, int32_t D, const float* grad_output,
+                             const int32_t* cache_locations,
+                             const int64_t* rowidx, int64_t cache_size,
+                             float* grad_cache_weight, ttx_stream_t stream);
+
+/* replaces cache_backward_rowwise_adagrad_approx_cuda (tt_embeddings.cpp:121-129,
+ * tt_embeddings_cuda.cu:1735-1835): per bag g2 = mean(g*g); per cached lookup
+ * old = state[loc] (then state[loc] += g2), w[loc,:] -= g * lr/(sqrt(old+g2)+eps).
+ * Bags are processed in order (the reference leaves the order of two bags that
+ * hit the same cache row to the hardware). */
+int ttx_cache_backward_rowwise_adagrad_approx(
+    int64_t nnz, int32_t D, const float* grad_output,
+    const int32_t* cache_locations, const int64_t* rowidx, float learning_rate,
+    float eps, float* cache_optimizer_state, float* cache_weight,
+    ttx_stream_t stream);
+
+/* ------------------------------------------------------------- profiling ---
+ * Live kernel timing for bench.py's roofline block: when enabled, every launch
+ * of the named hot kernels is bracketed by HIP events on the launch stream.
+ * ttx_profile_read synchronises the pending events and returns, for kernel
+ * `which` (0 = forward contraction, 1 = backward contraction, 2 = reduce/apply,
+ * 3 = plan, 4 = bag pooling, 5 = cache gather fwd), the launch count and the
+ * summed duration in milliseconds since the last reset. */
+#define TTX_PROF_FWD 0
+#define TTX_PROF_BWD 1
+#define TTX_PROF_APPLY 2
+#define TTX_PROF_PLAN 3
+#define TTX_PROF_POOL 4
+#define TTX_PROF_CACHE_FWD 5
+#define TTX_PROF_NUM 6
+int ttx_profile_enable(int on);
+int ttx_profile_reset(void);
+int ttx_profile_read(int which, int64_t* launches, double* total_ms);
+
+/* tuning knob (bench / tests): indices per work-group chunk; 0 = heuristic */
+int ttx_set_chunk(int32_t indices_per_chunk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTX_H_ */

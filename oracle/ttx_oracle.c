@@ -1,0 +1,505 @@
+/*
+ * ttx_oracle.c -- CPU restatement of the FBTT-Embedding hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: it may be loaded
+ * by tests/, by __graft_entry__.smoke() and by bench.py's cpu_baseline leg, and
+ * by nothing else.  The product (fbtt-embedding_amd/) never imports, links or
+ * calls it; without the HIP library the product fails loudly.
+ *
+ * Every function restates, in scalar fp32/int64 C, what the reference's CUDA
+ * code computes for the same inputs, and cites the reference lines it follows
+ * (paths relative to /root/reference).  Where the reference leaves an order to
+ * the hardware (float atomics, concurrent hash-table inserts) the oracle uses
+ * index order 0..nnz-1.
+ *
+ * Pinning:
+ *  - numerics: tests/golden/ vectors generated in the build container by
+ *    importing the reference's own Python oracle (tt_matrix_to_full +
+ *    nn.EmbeddingBag + autograd, tt_embeddings_ops.py:80-127,
+ *    tt_embeddings_test.py:95-107, :161-174, :243-246, :317-333), script
+ *    tests/golden/make_golden.py;
+ *  - hash table: known-answer vectors produced by the reference's own
+ *    hashtbl_cuda_utils.cuh:44-154 compiled on the host (oracle/_ref, recipe
+ *    oracle/Makefile), committed as tests/golden/hashtbl_kat.json.
+ *  - the cache life-cycle (populate / lookup / partition / gather) has NO test
+ *    in the reference; for those functions parity is pinned only through the
+ *    hash-table KATs and the library semantics cited below ("parity unpinned"
+ *    beyond that).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/ttx.h"
+
+#define MAX_PROBES 3 /* tt_embeddings_cuda.cu:29 */
+#define UNUSED_KEY (-1) /* hashtbl_cuda_utils.cuh:100 */
+
+/* ------------------------------------------------------------------ hash --- */
+
+static inline uint32_t rotl32(uint32_t x, int r) { /* hashtbl_cuda_utils.cuh:44-46 */
+  return (x << r) | (x >> (32 - r));
+}
+
+/* hashtbl_cuda_utils.cuh:48-76 : murmur3-style mix of the two 32-bit halves of
+ * the key, then the multiply-shift range reduction ((uint64)h * C) >> 32. */
+uint32_t ttxo_hash64(int64_t key, int32_t C) {
+  const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u; /* :25-26 */
+  uint64_t u = (uint64_t)key;
+  uint32_t h = 0;
+  uint32_t k1 = (uint32_t)(u & 0xffffffffu);
+  k1 *= c1;
+  k1 = rotl32(k1, 15);
+  k1 *= c2;
+  h ^= k1;
+  h = rotl32(h, 13);
+  h = h * 5 + 0xe6546b64u;
+  uint32_t k2 = (uint32_t)(u >> 32);
+  k2 *= c1;
+  k2 = rotl32(k2, 15);
+  k2 *= c2;
+  h ^= k2;
+  h = rotl32(h, 13);
+  h = h * 5 + 0xe6546b64u;
+  h ^= 2;
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return (uint32_t)(((uint64_t)h * (uint64_t)(uint32_t)C) >> 32);
+}
+
+/* pre-reduction hash value (for the known-answer vectors) */
+uint32_t ttxo_hash64_raw(int64_t key) {
+  /* C = 2^32 would overflow int32; recompute without the reduction */
+  const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u;
+  uint64_t u = (uint64_t)key;
+  uint32_t h = 0;
+  uint32_t k1 = (uint32_t)(u & 0xffffffffu);
+  k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2;
+  h ^= k1; h = rotl32(h, 13); h = h * 5 + 0xe6546b64u;
+  uint32_t k2 = (uint32_t)(u >> 32);
+  k2 *= c1; k2 = rotl32(k2, 15); k2 *= c2;
+  h ^= k2; h = rotl32(h, 13); h = h * 5 + 0xe6546b64u;
+  h ^= 2;
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+
+/* hashtbl_cuda_utils.cuh:78-98 : the int32-key overload (unused on the hot
+ * path; kept for the known-answer vector (12345, 1000) -> 57). */
+uint32_t ttxo_hash32(int32_t key, int32_t C) {
+  const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u;
+  uint32_t h = 0;
+  uint32_t k = (uint32_t)key;
+  k *= c1; k = rotl32(k, 15); k *= c2;
+  h ^= k; h = rotl32(h, 13); h = h * 5 + 0xe6546b64u;
+  h ^= 1;
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return (uint32_t)(((uint64_t)h * (uint64_t)(uint32_t)C) >> 32);
+}
+
+/* hashtbl_cuda_utils.cuh:102-133, accumulate == true, sequential CAS/add. */
+int32_t ttxo_hashtbl_insert(int64_t key, int64_t value, int32_t size,
+                            int32_t max_probes, int64_t* keys, int64_t* values) {
+  int32_t idx = (int32_t)ttxo_hash64(key, size);
+  int32_t counter = 0;
+  while (counter++ < max_probes) {
+    int64_t old = keys[idx]; /* CAS(&keys[idx], UNUSED_KEY, key) */
+    if (old == UNUSED_KEY) keys[idx] = key;
+    if (old == UNUSED_KEY || old == key) {
+      values[idx] += value;
+      return idx;
+    }
+    idx = (idx + 1) % size;
+  }
+  return -1;
+}
+
+/* hashtbl_cuda_utils.cuh:135-154.  NB the early-out tests the SEARCH key
+ * (:146), so probing never stops at an empty slot. */
+int32_t ttxo_hashtbl_find(int64_t key, int32_t size, int32_t max_probes,
+                          const int64_t* keys) {
+  int32_t idx = (int32_t)ttxo_hash64(key, size);
+  int32_t counter = 0;
+  while (counter++ < max_probes) {
+    if (key == keys[idx]) return idx;
+    else if (UNUSED_KEY == key) return -1;
+    idx = (idx + 1) % size;
+  }
+  return -1;
+}
+
+/* ------------------------------------------------------- TT contraction --- */
+
+typedef struct {
+  int T;
+  int64_t L[TTX_MAX_CORES];   /* tt_embeddings_ops.py:506-512 */
+  int m[TTX_MAX_CORES], k[TTX_MAX_CORES], n[TTX_MAX_CORES]; /* cu:993-1004 */
+  int64_t slice[TTX_MAX_CORES]; /* r_t*q_t*r_{t+1} */
+  int64_t max_x;                /* largest intermediate m_t*n_t */
+} dims_t;
+
+static int make_dims(const ttx_geom* g, dims_t* d) {
+  if (!g || g->T < 2 || g->T > TTX_MAX_CORES || g->num_tables <= 0) return -1;
+  d->T = g->T;
+  int64_t Lv = 1;
+  for (int t = g->T - 1; t >= 0; --t) {
+    if (g->p[t] <= 0 || g->q[t] <= 0 || g->r[t] <= 0 || g->r[t + 1] <= 0) return -1;
+    d->L[t] = Lv;
+    Lv *= g->p[t];
+    d->slice[t] = (int64_t)g->r[t] * g->q[t] * g->r[t + 1];
+  }
+  int m_ = g->q[0];
+  d->max_x = 0;
+  for (int t = 0; t < g->T - 1; ++t) {
+    d->m[t] = m_;
+    d->k[t] = g->r[t + 1];
+    d->n[t] = g->q[t + 1] * g->r[t + 2];
+    m_ *= g->q[t + 1];
+    int64_t x = (int64_t)d->m[t] * d->n[t];
+    if (x > d->max_x) d->max_x = x;
+  }
+  return 0;
+}
+
+/* index decode, tt_embeddings_cuda.cu:795-799 (3T; 2T/4T analogous) */
+static void decode(const dims_t* d, int64_t idx, int64_t* ii) {
+  for (int t = 0; t < d->T; ++t) {
+    ii[t] = idx / d->L[t];
+    idx = idx % d->L[t];
+  }
+}
+
+/* C[m x n] = A[m x k] * B[k x n], row-major, fp32, k-ordered fmaf chain per
+ * output element (cublasGemmBatchedEx fp32, cu:39-77 / :1040-1054; its internal
+ * order is unspecified -- parity is to tolerance, see tests). */
+static void gemm_nn(int m, int n, int k, const float* A, const float* B, float* C) {
+  for (int i = 0; i < m; ++i) {
+    float* c = C + (int64_t)i * n;
+    for (int j = 0; j < n; ++j) c[j] = 0.0f;
+    for (int kk = 0; kk < k; ++kk) {
+      const float a = A[(int64_t)i * k + kk];
+      const float* b = B + (int64_t)kk * n;
+      for (int j = 0; j < n; ++j) c[j] = fmaf(a, b[j], c[j]);
+    }
+  }
+}
+
+/* C[k x n] = A[m x k]^T * G[m x n]  (grad-core GEMM, cu:548-562) */
+static void gemm_tn(int m, int n, int k, const float* A, const float* G, float* C) {
+  for (int64_t e = 0; e < (int64_t)k * n; ++e) C[e] = 0.0f;
+  for (int i = 0; i < m; ++i) {
+    const float* gr = G + (int64_t)i * n;
+    for (int kk = 0; kk < k; ++kk) {
+      const float a = A[(int64_t)i * k + kk];
+      float* c = C + (int64_t)kk * n;
+      for (int j = 0; j < n; ++j) c[j] = fmaf(a, gr[j], c[j]);
+    }
+  }
+}
+
+/* C[m x k] = G[m x n] * B[k x n]^T  (grad-prev GEMM, cu:577-591) */
+static void gemm_nt(int m, int n, int k, const float* G, const float* B, float* C) {
+  for (int i = 0; i < m; ++i) {
+    const float* gr = G + (int64_t)i * n;
+    for (int kk = 0; kk < k; ++kk) {
+      const float* b = B + (int64_t)kk * n;
+      float acc = 0.0f;
+      for (int j = 0; j < n; ++j) acc = fmaf(gr[j], b[j], acc);
+      C[(int64_t)i * k + kk] = acc;
+    }
+  }
+}
+
+static const float* core_slice(const ttx_geom* g, const dims_t* d,
+                               const float* const* cores, int t, int64_t table,
+                               int64_t it) {
+  return cores[t] + (table * g->p[t] + it) * d->slice[t];
+}
+
+/* forward chain of one lookup: x[t] (t = 0..T-2) <- intermediates,
+ * x[T-2] is the embedding row (cu:1039-1055). */
+static void chain(const ttx_geom* g, const dims_t* d, const float* const* cores,
+                  int64_t table, const int64_t* ii, float* const* x) {
+  const float* prev = core_slice(g, d, cores, 0, table, ii[0]);
+  for (int t = 0; t < d->T - 1; ++t) {
+    gemm_nn(d->m[t], d->n[t], d->k[t], prev,
+            core_slice(g, d, cores, t + 1, table, ii[t + 1]), x[t]);
+    prev = x[t];
+  }
+}
+
+/* rows[n,:] = TT row of indices[n] (table tableidx[n], or 0 when NULL) */
+int ttxo_tt_rows(const ttx_geom* g, int32_t D, int64_t nnz, const int64_t* indices,
+                 const int64_t* tableidx, const float* const* cores, float* rows) {
+  dims_t d;
+  if (make_dims(g, &d)) return TTX_EINVAL;
+  float* x[TTX_MAX_CORES];
+  for (int t = 0; t < d.T - 1; ++t) x[t] = (float*)malloc(sizeof(float) * d.max_x);
+  int64_t ii[TTX_MAX_CORES];
+  for (int64_t n = 0; n < nnz; ++n) {
+    decode(&d, indices[n], ii);
+    chain(g, &d, cores, tableidx ? tableidx[n] : 0, ii, x);
+    memcpy(rows + n * D, x[d.T - 2], sizeof(float) * D);
+  }
+  for (int t = 0; t < d.T - 1; ++t) free(x[t]);
+  return TTX_OK;
+}
+
+/* tt_embeddings_forward_cuda, cu:964-1075: zeros, then per lookup the GEMM
+ * chain and out[table,row,:] += row (reduce_output_kernel cu:920-962 adds the
+ * lookups of a bag in index order starting from the current output value). */
+int ttxo_tt_forward(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz,
+                    const int64_t* indices, const int64_t* rowidx,
+                    const int64_t* tableidx, const float* const* cores,
+                    float* output) {
+  dims_t d;
+  if (make_dims(g, &d)) return TTX_EINVAL;
+  memset(output, 0, sizeof(float) * (size_t)g->num_tables * B * D);
+  if (nnz == 0) return TTX_OK;
+  if (D <= 0) return TTX_EINVAL;
+  float* x[TTX_MAX_CORES];
+  for (int t = 0; t < d.T - 1; ++t) x[t] = (float*)malloc(sizeof(float) * d.max_x);
+  int64_t ii[TTX_MAX_CORES];
+  for (int64_t n = 0; n < nnz; ++n) {
+    decode(&d, indices[n], ii);
+    chain(g, &d, cores, tableidx[n], ii, x);
+    float* o = output + (tableidx[n] * B + rowidx[n]) * D;
+    const float* r = x[d.T - 2];
+    for (int e = 0; e < D; ++e) o[e] += r[e];
+  }
+  for (int t = 0; t < d.T - 1; ++t) free(x[t]);
+  return TTX_OK;
+}
+
+/* tt_embeddings_backward_cuda, cu:419-652.
+ * per lookup: recompute x[0..T-3] (cu:529-545), then for t = T-2..0
+ *   dcore_{t+1}[i_{t+1}] += x[t-1]^T * G     (cu:548-576, atomicAdd scatter)
+ *   G <- G * core_{t+1}[i_{t+1}]^T           (cu:577-591, overwrites x[t-1])
+ * and dcore_0[i_0] += G (cu:592-607).  Then the optimizer, applied to EVERY
+ * element (the maths tt_embeddings_test.py:243-246 / :317-333 pins; the
+ * reference kernels' launch grid misses rows):
+ *   SGD     cu:379-395   w -= lr * g
+ *   ADAGRAD cu:397-417   s += g*g; w -= lr * g / (sqrtf(s) + eps)
+ *   DENSE   cu:654-684   d_cores <- g                                        */
+int ttxo_tt_backward(const ttx_geom* g, int32_t optim, int32_t B, int32_t D,
+                     float lr, float eps, int64_t nnz, const int64_t* indices,
+                     const int64_t* rowidx, const int64_t* tableidx,
+                     const float* d_output, float* const* cores,
+                     float* const* state, float* const* d_cores) {
+  dims_t d;
+  if (make_dims(g, &d)) return TTX_EINVAL;
+  const int T = d.T;
+  float* dc[TTX_MAX_CORES];
+  int64_t csz[TTX_MAX_CORES];
+  for (int t = 0; t < T; ++t) {
+    csz[t] = (int64_t)g->num_tables * g->p[t] * d.slice[t];
+    if (optim == TTX_OPTIM_DENSE) {
+      dc[t] = d_cores[t];
+      memset(dc[t], 0, sizeof(float) * csz[t]); /* zeros_like, cu:444 */
+    } else {
+      dc[t] = (float*)calloc(csz[t], sizeof(float));
+    }
+  }
+  if (nnz > 0) {
+    int64_t maxs = d.max_x;
+    for (int t = 0; t < T; ++t) if (d.slice[t] > maxs) maxs = d.slice[t];
+    float* x[TTX_MAX_CORES];
+    for (int t = 0; t < T - 1; ++t) x[t] = (float*)malloc(sizeof(float) * d.max_x);
+    float* G = (float*)malloc(sizeof(float) * maxs);
+    float* G2 = (float*)malloc(sizeof(float) * maxs);
+    float* tmp = (float*)malloc(sizeof(float) * maxs);
+    int64_t ii[TTX_MAX_CORES];
+    for (int64_t n = 0; n < nnz; ++n) {
+      decode(&d, indices[n], ii);
+      const int64_t tb = tableidx[n];
+      chain(g, &d, (const float* const*)cores, tb, ii, x); /* x[T-2] unused */
+      memcpy(G, d_output + (tb * B + rowidx[n]) * D, sizeof(float) * D);
+      for (int t = T - 2; t >= 0; --t) {
+        const float* in = (t == 0) ? core_slice(g, &d, (const float* const*)cores, 0, tb, ii[0])
+                                   : x[t - 1];
+        const float* ct = core_slice(g, &d, (const float* const*)cores, t + 1, tb, ii[t + 1]);
+        gemm_tn(d.m[t], d.n[t], d.k[t], in, G, tmp);
+        float* dst = dc[t + 1] + (tb * g->p[t + 1] + ii[t + 1]) * d.slice[t + 1];
+        for (int64_t e = 0; e < d.slice[t + 1]; ++e) dst[e] += tmp[e];
+        gemm_nt(d.m[t], d.n[t], d.k[t], G, ct, G2);
+        float* sw = G; G = G2; G2 = sw;
+      }
+      float* dst0 = dc[0] + (tb * g->p[0] + ii[0]) * d.slice[0];
+      for (int64_t e = 0; e < d.slice[0]; ++e) dst0[e] += G[e];
+    }
+    for (int t = 0; t < T - 1; ++t) free(x[t]);
+    free(G); free(G2); free(tmp);
+  }
+  if (optim == TTX_OPTIM_SGD) {
+    for (int t = 0; t < T; ++t)
+      for (int64_t e = 0; e < csz[t]; ++e) cores[t][e] -= lr * dc[t][e];
+  } else if (optim == TTX_OPTIM_ADAGRAD) {
+    for (int t = 0; t < T; ++t)
+      for (int64_t e = 0; e < csz[t]; ++e) {
+        const float gg = dc[t][e];
+        if (gg == 0.0f) continue; /* s += 0; w -= 0 : unchanged (eps > 0) */
+        state[t][e] += gg * gg;
+        cores[t][e] -= lr * gg / (sqrtf(state[t][e]) + eps);
+      }
+  }
+  if (optim != TTX_OPTIM_DENSE)
+    for (int t = 0; t < T; ++t) free(dc[t]);
+  return TTX_OK;
+}
+
+/* ------------------------------------------------------- software cache --- */
+
+/* update_cache_state_kernel, cu:1077-1089: insert<accumulate>(idx, 1) */
+int ttxo_update_cache_state(int64_t nnz, const int64_t* indices, int64_t H,
+                            int64_t* hashtbl, int64_t* cache_freq) {
+  if (nnz == 0) return TTX_OK;
+  if (H <= 0) return TTX_EINVAL; /* cu:1099 */
+  for (int64_t n = 0; n < nnz; ++n)
+    ttxo_hashtbl_insert(indices[n], 1, (int32_t)H, MAX_PROBES, hashtbl, cache_freq);
+  return TTX_OK;
+}
+
+/* preprocess_indices_sync_cuda, cu:1377-1496.
+ * compute_rowidx_kernel cu:1338-1354; cache_lookup_kernel cu:1356-1375;
+ * cub::DevicePartition::Flagged cu:1437-1479 (selected keep order, rejected
+ * written from the rear in reverse order).  tableidx is not partitioned
+ * (cu:1492).  part_cache_locations of TT entries is -1 here (uninitialised in
+ * the reference, cu:1371-1373). */
+int ttxo_preprocess_indices(int64_t nnz, const int64_t* colidx, int64_t num_bags_total,
+                            const int64_t* offsets, int32_t num_tables, int32_t warmup,
+                            int64_t H, const int64_t* hashtbl, const int32_t* cache_state,
+                            int64_t* rowidx, int64_t* tableidx, int64_t* part_colidx,
+                            int64_t* part_rowidx, int32_t* part_loc, int32_t* num_tt,
+                            int32_t* partitioned) {
+  *num_tt = (int32_t)nnz;
+  *partitioned = 0;
+  if (nnz == 0) return TTX_OK;
+  const int64_t B = num_bags_total / num_tables; /* cu:1393 */
+  for (int64_t b = 0; b < num_bags_total; ++b)
+    for (int64_t l = offsets[b]; l < offsets[b + 1]; ++l) {
+      rowidx[l] = b % B;
+      tableidx[l] = b / B;
+    }
+  if (warmup || num_tables != 1) return TTX_OK; /* cu:1410-1412 */
+  int64_t front = 0, rear = nnz - 1;
+  for (int64_t n = 0; n < nnz; ++n) {
+    int32_t slot = ttxo_hashtbl_find(colidx[n], (int32_t)H, MAX_PROBES, hashtbl);
+    if (slot != -1 && cache_state[slot] != -1) {
+      part_colidx[rear] = colidx[n];
+      part_rowidx[rear] = rowidx[n];
+      part_loc[rear] = cache_state[slot];
+      --rear;
+    } else {
+      part_colidx[front] = colidx[n];
+      part_rowidx[front] = rowidx[n];
+      part_loc[front] = -1;
+      ++front;
+    }
+  }
+  *num_tt = (int32_t)front;
+  *partitioned = 1;
+  return TTX_OK;
+}
+
+typedef struct { int64_t freq; int64_t key; int64_t slot; } fk_t;
+static int cmp_desc(const void* a, const void* b) {
+  const fk_t* x = (const fk_t*)a; const fk_t* y = (const fk_t*)b;
+  if (x->freq != y->freq) return (x->freq > y->freq) ? -1 : 1;
+  return (x->slot < y->slot) ? -1 : (x->slot > y->slot); /* stable: ascending slot */
+}
+
+/* cache_populate_cuda, cu:1260-1336.
+ * SortPairsDescending(cache_freq -> hashtbl keys) cu:1281-1307 is stable;
+ * mark_popular_colidx_kernel cu:1115-1139; prefetch cu:1156-1258 (table 0).
+ * Slots are visited in sorted order 0..H-1; a key that can no longer be found
+ * (only possible after a second populate) is skipped where
+ * the reference would write out of bounds. */
+int ttxo_cache_populate(const ttx_geom* g, const float* const* cores, int64_t H,
+                        int64_t* hashtbl, int64_t* cache_freq, int32_t* cache_state,
+                        int64_t cache_size, int32_t D, float* cache_weight) {
+  if (H <= 0 || cache_size > H) return TTX_EINVAL; /* cu:1271-1274 */
+  fk_t* v = (fk_t*)malloc(sizeof(fk_t) * H);
+  for (int64_t s = 0; s < H; ++s) { v[s].freq = cache_freq[s]; v[s].key = hashtbl[s]; v[s].slot = s; }
+  qsort(v, H, sizeof(fk_t), cmp_desc);
+  int64_t* sorted = (int64_t*)malloc(sizeof(int64_t) * (H > 0 ? H : 1));
+  for (int64_t n = 0; n < H; ++n) sorted[n] = v[n].key;
+  free(v);
+  for (int64_t n = 0; n < H; ++n) {
+    if (sorted[n] != -1) {
+      int32_t slot = ttxo_hashtbl_find(sorted[n], (int32_t)H, MAX_PROBES, hashtbl);
+      if (slot < 0) continue;
+      if (n < cache_size) cache_state[slot] = (int32_t)n;
+      else { hashtbl[slot] = -1; cache_freq[slot] = 0; }
+    } else if (n < cache_size) {
+      sorted[n] = 0; /* "a hack to use batch gemm", cu:1135-1138 */
+    }
+  }
+  int rc = TTX_OK;
+  if (cache_size > 0) rc = ttxo_tt_rows(g, D, cache_size, sorted, NULL, cores, cache_weight);
+  free(sorted);
+  return rc;
+}
+
+/* cache_forward_kernel, cu:1498-1538: per run of equal rowidx,
+ * out[row,:] = out[row,:] + w[loc0,:] + w[loc1,:] ... (table 0 only) */
+int ttxo_cache_forward(int32_t B, int64_t nnz, const int32_t* loc, const int64_t* rowidx,
+                       int32_t D, const float* cache_weight, float* output) {
+  (void)B;
+  for (int64_t n = 0; n < nnz; ++n) {
+    float* o = output + rowidx[n] * D;
+    const float* w = cache_weight + (int64_t)loc[n] * D;
+    for (int e = 0; e < D; ++e) o[e] += w[e];
+  }
+  return TTX_OK;
+}
+
+/* cache_backward_sgd_kernel, cu:1574-1621 */
+int ttxo_cache_backward_sgd(int64_t nnz, int32_t D, const float* grad, const int32_t* loc,
+                            const int64_t* rowidx, float lr, float* cache_weight) {
+  for (int64_t n = 0; n < nnz; ++n) {
+    const float* gr = grad + rowidx[n] * D;
+    float* w = cache_weight + (int64_t)loc[n] * D;
+    for (int e = 0; e < D; ++e) w[e] += -gr[e] * lr;
+  }
+  return TTX_OK;
+}
+
+/* cache_backward_dense_kernel, cu:1659-1733 */
+int ttxo_cache_backward_dense(int64_t nnz, int32_t D, const float* grad, const int32_t* loc,
+                              const int64_t* rowidx, int64_t cache_size, float* gcw) {
+  memset(gcw, 0, sizeof(float) * (size_t)cache_size * D);
+  for (int64_t n = 0; n < nnz; ++n) {
+    const float* gr = grad + rowidx[n] * D;
+    float* w = gcw + (int64_t)loc[n] * D;
+    for (int e = 0; e < D; ++e) w[e] += gr[e];
+  }
+  return TTX_OK;
+}
+
+/* cache_backward_rowwise_adagrad_approx_kernel, cu:1735-1795.
+ * g2 = sum(g*g)/D per bag (the reference sums 4 squares per lane then
+ * warp-reduces; here a plain left-to-right float sum); per cached lookup
+ * old = state[loc]; state[loc] += g2;
+ * mult = (float)(lr * (1.0 / (sqrtf(old + g2) + eps)))   (double intermediate,
+ * cu:1781-1782); w -= g * mult. */
+int ttxo_cache_backward_rowwise_adagrad_approx(int64_t nnz, int32_t D, const float* grad,
+                                               const int32_t* loc, const int64_t* rowidx,
+                                               float lr, float eps, float* state,
+                                               float* cache_weight) {
+  for (int64_t n = 0; n < nnz; ++n) {
+    const float* gr = grad + rowidx[n] * D;
+    float s = 0.0f;
+    for (int e = 0; e < D; ++e) s += gr[e] * gr[e];
+    const float g2 = s / D;
+    const float old = state[loc[n]];
+    state[loc[n]] = old + g2;
+    const float mult = (float)(lr * (1.0 / (sqrtf(old + g2) + eps)));
+    float* w = cache_weight + (int64_t)loc[n] * D;
+    for (int e = 0; e < D; ++e) w[e] -= gr[e] * mult;
+  }
+  return TTX_OK;
+}
