@@ -1,0 +1,539 @@
+// ttx_cache.hip -- LFU software cache of decompressed rows: hash table
+// insert / lookup, stable partition, cache-row gather forward / backward,
+// populate (radix sort + mark/evict + decompress).  gfx950, wave64.
+//
+// Replaces tt_embeddings_cuda.cu:1077-1835 and hashtbl_cuda_utils.cuh, and the
+// two CUB device algorithms the reference calls (DeviceRadixSort::
+// SortPairsDescending cu:1281-1307, DevicePartition::Flagged cu:1437-1479) with
+// wave-ballot ranking: a "wave unit" (one wavefront walking a contiguous range
+// in order) ranks 64 keys at a time with wave_match8 / ballot + popcount, keeps
+// its running digit offsets in LDS, and unit totals are combined by a single
+// exclusive scan -- stable, atomic-free and deterministic.
+#include "ttx_internal.h"
+
+namespace ttx {
+
+constexpr int kMaxProbes = 3;  // tt_embeddings_cuda.cu:29
+constexpr int kCT = 256;
+
+// hashtbl_cuda_utils.cuh:48-76 (bit-exact restatement; KATs in tests/golden)
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+__device__ __forceinline__ uint32_t hash64(int64_t key, int32_t C) {
+  const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u;
+  const uint64_t u = (uint64_t)key;
+  uint32_t h = 0;
+  uint32_t k1 = (uint32_t)u;
+  k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2;
+  h ^= k1; h = rotl32(h, 13); h = h * 5 + 0xe6546b64u;
+  uint32_t k2 = (uint32_t)(u >> 32);
+  k2 *= c1; k2 = rotl32(k2, 15); k2 *= c2;
+  h ^= k2; h = rotl32(h, 13); h = h * 5 + 0xe6546b64u;
+  h ^= 2;
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return (uint32_t)(((uint64_t)h * (uint64_t)(uint32_t)C) >> 32);
+}
+
+// hashtbl_cuda_utils.cuh:135-154 (incl. the early-out on the SEARCH key, :146)
+__device__ __forceinline__ int32_t hashtbl_find(int64_t key, int32_t size, const int64_t* keys) {
+  int32_t idx = (int32_t)hash64(key, size);
+#pragma unroll
+  for (int c = 0; c < kMaxProbes; ++c) {
+    if (key == keys[idx]) return idx;
+    else if (key == -1) return -1;
+    idx = (idx + 1) % size;
+  }
+  return -1;
+}
+
+// hashtbl_cuda_utils.cuh:102-133 with accumulate == true: 64-bit CAS claims the
+// slot, 64-bit atomic add bumps the frequency.
+__global__ __launch_bounds__(kCT) void update_cache_state_kernel(
+    int64_t N, const int64_t* __restrict__ colidx, int32_t H, int64_t* hashtbl, int64_t* cache_freq) {
+  const int64_t n = (int64_t)blockIdx.x * kCT + threadIdx.x;
+  if (n >= N) return;
+  const int64_t key = colidx[n];
+  int32_t idx = (int32_t)hash64(key, H);
+  for (int c = 0; c < kMaxProbes; ++c) {
+    const unsigned long long old = atomicCAS((unsigned long long*)&hashtbl[idx],
+                                             (unsigned long long)(-1ll), (unsigned long long)key);
+    if ((int64_t)old == -1 || (int64_t)old == key) {
+      atomicAdd((unsigned long long*)&cache_freq[idx], 1ull);
+      return;
+    }
+    idx = (idx + 1) % H;
+  }
+}
+
+// compute_rowidx_kernel, cu:1338-1354: one 8-lane group per bag
+__global__ __launch_bounds__(kCT) void compute_rowidx_kernel(int64_t nb, int32_t B,
+                                                            const int64_t* __restrict__ offsets,
+                                                            int64_t* rowidx, int64_t* tableidx) {
+  const int64_t b = (int64_t)blockIdx.x * (kCT / 8) + threadIdx.x / 8;
+  if (b >= nb) return;
+  const int64_t beg = offsets[b], end = offsets[b + 1];
+  for (int64_t l = beg + (threadIdx.x & 7); l < end; l += 8) {
+    rowidx[l] = b % B;
+    tableidx[l] = b / B;
+  }
+}
+
+// ---- stable partition (cache_lookup_kernel cu:1356-1375 + Flagged) ---------
+// pass 1: look every index up, record flag / location, count TT entries per
+// wave unit.  unit u covers [u*WT, (u+1)*WT).
+__global__ __launch_bounds__(kCT) void lookup_count_kernel(
+    int N, int WT, const int64_t* __restrict__ colidx, int32_t H, const int64_t* __restrict__ hashtbl,
+    const int32_t* __restrict__ cache_state, int32_t* loc, int* unit_cnt) {
+  const int u = blockIdx.x * (kCT / kWave) + threadIdx.x / kWave;
+  const int beg = u * WT;
+  if (beg >= N) return;
+  const int end = min(N, beg + WT);
+  const int lane = lane_id();
+  int cnt = 0;
+  for (int base = beg; base < end; base += kWave) {
+    const int i = base + lane;
+    bool tt = false;
+    if (i < end) {
+      const int32_t slot = hashtbl_find(colidx[i], H, hashtbl);
+      int32_t cl = -1;
+      if (slot != -1) cl = cache_state[slot];
+      tt = (cl == -1);
+      loc[i] = cl;  // -1 <=> TT entry
+    }
+    cnt += __popcll(__ballot(tt));
+  }
+  if (lane == 0) unit_cnt[u] = cnt;
+}
+
+// single work-group exclusive scan of U ints (U <= a few thousand)
+__global__ __launch_bounds__(1024) void scan_units_kernel(int U, int* unit_cnt, int* total_out) {
+  __shared__ int wt[17];
+  int carry = 0;
+  for (int b0 = 0; b0 < U; b0 += 1024) {
+    const int i = b0 + threadIdx.x;
+    const int v = i < U ? unit_cnt[i] : 0;
+    const int inc = wave_incl_scan(v);
+    const int w = threadIdx.x / kWave;
+    if (lane_id() == kWave - 1) wt[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int run = 0;
+      for (int k = 0; k < 16; ++k) { int c = wt[k]; wt[k] = run; run += c; }
+      wt[16] = run;
+    }
+    __syncthreads();
+    if (i < U) unit_cnt[i] = carry + wt[w] + inc - v;
+    carry += wt[16];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(kCT) void partition_scatter_kernel(
+    int N, int WT, const int64_t* __restrict__ colidx, const int64_t* __restrict__ rowidx,
+    const int32_t* __restrict__ loc, const int* __restrict__ unit_base, int64_t* pcol, int64_t* prow,
+    int32_t* ploc) {
+  const int u = blockIdx.x * (kCT / kWave) + threadIdx.x / kWave;
+  const int beg = u * WT;
+  if (beg >= N) return;
+  const int end = min(N, beg + WT);
+  const int lane = lane_id();
+  int run = unit_base[u];  // TT entries before this unit
+  for (int base = beg; base < end; base += kWave) {
+    const int i = base + lane;
+    const bool valid = i < end;
+    const int32_t cl = valid ? loc[i] : 0;
+    const bool tt = valid && cl == -1;
+    const unsigned long long m = __ballot(tt);
+    if (valid) {
+      const int tt_before = run + __popcll(m & lanemask_lt());
+      // selected keep their order at the front; rejected go to the rear, reversed
+      const int dst = tt ? tt_before : (N - 1 - (i - tt_before));
+      pcol[dst] = colidx[i];
+      prow[dst] = rowidx[i];
+      ploc[dst] = cl;
+    }
+    run += __popcll(m);
+  }
+}
+
+// ---- cache row gather / scatter --------------------------------------------
+// cache_forward_kernel cu:1498-1538: run heads add their run's cache rows, in
+// index order, onto the current output value.  32 lanes per lookup.
+__global__ __launch_bounds__(kCT) void cache_forward_kernel(int N, int D,
+                                                           const int64_t* __restrict__ rowidx,
+                                                           const int32_t* __restrict__ loc,
+                                                           const float* __restrict__ w, float* out) {
+  const int n = blockIdx.x * (kCT / 32) + threadIdx.x / 32;
+  const int l = threadIdx.x & 31;
+  if (n >= N) return;
+  const int64_t r = rowidx[n];
+  if (n > 0 && rowidx[n - 1] == r) return;
+  int sl = 1;
+  while (n + sl < N && rowidx[n + sl] == r) ++sl;
+  float* o = out + (size_t)r * D;
+  for (int e = l; e < D; e += 32) {
+    float acc = o[e];
+    for (int j = 0; j < sl; ++j) acc += w[(size_t)loc[n + j] * D + e];
+    o[e] = acc;
+  }
+}
+
+// cache_backward_sgd_kernel cu:1574-1621 / dense cu:1659-1697: hardware fp32
+// atomic add (the same row can be hit from several bags).  scale = -lr (SGD)
+// or +1 (dense gradient).
+__global__ __launch_bounds__(kCT) void cache_scatter_add_kernel(int N, int D, float scale,
+                                                               const float* __restrict__ grad,
+                                                               const int32_t* __restrict__ loc,
+                                                               const int64_t* __restrict__ rowidx,
+                                                               float* dst) {
+  const int n = blockIdx.x * (kCT / 32) + threadIdx.x / 32;
+  const int l = threadIdx.x & 31;
+  if (n >= N) return;
+  const float* g = grad + (size_t)rowidx[n] * D;
+  float* w = dst + (size_t)loc[n] * D;
+  for (int e = l; e < D; e += 32) unsafeAtomicAdd(&w[e], g[e] * scale);
+}
+
+// cache_backward_rowwise_adagrad_approx_kernel cu:1735-1795.  One wave per
+// lookup: g2 = mean(g^2) of its bag, old = atomicAdd(state[loc], g2),
+// mult = lr / (sqrt(old + g2) + eps) with the reference's double intermediate,
+// w[loc,:] -= g * mult (atomic: the sum over lookups is order independent; only
+// the `old` each lookup observes depends on arrival order, as in the reference).
+__global__ __launch_bounds__(kCT) void cache_rowwise_adagrad_kernel(
+    int N, int D, const float* __restrict__ grad, const int32_t* __restrict__ loc,
+    const int64_t* __restrict__ rowidx, float lr, float eps, float* state, float* wgt) {
+  const int n = blockIdx.x * (kCT / kWave) + threadIdx.x / kWave;
+  const int l = lane_id();
+  if (n >= N) return;
+  const float* g = grad + (size_t)rowidx[n] * D;
+  float s = 0.f;
+  for (int e = l; e < D; e += kWave) s = fmaf(g[e], g[e], s);
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
+  const float g2 = s / D;
+  const int32_t c = loc[n];
+  float mult = 0.f;
+  if (l == 0) {
+    const float old = unsafeAtomicAdd(&state[c], g2);
+    mult = (float)(lr * (1.0 / (sqrtf(old + g2) + eps)));
+  }
+  mult = __shfl(mult, 0, kWave);
+  float* w = wgt + (size_t)c * D;
+  for (int e = l; e < D; e += kWave) unsafeAtomicAdd(&w[e], -g[e] * mult);
+}
+
+// ---- multi-block stable LSD radix sort of (int64 key, int64 value) pairs ----
+// descending on the key (digit' = 255 - digit), 8 bits per pass.  A wave unit
+// walks WT consecutive elements; cnt is [256][U] (digit major).
+__global__ __launch_bounds__(kCT) void radix_count_kernel(int N, int WT, int U, int shift,
+                                                         const int64_t* __restrict__ keys, int* cnt) {
+  __shared__ int hist[kCT / kWave][256];
+  const int w = threadIdx.x / kWave, lane = lane_id();
+  const int u = blockIdx.x * (kCT / kWave) + w;
+  for (int e = lane; e < 256; e += kWave) hist[w][e] = 0;
+  const int beg = u * WT;
+  const int end = min(N, beg + WT);
+  for (int base = beg; base < end; base += kWave) {
+    const int i = base + lane;
+    const bool valid = i < end;
+    const unsigned dg = valid ? 255u - (unsigned)(((uint64_t)keys[i] >> shift) & 255u) : 0u;
+    const unsigned long long peers = wave_match8(dg, valid);
+    if (valid && (peers & lanemask_lt()) == 0) hist[w][dg] += __popcll(peers);
+  }
+  if (u < U)
+    for (int e = lane; e < 256; e += kWave) cnt[(size_t)e * U + u] = hist[w][e];
+}
+
+__global__ __launch_bounds__(1024) void radix_scan_kernel(int total, int* cnt) {
+  __shared__ int wt[17];
+  const int per = (total + 1023) / 1024;
+  const int beg = threadIdx.x * per;
+  const int end = min(total, beg + per);
+  int s = 0;
+  for (int i = beg; i < end; ++i) s += cnt[i];
+  const int inc = wave_incl_scan(s);
+  const int w = threadIdx.x / kWave;
+  if (lane_id() == kWave - 1) wt[w] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 0; k < 16; ++k) { int c = wt[k]; wt[k] = run; run += c; }
+  }
+  __syncthreads();
+  int run = wt[w] + inc - s;
+  for (int i = beg; i < end; ++i) { const int c = cnt[i]; cnt[i] = run; run += c; }
+}
+
+__global__ __launch_bounds__(kCT) void radix_scatter_kernel(int N, int WT, int U, int shift,
+                                                           const int64_t* __restrict__ keys,
+                                                           const int64_t* __restrict__ vals,
+                                                           const int* __restrict__ cnt,
+                                                           int64_t* okeys, int64_t* ovals) {
+  __shared__ int run[kCT / kWave][256];
+  const int w = threadIdx.x / kWave, lane = lane_id();
+  const int u = blockIdx.x * (kCT / kWave) + w;
+  if (u < U)
+    for (int e = lane; e < 256; e += kWave) run[w][e] = cnt[(size_t)e * U + u];
+  const int beg = u * WT;
+  const int end = min(N, beg + WT);
+  for (int base = beg; base < end; base += kWave) {
+    const int i = base + lane;
+    const bool valid = i < end;
+    int64_t k = 0;
+    unsigned dg = 0;
+    if (valid) {
+      k = keys[i];
+      dg = 255u - (unsigned)(((uint64_t)k >> shift) & 255u);
+    }
+    const unsigned long long peers = wave_match8(dg, valid);
+    if (valid) {
+      const int before = run[w][dg];
+      const int pos = before + __popcll(peers & lanemask_lt());
+      okeys[pos] = k;
+      ovals[pos] = vals[i];
+      if ((peers & lanemask_lt()) == 0) run[w][dg] = before + __popcll(peers);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void max_key_kernel(int N, const int64_t* __restrict__ keys,
+                                                      unsigned long long* out) {
+  __shared__ unsigned long long wm[16];
+  unsigned long long m = 0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    const unsigned long long k = (unsigned long long)keys[i];
+    m = k > m ? k : m;
+  }
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    const unsigned long long v = __shfl_xor(m, o, kWave);
+    m = v > m ? v : m;
+  }
+  if (lane_id() == 0) wm[threadIdx.x / kWave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k) m = wm[k] > m ? wm[k] : m;
+    *out = m;
+  }
+}
+
+// mark_popular_colidx_kernel cu:1115-1139
+__global__ __launch_bounds__(kCT) void mark_popular_kernel(int32_t H, int64_t cache_size,
+                                                          int64_t* sorted_keys, int64_t* hashtbl,
+                                                          int64_t* cache_freq, int32_t* cache_state) {
+  const int64_t n = (int64_t)blockIdx.x * kCT + threadIdx.x;
+  if (n >= H) return;
+  const int64_t key = sorted_keys[n];
+  if (key != -1) {
+    const int32_t slot = hashtbl_find(key, H, hashtbl);
+    if (slot < 0) return;  // only after a repeated populate; the reference writes OOB
+    if (n < cache_size) {
+      cache_state[slot] = (int32_t)n;
+    } else {
+      hashtbl[slot] = -1;
+      cache_freq[slot] = 0;
+    }
+  } else if (n < cache_size) {
+    sorted_keys[n] = 0;  // "a hack to use batch gemm"
+  }
+}
+
+static void unit_shape(long long n, int* WT, int* U) {
+  long long wt = (n + 2047) / 2048;
+  wt = (wt + kWave - 1) / kWave * kWave;
+  if (wt < 256) wt = 256;
+  *WT = (int)wt;
+  *U = (int)((n + wt - 1) / wt);
+  if (*U < 1) *U = 1;
+}
+
+}  // namespace ttx
+
+using namespace ttx;
+
+extern "C" {
+
+int ttx_update_cache_state(int64_t nnz, const int64_t* indices, int64_t H, int64_t* hashtbl,
+                           int64_t* cache_freq, ttx_stream_t stream) {
+  if (nnz == 0) return TTX_OK;  // cu:1095-1097
+  if (H <= 0 || H >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
+  if (!indices || !hashtbl || !cache_freq) TTX_FAIL(TTX_EINVAL, "NULL input");
+  hipLaunchKernelGGL(update_cache_state_kernel, dim3((unsigned)((nnz + kCT - 1) / kCT)), dim3(kCT), 0,
+                     (hipStream_t)stream, nnz, indices, (int32_t)H, hashtbl, cache_freq);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
+size_t ttx_preprocess_workspace_bytes(int64_t nnz) {
+  int WT, U;
+  unit_shape(nnz, &WT, &U);
+  return align_up((size_t)nnz * 4) + align_up((size_t)(U + 64) * 4) + 256;
+}
+
+int ttx_preprocess_indices_sync(int64_t nnz, const int64_t* colidx, int64_t nb,
+                                const int64_t* offsets, int32_t num_tables, int32_t warmup,
+                                int64_t H, const int64_t* hashtbl, const int32_t* cache_state,
+                                int64_t* rowidx, int64_t* tableidx, int64_t* pcol, int64_t* prow,
+                                int32_t* ploc, int32_t* num_tt_host, int32_t* partitioned_host,
+                                void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!num_tt_host || !partitioned_host) TTX_FAIL(TTX_EINVAL, "NULL output");
+  *num_tt_host = (int32_t)nnz;
+  *partitioned_host = 0;
+  if (nnz == 0) return TTX_OK;  // cu:1389-1391
+  if (nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz too large");
+  if (num_tables <= 0 || nb % num_tables != 0)
+    TTX_FAIL(TTX_EINVAL, "offsets has %lld bags, not a multiple of num_tables=%d", (long long)nb, num_tables);
+  if (!colidx || !offsets || !rowidx || !tableidx) TTX_FAIL(TTX_EINVAL, "NULL input");
+  const int32_t B = (int32_t)(nb / num_tables);
+  hipLaunchKernelGGL(compute_rowidx_kernel, dim3((unsigned)((nb + kCT / 8 - 1) / (kCT / 8))), dim3(kCT), 0,
+                     st, nb, B, offsets, rowidx, tableidx);
+  TTX_HIP(hipGetLastError());
+  if (warmup || num_tables != 1) return TTX_OK;  // cu:1410-1412
+  if (H <= 0 || H >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
+  if (!hashtbl || !cache_state || !pcol || !prow || !ploc) TTX_FAIL(TTX_EINVAL, "NULL cache input");
+  if (!workspace || workspace_bytes < ttx_preprocess_workspace_bytes(nnz))
+    TTX_FAIL(TTX_EWORKSPACE, "preprocess workspace too small");
+  int WT, U;
+  unit_shape(nnz, &WT, &U);
+  int32_t* loc = (int32_t*)workspace;
+  int* unit_cnt = (int*)((char*)workspace + align_up((size_t)nnz * 4));
+  int* total = unit_cnt + U;
+  const int N = (int)nnz;
+  const unsigned blocks = (unsigned)((U + kCT / kWave - 1) / (kCT / kWave));
+  hipLaunchKernelGGL(lookup_count_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, colidx, (int32_t)H,
+                     hashtbl, cache_state, loc, unit_cnt);
+  hipLaunchKernelGGL(scan_units_kernel, dim3(1), dim3(1024), 0, st, U, unit_cnt, total);
+  hipLaunchKernelGGL(partition_scatter_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, colidx, rowidx,
+                     loc, unit_cnt, pcol, prow, ploc);
+  TTX_HIP(hipGetLastError());
+  // the one host synchronisation of the hot path (cu:1481-1488)
+  TTX_HIP(hipMemcpyAsync(num_tt_host, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  TTX_HIP(hipStreamSynchronize(st));
+  *partitioned_host = 1;
+  return TTX_OK;
+}
+
+int ttx_cache_forward(int32_t B, int64_t nnz, const int32_t* loc, const int64_t* rowidx, int32_t D,
+                      const float* cache_weight, float* output, ttx_stream_t stream) {
+  if (B <= 0) TTX_FAIL(TTX_EINVAL, "B=%d must be > 0", B);  // cu:1549
+  if (D <= 0) TTX_FAIL(TTX_EINVAL, "D=%d must be > 0", D);
+  if (nnz == 0) return TTX_OK;
+  if (!loc || !rowidx || !cache_weight || !output) TTX_FAIL(TTX_EINVAL, "NULL input");
+  ProfScope ps(TTX_PROF_CACHE_FWD, (hipStream_t)stream);
+  hipLaunchKernelGGL(cache_forward_kernel, dim3((unsigned)((nnz + kCT / 32 - 1) / (kCT / 32))), dim3(kCT), 0,
+                     (hipStream_t)stream, (int)nnz, D, rowidx, loc, cache_weight, output);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
+int ttx_cache_backward_sgd(int64_t nnz, int32_t D, const float* grad, const int32_t* loc,
+                           const int64_t* rowidx, float lr, float* cache_weight, ttx_stream_t stream) {
+  if (nnz == 0) return TTX_OK;
+  if (D <= 0) TTX_FAIL(TTX_EINVAL, "D=%d must be > 0", D);
+  if (!grad || !loc || !rowidx || !cache_weight) TTX_FAIL(TTX_EINVAL, "NULL input");
+  hipLaunchKernelGGL(cache_scatter_add_kernel, dim3((unsigned)((nnz + kCT / 32 - 1) / (kCT / 32))), dim3(kCT),
+                     0, (hipStream_t)stream, (int)nnz, D, -lr, grad, loc, rowidx, cache_weight);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
+int ttx_cache_backward_dense(int64_t nnz, int32_t D, const float* grad, const int32_t* loc,
+                             const int64_t* rowidx, int64_t cache_size, float* gcw, ttx_stream_t stream) {
+  if (D <= 0 || cache_size < 0) TTX_FAIL(TTX_EINVAL, "bad D / cache_size");
+  if (!gcw) TTX_FAIL(TTX_EINVAL, "NULL output");
+  if (cache_size > 0)
+    TTX_HIP(hipMemsetAsync(gcw, 0, (size_t)cache_size * D * sizeof(float), (hipStream_t)stream));
+  if (nnz == 0) return TTX_OK;
+  if (!grad || !loc || !rowidx) TTX_FAIL(TTX_EINVAL, "NULL input");
+  hipLaunchKernelGGL(cache_scatter_add_kernel, dim3((unsigned)((nnz + kCT / 32 - 1) / (kCT / 32))), dim3(kCT),
+                     0, (hipStream_t)stream, (int)nnz, D, 1.0f, grad, loc, rowidx, gcw);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
+int ttx_cache_backward_rowwise_adagrad_approx(int64_t nnz, int32_t D, const float* grad,
+                                              const int32_t* loc, const int64_t* rowidx, float lr,
+                                              float eps, float* state, float* cache_weight,
+                                              ttx_stream_t stream) {
+  if (nnz == 0) return TTX_OK;
+  if (D <= 0) TTX_FAIL(TTX_EINVAL, "D=%d must be > 0", D);
+  if (!grad || !loc || !rowidx || !state || !cache_weight) TTX_FAIL(TTX_EINVAL, "NULL input");
+  hipLaunchKernelGGL(cache_rowwise_adagrad_kernel, dim3((unsigned)((nnz + kCT / kWave - 1) / (kCT / kWave))),
+                     dim3(kCT), 0, (hipStream_t)stream, (int)nnz, D, grad, loc, rowidx, lr, eps, state,
+                     cache_weight);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
+size_t ttx_cache_populate_workspace_bytes(const ttx_geom* g, int64_t H, int64_t cache_size, int32_t D) {
+  (void)D;
+  Dims d;
+  if (make_dims(g, &d) != TTX_OK || H <= 0 || cache_size < 0) return 0;
+  int WT, U;
+  unit_shape(H, &WT, &U);
+  return 4 * align_up((size_t)H * 8) + align_up((size_t)256 * U * 4) + 256 + plan_bytes(d, cache_size) + 256;
+}
+
+int ttx_cache_populate(const ttx_geom* g, const float* const* tt_cores, int64_t H, int64_t* hashtbl,
+                       int64_t* cache_freq, int32_t* cache_state, int64_t cache_size, int32_t D,
+                       float* cache_weight, void* workspace, size_t workspace_bytes,
+                       ttx_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Dims d;
+  int rc = make_dims(g, &d);
+  if (rc) return rc;
+  // cu:1271-1274
+  if (H <= 0 || H >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
+  if (cache_size < 0 || cache_size > H) TTX_FAIL(TTX_EINVAL, "cache_size=%lld must be <= hashtbl_size", (long long)cache_size);
+  if (!hashtbl || !cache_freq || !cache_state || !tt_cores) TTX_FAIL(TTX_EINVAL, "NULL input");
+  if (!workspace || workspace_bytes < ttx_cache_populate_workspace_bytes(g, H, cache_size, D))
+    TTX_FAIL(TTX_EWORKSPACE, "cache_populate workspace too small");
+  int WT, U;
+  unit_shape(H, &WT, &U);
+  char* ws = (char*)workspace;
+  const size_t hb = align_up((size_t)H * 8);
+  int64_t* kA = (int64_t*)ws;
+  int64_t* kB = (int64_t*)(ws + hb);
+  int64_t* vA = (int64_t*)(ws + 2 * hb);
+  int64_t* vB = (int64_t*)(ws + 3 * hb);
+  int* cnt = (int*)(ws + 4 * hb);
+  unsigned long long* dmax = (unsigned long long*)(cnt + (size_t)256 * U);
+  char* rows_ws = ws + 4 * hb + align_up((size_t)256 * U * 4) + 256;
+  const int N = (int)H;
+  // size the sort: highest set bit of the largest frequency (8-byte read-back)
+  hipLaunchKernelGGL(max_key_kernel, dim3(1), dim3(1024), 0, st, N, cache_freq, dmax);
+  unsigned long long hmax = 0;
+  TTX_HIP(hipMemcpyAsync(&hmax, dmax, 8, hipMemcpyDeviceToHost, st));
+  TTX_HIP(hipStreamSynchronize(st));
+  int bits = 0;
+  while (bits < 64 && (hmax >> bits)) ++bits;
+  const int passes = bits == 0 ? 1 : (bits + 7) / 8;  // >= 1: also produces the sorted copy
+  const unsigned blocks = (unsigned)((U + kCT / kWave - 1) / (kCT / kWave));
+  const int64_t* ik = cache_freq;
+  const int64_t* iv = hashtbl;
+  int64_t* ok = kA;
+  int64_t* ov = vA;
+  for (int ps = 0; ps < passes; ++ps) {
+    hipLaunchKernelGGL(radix_count_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, U, ps * 8, ik, cnt);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, 256 * U, cnt);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, U, ps * 8, ik, iv, cnt,
+                       ok, ov);
+    ik = ok;
+    iv = ov;
+    ok = (ok == kA) ? kB : kA;
+    ov = (ov == vA) ? vB : vA;
+  }
+  TTX_HIP(hipGetLastError());
+  int64_t* sorted_keys = (int64_t*)iv;
+  hipLaunchKernelGGL(mark_popular_kernel, dim3((unsigned)((H + kCT - 1) / kCT)), dim3(kCT), 0, st, (int32_t)H,
+                     cache_size, sorted_keys, hashtbl, cache_freq, cache_state);
+  TTX_HIP(hipGetLastError());
+  if (cache_size == 0) return TTX_OK;
+  if (!cache_weight) TTX_FAIL(TTX_EINVAL, "cache_weight is NULL");
+  return ttx_tt_rows(g, D, cache_size, sorted_keys, nullptr, tt_cores, cache_weight, rows_ws,
+                     plan_bytes(d, cache_size), stream);
+}
+
+}  // extern "C"

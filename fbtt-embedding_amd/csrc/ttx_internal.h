@@ -1,0 +1,116 @@
+// ttx_internal.h -- shared host/device definitions of libttx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ttx.h"
+
+namespace ttx {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---------------------------------------------------------------- errors ----
+void set_error(const char* fmt, ...);
+#define TTX_FAIL(code, ...)     \
+  do {                          \
+    ttx::set_error(__VA_ARGS__); \
+    return (code);              \
+  } while (0)
+#define TTX_HIP(call)                                                         \
+  do {                                                                        \
+    hipError_t e__ = (call);                                                  \
+    if (e__ != hipSuccess)                                                    \
+      TTX_FAIL(TTX_EHIP, "%s failed: %s", #call, hipGetErrorString(e__));     \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ------------------------------------------------------------- geometry ----
+// Derived per-stage GEMM shapes of the TT chain:
+//   x_t[m_t x n_t] = x_{t-1}[m_t x k_t] * core_{t+1}[i_{t+1}][k_t x n_t]
+struct Dims {
+  int T, num_tables;
+  int p[TTX_MAX_CORES], q[TTX_MAX_CORES], r[TTX_MAX_CORES + 1];
+  long long L[TTX_MAX_CORES];
+  int slice[TTX_MAX_CORES];  // r_t q_t r_{t+1}
+  int S[TTX_MAX_CORES];      // num_tables * p_t  (slices of core t)
+  int m[TTX_MAX_CORES], k[TTX_MAX_CORES], n[TTX_MAX_CORES];
+  int D;
+};
+
+int make_dims(const ttx_geom* g, Dims* d);  // TTX_OK or TTX_EINVAL (+message)
+
+// ----------------------------------------------------------------- plan ----
+// Device-resident lookup plan (see include/ttx.h).  All arrays int32.
+//   sid[t][n]   = table*p_t + i_t                      (original order)
+//   perm[t][*]  = lookups n sorted (stably) by sid[t]
+//   off[t][s]   = first position in perm[t] of slice s  (S_t + 1 entries)
+//   chunk_*     = work list of the pivot core (core 1): each slice's run of
+//                 lookups cut into chunks of <= MC lookups
+struct Plan {
+  int* hdr;  // [0] = number of chunks, [1] = MC, [2] = nnz
+  int* sid[TTX_MAX_CORES];
+  int* perm[TTX_MAX_CORES];
+  int* off[TTX_MAX_CORES];
+  int* chunk_off;    // [S_1 + 1]
+  int* chunk_slice;  // [max_chunks]
+  int* chunk_start;  // [max_chunks]
+  int* scratch[3];   // rank / ping / pong, [nnz] each
+  int max_chunks;
+  int MC;
+};
+
+int choose_chunk(const Dims& d);  // lookups per chunk (LDS-budget heuristic)
+int max_chunks(const Dims& d, long long nnz, int MC);
+size_t plan_bytes(const Dims& d, long long nnz);
+// carve `base` into the plan arrays (same function for builder and consumers)
+Plan carve_plan(const Dims& d, long long nnz, void* base);
+int plan_build(const Dims& d, long long nnz, const int64_t* indices,
+               const int64_t* tableidx, const Plan& P, hipStream_t stream);
+
+// ------------------------------------------------------------ profiling ----
+void prof_begin(int which, hipStream_t s);
+void prof_end(int which, hipStream_t s);
+struct ProfScope {
+  int w;
+  hipStream_t s;
+  ProfScope(int which, hipStream_t st) : w(which), s(st) { prof_begin(w, s); }
+  ~ProfScope() { prof_end(w, s); }
+};
+
+// ------------------------------------------------------- device helpers ----
+#ifdef __HIPCC__
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// peers of this lane: valid lanes of the wave holding the same 8-bit digit.
+// Built from 9 wave ballots (the gfx950 replacement for a CUB rank pass).
+// Must be called by all lanes of the wave (wave-uniform control flow).
+__device__ __forceinline__ unsigned long long wave_match8(unsigned dgt, bool valid) {
+  unsigned long long mask = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (dgt >> b) & 1u;
+    const unsigned long long bm = __ballot(bit && valid);
+    mask &= bit ? bm : ~bm;
+  }
+  return mask;
+}
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+  return (1ull << lane_id()) - 1ull;
+}
+
+// wave-wide inclusive scan (sum) via DPP-friendly shuffles
+__device__ __forceinline__ int wave_incl_scan(int v) {
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    int u = __shfl_up(v, o, kWave);
+    if (lane_id() >= o) v += u;
+  }
+  return v;
+}
+#endif
+
+}  // namespace ttx

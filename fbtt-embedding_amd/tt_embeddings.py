@@ -1,0 +1,474 @@
+"""`tt_embeddings` -- drop-in for the reference's native extension module.
+
+The reference builds a pybind11/CUDA extension called `tt_embeddings` exporting
+eleven functions (reference tt_embeddings.cpp:131-161).  This module exports the
+same eleven names with the same positional arguments, tensor conventions and
+error behaviour (RuntimeError where the reference's TORCH_CHECK fires), and
+forwards every call to the hand-written HIP library `libttx.so` (gfx950) through
+its C ABI (include/ttx.h) with ctypes.  PyTorch is used only for device memory
+and the current HIP stream.
+
+There is NO CPU or PyTorch fallback: if `libttx.so` is missing, or a tensor is
+not on a GPU, the call raises.
+
+Extras beyond the reference's eleven names (used by tt_embeddings_ops.py and
+bench.py): `make_plan` (share the lookup plan between forward and backward),
+`profile_*` (live kernel timings), `lib()` (the loaded ctypes library).
+"""
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libttx.so")
+
+MAX_CORES = 4
+OPTIM_SGD, OPTIM_ADAGRAD, OPTIM_DENSE = 0, 1, 2
+PROF_FWD, PROF_BWD, PROF_APPLY, PROF_PLAN, PROF_POOL, PROF_CACHE_FWD = range(6)
+
+
+class _Geom(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32),
+        ("num_tables", C.c_int32),
+        ("p", C.c_int32 * MAX_CORES),
+        ("q", C.c_int32 * MAX_CORES),
+        ("r", C.c_int32 * (MAX_CORES + 1)),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load libttx.so (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise RuntimeError(
+            f"tt_embeddings: the HIP library {_SO} is missing -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU / PyTorch fallback."
+        )
+    L = C.CDLL(_SO)
+    L.ttx_last_error.restype = C.c_char_p
+    for name in (
+        "ttx_plan_bytes",
+        "ttx_tt_forward_workspace_bytes",
+        "ttx_tt_backward_workspace_bytes",
+        "ttx_preprocess_workspace_bytes",
+        "ttx_cache_populate_workspace_bytes",
+    ):
+        getattr(L, name).restype = C.c_size_t
+    vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+    G = C.POINTER(_Geom)
+    L.ttx_plan_bytes.argtypes = [G, i64]
+    L.ttx_plan_build.argtypes = [G, i64, vp, vp, vp, sz, vp]
+    L.ttx_tt_forward_workspace_bytes.argtypes = [G, i32, i32, i64]
+    L.ttx_tt_forward.argtypes = [G, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.ttx_tt_rows.argtypes = [G, i32, i64, vp, vp, vp, vp, vp, sz, vp]
+    L.ttx_tt_backward_workspace_bytes.argtypes = [G, i32, i32, i64]
+    L.ttx_tt_backward.argtypes = [G, i32, i32, i32, f32, f32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.ttx_update_cache_state.argtypes = [i64, vp, i64, vp, vp, vp]
+    L.ttx_preprocess_workspace_bytes.argtypes = [i64]
+    L.ttx_preprocess_indices_sync.argtypes = [i64, vp, i64, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp,
+                                              C.POINTER(i32), C.POINTER(i32), vp, sz, vp]
+    L.ttx_cache_populate_workspace_bytes.argtypes = [G, i64, i64, i32]
+    L.ttx_cache_populate.argtypes = [G, vp, i64, vp, vp, vp, i64, i32, vp, vp, sz, vp]
+    L.ttx_cache_forward.argtypes = [i32, i64, vp, vp, i32, vp, vp, vp]
+    L.ttx_cache_backward_sgd.argtypes = [i64, i32, vp, vp, vp, f32, vp, vp]
+    L.ttx_cache_backward_dense.argtypes = [i64, i32, vp, vp, vp, i64, vp, vp]
+    L.ttx_cache_backward_rowwise_adagrad_approx.argtypes = [i64, i32, vp, vp, vp, f32, f32, vp, vp, vp]
+    L.ttx_profile_enable.argtypes = [C.c_int]
+    L.ttx_profile_read.argtypes = [C.c_int, C.POINTER(i64), C.POINTER(C.c_double)]
+    L.ttx_set_chunk.argtypes = [i32]
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError("tt_embeddings (libttx): " + lib().ttx_last_error().decode())
+
+
+_geom_cache = {}
+
+
+def _geom(num_tables: int, p: Sequence[int], q: Sequence[int], ranks: Sequence[int]) -> _Geom:
+    key = (int(num_tables), tuple(int(x) for x in p), tuple(int(x) for x in q), tuple(int(x) for x in ranks))
+    g = _geom_cache.get(key)
+    if g is None:
+        T = len(key[1])
+        if not (2 <= T <= MAX_CORES) or len(key[2]) != T or len(key[3]) != T + 1:
+            raise RuntimeError(
+                f"tt_embeddings: need 2..4 cores with len(q) == len(p) and len(ranks) == len(p)+1, got "
+                f"p={list(key[1])} q={list(key[2])} ranks={list(key[3])}")
+        g = _Geom()
+        g.T, g.num_tables = T, key[0]
+        for t in range(T):
+            g.p[t], g.q[t] = key[1][t], key[2][t]
+        for t in range(T + 1):
+            g.r[t] = key[3][t]
+        _geom_cache[key] = g
+    return g
+
+
+def _dev(t: torch.Tensor) -> torch.device:
+    if not t.is_cuda:
+        raise RuntimeError("tt_embeddings: tensors must live on a GPU (no CPU path in this build)")
+    return t.device
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _guard:
+    """OptionalCUDAGuard of the reference entry points (e.g. cu:436-437)."""
+
+    __slots__ = ("dev", "prev")
+
+    def __init__(self, dev):
+        self.dev = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.dev:
+            self.prev = cur
+            torch.cuda.set_device(self.dev)
+
+    def __exit__(self, *a):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+_ws_cache = {}
+
+
+def _workspace(dev: torch.device, stream: int, nbytes: int) -> torch.Tensor:
+    """Grow-only scratch per (device, stream): stream order makes reuse safe."""
+    key = (dev.index, stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _ptr_array(tensors: Sequence[torch.Tensor]):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _i64(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.int64:
+        raise RuntimeError(f"tt_embeddings: {name} must be int64, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"tt_embeddings: {name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _cores(tt_cores: Sequence[torch.Tensor], g: _Geom, name="tt_cores"):
+    if len(tt_cores) != g.T:
+        raise RuntimeError(f"tt_embeddings: expected {g.T} {name}, got {len(tt_cores)}")
+    out = []
+    for t, c in enumerate(tt_cores):
+        c = c.detach() if c.requires_grad else c
+        want = (g.num_tables, g.p[t], g.r[t] * g.q[t] * g.r[t + 1])
+        if tuple(c.shape) != want or c.dtype != torch.float32 or not c.is_contiguous() or not c.is_cuda:
+            raise RuntimeError(f"tt_embeddings: {name}[{t}] must be a contiguous float32 GPU tensor of shape {want}, "
+                               f"got {tuple(c.shape)} {c.dtype} on {c.device}")
+        out.append(c)
+    return out
+
+
+class Plan:
+    """Device-resident lookup plan shared by forward and backward of one batch."""
+
+    __slots__ = ("buf", "nnz", "key")
+
+    def __init__(self, buf, nnz, key):
+        self.buf, self.nnz, self.key = buf, nnz, key
+
+
+def make_plan(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, tableidx) -> Optional[Plan]:
+    if nnz == 0:
+        return None
+    g = _geom(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks)
+    dev = _dev(indices)
+    indices, tableidx = _i64(indices, "indices"), _i64(tableidx, "tableidx")
+    L = lib()
+    nb = L.ttx_plan_bytes(C.byref(g), nnz)
+    buf = torch.empty(nb, dtype=torch.uint8, device=dev)
+    with _guard(dev):
+        _check(L.ttx_plan_build(C.byref(g), nnz, indices.data_ptr(), tableidx.data_ptr(), buf.data_ptr(), nb, _stream(dev)))
+    return Plan(buf, nnz, (num_tables, tuple(tt_p_shapes), tuple(tt_q_shapes), tuple(tt_ranks)))
+
+
+def _plan_ptr(plan: Optional[Plan], nnz: int):
+    if plan is None:
+        return None
+    if plan.nnz != nnz:
+        raise RuntimeError("tt_embeddings: plan was built for a different nnz")
+    return plan.buf.data_ptr()
+
+
+# --------------------------------------------------------------------------- #
+# the eleven reference entry points (tt_embeddings.cpp:131-161)
+# --------------------------------------------------------------------------- #
+
+def tt_forward(batch_count: int, num_tables: int, B: int, D: int, tt_p_shapes: List[int], tt_q_shapes: List[int],
+               tt_ranks: List[int], L: torch.Tensor, nnz: int, indices: torch.Tensor, rowidx: torch.Tensor,
+               tableidx: torch.Tensor, tt_cores: List[torch.Tensor], plan: Optional[Plan] = None) -> torch.Tensor:
+    """tt_embeddings.cpp:13-26.  `batch_count` (the reference's GEMM chunk size)
+    is accepted and ignored: the HIP path has no chunk loop.  `L` is validated
+    for length only; strides are derived from tt_p_shapes."""
+    g = _geom(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks)
+    dev = _dev(tt_cores[0])
+    cores = _cores(tt_cores, g)
+    out = torch.empty((num_tables, B, D), dtype=torch.float32, device=dev)
+    if nnz > 0 and batch_count <= 0:
+        raise RuntimeError("tt_embeddings: batch_count must be > 0")  # cu:987
+    if L.numel() != g.T:
+        raise RuntimeError("tt_embeddings: L must have one stride per core")
+    indices, rowidx, tableidx = _i64(indices, "indices"), _i64(rowidx, "rowidx"), _i64(tableidx, "tableidx")
+    if nnz > indices.numel() or nnz > rowidx.numel() or nnz > tableidx.numel():
+        raise RuntimeError("tt_embeddings: nnz exceeds the index tensors")
+    lb = lib()
+    st = _stream(dev)
+    nb = lb.ttx_tt_forward_workspace_bytes(C.byref(g), B, D, nnz)
+    ws = _workspace(dev, st, nb)
+    with _guard(dev):
+        _check(lb.ttx_tt_forward(C.byref(g), B, D, nnz, indices.data_ptr(), rowidx.data_ptr(), tableidx.data_ptr(),
+                                 _ptr_array(cores), out.data_ptr(), _plan_ptr(plan, nnz), ws.data_ptr(), ws.numel(), st))
+    return out
+
+
+def _backward(optim, D, lr, eps, p, q, ranks, nnz, indices, rowidx, tableidx, d_output, tt_cores, state, plan):
+    num_tables = tt_cores[0].size(0)
+    g = _geom(num_tables, p, q, ranks)
+    dev = _dev(d_output)
+    cores = _cores(tt_cores, g)
+    d_output = _f32(d_output, "d_output")
+    if d_output.dim() != 3 or d_output.size(0) != num_tables or d_output.size(2) != D:
+        raise RuntimeError(f"tt_embeddings: d_output must be [num_tables, B, D], got {tuple(d_output.shape)}")
+    B = d_output.size(1)
+    indices, rowidx, tableidx = _i64(indices, "indices"), _i64(rowidx, "rowidx"), _i64(tableidx, "tableidx")
+    grads = None
+    gptr = sptr = None
+    if optim == OPTIM_DENSE:
+        grads = [torch.empty_like(c) for c in cores]
+        gptr = _ptr_array(grads)
+    if optim == OPTIM_ADAGRAD:
+        sptr = _ptr_array(_cores(state, g, "optimizer_state"))
+    lb = lib()
+    st = _stream(dev)
+    nb = lb.ttx_tt_backward_workspace_bytes(C.byref(g), B, D, nnz)
+    ws = _workspace(dev, st, nb)
+    with _guard(dev):
+        _check(lb.ttx_tt_backward(C.byref(g), optim, B, D, lr, eps, nnz, indices.data_ptr(), rowidx.data_ptr(),
+                                  tableidx.data_ptr(), d_output.data_ptr(), _ptr_array(cores), sptr, gptr,
+                                  _plan_ptr(plan, nnz), ws.data_ptr(), ws.numel(), st))
+    return grads
+
+
+def tt_dense_backward(batch_count, D, tt_p_shapes, tt_q_shapes, tt_ranks, L, nnz, indices, rowidx, tableidx, d_output,
+                      tt_cores, plan: Optional[Plan] = None) -> List[torch.Tensor]:
+    """tt_embeddings.cpp:28-40: returns the list of dense core gradients."""
+    return _backward(OPTIM_DENSE, D, 0.0, 0.0, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, rowidx, tableidx,
+                     d_output, tt_cores, None, plan)
+
+
+def tt_sgd_backward(batch_count, D, learning_rate, tt_p_shapes, tt_q_shapes, tt_ranks, L, nnz, indices, rowidx,
+                    tableidx, d_output, tt_cores, plan: Optional[Plan] = None) -> None:
+    """tt_embeddings.cpp:42-55: fused gradient + SGD, cores updated in place."""
+    _backward(OPTIM_SGD, D, learning_rate, 0.0, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, rowidx, tableidx,
+              d_output, tt_cores, None, plan)
+
+
+def tt_adagrad_backward(batch_count, D, learning_rate, eps, tt_p_shapes, tt_q_shapes, tt_ranks, L, nnz, indices,
+                        rowidx, tableidx, d_output, optimizer_state, tt_cores, plan: Optional[Plan] = None) -> None:
+    """tt_embeddings.cpp:57-72: fused gradient + Adagrad, cores and state in place."""
+    _backward(OPTIM_ADAGRAD, D, learning_rate, eps, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, rowidx,
+              tableidx, d_output, tt_cores, list(optimizer_state), plan)
+
+
+def update_cache_state(indices: torch.Tensor, hashtbl: torch.Tensor, cache_freq: torch.Tensor) -> None:
+    """tt_embeddings.cpp:74."""
+    nnz = indices.numel()
+    if nnz == 0:
+        return
+    dev = _dev(indices)
+    if hashtbl.numel() <= 0 or hashtbl.numel() != cache_freq.numel():  # cu:1099-1100
+        raise RuntimeError("tt_embeddings: hashtbl must be non-empty and match cache_freq")
+    indices = _i64(indices, "indices")
+    _i64(hashtbl, "hashtbl"), _i64(cache_freq, "cache_freq")
+    with _guard(dev):
+        _check(lib().ttx_update_cache_state(nnz, indices.data_ptr(), hashtbl.numel(), hashtbl.data_ptr(),
+                                            cache_freq.data_ptr(), _stream(dev)))
+
+
+def cache_populate(num_embeddings: int, tt_p_shapes, tt_q_shapes, tt_ranks, tt_cores, L, hashtbl, cache_freq,
+                   cache_state, cache_weight) -> None:
+    """tt_embeddings.cpp:76-86."""
+    g = _geom(tt_cores[0].size(0), tt_p_shapes, tt_q_shapes, tt_ranks)
+    dev = _dev(cache_weight)
+    cores = _cores(list(tt_cores), g)
+    H = hashtbl.numel()
+    if H <= 0 or H != cache_freq.numel() or H < cache_weight.size(0):  # cu:1271-1274
+        raise RuntimeError("tt_embeddings: need 0 < hashtbl.numel() == cache_freq.numel() >= cache_size")
+    if cache_state.dtype != torch.int32 or cache_state.numel() != H:
+        raise RuntimeError("tt_embeddings: cache_state must be int32[hashtbl_size]")
+    cw = cache_weight.detach()
+    if cw.dtype != torch.float32 or not cw.is_contiguous():
+        raise RuntimeError("tt_embeddings: cache_weight must be contiguous float32")
+    cs, D = cw.size(0), cw.size(1)
+    lb = lib()
+    st = _stream(dev)
+    nb = lb.ttx_cache_populate_workspace_bytes(C.byref(g), H, cs, D)
+    ws = _workspace(dev, st, nb)
+    with _guard(dev):
+        _check(lb.ttx_cache_populate(C.byref(g), _ptr_array(cores), H, hashtbl.data_ptr(), cache_freq.data_ptr(),
+                                     cache_state.data_ptr(), cs, D, cw.data_ptr(), ws.data_ptr(), ws.numel(), st))
+
+
+def preprocess_indices_sync(colidx: torch.Tensor, offsets: torch.Tensor, num_tables: int, warmup: bool,
+                            hashtbl: torch.Tensor, cache_state: torch.Tensor
+                            ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int, Optional[torch.Tensor]]:
+    """tt_embeddings.cpp:88-95.  Host-synchronous iff not warmup and num_tables == 1."""
+    dev = _dev(colidx)
+    colidx, offsets = _i64(colidx, "colidx"), _i64(offsets, "offsets")
+    nnz = colidx.numel()
+    rowidx = torch.empty_like(colidx)
+    tableidx = torch.empty_like(colidx)
+    if nnz == 0:
+        return colidx, rowidx, tableidx, 0, None
+    live = (not warmup) and num_tables == 1
+    pcol = prow = ploc = None
+    lb = lib()
+    st = _stream(dev)
+    wsp, wsn = None, 0
+    if live:
+        pcol, prow = torch.empty_like(colidx), torch.empty_like(colidx)
+        ploc = torch.empty(nnz, dtype=torch.int32, device=dev)
+        ws = _workspace(dev, st, lb.ttx_preprocess_workspace_bytes(nnz))
+        wsp, wsn = ws.data_ptr(), ws.numel()
+    num_tt, part = C.c_int32(0), C.c_int32(0)
+    with _guard(dev):
+        _check(lb.ttx_preprocess_indices_sync(
+            nnz, colidx.data_ptr(), offsets.numel() - 1, offsets.data_ptr(), num_tables, int(bool(warmup)),
+            hashtbl.numel(), hashtbl.data_ptr() if live else None, cache_state.data_ptr() if live else None,
+            rowidx.data_ptr(), tableidx.data_ptr(), pcol.data_ptr() if live else None,
+            prow.data_ptr() if live else None, ploc.data_ptr() if live else None,
+            C.byref(num_tt), C.byref(part), wsp, wsn, st))
+    if part.value:
+        return pcol, prow, tableidx, int(num_tt.value), ploc
+    return colidx, rowidx, tableidx, nnz, None
+
+
+def cache_forward(B: int, nnz: int, cache_locations: torch.Tensor, rowidx: torch.Tensor, cache_weight: torch.Tensor,
+                  output: torch.Tensor) -> None:
+    """tt_embeddings.cpp:97-103: output[rowidx[n], :] += cache_weight[cache_locations[n], :]."""
+    dev = _dev(output)
+    if B <= 0:
+        raise RuntimeError("tt_embeddings: B must be > 0")  # cu:1549
+    if nnz == 0:
+        return
+    cw = cache_weight.detach()
+    with _guard(dev):
+        _check(lib().ttx_cache_forward(B, nnz, cache_locations.data_ptr(), _i64(rowidx, "rowidx").data_ptr(), cw.size(1),
+                                       cw.data_ptr(), output.data_ptr(), _stream(dev)))
+
+
+def cache_backward_sgd(nnz: int, grad_output: torch.Tensor, cache_locations: torch.Tensor, rowidx: torch.Tensor,
+                       learning_rate: float, cache_weight: torch.Tensor) -> None:
+    """tt_embeddings.cpp:105-111."""
+    if nnz == 0:
+        return
+    dev = _dev(cache_weight)
+    cw = cache_weight.detach()
+    go = _f32(grad_output, "grad_output")
+    with _guard(dev):
+        _check(lib().ttx_cache_backward_sgd(nnz, cw.size(1), go.data_ptr(), cache_locations.data_ptr(),
+                                            _i64(rowidx, "rowidx").data_ptr(), learning_rate, cw.data_ptr(), _stream(dev)))
+
+
+def cache_backward_dense(nnz: int, grad_output: torch.Tensor, cache_locations: torch.Tensor, rowidx: torch.Tensor,
+                         learning_rate: float, cache_weight: torch.Tensor) -> torch.Tensor:
+    """tt_embeddings.cpp:113-119 (learning_rate unused, as in the reference)."""
+    dev = _dev(cache_weight)
+    cw = cache_weight.detach()
+    out = torch.empty_like(cw)
+    go = _f32(grad_output, "grad_output")
+    with _guard(dev):
+        _check(lib().ttx_cache_backward_dense(nnz, cw.size(1), go.data_ptr(),
+                                              cache_locations.data_ptr() if nnz else None,
+                                              _i64(rowidx, "rowidx").data_ptr() if nnz else None, cw.size(0),
+                                              out.data_ptr(), _stream(dev)))
+    return out
+
+
+def cache_backward_rowwise_adagrad_approx(nnz: int, grad_output: torch.Tensor, cache_locations: torch.Tensor,
+                                          rowidx: torch.Tensor, learning_rate: float, eps: float,
+                                          cache_optimizer_state: torch.Tensor, cache_weight: torch.Tensor) -> None:
+    """tt_embeddings.cpp:121-129."""
+    if nnz == 0:
+        return
+    dev = _dev(cache_weight)
+    cw = cache_weight.detach()
+    go = _f32(grad_output, "grad_output")
+    _dev(cache_optimizer_state)
+    with _guard(dev):
+        _check(lib().ttx_cache_backward_rowwise_adagrad_approx(
+            nnz, cw.size(1), go.data_ptr(), cache_locations.data_ptr(), _i64(rowidx, "rowidx").data_ptr(),
+            learning_rate, eps, cache_optimizer_state.data_ptr(), cw.data_ptr(), _stream(dev)))
+
+
+# --------------------------------------------------------------------------- #
+# extras
+# --------------------------------------------------------------------------- #
+
+def tt_rows(num_tables, D, tt_p_shapes, tt_q_shapes, tt_ranks, indices, tableidx, tt_cores) -> torch.Tensor:
+    """Decompress rows: rows[n, :] = TT row of indices[n] (contraction only)."""
+    g = _geom(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks)
+    dev = _dev(tt_cores[0])
+    cores = _cores(tt_cores, g)
+    indices = _i64(indices, "indices")
+    nnz = indices.numel()
+    rows = torch.empty((nnz, D), dtype=torch.float32, device=dev)
+    lb = lib()
+    st = _stream(dev)
+    ws = _workspace(dev, st, lb.ttx_plan_bytes(C.byref(g), nnz) + 256)
+    with _guard(dev):
+        _check(lb.ttx_tt_rows(C.byref(g), D, nnz, indices.data_ptr(),
+                              None if tableidx is None else _i64(tableidx, "tableidx").data_ptr(), _ptr_array(cores),
+                              rows.data_ptr(), ws.data_ptr(), ws.numel(), st))
+    return rows
+
+
+def profile_enable(on: bool) -> None:
+    _check(lib().ttx_profile_enable(int(on)))
+
+
+def profile_reset() -> None:
+    _check(lib().ttx_profile_reset())
+
+
+def profile_read(which: int) -> Tuple[int, float]:
+    n, ms = C.c_int64(0), C.c_double(0.0)
+    _check(lib().ttx_profile_read(which, C.byref(n), C.byref(ms)))
+    return int(n.value), float(ms.value)
+
+
+def set_chunk(mc: int) -> None:
+    _check(lib().ttx_set_chunk(mc))

@@ -1,0 +1,39 @@
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+PKG = os.path.join(ROOT, "fbtt-embedding_amd")
+for p in (HERE, PKG, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def small_cases():
+    import numpy as np
+
+    z = np.load(os.path.join(HERE, "golden", "small_cases.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    cases = {}
+    for name in names:
+        meta = z[f"{name}/meta"]
+        tables, T = int(meta[0]), int(meta[1])
+        c = dict(
+            tables=tables, T=T,
+            p=meta[2:2 + T].tolist(), q=meta[2 + T:2 + 2 * T].tolist(), r=meta[2 + 2 * T:].tolist(),
+            indices=z[f"{name}/indices"], offsets=z[f"{name}/offsets"], d_out=z[f"{name}/d_out"], out=z[f"{name}/out"],
+            cores=[z[f"{name}/core{t}"] for t in range(T)], grads=[z[f"{name}/grad{t}"] for t in range(T)],
+        )
+        if len(c["r"]) == T - 1:  # stored unpadded -> [1, r1, .., 1]
+            c["r"] = [1] + c["r"] + [1]
+        c["B"] = (c["offsets"].size - 1) // tables
+        c["D"] = int(np.prod(c["q"]))
+        cases[name] = c
+    return cases
