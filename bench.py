@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- fwd+bwd throughput of the TT-EmbeddingBag hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one forward + backward (fused SGD) of the module over one batch of
+synthetic lookups already resident in HBM, i.e. what the reference's own
+benchmark times (tt_embeddings_benchmark.py:183-187).
+
+N = 1 : BASELINE.json configs[1], the repo benchmark config (E=11M, D=64,
+        p=[200,220,250], q=[4,4,4], ranks=[32,32], B=512, L=20 -> nnz=10240,
+        sparse SGD, use_cache=True but never populated -- exactly what the
+        reference benchmark instantiates, :166-175 -- so every step also runs
+        the hash-table frequency update).
+N > 1 : N such tables, one per rank (table-sharded, ttx_sharded.py), the 512-bag
+        batch split across ranks, RCCL all-to-all of indices in / pooled vectors
+        out.  Per-GPU lookups stay 10240 per step ("weak").
+
+value = true algorithmic GFLOP/s = 3 * 2*(q0 r1 q1 r2 + q0 q1 r2 q2) * nnz / time
+(the reference's formula, :154-158/:190, WITHOUT its x iters slip; the README's
+2657.6 "GFLOPS" is 265.8 on this scale -- BASELINE.md).  Printed as ONE JSON line
+by rank 0, with the roofline of the dominant kernel (backward contraction,
+timed live with HIP events on its stream) and a CPU baseline (the oracle, a
+scalar port, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "fbtt-embedding_amd"), os.path.join(ROOT, "tests"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+P_SHAPES, Q_SHAPES, RANKS = [200, 220, 250], [4, 4, 4], [32, 32]
+B_GLOBAL, POOL = 512, 20
+PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 MFMA/VALU dense peak (MI355X_MICROARCH.md)
+
+
+def flop_per_nnz_fwd(q, r):
+    return 2.0 * (q[0] * r[0] * q[1] * r[1] + q[0] * q[1] * r[1] * q[2])
+
+
+def cpu_baseline(requests, cores, d_out, budget_s=12.0):
+    """the oracle (scalar C port, 1 thread) on the same requests: fwd + fused-SGD bwd"""
+    import oracle_lib as O
+
+    g = O.make_geom(1, P_SHAPES, Q_SHAPES, RANKS)
+    D = int(np.prod(Q_SHAPES))
+    cores = [c.copy() for c in cores]
+    done, t0 = 0, time.perf_counter()
+    nnz = 0
+    while True:
+        idx, off = requests[done % len(requests)]
+        rowidx, tableidx = O.rowidx_from_offsets(off, 1)
+        O.tt_forward(g, B_GLOBAL, D, idx, rowidx, tableidx, cores)
+        O.tt_backward(g, O.OPTIM_SGD, B_GLOBAL, D, 0.1, 0.0, idx, rowidx, tableidx, d_out, cores)
+        done += 1
+        nnz += idx.size
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 64:
+            break
+    gflops = 3.0 * flop_per_nnz_fwd(Q_SHAPES, RANKS) * nnz / el / 1e9
+    return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": f"{done} fwd+bwd(SGD) steps of the same cfg2 requests ({nnz} lookups) in {el:.1f} s, "
+                      f"oracle/ttx_oracle.c single thread; {el / nnz * 1e6:.2f} us/nnz"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cache", action="store_true", help="use_cache=False (skip the hash-table frequency update)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adagrad"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import gen_inputs as G
+    import tt_embeddings as E
+    import tt_embeddings_ops as ops
+    import ttx_sharded
+
+    E_, D = int(np.prod(P_SHAPES)), int(np.prod(Q_SHAPES))
+    opt = ops.OptimType.SGD if args.optimizer == "sgd" else ops.OptimType.EXACT_ADAGRAD
+    iters = 10  # request batches, like the reference's --iters
+    B_local = B_GLOBAL // world
+    assert B_local * world == B_GLOBAL
+    torch.manual_seed(1234 + rank)
+    if world == 1:
+        mod = ops.TTEmbeddingBag(E_, D, RANKS, P_SHAPES, Q_SHAPES, sparse=True, optimizer=opt, learning_rate=0.1,
+                                 use_cache=not args.no_cache, weight_dist="uniform", device=dev)
+        cores_np = G.make_cores(1234, 1, P_SHAPES, Q_SHAPES, RANKS, "uniform")
+        with torch.no_grad():
+            for dst, src in zip(mod.tt_cores, cores_np):
+                dst.copy_(torch.from_numpy(src))
+        reqs_np = G.make_requests(1235, iters, B_GLOBAL, 1, POOL, E_)
+        reqs = [(torch.from_numpy(i).to(dev), torch.from_numpy(o).to(dev)) for i, o in reqs_np]
+        d_out_np = G.make_grad(1236, 1, B_GLOBAL, D)
+        grad = torch.from_numpy(d_out_np[0]).to(dev)
+        step = lambda i, o: mod(i, o).backward(grad)  # noqa: E731
+        nnz_step_total = B_GLOBAL * POOL
+    else:
+        mod = ttx_sharded.ShardedTableBatchedTTEmbeddingBag(
+            world, E_, D, RANKS, tt_p_shapes=P_SHAPES, tt_q_shapes=Q_SHAPES, sparse=True, optimizer=opt,
+            learning_rate=0.1, use_cache=False, weight_dist="uniform", device=dev)
+        reqs_np = G.make_requests(1235 + rank, iters, B_local, world, POOL, E_)
+        reqs = [(torch.from_numpy(i).to(dev), torch.from_numpy(o).to(dev)) for i, o in reqs_np]
+        grad = torch.from_numpy(G.make_grad(1236 + rank, world, B_local, D)).to(dev)
+        step = lambda i, o: mod(i, o, fixed_pooling=POOL).backward(grad)  # noqa: E731
+        nnz_step_total = world * B_GLOBAL * POOL  # every table sees the whole 512-bag batch
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(*reqs[k % iters])
+    sync()
+    E.profile_reset()
+    E.profile_enable(1 << E.PROF_BWD)  # live HIP-event timing of the dominant kernel only
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(*reqs[k % iters])
+    sync()
+    t1 = time.perf_counter()
+    E.profile_enable(0)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    n_bwd, ms_bwd = E.profile_read(E.PROF_BWD)
+
+    # second, untimed pass: per-kernel breakdown (all kernel slots bracketed)
+    E.profile_reset()
+    E.profile_enable(0x3F)
+    for k in range(min(args.steps, 50)):
+        step(*reqs[k % iters])
+    sync()
+    E.profile_enable(0)
+    names = ["fwd_contract", "bwd_contract", "reduce_apply", "plan", "bag_pool", "cache_gather"]
+    breakdown = {}
+    for w, nm in enumerate(names):
+        n, ms = E.profile_read(w)
+        if n:
+            breakdown[nm + "_us"] = round(ms / n * 1e3, 2)
+
+    if rank == 0:
+        fl_fwd = flop_per_nnz_fwd(Q_SHAPES, RANKS)
+        ms_per_step = elapsed / args.steps * 1e3
+        gflops = 3.0 * fl_fwd * nnz_step_total / (elapsed / args.steps) / 1e9
+        per_rank_nnz = nnz_step_total // world
+        # dominant kernel = backward contraction: 2/3 of the algorithmic fwd+bwd FLOP
+        bwd_flop_per_launch = 2.0 * fl_fwd * per_rank_nnz
+        bwd_us = ms_bwd / max(n_bwd, 1) * 1e3
+        achieved = bwd_flop_per_launch / (bwd_us * 1e-6) / 1e12 if n_bwd else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_bwd_bytes.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "fwd+bwd GFLOPS (true algorithmic: 3 x fwd FLOP / time), TT-EmbeddingBag E=11M D=64 ranks=[32,32] nnz=10240",
+            "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("cfg2: TTEmbeddingBag E=11000000 D=64 p=[200,220,250] q=[4,4,4] ranks=[32,32] B=512 L=20 "
+                                    f"nnz=10240 sparse {args.optimizer.upper()}, use_cache={'False' if (args.no_cache or world > 1) else 'True(unpopulated)'}"
+                                    + ("" if world == 1 else f"; {world} such tables, one per rank, table-sharded, RCCL all-to-all; B_local={B_local}")),
+                       "nnz_per_step_total": nnz_step_total, "flop_per_nnz_fwd_bwd": 3.0 * fl_fwd,
+                       "path": "Python module -> ctypes -> C ABI -> HIP"},
+            "us_per_nnz": round(elapsed / args.steps / nnz_step_total * 1e6, 5),
+            "ref_formula_gflops_x_iters": round(gflops * 10, 1),
+            "reference_readme_true_gflops": 265.8,
+            "kernel_us": breakdown,
+            "roofline": {"bound": "mfma", "kernel": "bwd_kernel (backward contraction)", "achieved": round(achieved, 3),
+                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 5),
+                         "traffic": traffic, "launches": n_bwd, "avg_us": round(bwd_us, 2),
+                         "flop_per_launch": bwd_flop_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(reqs_np, cores_np, d_out_np)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,7 +58,7 @@ int make_dims(const ttx_geom* g, Dims* d) {
 
 // ------------------------------------------------------------ profiling ----
 struct ProfState {
-  bool on = false;
+  unsigned mask = 0;  // bit w: time kernel slot w
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[TTX_PROF_NUM];
   std::vector<hipEvent_t> pool;
   hipEvent_t open[TTX_PROF_NUM] = {};
@@ -79,7 +79,7 @@ static hipEvent_t get_event() {
 }
 
 void prof_begin(int which, hipStream_t s) {
-  if (!g_prof.on) return;
+  if (!(g_prof.mask >> which & 1u)) return;
   hipEvent_t e = get_event();
   if (!e) return;
   (void)hipEventRecord(e, s);
@@ -87,7 +87,7 @@ void prof_begin(int which, hipStream_t s) {
 }
 
 void prof_end(int which, hipStream_t s) {
-  if (!g_prof.on || !g_prof.open[which]) return;
+  if (!g_prof.open[which]) return;
   hipEvent_t e = get_event();
   if (!e) return;
   (void)hipEventRecord(e, s);
@@ -118,9 +118,9 @@ extern "C" {
 const char* ttx_last_error(void) { return ttx::g_err; }
 int ttx_version(void) { return 100; }
 
-int ttx_profile_enable(int on) {
+int ttx_profile_enable(int mask) {
   ttx::prof_drain();
-  ttx::g_prof.on = on != 0;
+  ttx::g_prof.mask = (unsigned)mask;
   return TTX_OK;
 }
 

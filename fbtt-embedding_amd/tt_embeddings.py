@@ -456,8 +456,9 @@ def tt_rows(num_tables, D, tt_p_shapes, tt_q_shapes, tt_ranks, indices, tableidx
     return rows
 
 
-def profile_enable(on: bool) -> None:
-    _check(lib().ttx_profile_enable(int(on)))
+def profile_enable(mask: int) -> None:
+    """bit w of `mask` turns on live HIP-event timing of kernel slot w (PROF_*); 0 = off."""
+    _check(lib().ttx_profile_enable(int(mask)))
 
 
 def profile_reset() -> None:

@@ -1,0 +1,460 @@
+"""`tt_embeddings_ops` -- the TTEmbeddingBag module surface on top of libttx.
+
+Same public names, constructor keywords, forward() call form, autograd contract
+and state_dict keys as the reference's tt_embeddings_ops.py, so a model that
+uses `TTEmbeddingBag` / `TableBatchedTTEmbeddingBag` in place of
+`nn.EmbeddingBag(mode="sum", include_last_offset=True)` switches by import
+path only.  All compute goes through the module `tt_embeddings` of this package
+(ctypes -> C ABI -> hand-written HIP for gfx950); nothing here computes on the
+CPU.
+
+Reference map (file:line in /root/reference/tt_embeddings_ops.py):
+  OptimType :18-33 | BufferList :36-77 | tt_matrix_to_full :80-127 |
+  TTLookupFunction :130-356 | suggested_tt_shapes :359-418 |
+  TableBatchedTTEmbeddingBag :421-886 | TTEmbeddingBag :889-934
+
+Deliberate differences (each is a superset or a fix):
+  * optional trailing ctor keyword `device` (default: current GPU);
+  * D % 4 != 0 is supported; the README's toy example (E=10, D=3) runs;
+  * `cache_optimizer_state` lives on the module's device (the reference leaves
+    it on the CPU, :582-585); `reset_cache()` works (:795 has a typo);
+    `get_params()` does not grow the ParameterList on every call (:882-886);
+  * fused optimizers update every looked-up slice (the reference's apply-kernel
+    grid skips rows).
+"""
+import itertools
+import logging
+import math
+import random
+from enum import Enum, unique
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+import tt_embeddings as _engine  # the 11-function native-module surface
+
+
+@unique
+class OptimType(Enum):
+    SGD = "sgd"
+    EXACT_SGD = "exact_sgd"
+    LAMB = "lamb"
+    ADAM = "adam"
+    EXACT_ADAGRAD = "exact_adagrad"
+    EXACT_ROWWISE_ADAGRAD = "exact_row_wise_adagrad"
+    LARS_SGD = "lars_sgd"
+    PARTIAL_ROWWISE_ADAM = "partial_row_wise_adam"
+    PARTIAL_ROWWISE_LAMB = "partial_row_wise_lamb"
+
+    def __str__(self) -> str:
+        return self.value
+
+
+_SGD_LIKE = (OptimType.SGD, OptimType.EXACT_SGD)  # everything else -> Adagrad kernel (:221,:248)
+
+
+class BufferList(nn.Module):
+    """An indexable list of registered buffers named `<name><i>` (state_dict
+    keys `optimizer_state.optimizer_state0`, ...)."""
+
+    def __init__(self, name: str, buffers: Optional[Sequence[torch.Tensor]] = None) -> None:
+        super().__init__()
+        self._name = name
+        self._count = 0
+        for b in buffers or ():
+            self.append(b)
+
+    def append(self, buffer: torch.Tensor) -> "BufferList":
+        self.register_buffer(f"{self._name}{self._count}", buffer)
+        self._count += 1
+        return self
+
+    def extend(self, buffers: Sequence[torch.Tensor]) -> "BufferList":
+        for b in buffers:
+            self.append(b)
+        return self
+
+    def __len__(self) -> int:
+        return self._count
+
+    def __getitem__(self, index: int) -> torch.Tensor:
+        if not -self._count <= index < self._count:
+            raise IndexError(index)
+        return getattr(self, f"{self._name}{index % self._count}")
+
+    def __iter__(self) -> Iterator[torch.Tensor]:
+        return (self[i] for i in range(self._count))
+
+
+def tt_matrix_to_full(tt_p_shapes: List[int], tt_q_shapes: List[int], tt_ranks: List[int],
+                      tt_cores: Sequence[torch.Tensor], tt_permute: Optional[List[int]] = None) -> torch.Tensor:
+    """Expand TT cores to the dense [prod(p), prod(q)] matrix (test oracle /
+    `full_weight`).  With tt_permute=[1,0,2,3] the cores are in the module's
+    storage layout [1, p, r*q*r']; otherwise they are [r, p, q, r'] tensors."""
+    T = len(tt_p_shapes)
+    ranks = list(tt_ranks)
+    if len(ranks) == T - 1:
+        ranks = [1] + ranks + [1]
+    mats = []
+    for t, core in enumerate(tt_cores):
+        shape = [ranks[t], tt_p_shapes[t], tt_q_shapes[t], ranks[t + 1]]
+        if tt_permute is not None:
+            stored = [shape[a] for a in tt_permute]
+            core = core.reshape(stored).permute(*tt_permute)
+        else:
+            core = torch.squeeze(core)
+        if list(core.shape) != shape:
+            raise ValueError(f"core {t}: expected {shape}, got {list(core.shape)}")
+        mats.append(core.contiguous())
+    acc = mats[0]
+    for t in range(1, T):
+        acc = acc.reshape(-1, ranks[t]) @ mats[t].reshape(ranks[t], -1)
+    inter = [d for pq in zip(tt_p_shapes, tt_q_shapes) for d in pq]
+    acc = acc.reshape(inter)
+    order = list(range(0, 2 * T, 2)) + list(range(1, 2 * T, 2))
+    n_rows = int(np.prod(np.asarray(tt_p_shapes, dtype=np.int64)))
+    n_cols = int(np.prod(np.asarray(tt_q_shapes, dtype=np.int64)))
+    return acc.permute(order).contiguous().reshape(n_rows, n_cols).float()
+
+
+class TTLookupFunction(torch.autograd.Function):
+    """Autograd node of one (table-batched) TT lookup.  Argument order and the
+    gradient tuple (19 x None, `d_cache_weight` in slot 17 for dense mode, then
+    one entry per core) follow the reference (:133-155, :280-356)."""
+
+    @staticmethod
+    def forward(ctx, B: int, D: int, tt_p_shapes: List[int], tt_q_shapes: List[int], tt_ranks: List[int],
+                L: torch.Tensor, nnz_tt: int, nnz_cached: int, indices: torch.Tensor, rowidx: torch.Tensor,
+                tableidx: torch.Tensor, optimizer: OptimType, learning_rate: float, eps: float, sparse: bool,
+                cache_locations: Optional[torch.Tensor], cache_optimizer_state: Optional[torch.Tensor],
+                cache_weight: Optional[torch.Tensor], optimizer_state: List[torch.Tensor],
+                *tt_cores: torch.Tensor) -> torch.Tensor:
+        ctx.geometry = (tt_p_shapes, tt_q_shapes, tt_ranks)
+        ctx.D = D
+        ctx.optimizer, ctx.learning_rate, ctx.eps, ctx.sparse = optimizer, learning_rate, eps, sparse
+        ctx.tt_cores = tt_cores
+        ctx.optimizer_state = optimizer_state
+        ctx.nnz_tt, ctx.nnz_cached = nnz_tt, nnz_cached
+        ctx.has_cache = cache_weight is not None
+        ctx.save_for_backward(L, indices, rowidx, tableidx, cache_locations, cache_optimizer_state, cache_weight)
+        num_tables = tt_cores[0].size(0)
+        # one lookup plan serves forward and backward of this batch
+        mk = getattr(_engine, "make_plan", None)
+        ctx.plan = mk(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz_tt, indices, tableidx) if mk else None
+        extra = {"plan": ctx.plan} if ctx.plan is not None else {}
+        output = _engine.tt_forward(1000, num_tables, B, D, tt_p_shapes, tt_q_shapes, tt_ranks, L, nnz_tt, indices,
+                                    rowidx, tableidx, list(tt_cores), **extra)
+        if nnz_cached > 0:
+            _engine.cache_forward(B, nnz_cached, cache_locations[nnz_tt:], rowidx[nnz_tt:], cache_weight, output)
+        return output
+
+    @staticmethod
+    def backward(ctx, d_output: torch.Tensor):
+        L, indices, rowidx, tableidx, cache_locations, cache_optimizer_state, cache_weight = ctx.saved_tensors
+        p, q, ranks = ctx.geometry
+        n_tt, n_c = ctx.nnz_tt, ctx.nnz_cached
+        extra = {"plan": ctx.plan} if ctx.plan is not None else {}
+        cores = list(ctx.tt_cores)
+        d_output = d_output.contiguous()
+        head: List[Optional[torch.Tensor]] = [None] * 19
+        if ctx.sparse:
+            if ctx.optimizer in _SGD_LIKE:
+                _engine.tt_sgd_backward(1000, ctx.D, ctx.learning_rate, p, q, ranks, L, n_tt, indices, rowidx, tableidx,
+                                        d_output, cores, **extra)
+                if n_c > 0:
+                    _engine.cache_backward_sgd(n_c, d_output, cache_locations[n_tt:], rowidx[n_tt:],
+                                               ctx.learning_rate, cache_weight)
+            else:
+                _engine.tt_adagrad_backward(1000, ctx.D, ctx.learning_rate, ctx.eps, p, q, ranks, L, n_tt, indices,
+                                            rowidx, tableidx, d_output, ctx.optimizer_state, cores, **extra)
+                if n_c > 0:
+                    _engine.cache_backward_rowwise_adagrad_approx(n_c, d_output, cache_locations[n_tt:],
+                                                                  rowidx[n_tt:], ctx.learning_rate, ctx.eps,
+                                                                  cache_optimizer_state, cache_weight)
+            return tuple(head + [None] * len(cores))
+        grads = _engine.tt_dense_backward(1000, ctx.D, p, q, ranks, L, n_tt, indices, rowidx, tableidx, d_output,
+                                          cores, **extra)
+        if n_c > 0:
+            head[17] = _engine.cache_backward_dense(n_c, d_output, cache_locations[n_tt:], rowidx[n_tt:],
+                                                    ctx.learning_rate, cache_weight)
+        return tuple(head + list(grads))
+
+
+# --------------------------------------------------------------------------- #
+# shape factoring (init-time helper; reference :359-418)
+# --------------------------------------------------------------------------- #
+
+def _prime_factors(n: int) -> Dict[int, int]:
+    out: Dict[int, int] = {}
+    f = 2
+    while f * f <= n:
+        while n % f == 0:
+            out[f] = out.get(f, 0) + 1
+            n //= f
+        f += 1 if f == 2 else 2
+    if n > 1:
+        out[n] = out.get(n, 0) + 1
+    return out
+
+
+def _entropy(xs: Sequence[int]) -> float:
+    v = np.asarray(xs, dtype=np.float64)
+    pk = v / v.sum()
+    pk = pk[pk > 0]
+    return float(-(pk * np.log(pk)).sum())
+
+
+def _balanced_factors(n: int, d: int) -> List[int]:
+    """The factorisation of n into d factors with maximal entropy of the
+    normalised factors, listed small/large interleaved like the reference."""
+    primes = _prime_factors(n)
+    splits = []  # per prime: all ways to spread its exponent over d ordered bins
+    for prime, e in primes.items():
+        ways = []
+        for cuts in itertools.combinations(range(e + d - 1), d - 1):
+            prev, exps = -1, []
+            for c in cuts + (e + d - 1,):
+                exps.append(c - prev - 1)
+                prev = c
+            ways.append([prime ** k for k in exps])
+        splits.append(ways)
+    seen = set()
+    for combo in itertools.product(*splits) if splits else [()]:
+        bins = [1] * d
+        for way in combo:
+            bins = [b * w for b, w in zip(bins, way)]
+        seen.add(tuple(sorted(bins)))
+    best = max(sorted(seen), key=_entropy)
+    lo, hi = list(best[: d // 2]), list(best[d // 2:])
+    out: List[int] = []
+    for a, b in itertools.zip_longest(lo, hi):
+        if a is not None:
+            out.append(a)
+        if b is not None:
+            out.append(b)
+    return out
+
+
+def suggested_tt_shapes(n: int, d: int = 3, allow_round_up: bool = True) -> List[int]:
+    n = int(n)
+    if not allow_round_up:
+        return _balanced_factors(n, d)
+    candidates = []
+    for k in range(len(str(n))):
+        step = 10 ** k
+        candidates.append(_balanced_factors(-(-n // step) * step, d))
+    return candidates[int(np.argmax([_entropy(c) for c in candidates]))]
+
+
+# --------------------------------------------------------------------------- #
+# modules
+# --------------------------------------------------------------------------- #
+
+class TableBatchedTTEmbeddingBag(nn.Module):
+    """`num_tables` TT-compressed embedding tables of identical shape looked up
+    in one pass (sum pooling, include_last_offset form: offsets has
+    num_tables*B + 1 entries, bags ordered table-major)."""
+
+    __constants__ = ["num_tables", "num_embeddings", "embedding_dim", "tt_shape", "tt_rank"]
+
+    def __init__(self, num_tables: int, num_embeddings: int, embedding_dim: int, tt_ranks: List[int],
+                 tt_p_shapes: Optional[List[int]] = None, tt_q_shapes: Optional[List[int]] = None,
+                 optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
+                 sparse: bool = True, use_cache: bool = False, cache_size: int = 0, hashtbl_size: int = 0,
+                 weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
+                 device: Optional[torch.device] = None) -> None:
+        super().__init__()
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("TTEmbeddingBag needs a GPU (the reference asserts torch.cuda.is_available(), :454)")
+            device = torch.device("cuda", torch.cuda.current_device())
+        device = torch.device(device)
+        num_embeddings, embedding_dim = int(num_embeddings), int(embedding_dim)
+        assert num_tables > 0 and num_embeddings > 0 and embedding_dim > 0
+        assert num_tables == 1 or not use_cache, "cannot use cache when num_tables != 1"
+        tt_ranks = [int(x) for x in tt_ranks]
+        nd = len(tt_ranks) + 1
+        self.tt_p_shapes: List[int] = [int(x) for x in tt_p_shapes] if tt_p_shapes is not None \
+            else suggested_tt_shapes(num_embeddings, nd)
+        self.tt_q_shapes: List[int] = [int(x) for x in tt_q_shapes] if tt_q_shapes is not None \
+            else suggested_tt_shapes(embedding_dim, nd, allow_round_up=not enforce_embedding_dim)
+        assert 2 <= len(self.tt_p_shapes) <= 4
+        assert len(self.tt_p_shapes) == nd == len(self.tt_q_shapes)
+        assert all(v > 0 for v in self.tt_p_shapes + self.tt_q_shapes + tt_ranks)
+        assert int(np.prod(np.asarray(self.tt_p_shapes, dtype=np.int64))) >= num_embeddings
+        assert int(np.prod(np.asarray(self.tt_q_shapes, dtype=np.int64))) == embedding_dim
+        self.num_tables, self.tt_ndim = num_tables, nd
+        self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
+        self.tt_ranks = [1] + tt_ranks + [1]
+        self.sparse, self.optimizer, self.learning_rate, self.eps = sparse, optimizer, learning_rate, eps
+        logging.info("Creating TTEmbeddingBag tt_p_shapes: %s, tt_q_shapes: %s, tt_ranks: %s, sparse: %s, "
+                     "optimizer: %s, learning_rate: %s, eps: %s, use_cache: %s, cache_size: %s, hashtbl_size: %s",
+                     self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks, sparse, optimizer, learning_rate, eps,
+                     use_cache, cache_size, hashtbl_size)
+        strides = [int(np.prod(np.asarray(self.tt_p_shapes[t + 1:], dtype=np.int64))) for t in range(nd)]
+        self.register_buffer("L", torch.tensor(strides, dtype=torch.int64, device=device))
+        self.tt_cores = nn.ParameterList()
+        self.optimizer_state = BufferList("optimizer_state")
+        stateful = optimizer not in _SGD_LIKE
+        for t in range(nd):
+            shape = (num_tables, self.tt_p_shapes[t], self.tt_ranks[t] * self.tt_q_shapes[t] * self.tt_ranks[t + 1])
+            self.tt_cores.append(nn.Parameter(torch.empty(shape, device=device, dtype=torch.float32)))
+            self.optimizer_state.append(torch.zeros(shape if stateful else 0, device=device, dtype=torch.float32))
+        self.reset_parameters(weight_dist)
+        self.use_cache = use_cache
+        if use_cache:
+            cache_size = cache_size if cache_size > 0 else int(0.1 * num_embeddings)
+            hashtbl_size = hashtbl_size if hashtbl_size > 0 else num_embeddings
+            assert hashtbl_size >= cache_size
+            self.register_buffer("hashtbl", torch.full((hashtbl_size,), -1, device=device, dtype=torch.int64))
+            self.register_buffer("cache_freq", torch.zeros(hashtbl_size, device=device, dtype=torch.int64))
+            self.register_buffer("cache_state", torch.full((hashtbl_size,), -1, device=device, dtype=torch.int32))
+            self.cache_weight = nn.Parameter(torch.zeros((cache_size, embedding_dim), device=device, dtype=torch.float32))
+            if sparse and stateful:
+                shape = (cache_size, embedding_dim) if optimizer == OptimType.EXACT_ADAGRAD else (cache_size,)
+                self.register_buffer("cache_optimizer_state", torch.zeros(shape, device=device, dtype=torch.float32))
+            else:
+                self.cache_optimizer_state = None
+        else:
+            self.register_buffer("hashtbl", torch.empty(0, device=device, dtype=torch.int64))
+            self.register_buffer("cache_state", torch.empty(0, device=device, dtype=torch.int32))
+            self.cache_optimizer_state = None
+            self.cache_weight = None
+        self.warmup = True
+
+    # ------------------------------------------------------------------ init
+    def full_weight(self) -> torch.Tensor:
+        assert self.num_tables == 1, "full_weight() only supported for num_tables == 1 for now"
+        return tt_matrix_to_full(self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks, list(self.tt_cores), [1, 0, 2, 3])
+
+    def _assign(self, t: int, values: np.ndarray) -> None:
+        core = self.tt_cores[t]
+        with torch.no_grad():
+            core.copy_(torch.from_numpy(np.ascontiguousarray(values, dtype=np.float32)).reshape(core.shape))
+
+    def reset_parameters(self, weight_dist: str) -> None:
+        """The five initialisations of the reference (:613-792)."""
+        nd, E, D = self.tt_ndim, self.num_embeddings, self.embedding_dim
+        if weight_dist == "uniform":
+            sigma = math.sqrt(2.0 / (E + D))
+            shrink = float(np.prod(np.asarray(self.tt_ranks, dtype=np.float64) ** (-1.0 / (2 * nd))))
+            hi = sigma ** (1.0 / nd) * shrink
+            for core in self.tt_cores:
+                nn.init.uniform_(core, 0.0, hi)
+        elif weight_dist == "naive-uniform":
+            for core in self.tt_cores:
+                nn.init.uniform_(core, 0.0, 1.0 / math.sqrt(E))
+        elif weight_dist == "normal":
+            for core in self.tt_cores:
+                nn.init.normal_(core, 0.0, 1.0 / math.sqrt(E))
+                with torch.no_grad():
+                    core.mul_(1.0 / self.tt_ranks[0])
+        elif weight_dist == "approx-normal":
+            # N(0,1) truncated to |x| >= 2 by rejection, scaled by (3E)^(-1/6)
+            scale = (1.0 / math.sqrt(3 * E)) ** (1.0 / 3.0)
+            for t, core in enumerate(self.tt_cores):
+                w = np.random.normal(0.0, 1.0, size=tuple(core.shape)).astype(np.float32)
+                small = np.abs(w) < 2
+                while small.any():
+                    w[small] = np.random.normal(0.0, 1.0, size=int(small.sum())).astype(np.float32)
+                    small = np.abs(w) < 2
+                self._assign(t, w * scale)
+        elif weight_dist == "approx-uniform":
+            self._init_approx_uniform()
+        else:
+            raise AssertionError(f"unknown weight_dist {weight_dist!r}")
+
+    def _init_approx_uniform(self, sigma: float = 0.01, gridpts: int = 15, width: float = 0.7 / 30.0) -> None:
+        """'flat saw-tooth' construction (:660-792): the product of the three
+        cores is a train of narrow teeth j/gridpts + U(-width/2, width/2) that
+        a narrow Gaussian smears into a uniform density.  3 cores, 1 table."""
+        assert self.tt_ndim == 3, "approx-uniform needs exactly 3 TT cores"
+        assert self.num_tables == 1, "approx_uniform only supported for num_tables == 1"
+        r, p, q = self.tt_ranks, self.tt_p_shapes, self.tt_q_shapes
+        scale = 1.0 / (math.sqrt(self.num_embeddings) ** (1.0 / 3.0))
+
+        def teeth(count: int) -> np.ndarray:
+            j = np.random.randint(-(gridpts - 1), gridpts, count)
+            return j * (1.0 / gridpts) + (-width / 2.0 + width * np.random.rand(count))
+
+        # head: all entries ~ N(1/sqrt(r1), sigma)
+        head = (1.0 / math.sqrt(r[1])) + np.random.randn(r[0], p[0], q[0], r[1]) * sigma
+        # middle: ~ N(1/sqrt(r1), sigma); per (m, n) one even column k is made tiny except one tooth entry
+        mid_scale = 1.0 / math.sqrt(r[1])
+        mid = (mid_scale + np.random.randn(r[1], p[1] * q[1], r[2]) * sigma)
+        vals = teeth(p[1] * q[1]) / mid_scale
+        for ell in range(p[1] * q[1]):
+            k = random.randrange(0, r[2], 2)
+            mid[:, ell, k] = np.random.randn(r[1]) * (sigma * sigma / mid_scale)
+            mid[random.randrange(r[1]), ell, k] = vals[ell]
+        mid = mid.reshape(r[1], p[1], q[1], r[2])
+        # tail: small background, per (m, n) one odd row carries a tooth
+        tail = (np.random.randn(r[2], p[2] * q[2]) * sigma)
+        vals = teeth(p[2] * q[2])
+        for ell in range(p[2] * q[2]):
+            tail[random.randrange(1, r[2], 2) if r[2] > 1 else 0, ell] = vals[ell]
+        tail = tail.reshape(r[2], p[2], q[2], r[3])
+        for t, w in enumerate((head, mid, tail)):
+            self._assign(t, (w * scale).transpose(1, 0, 2, 3).reshape(1, p[t], -1))
+
+    # ----------------------------------------------------------------- cache
+    def reset_cache(self) -> None:
+        if self.use_cache:
+            self.hashtbl.fill_(-1)
+            self.cache_freq.fill_(0)
+            self.cache_state.fill_(-1)
+            self.warmup = True
+
+    def cache_populate(self) -> None:
+        if self.use_cache:
+            _engine.cache_populate(self.num_embeddings, self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks,
+                                   list(self.tt_cores), self.L, self.hashtbl, self.cache_freq, self.cache_state,
+                                   self.cache_weight)
+            self.warmup = False
+
+    def update_cache(self, indices: torch.Tensor) -> None:
+        if self.use_cache:
+            _engine.update_cache_state(indices, self.hashtbl, self.cache_freq)
+
+    # --------------------------------------------------------------- forward
+    def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True) -> torch.Tensor:
+        """-> [num_tables, B, D].  (`warmup` is ignored like in the reference,
+        which uses self.warmup, :822,:841.)"""
+        indices, offsets = indices.long(), offsets.long()
+        self.update_cache(indices)
+        indices, rowidx, tableidx, n_tt, cache_locations = _engine.preprocess_indices_sync(
+            indices, offsets, self.num_tables, self.warmup, self.hashtbl, self.cache_state)
+        n_cached = indices.numel() - n_tt
+        return TTLookupFunction.apply(
+            (offsets.numel() - 1) // self.num_tables, self.embedding_dim, self.tt_p_shapes, self.tt_q_shapes,
+            self.tt_ranks, self.L, n_tt, n_cached, indices, rowidx, tableidx, self.optimizer, self.learning_rate,
+            self.eps, self.sparse, cache_locations, self.cache_optimizer_state, self.cache_weight,
+            list(self.optimizer_state), *self.tt_cores)
+
+    def set_learning_rate(self, lr: float) -> None:
+        self.learning_rate = lr
+
+    def get_params(self) -> List[torch.Tensor]:
+        params = list(self.tt_cores)
+        if self.use_cache:
+            params.append(self.cache_weight)
+        return params
+
+
+class TTEmbeddingBag(TableBatchedTTEmbeddingBag):
+    """TT embedding bag for exactly one table; forward returns [B, D]."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, tt_ranks: List[int],
+                 tt_p_shapes: Optional[List[int]] = None, tt_q_shapes: Optional[List[int]] = None,
+                 optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
+                 sparse: bool = True, use_cache: bool = True, cache_size: int = 0, hashtbl_size: int = 0,
+                 weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
+                 device: Optional[torch.device] = None) -> None:
+        super().__init__(1, num_embeddings, embedding_dim, tt_ranks, tt_p_shapes, tt_q_shapes, optimizer,
+                         learning_rate, eps, sparse, use_cache, cache_size, hashtbl_size, weight_dist,
+                         enforce_embedding_dim, device)
+
+    def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True) -> torch.Tensor:
+        return super().forward(indices, offsets, warmup)[0]

@@ -1,0 +1,143 @@
+"""Table-sharded multi-GPU TT embedding lookup (one process per GPU).
+
+The reference is single-device.  Tables are
+independent, so the path shards by table: table t lives on rank t % W with its
+TT cores, optimizer state and fused optimizer entirely rank-local (no gradient
+all-reduce -- the cores are model-parallel).  Per step there are exactly two
+exchanges, both `all_to_all_single` over RCCL/xGMI (point-to-point links, every
+pair of GPUs talks directly):
+
+  1. lookups in : every rank sends, to each owner, the (lengths, indices) of its
+                  LOCAL batch for the owner's tables;
+  2. pooled out : every owner returns the pooled [tables_owned, B_local, D] block
+                  of each requester's batch; backward sends the gradient of that
+                  block the opposite way.
+
+forward(indices, offsets) takes the local batch for ALL tables (table-major,
+include_last_offset form: offsets has num_tables*B_local + 1 entries) and
+returns [num_tables, B_local, D], like TableBatchedTTEmbeddingBag on one GPU.
+"""
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+import tt_embeddings_ops as _ops
+
+
+class _PooledAllToAll(torch.autograd.Function):
+    """differentiable all_to_all_single with explicit split sizes (rows of D floats)"""
+
+    @staticmethod
+    def forward(ctx, group, x: torch.Tensor, in_splits: List[int], out_splits: List[int]) -> torch.Tensor:
+        ctx.group, ctx.in_splits, ctx.out_splits = group, in_splits, out_splits
+        out = x.new_empty((sum(out_splits),) + tuple(x.shape[1:]))
+        dist.all_to_all_single(out, x.contiguous(), out_splits, in_splits, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: torch.Tensor):
+        gin = g.new_empty((sum(ctx.in_splits),) + tuple(g.shape[1:]))
+        dist.all_to_all_single(gin, g.contiguous(), ctx.in_splits, ctx.out_splits, group=ctx.group)
+        return None, gin, None, None
+
+
+class ShardedTableBatchedTTEmbeddingBag(nn.Module):
+    """`num_tables` identical-shape TT tables sharded table-wise over a process group.
+
+    Constructor keywords are those of TableBatchedTTEmbeddingBag plus `group`.
+    `fixed_pooling=L` (optional, forward kw) promises every bag holds exactly L
+    lookups, which removes the host read-back of split sizes."""
+
+    def __init__(self, num_tables: int, num_embeddings: int, embedding_dim: int, tt_ranks: List[int],
+                 group: Optional["dist.ProcessGroup"] = None, **kw) -> None:
+        super().__init__()
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.num_tables, self.embedding_dim = num_tables, embedding_dim
+        W = self.world
+        self.owned = [[t for t in range(num_tables) if t % W == d] for d in range(W)]
+        self.my_tables = self.owned[self.rank]
+        # owner-major table order used on the wire, and its inverse
+        order = [t for d in range(W) for t in self.owned[d]]
+        inv = [0] * num_tables
+        for pos, t in enumerate(order):
+            inv[t] = pos
+        self._order, self._inv = order, inv
+        assert not kw.get("use_cache", False), "cache is single-table only (reference :458)"
+        self.local = None
+        if self.my_tables:
+            self.local = _ops.TableBatchedTTEmbeddingBag(len(self.my_tables), num_embeddings, embedding_dim, tt_ranks, **kw)
+
+    def _a2a(self, out, inp, out_splits=None, in_splits=None):
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def forward(self, indices: torch.Tensor, offsets: torch.Tensor, fixed_pooling: Optional[int] = None) -> torch.Tensor:
+        W, NT, D = self.world, self.num_tables, self.embedding_dim
+        indices, offsets = indices.long(), offsets.long()
+        B = (offsets.numel() - 1) // NT
+        if W == 1:
+            return self.local(indices, offsets)
+        dev = indices.device
+        n_own = [len(o) for o in self.owned]
+        n_me = n_own[self.rank]
+        order = torch.tensor(self._order, device=dev)
+        # ---- 1. lookups in -------------------------------------------------
+        if fixed_pooling is not None:
+            Lp = int(fixed_pooling)
+            send_idx = indices.view(NT, B * Lp)[order].contiguous().view(-1)
+            in_splits = [k * B * Lp for k in n_own]
+            out_splits = [n_me * B * Lp] * W
+            recv_idx = indices.new_empty(sum(out_splits))
+            self._a2a(recv_idx, send_idx, out_splits, in_splits)
+            # wire order [src][k][b][l] -> table-major [k][src][b][l]
+            loc_idx = recv_idx.view(W, n_me, B * Lp).permute(1, 0, 2).contiguous().view(-1)
+            loc_off = torch.arange(0, n_me * W * B * Lp + 1, Lp, device=dev, dtype=torch.int64)
+        else:
+            lengths = (offsets[1:] - offsets[:-1]).view(NT, B)
+            send_len = lengths[order].contiguous()                       # owner-major
+            recv_len = lengths.new_empty((W, n_me, B))
+            self._a2a(recv_len.view(-1), send_len.view(-1), [n_me * B] * W, [k * B for k in n_own])
+            # split sizes of the index exchange: ONE host read-back
+            tbl_cnt = send_len.sum(dim=1)
+            bounds = [0]
+            for k in n_own:
+                bounds.append(bounds[-1] + k)
+            host = torch.cat([torch.stack([tbl_cnt[bounds[d]:bounds[d + 1]].sum() for d in range(W)]),
+                              recv_len.view(W, -1).sum(dim=1)]).tolist()
+            in_splits, out_splits = [int(x) for x in host[:W]], [int(x) for x in host[W:]]
+            # indices in owner-major table order
+            tbl_off = offsets[::B]                                         # [NT+1] start of each table's run
+            seg_start = tbl_off[:-1][order]
+            seg_len = tbl_cnt
+            send_idx = indices[_segment_gather(seg_start, seg_len, sum(in_splits))]
+            recv_idx = indices.new_empty(sum(out_splits))
+            self._a2a(recv_idx, send_idx, out_splits, in_splits)
+            # per-(src, k) segments -> table-major [k][src]
+            seg_len_w = recv_len.sum(dim=2)                                # [W, n_me] wire order
+            seg_start_w = (torch.cumsum(seg_len_w.view(-1), 0) - seg_len_w.view(-1)).view(W, n_me)
+            loc_idx = recv_idx[_segment_gather(seg_start_w.t().reshape(-1), seg_len_w.t().reshape(-1), sum(out_splits))]
+            loc_len = recv_len.permute(1, 0, 2).reshape(-1)                # [k][src][b]
+            loc_off = torch.cat([loc_len.new_zeros(1), torch.cumsum(loc_len, 0)])
+        # ---- 2. local lookup of the GLOBAL batch for my tables ---------------
+        if n_me:
+            pooled = self.local(loc_idx, loc_off)                          # [n_me, W*B, D]
+            send = pooled.view(n_me, W, B, D).permute(1, 0, 2, 3).reshape(W * n_me * B, D)
+        else:
+            send = torch.zeros((0, D), device=dev, dtype=torch.float32)
+        # ---- 3. pooled out ---------------------------------------------------
+        got = _PooledAllToAll.apply(self.group, send, [n_me * B] * W, [k * B for k in n_own])
+        return got.view(NT, B, D)[torch.tensor(self._inv, device=dev)]
+
+    def set_learning_rate(self, lr: float) -> None:
+        if self.local is not None:
+            self.local.set_learning_rate(lr)
+
+
+def _segment_gather(seg_start: torch.Tensor, seg_len: torch.Tensor, total: int) -> torch.Tensor:
+    """positions of the concatenation of segments [start_i, start_i + len_i)"""
+    dst_start = torch.cumsum(seg_len, 0) - seg_len
+    rep = torch.repeat_interleave(seg_start - dst_start, seg_len, output_size=total)
+    return rep + torch.arange(total, device=seg_start.device, dtype=seg_start.dtype)

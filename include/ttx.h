@@ -211,8 +211,9 @@ int ttx_cache_backward_rowwise_adagrad_approx(
     ttx_stream_t stream);
 
 /* ------------------------------------------------------------- profiling ---
- * Live kernel timing for bench.py's roofline block: when enabled, every launch
- * of the named hot kernels is bracketed by HIP events on the launch stream.
+ * Live kernel timing for bench.py's roofline block: ttx_profile_enable(mask)
+ * selects kernel slots (bit w = slot w, 0 = off); every launch of a selected
+ * kernel is bracketed by two HIP events on the launch stream.
  * ttx_profile_read synchronises the pending events and returns, for kernel
  * `which` (0 = forward contraction, 1 = backward contraction, 2 = reduce/apply,
  * 3 = plan, 4 = bag pooling, 5 = cache gather fwd), the launch count and the
@@ -224,7 +225,7 @@ int ttx_cache_backward_rowwise_adagrad_approx(
 #define TTX_PROF_POOL 4
 #define TTX_PROF_CACHE_FWD 5
 #define TTX_PROF_NUM 6
-int ttx_profile_enable(int on);
+int ttx_profile_enable(int mask);
 int ttx_profile_reset(void);
 int ttx_profile_read(int which, int64_t* launches, double* total_ms);
 

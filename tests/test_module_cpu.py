@@ -1,0 +1,202 @@
+"""CPU tests (no GPU) of the host logic: the Python module surface
+(tt_embeddings_ops) driven on top of the oracle engine, the C-ABI export list,
+shape factoring, initialisers, state_dict keys."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import gen_inputs as G
+import oracle_engine
+from util import LR, EPS, adagrad_expected, assert_adagrad_close, assert_close, sgd_expected
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def ops(monkeypatch):
+    import tt_embeddings_ops as m
+
+    monkeypatch.setattr(m, "_engine", oracle_engine)
+    return m
+
+
+def test_abi_exports_every_declared_symbol():
+    """libttx.so loads (no GPU needed) and exports every entry point include/ttx.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "ttx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(ttx_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    so = os.path.join(ROOT, "fbtt-embedding_amd", "libttx.so")
+    assert os.path.exists(so), "libttx.so not built: run __graft_entry__.build()"
+    lib = ctypes.CDLL(so)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, f"libttx.so lacks {missing}"
+    assert lib.ttx_version() >= 100
+    # host-only queries work without a GPU
+    import tt_embeddings as E
+
+    g = E._geom(1, [200, 220, 250], [4, 4, 4], [1, 32, 32, 1])
+    L = E.lib()
+    assert L.ttx_plan_bytes(ctypes.byref(g), 10240) > 10240 * 4 * 6
+    assert L.ttx_tt_forward_workspace_bytes(ctypes.byref(g), 512, 64, 10240) >= 10240 * 64 * 4
+    assert L.ttx_tt_backward_workspace_bytes(ctypes.byref(g), 512, 64, 10240) >= 10240 * 256 * 4
+    bad = E._geom(1, [2, 2], [2, 2], [1, 2, 1])
+    bad2 = type(g)()
+    bad2.T = 7
+    assert L.ttx_plan_bytes(ctypes.byref(bad2), 10) == 0
+    assert L.ttx_plan_bytes(ctypes.byref(bad), 10) > 0
+
+
+def test_shim_fails_loudly_without_gpu_tensors():
+    import tt_embeddings as E
+
+    i = torch.zeros(4, dtype=torch.int64)
+    cores = [torch.zeros(s) for s in G.core_shapes(1, [7, 9, 11], [3, 4, 5], [13, 12])]
+    with pytest.raises(RuntimeError, match="GPU"):
+        E.tt_forward(1000, 1, 2, 60, [7, 9, 11], [3, 4, 5], [1, 13, 12, 1], torch.zeros(3, dtype=torch.int64), 4, i, i, i, cores)
+    with pytest.raises(RuntimeError, match="GPU"):
+        E.update_cache_state(i, torch.zeros(8, dtype=torch.int64), torch.zeros(8, dtype=torch.int64))
+
+
+def test_suggested_tt_shapes(ops):
+    """values captured from the reference's own function"""
+    f = ops.suggested_tt_shapes
+    assert f(10, 3) == [1, 2, 5] and f(3, 3) == [1, 1, 3]
+    assert f(1000000, 3) == [100, 100, 100]
+    assert f(64, 3, allow_round_up=False) == [4, 4, 4]
+    assert f(11000000, 3) == [200, 220, 250]
+    assert f(128, 3, allow_round_up=False) == [4, 4, 8] and f(128, 3) == [5, 5, 8]
+
+
+def test_toy_module_layout_and_state_dict(ops):
+    m = ops.TTEmbeddingBag(num_embeddings=10, embedding_dim=3, tt_ranks=[2, 2], sparse=False, use_cache=False,
+                           weight_dist="uniform", device="cpu")
+    assert m.tt_p_shapes == [1, 2, 5] and m.tt_q_shapes == [1, 1, 3] and m.tt_ranks == [1, 2, 2, 1]
+    assert m.L.tolist() == [10, 5, 1]
+    assert [tuple(c.shape) for c in m.tt_cores] == [(1, 1, 2), (1, 2, 4), (1, 5, 6)]
+    assert sorted(m.state_dict().keys()) == sorted(
+        ["L", "hashtbl", "cache_state", "tt_cores.0", "tt_cores.1", "tt_cores.2",
+         "optimizer_state.optimizer_state0", "optimizer_state.optimizer_state1", "optimizer_state.optimizer_state2"])
+    m2 = ops.TTEmbeddingBag(10, 3, [2, 2], optimizer=ops.OptimType.EXACT_ADAGRAD, use_cache=True, cache_size=4,
+                            hashtbl_size=16, weight_dist="normal", device="cpu")
+    keys = set(m2.state_dict().keys())
+    assert {"cache_weight", "cache_freq", "cache_optimizer_state", "hashtbl", "cache_state"} <= keys
+    assert m2.optimizer_state[1].shape == m2.tt_cores[1].shape and m.optimizer_state[1].numel() == 0
+    assert len(m2.get_params()) == 4 and len(m2.get_params()) == 4  # does not grow
+    with pytest.raises(TypeError):  # the README's positional form is a TypeError in the reference too
+        ops.TTEmbeddingBag(10, 3, None, None, tt_ranks=[2, 2])
+
+
+@pytest.mark.parametrize("dist", ["uniform", "naive-uniform", "normal", "approx-normal", "approx-uniform"])
+def test_initialisers(ops, dist):
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = ops.TTEmbeddingBag(20 * 22 * 25, 64, [8, 8], [20, 22, 25], [4, 4, 4], use_cache=False, weight_dist=dist, device="cpu")
+    for c in m.tt_cores:
+        assert torch.isfinite(c).all() and float(c.detach().abs().max()) > 0
+    if dist == "approx-normal":  # every entry came from |x| >= 2
+        scale = (1.0 / np.sqrt(3 * 11000)) ** (1 / 3)
+        assert float(m.tt_cores[1].abs().min()) >= 2 * scale * 0.999
+    if dist == "uniform":
+        assert float(m.tt_cores[0].min()) >= 0
+    if dist == "approx-uniform":  # entries of the full table spread over (-1, 1)*scale, not concentrated
+        w = m.full_weight().detach().flatten().numpy() * np.sqrt(11000)
+        hist, _ = np.histogram(w, bins=8, range=(-1, 1))
+        assert hist.min() > 0.02 * w.size
+
+
+def _module_for(ops, c, **kw):
+    m = ops.TableBatchedTTEmbeddingBag(c["tables"], int(np.prod(c["p"])), c["D"], c["r"][1:-1], c["p"], c["q"],
+                                       weight_dist="uniform", use_cache=False, device="cpu", **kw)
+    with torch.no_grad():
+        for dst, src in zip(m.tt_cores, c["cores"]):
+            dst.copy_(torch.from_numpy(src))
+    return m
+
+
+def test_module_forward_backward_dense(ops, small_cases):
+    """test_forward / test_backward_dense / *_table_batched of the reference, on the golden vectors"""
+    for name, c in small_cases.items():
+        m = _module_for(ops, c, sparse=False)
+        out = m(torch.from_numpy(c["indices"]), torch.from_numpy(c["offsets"]))
+        assert_close(out.detach().numpy(), c["out"], f"{name} out")
+        out.backward(torch.from_numpy(c["d_out"]))
+        for k in range(c["T"]):
+            assert_close(m.tt_cores[k].grad.numpy(), c["grads"][k], f"{name} grad{k}")
+
+
+def test_module_fused_optimizers(ops, small_cases):
+    for name in ("t3_tb1_s0", "t2_tb3_s0", "t4_tb1_s0"):
+        c = small_cases[name]
+        m = _module_for(ops, c, sparse=True, optimizer=ops.OptimType.SGD, learning_rate=LR)
+        m(torch.from_numpy(c["indices"]), torch.from_numpy(c["offsets"])).backward(torch.from_numpy(c["d_out"]))
+        for k, e in enumerate(sgd_expected(c["cores"], c["grads"])):
+            assert_close(m.tt_cores[k].detach().numpy(), e, f"{name} sgd{k}")
+            assert m.tt_cores[k].grad is None
+        m = _module_for(ops, c, sparse=True, optimizer=ops.OptimType.EXACT_ADAGRAD, learning_rate=LR, eps=EPS)
+        m(torch.from_numpy(c["indices"]), torch.from_numpy(c["offsets"])).backward(torch.from_numpy(c["d_out"]))
+        exp, st = adagrad_expected(c["cores"], c["grads"])
+        for k in range(c["T"]):
+            assert_close(m.optimizer_state[k].numpy(), st[k], f"{name} state{k}")
+            assert_adagrad_close(m.tt_cores[k].detach().numpy(), exp[k], c["grads"][k], f"{name} ada{k}")
+
+
+def test_single_table_module_and_tt_matrix_to_full(ops, small_cases):
+    c = small_cases["t3_tb1_s0"]
+    m = ops.TTEmbeddingBag(int(np.prod(c["p"])), c["D"], c["r"][1:-1], c["p"], c["q"], sparse=False, use_cache=False,
+                           weight_dist="uniform", device="cpu")
+    with torch.no_grad():
+        for dst, src in zip(m.tt_cores, c["cores"]):
+            dst.copy_(torch.from_numpy(src))
+    idx, off = torch.from_numpy(c["indices"]), torch.from_numpy(c["offsets"])
+    out = m(idx, off)
+    assert out.shape == (c["B"], c["D"])
+    ref = torch.nn.functional.embedding_bag(idx, m.full_weight(), off, mode="sum", include_last_offset=True)
+    assert_close(out.detach().numpy(), ref.detach().numpy(), "vs nn.EmbeddingBag on full_weight()")
+    assert_close(out.detach().numpy(), c["out"][0], "vs golden")
+
+
+def test_cache_life_cycle(ops):
+    """warm-up -> cache_populate -> steady state: outputs with a live cache equal
+    the TT-only outputs; hit rows come from cache_weight; fused SGD updates both."""
+    p, q, r = [7, 9, 11], [3, 4, 5], [13, 12]
+    E_ = 7 * 9 * 11
+    rs = np.random.RandomState(0)
+    kw = dict(num_embeddings=E_, embedding_dim=60, tt_ranks=r, tt_p_shapes=p, tt_q_shapes=q, weight_dist="uniform", device="cpu")
+    m = ops.TTEmbeddingBag(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=LR, use_cache=True, cache_size=32,
+                           hashtbl_size=4096, **kw)
+    base = ops.TTEmbeddingBag(sparse=False, use_cache=False, **kw)
+    with torch.no_grad():
+        for a, b in zip(base.tt_cores, m.tt_cores):
+            a.copy_(b)
+    hot = rs.choice(E_, size=40, replace=False)
+    off = torch.arange(0, 50 * 6 + 1, 6)
+
+    def batch():
+        mix = np.where(rs.rand(300) < 0.7, rs.choice(hot, size=300), rs.randint(0, E_, size=300))
+        return torch.from_numpy(mix.astype(np.int64))
+
+    for _ in range(5):  # warm-up: TT path only, frequencies counted
+        idx = batch()
+        assert m.warmup
+        with torch.no_grad():
+            assert_close(m(idx, off).numpy(), base(idx, off).numpy(), "warm-up output")
+    assert int(m.cache_freq.sum()) == 5 * 300
+    m.cache_populate()
+    assert not m.warmup
+    assert int((m.cache_state >= 0).sum()) == 32 and int((m.hashtbl >= 0).sum()) == 32
+    idx = batch()
+    with torch.no_grad():
+        _, _, _, n_tt, loc = oracle_engine.preprocess_indices_sync(idx, off, 1, False, m.hashtbl, m.cache_state)
+        assert loc is not None and 0 < n_tt < idx.numel()
+        assert_close(m(idx, off).numpy(), base(idx, off).numpy(), "steady-state output (cache hits + TT)")
+    w0 = m.cache_weight.detach().clone()
+    c0 = [c.detach().clone() for c in m.tt_cores]
+    m(idx, off).backward(torch.rand(50, 60) * 0.1)
+    assert not torch.equal(m.cache_weight.detach(), w0) and not torch.equal(m.tt_cores[1].detach(), c0[1])
+    m.reset_cache()
+    assert m.warmup and int((m.hashtbl >= 0).sum()) == 0

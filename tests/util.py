@@ -13,6 +13,8 @@ def assert_close(got, ref, what="", rtol=RTOL, atol_scale=ATOL_SCALE):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    assert np.isfinite(ref).all(), f"{what}: reference has non-finite values"
+    assert np.isfinite(got).all(), f"{what}: result has non-finite values"
     atol = atol_scale * max(float(np.abs(ref).max()) if ref.size else 0.0, 1e-30)
     err = np.abs(got - ref)
     bad = err > atol + rtol * np.abs(ref)
@@ -44,6 +46,7 @@ def assert_adagrad_close(got_w, ref_w, ref_g, what="", lr=LR, eps=EPS, state0=No
     got_w = np.asarray(got_w, dtype=np.float64)
     ref_w = np.asarray(ref_w, dtype=np.float64)
     g = np.abs(np.asarray(ref_g, dtype=np.float64))
+    assert np.isfinite(got_w).all() and np.isfinite(ref_w).all(), f"{what}: non-finite values"
     dg = ATOL_SCALE * max(float(g.max()), 1e-30) + RTOL * g
     denom = (np.sqrt(g * g + (0.0 if state0 is None else np.asarray(state0, dtype=np.float64))) + eps)
     tol = RTOL * np.abs(ref_w) + 2e-7 * max(float(np.abs(ref_w).max()), 1e-30) + lr * dg * (eps + denom) / (denom * denom)
