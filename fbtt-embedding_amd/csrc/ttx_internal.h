@@ -47,17 +47,19 @@ int make_dims(const ttx_geom* g, Dims* d);  // TTX_OK or TTX_EINVAL (+message)
 //   sid[t][n]   = table*p_t + i_t                      (original order)
 //   perm[t][*]  = lookups n sorted (stably) by sid[t]
 //   off[t][s]   = first position in perm[t] of slice s  (S_t + 1 entries)
-//   chunk_*     = work list of the pivot core (core 1): each slice's run of
-//                 lookups cut into chunks of <= MC lookups
+//   chunk_rec[c]= {pivot slice, start in perm[1], lookups in chunk, 0}: the work
+//                 list of the pivot core (core 1), each slice's run of lookups
+//                 cut into chunks of <= MC lookups; chunk_off[s] = first chunk of s
+//   lrec[i]     = {n, sid_0, sid_2, sid_3} of the i-th lookup in pivot order
 struct Plan {
   int* hdr;  // [0] = number of chunks, [1] = MC, [2] = nnz
   int* sid[TTX_MAX_CORES];
   int* perm[TTX_MAX_CORES];
   int* off[TTX_MAX_CORES];
   int* chunk_off;    // [S_1 + 1]
-  int* chunk_slice;  // [max_chunks]
-  int* chunk_start;  // [max_chunks]
-  int* scratch[3];   // rank / ping / pong, [nnz] each
+  int4* chunk_rec;   // [max_chunks]
+  int4* lrec;        // [nnz]
+  int* scratch[TTX_MAX_CORES][3];  // rank / ping / pong per core, [nnz] each
   int max_chunks;
   int MC;
 };

@@ -6,16 +6,19 @@
 // (:362-377): after this kernel every core slice knows, in index order, the
 // lookups that touch it, so gradients are reduced by one owner per slice.
 //
-// One work-group of 1024 threads (16 waves) does the whole plan for a batch:
-//   1. decode idx -> (i_0..i_{T-1}) exactly as the reference (int64 / and %,
-//      cu:795-799) and form the slice id  sid[t][n] = table*p_t + i_t;
-//   2. per core, a stable LSD radix sort (8-bit digits) of the lookups by
-//      sid[t].  Ranking inside a wave uses 9 ballots per 64 keys
-//      (wave_match8); per-wave digit counters live in LDS and are combined by
-//      one block-wide exclusive scan per pass -- no atomics, deterministic;
+// One launch, T work-groups of 1024 threads (16 waves); work-group t plans core t:
+//   1. decode idx -> i_t exactly as the reference (idx / L_t % p_t, cu:795-799;
+//      the int64 divisions are done as a double-reciprocal multiply + fix-up
+//      when prod(p) < 2^31) and form the slice id  sid[t][n] = table*p_t + i_t;
+//   2. a stable LSD radix sort (8-bit digits) of the lookups by sid[t].  Ranking
+//      inside a wave uses 9 ballots per 64 keys (wave_match8); per-wave digit
+//      counters live in LDS and are combined by one block-wide exclusive scan
+//      per pass -- no atomics, deterministic;
 //   3. slice offsets by run-head detection on the sorted keys;
-//   4. the chunk work-list of the pivot core (core 1).
-// The plan is HBM-resident integer work: ~ (4 + 8*passes) bytes per lookup per
+//   4. (pivot core 1 only) the chunk work-list and one flat record per sorted
+//      lookup {n, sid_0, sid_2, sid_3}, so a contraction work-group reaches its
+//      operands with two dependent loads instead of a five-deep pointer chase.
+// The plan is HBM-resident integer work: ~ (8 + 8*passes) bytes per lookup per
 // core; at the benchmark shape (nnz 10240, 200/220/250 slices) every sort is a
 // single 8-bit pass.
 #include "ttx_internal.h"
@@ -31,15 +34,14 @@ int max_chunks(const Dims& d, long long nnz, int MC) {
   return (int)v;
 }
 
+static size_t r64(size_t k) { return (k + 63) / 64 * 64; }
+
 static size_t plan_ints(const Dims& d, long long nnz, int MC) {
-  size_t n = 0;
-  auto add = [&](size_t k) { n += (k + 63) / 64 * 64; };
-  add(64);                                                    // hdr
-  for (int t = 0; t < d.T; ++t) { add(nnz); add(nnz); add((size_t)d.S[t] + 1); }
-  add((size_t)d.S[1] + 1);                                    // chunk_off
-  add(max_chunks(d, nnz, MC));                                // chunk_slice
-  add(max_chunks(d, nnz, MC));                                // chunk_start
-  add(nnz); add(nnz); add(nnz);                               // scratch
+  size_t n = r64(64);                                               // hdr
+  for (int t = 0; t < d.T; ++t) n += r64(nnz) * 5 + r64((size_t)d.S[t] + 1);  // sid, perm, 3 scratch, off
+  n += r64((size_t)d.S[1] + 1);                                     // chunk_off
+  n += r64((size_t)max_chunks(d, nnz, MC) * 4);                     // chunk_rec
+  n += r64((size_t)nnz * 4);                                        // lrec
   return n;
 }
 
@@ -53,17 +55,17 @@ Plan carve_plan(const Dims& d, long long nnz, void* base) {
   P.MC = choose_chunk(d);
   P.max_chunks = max_chunks(d, nnz, P.MC);
   int* cur = (int*)base;
-  auto take = [&](size_t k) { int* r = cur; cur += (k + 63) / 64 * 64; return r; };
+  auto take = [&](size_t k) { int* r = cur; cur += r64(k); return r; };
   P.hdr = take(64);
+  P.chunk_rec = (int4*)take((size_t)P.max_chunks * 4);
+  P.lrec = (int4*)take((size_t)nnz * 4);
   for (int t = 0; t < d.T; ++t) {
     P.sid[t] = take(nnz);
     P.perm[t] = take(nnz);
     P.off[t] = take((size_t)d.S[t] + 1);
+    for (int i = 0; i < 3; ++i) P.scratch[t][i] = take(nnz);
   }
   P.chunk_off = take((size_t)d.S[1] + 1);
-  P.chunk_slice = take(P.max_chunks);
-  P.chunk_start = take(P.max_chunks);
-  for (int i = 0; i < 3; ++i) P.scratch[i] = take(nnz);
   return P;
 }
 
@@ -87,27 +89,50 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wtot, int* total) {
   return res;
 }
 
+// floor(n / dv) for 0 <= n < 2^31 via one fp64 multiply and a fix-up
+__device__ __forceinline__ unsigned div_small(unsigned n, unsigned dv, double rcp) {
+  unsigned q = (unsigned)((double)n * rcp);
+  const long long r = (long long)n - (long long)q * dv;
+  if (r < 0) q -= 1;
+  else if (r >= (long long)dv) q += 1;
+  return q;
+}
+
+// i_t of lookup idx (reference decode: i_t = idx / L_t % p_t; out-of-range
+// indices, which the reference reads out of bounds with, are clamped)
+__device__ __forceinline__ int decode_core(const Dims& d, int t, long long idx, bool small,
+                                           double rcpL, double rcpP) {
+  if (idx < 0) idx = 0;
+  long long a;
+  if (small && idx < (1ll << 31)) {
+    const unsigned q = div_small((unsigned)idx, (unsigned)d.L[t], rcpL);
+    if (t == 0) a = q;
+    else a = q - div_small(q, (unsigned)d.p[t], rcpP) * (unsigned)d.p[t];
+  } else {
+    a = idx / d.L[t];
+    if (t > 0) a = a % d.p[t];
+  }
+  if (a >= d.p[t]) a = d.p[t] - 1;
+  return (int)a;
+}
+
 __global__ __launch_bounds__(kPlanThreads) void plan_kernel(
-    Dims d, int N, const int64_t* indices, const int64_t* tableidx, Plan P) {
+    Dims d, int N, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx, Plan P) {
   __shared__ int hist[256 * kPlanWaves];  // [digit][wave]
   __shared__ int wtot[kPlanWaves + 1];
   const int tid = threadIdx.x;
   const int lane = lane_id();
   const int w = tid / kWave;
+  const int t = blockIdx.x;  // the core this work-group plans
+  const bool small = d.L[0] * (long long)d.p[0] < (1ll << 31);
+  int* key = P.sid[t];
 
   // ---- 1. decode ----------------------------------------------------------
-  for (int n = tid; n < N; n += kPlanThreads) {
-    long long idx = indices[n];
-    const long long tb = tableidx ? tableidx[n] : 0;
-    if (idx < 0) idx = 0;  // the reference reads out of bounds here; we clamp
-#pragma unroll
-    for (int t = 0; t < TTX_MAX_CORES; ++t) {
-      if (t < d.T) {
-        long long it = idx / d.L[t];
-        idx = idx % d.L[t];
-        if (it >= d.p[t]) it = d.p[t] - 1;  // idx >= prod(p): clamp (ref: OOB)
-        P.sid[t][n] = (int)(tb * d.p[t] + it);
-      }
+  {
+    const double rcpL = 1.0 / (double)d.L[t], rcpP = 1.0 / (double)d.p[t];
+    for (int n = tid; n < N; n += kPlanThreads) {
+      const long long tb = tableidx ? tableidx[n] : 0;
+      key[n] = (int)(tb * d.p[t]) + decode_core(d, t, indices[n], small, rcpL, rcpP);
     }
   }
   __syncthreads();
@@ -117,17 +142,16 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(
   const int wbeg = w * per;
   const int wend = min(N, wbeg + per);
 
-  // ---- 2. stable LSD radix sort per core ----------------------------------
-  for (int t = 0; t < d.T; ++t) {
-    const int* key = P.sid[t];
+  // ---- 2. stable LSD radix sort by sid[t] ----------------------------------
+  {
     int bits = 32 - __clz(max(d.S[t] - 1, 1));
     int passes = (bits + 7) / 8;
     if (passes < 1) passes = 1;
-    int* rk = P.scratch[0];
+    int* rk = P.scratch[t][0];
     for (int ps = 0; ps < passes; ++ps) {
       const int shift = ps * 8;
-      const int* src = (ps == 0) ? nullptr : ((ps & 1) ? P.scratch[1] : P.scratch[2]);
-      int* dst = (ps == passes - 1) ? P.perm[t] : ((ps & 1) ? P.scratch[2] : P.scratch[1]);
+      const int* src = (ps == 0) ? nullptr : ((ps & 1) ? P.scratch[t][1] : P.scratch[t][2]);
+      int* dst = (ps == passes - 1) ? P.perm[t] : ((ps & 1) ? P.scratch[t][2] : P.scratch[t][1]);
       for (int e = tid; e < 256 * kPlanWaves; e += kPlanThreads) hist[e] = 0;
       __syncthreads();
       // count + rank inside the wave's range
@@ -172,21 +196,22 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(
       }
       __syncthreads();
     }
-    // ---- 3. slice offsets by run-head detection ---------------------------
-    {
-      const int* pm = P.perm[t];
-      int* off = P.off[t];
-      const int S = d.S[t];
-      for (int i = tid; i <= N; i += kPlanThreads) {
-        const int kprev = (i == 0) ? -1 : key[pm[i - 1]];
-        const int kcur = (i == N) ? S : key[pm[i]];
-        for (int s = kprev + 1; s <= kcur; ++s) off[s] = i;
-      }
-    }
-    __syncthreads();
   }
+  // ---- 3. slice offsets by run-head detection -------------------------------
+  const int* pm = P.perm[t];
+  {
+    int* off = P.off[t];
+    const int S = d.S[t];
+    for (int i = tid; i <= N; i += kPlanThreads) {
+      const int kprev = (i == 0) ? -1 : key[pm[i - 1]];
+      const int kcur = (i == N) ? S : key[pm[i]];
+      for (int s = kprev + 1; s <= kcur; ++s) off[s] = i;
+    }
+  }
+  if (t != 1) return;
+  __syncthreads();
 
-  // ---- 4. chunk work-list of the pivot core (core 1) -----------------------
+  // ---- 4. pivot core: chunk work-list + flat per-lookup records ------------
   {
     const int S1 = d.S[1];
     const int MC = P.MC;
@@ -204,18 +229,35 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(
       const int ex = carry + block_excl_scan(nch, wtot, &total);
       if (s < S1) {
         P.chunk_off[s] = ex;
-        for (int j = 0; j < nch; ++j) {
-          P.chunk_slice[ex + j] = s;
-          P.chunk_start[ex + j] = beg + j * MC;
-        }
+        for (int j = 0; j < nch; ++j)
+          P.chunk_rec[ex + j] = make_int4(s, beg + j * MC, min(MC, cnt - j * MC), 0);
       }
       carry += total;
     }
+    // unused tail of the work list: len = 0 -> the contraction work-group exits
+    for (int c = carry + tid; c < P.max_chunks; c += kPlanThreads) P.chunk_rec[c] = make_int4(0, 0, 0, 0);
     if (tid == 0) {
       P.chunk_off[S1] = carry;
       P.hdr[0] = carry;
       P.hdr[1] = MC;
       P.hdr[2] = N;
+    }
+    double rcpL[TTX_MAX_CORES], rcpP[TTX_MAX_CORES];
+#pragma unroll
+    for (int u = 0; u < TTX_MAX_CORES; ++u) {
+      rcpL[u] = u < d.T ? 1.0 / (double)d.L[u] : 1.0;
+      rcpP[u] = u < d.T ? 1.0 / (double)d.p[u] : 1.0;
+    }
+    for (int i = tid; i < N; i += kPlanThreads) {
+      const int n = pm[i];
+      const long long idx = indices[n];
+      const int tb = tableidx ? (int)tableidx[n] : 0;
+      int4 r;
+      r.x = n;
+      r.y = tb * d.p[0] + decode_core(d, 0, idx, small, rcpL[0], rcpP[0]);
+      r.z = d.T > 2 ? tb * d.p[2] + decode_core(d, 2, idx, small, rcpL[2], rcpP[2]) : 0;
+      r.w = d.T > 3 ? tb * d.p[3] + decode_core(d, 3, idx, small, rcpL[3], rcpP[3]) : 0;
+      P.lrec[i] = r;
     }
   }
 }
@@ -224,7 +266,7 @@ int plan_build(const Dims& d, long long nnz, const int64_t* indices,
                const int64_t* tableidx, const Plan& P, hipStream_t stream) {
   if (nnz < 0 || nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz=%lld out of range", nnz);
   ProfScope ps(TTX_PROF_PLAN, stream);
-  hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, d, (int)nnz,
+  hipLaunchKernelGGL(plan_kernel, dim3(d.T), dim3(kPlanThreads), 0, stream, d, (int)nnz,
                      indices, tableidx, P);
   TTX_HIP(hipGetLastError());
   return TTX_OK;

@@ -1,62 +1,130 @@
-// ttx_tt.hip -- TT-core contraction forward / backward for gfx950.
+// ttx_tt.hip -- TT-core contraction forward / backward for gfx950 (CDNA4).
 //
 // Design: lookups are grouped by the slice of the PIVOT core
-// (core 1, the big r1 x q1 x r2 slice) they touch.  One work-group owns a chunk
-// of <= MC lookups of one pivot slice:
-//   forward   X0[MC*q0 x N1] = A[MC*q0 x r1] * B1[r1 x N1]   (B1 staged ONCE in LDS,
-//             A = the chunk's core-0 slices stacked), then the remaining
-//             T-2 stages per lookup out of LDS, rows -> HBM, bags pooled by a
-//             second tiny kernel in index order (same order as the reference's
-//             reduce_output_kernel, tt_embeddings_cuda.cu:920-962);
+// (core 1, the big r1 x q1 x r2 slice) they touch.  One work-group (4 waves)
+// owns a chunk of <= MC lookups of one pivot slice:
+//   forward   X0[M x N1] = A[M x r1] * B1[r1 x N1]     M = MC*q0, N1 = q1*r2
+//             (B1 staged ONCE in LDS, A = the chunk's core-0 slices stacked) on
+//             v_mfma_f32_16x16x4_f32 -- exact fp32, bit-identical to an fmaf
+//             chain -- then the remaining T-2 stages per lookup out of LDS,
+//             rows -> HBM, bags pooled by a second tiny kernel in index order
+//             (the order of the reference's reduce_output_kernel,
+//             tt_embeddings_cuda.cu:920-962);
 //   backward  recompute X0, per-lookup tail (grad of the last cores), then two
-//             chunk GEMMs  dB1 = A^T * dX0   and   dA = dX0 * B1^T.
-// Gradients never use atomics: every producer writes a private partial
-// (per lookup for the thin cores, per chunk for the pivot) and ONE owner per
-// core slice sums them in index order and applies DENSE / SGD / Adagrad
+//             more chunk GEMMs on MFMA:  dB1 = A^T * dX0  and  dA = dX0 * B1^T.
+// Gradients never use atomics: every producer writes a private partial (per
+// lookup for the thin cores, per chunk for the pivot) and ONE owner per core
+// slice sums them in index order and applies DENSE / SGD / Adagrad
 // (reduce_apply_kernel) -- deterministic, and the optimizer touches only
 // slices that were looked up.
+//
+// LDS layout: every operand is row-major with a row stride == 2 (mod 32) floats.
+// With that single choice all three GEMMs read their MFMA fragments with
+// ds_read_b32 conflict-free (or 2-way on the operand that is re-used from
+// registers), by choosing which 4 K-indices a k-step covers:
+//   X0  = A  * B1   k-step {k, k+8, k+16, k+24}  (B rows 8 apart: 8*ld == 16 mod 32)
+//   dB1 = A^T* dX0  k-step {m, m+8, m+16, m+24}  (both operands row-strided)
+//   dA  = dX0* B1^T k-step {c, c+1, c+2, c+3}    (both operands column-adjacent)
 #include "ttx_internal.h"
 
 namespace ttx {
 
 constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / kWave;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct CorePtrs {
   float* c[TTX_MAX_CORES];
 };
 
-// LDS carve of the contraction kernels (float offsets)
+// n / d and n % d for small operands via one fp32 multiply and a fix-up
+struct FastDiv {
+  unsigned d;
+  float rcp;
+};
+__host__ __device__ __forceinline__ FastDiv make_fd(int d) {
+  FastDiv f;
+  f.d = (unsigned)(d > 0 ? d : 1);
+  f.rcp = 1.0f / (float)f.d;
+  return f;
+}
+#define make_fd_dev make_fd
+__device__ __forceinline__ unsigned fdivmod(unsigned n, const FastDiv f, unsigned& rem) {
+  if (n >> 22) {
+    rem = n % f.d;
+    return n / f.d;
+  }
+  unsigned q = (unsigned)((float)n * f.rcp);
+  int r = (int)n - (int)(q * f.d);
+  if (r < 0) { q -= 1; r += (int)f.d; }
+  else if (r >= (int)f.d) { q += 1; r -= (int)f.d; }
+  rem = (unsigned)r;
+  return q;
+}
+
+// LDS carve of the contraction kernels (float offsets) + padded GEMM extents
 struct Lds {
   int MC;
-  int ldA;   // row stride of A  (>= r1)
-  int ldB;   // row stride of B1 / X0 rows (>= N1)
+  int K0p;   // r1 padded to a multiple of 32
+  int K0t;   // 16-wide tiles covering r1
+  int N1t;   // 16-wide tiles covering N1
+  int ld;    // row stride of Bs and X0 (>= 16*N1t, == 2 mod 32)
+  int ldA;   // row stride of As (>= K0p, == 2 mod 32)
+  int Mp;    // MC*q0 padded to a multiple of 32
   int oB, oA, oX0, oX1, oG, oI;
-  int szX0, szX1;  // per-lookup floats of X0 / X1
+  int szX1;  // per-lookup floats of X1 (T == 4)
   int bytes;
+  int dbg;   // ablation mask (bench/ablate only): phases to skip, results invalid when != 0
+  long long* stamps;  // debug: per work-group phase timestamps (100 MHz wall clock), or NULL
+  FastDiv fdD, fdD4, fdN1, fdN4, fdSl0, fdSl04, fdK0, fdK04, fdQ0, fdSl2;
 };
+
+static int g_chunk_override = 0;
+static int g_debug_skip = 0;
+static long long* g_stamps = nullptr;
+
+static int stride2(int n) {  // smallest s >= n with s % 32 == 2
+  int s = (n + 29) / 32 * 32 + 2;
+  return s;
+}
 
 static Lds make_lds(const Dims& d, int MC, bool bwd) {
   Lds L;
   memset(&L, 0, sizeof(L));
   L.MC = MC;
   const int K0 = d.k[0], N1 = d.n[0], q0 = d.q[0];
-  L.ldA = K0;
-  L.ldB = N1;
-  L.szX0 = q0 * L.ldB;
+  L.K0p = (K0 + 31) / 32 * 32;
+  L.K0t = (K0 + 15) / 16;
+  L.N1t = (N1 + 15) / 16;
+  L.ld = stride2(L.N1t * 16);
+  L.ldA = stride2(L.K0p);
+  L.Mp = (MC * q0 + 31) / 32 * 32;
   L.szX1 = (d.T == 4) ? d.m[1] * d.n[1] : 0;
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) / 4 * 4; return r; };
-  L.oB = take(K0 * L.ldB);
-  L.oA = take(MC * q0 * L.ldA);
-  L.oX0 = take(MC * L.szX0);
+  L.oB = take(L.K0p * L.ld);
+  L.oA = take(L.Mp * L.ldA);
+  L.oX0 = take(L.Mp * L.ld);
   L.oX1 = take(MC * L.szX1);
-  L.oG = take(bwd ? MC * d.D : 0);
-  L.oI = take(MC * (1 + TTX_MAX_CORES));
+  L.oG = take(bwd && d.T >= 3 ? MC * d.D : 0);
+  L.oI = take(MC * 4);  // int4 lookup records
   L.bytes = o * 4;
+  L.fdD = make_fd(d.D);
+  L.fdN1 = make_fd(N1);
+  L.fdSl0 = make_fd(d.slice[0]);
+  L.fdK0 = make_fd(K0);
+  L.fdQ0 = make_fd(q0);
+  L.fdD4 = make_fd(d.D / 4 > 0 ? d.D / 4 : 1);
+  L.fdN4 = make_fd(N1 / 4 > 0 ? N1 / 4 : 1);
+  L.fdSl04 = make_fd(d.slice[0] / 4 > 0 ? d.slice[0] / 4 : 1);
+  L.fdK04 = make_fd(K0 / 4 > 0 ? K0 / 4 : 1);
+  L.fdSl2 = make_fd(d.T > 2 ? d.slice[2] : 1);
+  L.dbg = g_debug_skip;
+  L.stamps = g_stamps;
   return L;
 }
 
-static int g_chunk_override = 0;
 
 int choose_chunk(const Dims& d) {
   if (g_chunk_override > 0) return g_chunk_override;
@@ -70,96 +138,296 @@ int choose_chunk(const Dims& d) {
 
 // ------------------------------------------------------------- kernels -----
 
-// chunk prologue shared by forward and backward: stage B1, the lookup ids and
-// the stacked core-0 slices in LDS.
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// address of element e (< q0*N1) of lookup j's X0 block: rows are padded to ld
+__device__ __forceinline__ int x0_addr(const Lds& L, int q0, int j, unsigned e) {
+  unsigned col;
+  const unsigned a = fdivmod(e, L.fdN1, col);
+  return (j * q0 + (int)a) * L.ld + (int)col;
+}
+
+// chunk prologue shared by forward and backward: stage B1, the lookup records
+// and the stacked core-0 slices in LDS (zero padded to the MFMA tile extents).
+// Dependent global loads: chunk_rec -> lrec -> core-0 rows (B1 needs only chunk_rec).
 __device__ __forceinline__ void stage_chunk(const Dims& d, const Plan& P, const CorePtrs& C,
-                                            const Lds& L, float* smem, int s, int start, int len) {
+                                            const Lds& L, float* smem, int s, int start, int len,
+                                            int rows32) {
   const int tid = threadIdx.x;
   const int K0 = d.k[0], N1 = d.n[0], q0 = d.q[0];
-  int* I = (int*)(smem + L.oI);
-  if (tid < len) {
-    const int n = P.perm[1][start + tid];
-    I[tid] = n;
-#pragma unroll
-    for (int t = 0; t < TTX_MAX_CORES; ++t)
-      if (t < d.T) I[(1 + t) * L.MC + tid] = P.sid[t][n];
-  }
-  const float* B1 = C.c[1] + (size_t)s * d.slice[1];
+  int4* I = (int4*)(smem + L.oI);
   float* Bs = smem + L.oB;
-  for (int e = tid; e < K0 * N1; e += kThreads) Bs[(e / N1) * L.ldB + (e % N1)] = B1[e];
-  __syncthreads();
   float* As = smem + L.oA;
+  const float* __restrict__ B1 = C.c[1] + (size_t)s * d.slice[1];
+  const bool padB = (L.K0p != K0) || (L.N1t * 16 != N1);
+  if (padB) {
+    for (int e = tid; e < L.K0p * L.ld; e += kThreads) Bs[e] = 0.f;
+    __syncthreads();
+  }
+  if ((N1 & 3) == 0) {
+    const int nv = K0 * N1 / 4;
+    for (int e = tid; e < nv; e += kThreads) {
+      const float4 v = ((const float4*)B1)[e];
+      unsigned c4;
+      const unsigned row = fdivmod((unsigned)e, L.fdN4, c4);
+      float2* dst = (float2*)(Bs + row * L.ld + c4 * 4);  // ld is even: 8-byte aligned
+      dst[0] = make_float2(v.x, v.y);
+      dst[1] = make_float2(v.z, v.w);
+    }
+  } else {
+    for (int e = tid; e < K0 * N1; e += kThreads) {
+      unsigned col;
+      const unsigned row = fdivmod((unsigned)e, L.fdN1, col);
+      Bs[row * L.ld + col] = B1[e];
+    }
+  }
+  if (tid < len) I[tid] = P.lrec[start + tid];
+  // zero A where the MFMA reads beyond the data: whole tile if r1 is padded,
+  // else only the rows past the chunk
+  const int mrows = len * q0;
+  if (L.K0p != K0) {
+    for (int e = tid; e < rows32 * L.ldA; e += kThreads) As[e] = 0.f;
+  } else {
+    for (int e = mrows * L.ldA + tid; e < rows32 * L.ldA; e += kThreads) As[e] = 0.f;
+  }
+  __syncthreads();
   const int sl0 = d.slice[0];  // q0 * r1
-  for (int e = tid; e < len * sl0; e += kThreads) {
-    const int j = e / sl0, rem = e % sl0;
-    const float* a = C.c[0] + (size_t)I[L.MC + j] * sl0;
-    As[(j * q0 + rem / K0) * L.ldA + (rem % K0)] = a[rem];
+  if ((K0 & 3) == 0) {
+    const int k4 = K0 / 4, per = sl0 / 4;
+    for (int e = tid; e < len * per; e += kThreads) {
+      unsigned rem, c4;
+      const unsigned j = fdivmod((unsigned)e, L.fdSl04, rem);
+      const unsigned a = fdivmod(rem, L.fdK04, c4);
+      (void)k4;
+      const float4 v = ((const float4*)(C.c[0] + (size_t)I[j].y * sl0))[rem];
+      float2* dst = (float2*)(As + (j * q0 + a) * L.ldA + c4 * 4);
+      dst[0] = make_float2(v.x, v.y);
+      dst[1] = make_float2(v.z, v.w);
+    }
+  } else {
+    for (int e = tid; e < len * sl0; e += kThreads) {
+      unsigned rem, k;
+      const unsigned j = fdivmod((unsigned)e, L.fdSl0, rem);
+      const unsigned a = fdivmod(rem, L.fdK0, k);
+      As[(j * q0 + a) * L.ldA + k] = (C.c[0] + (size_t)I[j].y * sl0)[rem];
+    }
   }
   __syncthreads();
 }
 
-// X0[rows x N1] = As[rows x K0] * Bs[K0 x N1]
-__device__ __forceinline__ void gemm_x0(const Dims& d, const Lds& L, float* smem, int rows) {
-  const int K0 = d.k[0], N1 = d.n[0];
-  const float* As = smem + L.oA;
-  const float* Bs = smem + L.oB;
-  float* X0 = smem + L.oX0;
-  for (int e = threadIdx.x; e < rows * N1; e += kThreads) {
-    const int row = e / N1, col = e % N1;
-    float acc = 0.f;
-    for (int k = 0; k < K0; ++k) acc = fmaf(As[row * L.ldA + k], Bs[k * L.ldB + col], acc);
-    X0[row * L.ldB + col] = acc;
+// ---- GEMM 1:  X0[16 x NB*16] tile row = As * Bs, k-step {k, k+8, k+16, k+24} ----
+template <int NB>
+__device__ __forceinline__ void x0_group(const Dims& d, const Lds& L, float* smem, int mt, int n0,
+                                         float* rows_out, int len) {
+  const int lane = lane_id();
+  const int i16 = lane & 15, kq = lane >> 4;
+  const float* arow = smem + L.oA + (mt * 16 + i16) * L.ldA + 8 * kq;
+  const float* bbase = smem + L.oB + 8 * kq * L.ld + n0 * 16 + i16;
+  f32x4 acc[NB];
+#pragma unroll
+  for (int x = 0; x < NB; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // software pipeline: the B fragments of k-step t+1 are read from LDS while the
+  // MFMAs of k-step t issue
+  float bcur[NB];
+#pragma unroll
+  for (int x = 0; x < NB; ++x) bcur[x] = bbase[x * 16];
+  for (int kb = 0; kb < L.K0p; kb += 32) {
+    float a[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) a[t] = arow[kb + t];
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the 8 A fragments (4 x ds_read2)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int kn = (t < 7) ? kb + t + 1 : kb + 32;  // k-steps of a block are kb+0..7 (+8*kq)
+      const float* bn = bbase + (kn < L.K0p ? kn : 0) * L.ld;  // last prefetch wraps (unused)
+      float bnxt[NB];
+#pragma unroll
+      for (int x = 0; x < NB; ++x) bnxt[x] = bn[x * 16];
+#pragma unroll
+      for (int x = 0; x < NB; ++x) acc[x] = mfma4(a[t], bcur[x], acc[x]);
+#pragma unroll
+      for (int x = 0; x < NB; ++x) bcur[x] = bnxt[x];
+      __builtin_amdgcn_sched_group_barrier(0x100, (NB + 1) / 2, 0);  // DS reads of step t+1
+      __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);            // MFMAs of step t
+    }
+  }
+  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + r
+  if (rows_out) {  // T == 2 forward: rows straight to HBM
+    const int4* I = (const int4*)(smem + L.oI);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = mt * 16 + kq * 4 + r;
+      unsigned a_;
+      const unsigned j = fdivmod((unsigned)row, L.fdQ0, a_);
+      if ((int)j < len) {
+        float* o = rows_out + (size_t)I[j].x * d.D + a_ * d.n[0];
+#pragma unroll
+        for (int x = 0; x < NB; ++x) {
+          const int col = (n0 + x) * 16 + i16;
+          if (col < d.n[0]) o[col] = acc[x][r];
+        }
+      }
+    }
+  } else {
+    float* xo = smem + L.oX0 + (mt * 16 + kq * 4) * L.ld + n0 * 16 + i16;
+#pragma unroll
+    for (int x = 0; x < NB; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xo[r * L.ld + x * 16] = acc[x][r];
   }
 }
 
-__global__ __launch_bounds__(kThreads) void fwd_kernel(Dims d, Plan P, CorePtrs C,
-                                                      float* __restrict__ rows, Lds L) {
+__device__ __forceinline__ void gemm_x0(const Dims& d, const Lds& L, float* smem, int mtiles,
+                                        float* rows_out, int len) {
+  const int w = threadIdx.x / kWave;
+  for (int mt = w; mt < mtiles; mt += kWaves) {
+    int n0 = 0;
+    for (; n0 + 8 <= L.N1t; n0 += 8) x0_group<8>(d, L, smem, mt, n0, rows_out, len);
+    if (n0 + 4 <= L.N1t) { x0_group<4>(d, L, smem, mt, n0, rows_out, len); n0 += 4; }
+    if (n0 + 2 <= L.N1t) { x0_group<2>(d, L, smem, mt, n0, rows_out, len); n0 += 2; }
+    if (n0 < L.N1t) x0_group<1>(d, L, smem, mt, n0, rows_out, len);
+  }
+}
+
+// ---- forward tail stage: out[m x NT] = x[m x k] * C[k x NT] per lookup, C from LDS or HBM ----
+// item = (lookup j, row); x addressing: row = a*nb + b -> xbase + a*sA + b*sB
+template <int NT>
+__device__ __forceinline__ void fwd_stage(int len, int m, int k, int nb, int sJ, int sA, int sB,
+                                          const float* X, const float* Cs, int cJ, bool c_lds,
+                                          const float* Cg, int slice, const int4* I, int which,
+                                          float* out_lds, int oJ, float* __restrict__ rows, int D) {
+  const FastDiv fm = make_fd(m), fnb = make_fd(nb);
+  for (int e = threadIdx.x; e < len * m; e += kThreads) {
+    unsigned row, b;
+    const unsigned j = fdivmod((unsigned)e, fm, row);
+    const unsigned a = fdivmod(row, fnb, b);
+    const float* xi = X + j * sJ + a * sA + b * sB;
+    const int sid = which == 2 ? I[j].z : I[j].w;
+    const float* c = c_lds ? Cs + j * cJ : Cg + (size_t)sid * slice;
+    float acc[NT];
+#pragma unroll
+    for (int x = 0; x < NT; ++x) acc[x] = 0.f;
+#pragma unroll 4
+    for (int kk = 0; kk < k; ++kk) {
+      const float xv = xi[kk];
+#pragma unroll
+      for (int x = 0; x < NT; ++x) acc[x] = fmaf(xv, c[kk * NT + x], acc[x]);
+    }
+    if (rows) {
+      float* o = rows + (size_t)I[j].x * D + row * NT;
+#pragma unroll
+      for (int x = 0; x < NT; ++x) o[x] = acc[x];
+    } else {
+      float* o = out_lds + j * oJ + row * NT;
+#pragma unroll
+      for (int x = 0; x < NT; ++x) o[x] = acc[x];
+    }
+  }
+}
+
+// generic (any n) version: item = (j, row, col), C from HBM
+__device__ __forceinline__ void fwd_stage_any(int len, int m, int k, int n, int nb, int sJ, int sA,
+                                              int sB, const float* X, const float* Cg, int slice,
+                                              const int4* I, int which, float* out_lds, int oJ,
+                                              float* __restrict__ rows, int D) {
+  const FastDiv fper = make_fd(m * n), fn = make_fd(n), fnb = make_fd(nb);
+  for (int e = threadIdx.x; e < len * m * n; e += kThreads) {
+    unsigned rem, col, b;
+    const unsigned j = fdivmod((unsigned)e, fper, rem);
+    const unsigned row = fdivmod(rem, fn, col);
+    const unsigned a = fdivmod(row, fnb, b);
+    const float* xi = X + j * sJ + a * sA + b * sB;
+    const int sid = which == 2 ? I[j].z : I[j].w;
+    const float* c = Cg + (size_t)sid * slice + col;
+    float acc = 0.f;
+    for (int kk = 0; kk < k; ++kk) acc = fmaf(xi[kk], c[kk * n], acc);
+    if (rows) rows[(size_t)I[j].x * D + rem] = acc;
+    else out_lds[j * oJ + rem] = acc;
+  }
+}
+
+#define TTX_NT_SWITCH(nt, CALL)          \
+  switch (nt) {                          \
+    case 1: { CALL(1); } break;          \
+    case 2: { CALL(2); } break;          \
+    case 3: { CALL(3); } break;          \
+    case 4: { CALL(4); } break;          \
+    case 5: { CALL(5); } break;          \
+    case 6: { CALL(6); } break;          \
+    case 7: { CALL(7); } break;          \
+    case 8: { CALL(8); } break;          \
+    default: break;                      \
+  }
+
+__global__ __launch_bounds__(kThreads, 2) void fwd_kernel(Dims d, Plan P, CorePtrs C,
+                                                         float* __restrict__ rows, Lds L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int chunk = blockIdx.x;
-  if (chunk >= P.hdr[0]) return;
-  const int s = P.chunk_slice[chunk];
-  const int start = P.chunk_start[chunk];
-  const int len = min(L.MC, P.off[1][s + 1] - start);
+  const int4 cr = P.chunk_rec[chunk];
+  const int s = cr.x, start = cr.y, len = cr.z;
+  if (len == 0) return;
   const int tid = threadIdx.x;
   const int q0 = d.q[0];
-  stage_chunk(d, P, C, L, smem, s, start, len);
-  gemm_x0(d, L, smem, len * q0);
-  __syncthreads();
-  const int* I = (const int*)(smem + L.oI);
-  const float* Xin = smem + L.oX0;
-  int szin = L.szX0;
-  for (int t = 1; t <= d.T - 2; ++t) {
-    const int mt = d.m[t], kt = d.k[t], nt = d.n[t];
-    const bool last = (t == d.T - 2);
-    float* Xout = smem + L.oX1;
-    const int per = mt * nt;
-    for (int e = tid; e < len * per; e += kThreads) {
-      const int j = e / per, rem = e % per;
-      const int row = rem / nt, col = rem % nt;
-      const float* ct = C.c[t + 1] + (size_t)I[(2 + t) * L.MC + j] * d.slice[t + 1];
-      const float* xi = Xin + j * szin + row * kt;
-      float acc = 0.f;
-      for (int k = 0; k < kt; ++k) acc = fmaf(xi[k], ct[k * nt + col], acc);
-      if (last) rows[(size_t)I[j] * d.D + rem] = acc;
-      else Xout[j * L.szX1 + rem] = acc;
-    }
-    __syncthreads();
-    Xin = Xout;
-    szin = L.szX1;
-  }
+  const int mrows = len * q0;
+  const int mtiles = (mrows + 15) / 16;
+  stage_chunk(d, P, C, L, smem, s, start, len, mtiles * 16);
   if (d.T == 2) {
-    const int per = d.D;  // q0 * q1
-    const int N1 = d.n[0];
-    for (int e = tid; e < len * per; e += kThreads) {
-      const int j = e / per, rem = e % per;
-      rows[(size_t)I[j] * d.D + rem] = Xin[j * L.szX0 + (rem / N1) * L.ldB + (rem % N1)];
+    gemm_x0(d, L, smem, mtiles, rows, len);
+    return;
+  }
+  if (!(L.dbg & 1)) gemm_x0(d, L, smem, mtiles, nullptr, len);
+  __syncthreads();
+  if (L.dbg & 2) return;
+  const int4* I = (const int4*)(smem + L.oI);
+  const float* X0 = smem + L.oX0;
+  float* X1 = smem + L.oX1;
+  float* Cs = smem + L.oB;  // Bs / As are dead after the GEMM: stage core slices there
+  const int cs_cap = L.oX0 - L.oB;
+  // tail stage t = 1: x_1[m1 x n1] = x_0[m1 x k1] * core_2[i_2][k1 x n1]
+  {
+    const int k1 = d.k[1], n1 = d.n[1], m1 = d.m[1], q1 = d.q[1];
+    const bool last = (d.T == 3);
+    const int sl2 = d.slice[2];
+    if (n1 <= 8) {
+      const bool c_lds = len * sl2 <= cs_cap;
+      if (c_lds) {
+        for (int e = tid; e < len * sl2; e += kThreads) {
+          unsigned rem;
+          const unsigned j = fdivmod((unsigned)e, L.fdSl2, rem);
+          Cs[e] = (C.c[2] + (size_t)I[j].z * sl2)[rem];
+        }
+        __syncthreads();
+      }
+#define CALL(NT) fwd_stage<NT>(len, m1, k1, q1, q0 * L.ld, L.ld, k1, X0, Cs, sl2, c_lds, C.c[2], sl2, I, 2, \
+                               X1, L.szX1, last ? rows : nullptr, d.D)
+      TTX_NT_SWITCH(n1, CALL)
+#undef CALL
+    } else {
+      fwd_stage_any(len, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, C.c[2], sl2, I, 2, X1, L.szX1,
+                    last ? rows : nullptr, d.D);
+    }
+  }
+  if (d.T == 4) {
+    __syncthreads();
+    // tail stage t = 2: row[m2 x n2] = x_1[m2 x k2] * core_3[i_3][k2 x n2]
+    const int k2 = d.k[2], n2 = d.n[2], m2 = d.m[2];
+    if (n2 <= 8) {
+#define CALL(NT) fwd_stage<NT>(len, m2, k2, m2, L.szX1, 0, k2, X1, nullptr, 0, false, C.c[3], d.slice[3], I, 3, \
+                               nullptr, 0, rows, d.D)
+      TTX_NT_SWITCH(n2, CALL)
+#undef CALL
+    } else {
+      fwd_stage_any(len, m2, k2, n2, m2, L.szX1, 0, k2, X1, C.c[3], d.slice[3], I, 3, nullptr, 0, rows, d.D);
     }
   }
 }
 
 // out[table,row,:] += sum of the run's rows, in index order (run = consecutive
 // lookups with equal (rowidx, tableidx); reference reduce_output_kernel
-// cu:920-962).  One 32-lane group per lookup; only run heads work.
+// cu:920-962).  One 32-lane group per lookup; only run heads work.  The run
+// length is found with one ballot per 32 candidates.
 __global__ __launch_bounds__(kThreads) void pool_kernel(int N, int B, int D,
                                                        const int64_t* __restrict__ rowidx,
                                                        const int64_t* __restrict__ tableidx,
@@ -170,12 +438,27 @@ __global__ __launch_bounds__(kThreads) void pool_kernel(int N, int B, int D,
   if (n >= N) return;
   const int64_t r = rowidx[n], tb = tableidx[n];
   if (n > 0 && rowidx[n - 1] == r && tableidx[n - 1] == tb) return;
+  // half-wave cooperative scan for the end of the run
+  const unsigned long long half = (threadIdx.x & 32) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
   int sl = 1;
-  while (n + sl < N && rowidx[n + sl] == r && tableidx[n + sl] == tb) ++sl;
+  for (;;) {
+    const int c = n + sl + l;
+    const bool same = c < N && rowidx[c] == r && tableidx[c] == tb;
+    unsigned long long m = (__ballot(!same) & half) >> (threadIdx.x & 32);
+    if (m) { sl += __builtin_ctzll(m); break; }
+    sl += 32;
+  }
   float* o = out + ((size_t)tb * B + r) * D;
+  const float* src = rows + (size_t)n * D;
   for (int e = l; e < D; e += 32) {
     float acc = o[e];
-    for (int j = 0; j < sl; ++j) acc += rows[(size_t)(n + j) * D + e];
+    int j = 0;
+    for (; j + 4 <= sl; j += 4) {
+      const float v0 = src[(size_t)j * D + e], v1 = src[(size_t)(j + 1) * D + e];
+      const float v2 = src[(size_t)(j + 2) * D + e], v3 = src[(size_t)(j + 3) * D + e];
+      acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; j < sl; ++j) acc += src[(size_t)j * D + e];
     o[e] = acc;
   }
 }
@@ -184,157 +467,444 @@ struct Partials {
   float* pc[TTX_MAX_CORES];  // pc[1] is per CHUNK, the others per lookup
 };
 
-__global__ __launch_bounds__(kThreads) void bwd_kernel(Dims d, Plan P, CorePtrs C, int B,
-                                                      const int64_t* __restrict__ rowidx,
-                                                      const float* __restrict__ d_output,
-                                                      Partials PC, Lds L) {
+// ---- backward tail stage, fused: for one (lookup j, column kk) pair walk the rows once,
+//   d core partial[kk][0..NT) = sum_row x[row][kk] * G[row][0..NT)     -> HBM
+//   d x[row][kk]              = sum_c   G[row][c]  * C[kk][c]          -> over x in place
+// (only this thread ever reads x[.][kk] of lookup j, so in place is safe without a barrier)
+template <int NT>
+__device__ __forceinline__ void bwd_stage_fused(int len, int k, int na, int nb, int sJ, int sA,
+                                                int sB, float* X, const float* G, int gJ,
+                                                const float* Cg, int slice, const int4* I, int which,
+                                                float* __restrict__ pc) {
+  const FastDiv fk = make_fd(k);
+  for (int e = threadIdx.x; e < len * k; e += kThreads) {
+    unsigned kk;
+    const unsigned j = fdivmod((unsigned)e, fk, kk);
+    const int sid = which == 2 ? I[j].z : I[j].w;
+    const float* cg = Cg + (size_t)sid * slice + kk * NT;
+    float c[NT], acc[NT];
+#pragma unroll
+    for (int x = 0; x < NT; ++x) { c[x] = cg[x]; acc[x] = 0.f; }
+    float* xb = X + j * sJ + kk;
+    const float* g = G + j * gJ;
+    for (int a = 0; a < na; ++a) {
+      float* xa = xb + a * sA;
+#pragma unroll 4
+      for (int b = 0; b < nb; ++b) {
+        const float xv = xa[b * sB];
+        float dx = 0.f;
+#pragma unroll
+        for (int x = 0; x < NT; ++x) {
+          const float gv = g[x];
+          acc[x] = fmaf(xv, gv, acc[x]);
+          dx = fmaf(gv, c[x], dx);
+        }
+        xa[b * sB] = dx;
+        g += NT;
+      }
+    }
+    float* o = pc + (size_t)I[j].x * slice + kk * NT;
+#pragma unroll
+    for (int x = 0; x < NT; ++x) o[x] = acc[x];
+  }
+}
+
+// generic two-phase version (any n): (a) partial, barrier, (b) d x in place
+__device__ __forceinline__ void bwd_stage_any(int len, int m, int k, int n, int nb, int sJ, int sA,
+                                              int sB, float* X, const float* G, int gJ,
+                                              const float* Cg, int slice, const int4* I, int which,
+                                              float* __restrict__ pc) {
+  const FastDiv fn = make_fd(n), fnb = make_fd(nb);
+  {
+    const FastDiv fp = make_fd(k * n);
+    for (int e = threadIdx.x; e < len * k * n; e += kThreads) {
+      unsigned rem, col;
+      const unsigned j = fdivmod((unsigned)e, fp, rem);
+      const unsigned kk = fdivmod(rem, fn, col);
+      const float* gi = G + j * gJ + col;
+      const float* xj = X + j * sJ + kk;
+      float acc = 0.f;
+      int row = 0;
+      for (int a = 0; a * nb < m; ++a)
+        for (int b = 0; b < nb; ++b, ++row) acc = fmaf(xj[a * sA + b * sB], gi[row * n], acc);
+      pc[(size_t)I[j].x * slice + rem] = acc;
+    }
+  }
+  __syncthreads();
+  {
+    const FastDiv fp = make_fd(m * k), fk = make_fd(k);
+    for (int e = threadIdx.x; e < len * m * k; e += kThreads) {
+      unsigned rem, kk, b;
+      const unsigned j = fdivmod((unsigned)e, fp, rem);
+      const unsigned row = fdivmod(rem, fk, kk);
+      const unsigned a = fdivmod(row, fnb, b);
+      const int sid = which == 2 ? I[j].z : I[j].w;
+      const float* ct = Cg + (size_t)sid * slice + kk * n;
+      const float* gi = G + j * gJ + row * n;
+      float acc = 0.f;
+      for (int c = 0; c < n; ++c) acc = fmaf(gi[c], ct[c], acc);
+      X[j * sJ + a * sA + b * sB + kk] = acc;
+    }
+  }
+}
+
+// ---- GEMM 2: d core_1 partial tile(s) = As^T * dX0, k-step rows {m, m+8, m+16, m+24} ----
+template <int KB, bool TWO>
+__device__ __forceinline__ void db1_group(const Dims& d, const Lds& L, const float* smem, int np,
+                                          int k0t, int rows32, float* __restrict__ pc) {
+  const int lane = lane_id();
+  const int i16 = lane & 15, kq = lane >> 4;
+  const float* xr = smem + L.oX0 + 8 * kq * L.ld + np * 32 + i16;
+  const float* ar = smem + L.oA + 8 * kq * L.ldA + k0t * 16 + i16;
+  f32x4 acc[2][KB];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < KB; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // software pipeline: operands of k-step t+1 are read while the MFMAs of step t issue
+  float bc0 = xr[0], bc1 = TWO ? xr[16] : 0.f, ac[KB];
+#pragma unroll
+  for (int y = 0; y < KB; ++y) ac[y] = ar[y * 16];
+  for (int mb = 0; mb < rows32; mb += 32) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int mx = (t < 7) ? mb + t + 1 : mb + 32;  // row steps of a block are mb+0..7 (+8*kq)
+      const int mn = (mx < rows32) ? mx : 0;          // last prefetch wraps (unused)
+      const float bn0 = xr[mn * L.ld];
+      const float bn1 = TWO ? xr[mn * L.ld + 16] : 0.f;
+      float an[KB];
+#pragma unroll
+      for (int y = 0; y < KB; ++y) an[y] = ar[mn * L.ldA + y * 16];
+#pragma unroll
+      for (int y = 0; y < KB; ++y) {
+        acc[0][y] = mfma4(ac[y], bc0, acc[0][y]);
+        if (TWO) acc[1][y] = mfma4(ac[y], bc1, acc[1][y]);
+      }
+      bc0 = bn0;
+      bc1 = bn1;
+#pragma unroll
+      for (int y = 0; y < KB; ++y) ac[y] = an[y];
+      __builtin_amdgcn_sched_group_barrier(0x100, (TWO ? 1 : 1) + (KB + 1) / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, (TWO ? 2 : 1) * KB, 0);
+    }
+  }
+  const int K0 = d.k[0], N1 = d.n[0];
+#pragma unroll
+  for (int x = 0; x < (TWO ? 2 : 1); ++x) {
+    const int col = (np * 2 + x) * 16 + i16;
+#pragma unroll
+    for (int y = 0; y < KB; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = (k0t + y) * 16 + kq * 4 + r;
+        if (kk < K0 && col < N1) pc[kk * N1 + col] = acc[x][y][r];
+      }
+  }
+}
+
+// ---- GEMM 3: d core_0 partial rows = dX0 * Bs^T, k-step columns {c, c+1, c+2, c+3} ----
+template <int KB>
+__device__ __forceinline__ void da_group(const Dims& d, const Lds& L, const float* smem, int mt,
+                                         int k0t, int mrows, float* __restrict__ pc) {
+  const int lane = lane_id();
+  const int i16 = lane & 15, kq = lane >> 4;
+  const float* xr = smem + L.oX0 + (mt * 16 + i16) * L.ld + kq;
+  const float* br = smem + L.oB + (k0t * 16 + i16) * L.ld + kq;
+  const int ncols = L.N1t * 16;
+  f32x4 acc[KB];
+#pragma unroll
+  for (int y = 0; y < KB; ++y) acc[y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // software pipeline over 16-column blocks: the 4 k-steps of block c+16 are read while
+  // the MFMAs of block c issue
+  float ac[4], bc[4][KB];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    ac[u] = xr[u * 4];
+#pragma unroll
+    for (int y = 0; y < KB; ++y) bc[u][y] = br[y * 16 * L.ld + u * 4];
+  }
+  for (int c = 0; c < ncols; c += 16) {
+    const int cn = (c + 16 < ncols) ? c + 16 : 0;  // last prefetch wraps (unused)
+    float an[4], bn[4][KB];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      an[u] = xr[cn + u * 4];
+#pragma unroll
+      for (int y = 0; y < KB; ++y) bn[u][y] = br[y * 16 * L.ld + cn + u * 4];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int y = 0; y < KB; ++y) acc[y] = mfma4(ac[u], bc[u][y], acc[y]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ac[u] = an[u];
+#pragma unroll
+      for (int y = 0; y < KB; ++y) bc[u][y] = bn[u][y];
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * KB, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * KB, 0);
+  }
+  const int4* I = (const int4*)(smem + L.oI);
+  const int K0 = d.k[0], sl0 = d.slice[0];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = mt * 16 + kq * 4 + r;
+    if (row < mrows) {
+      unsigned a_;
+      const unsigned j = fdivmod((unsigned)row, L.fdQ0, a_);
+      float* o = pc + (size_t)I[j].x * sl0 + a_ * K0;
+#pragma unroll
+      for (int y = 0; y < KB; ++y) {
+        const int kk = (k0t + y) * 16 + i16;
+        if (kk < K0) o[kk] = acc[y][r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void bwd_kernel(Dims d, Plan P, CorePtrs C, int B,
+                                                         const int64_t* __restrict__ rowidx,
+                                                         const float* __restrict__ d_output,
+                                                         Partials PC, Lds L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int chunk = blockIdx.x;
-  if (chunk >= P.hdr[0]) return;
-  const int s = P.chunk_slice[chunk];
-  const int start = P.chunk_start[chunk];
-  const int len = min(L.MC, P.off[1][s + 1] - start);
+#define STAMP(i) do { if (L.stamps && threadIdx.x == 0) L.stamps[(size_t)chunk * 16 + (i)] = wall_clock64(); } while (0)
+  STAMP(0);
+  const int4 cr = P.chunk_rec[chunk];
+  const int s = cr.x, start = cr.y, len = cr.z;
+  if (len == 0) return;
+  STAMP(1);
   const int tid = threadIdx.x;
-  const int T = d.T, q0 = d.q[0], K0 = d.k[0], N1 = d.n[0], D = d.D;
-  stage_chunk(d, P, C, L, smem, s, start, len);
-  const int* I = (const int*)(smem + L.oI);
+  const int T = d.T, q0 = d.q[0], D = d.D;
+  const int mrows = len * q0;
+  const int rows32 = (mrows + 31) / 32 * 32;  // K extent of the dB1 GEMM
+  const int mtiles = (mrows + 15) / 16;
+  stage_chunk(d, P, C, L, smem, s, start, len, rows32);
+  STAMP(2);
+  if (L.dbg & 16) return;
+  const int4* I = (const int4*)(smem + L.oI);
   float* X0 = smem + L.oX0;
   float* X1 = smem + L.oX1;
   float* Gb = smem + L.oG;
   const int table = s / d.p[1];
 
   if (T == 2) {
-    // dX0 is the bag gradient itself: [q0 x q1]
+    // dX0 is the bag gradient itself: [q0 x q1]; zero the MFMA padding
+    for (int e = tid; e < rows32 * L.ld; e += kThreads) X0[e] = 0.f;
+    __syncthreads();
     for (int e = tid; e < len * D; e += kThreads) {
-      const int j = e / D, rem = e % D;
-      const float g = d_output[((size_t)table * B + rowidx[I[j]]) * D + rem];
-      X0[j * L.szX0 + (rem / N1) * L.ldB + (rem % N1)] = g;
+      unsigned rem;
+      const unsigned j = fdivmod((unsigned)e, L.fdD, rem);
+      X0[x0_addr(L, q0, j, rem)] = d_output[((size_t)table * B + rowidx[I[j].x]) * D + rem];
     }
     __syncthreads();
   } else {
     // bag gradients of the chunk's lookups
-    for (int e = tid; e < len * D; e += kThreads) {
-      const int j = e / D, rem = e % D;
-      Gb[j * D + rem] = d_output[((size_t)table * B + rowidx[I[j]]) * D + rem];
+    if ((D & 3) == 0) {
+      const int d4 = D / 4;
+      for (int e = tid; e < len * d4; e += kThreads) {
+        unsigned rem;
+        const unsigned j = fdivmod((unsigned)e, L.fdD4, rem);
+        ((float4*)Gb)[e] = ((const float4*)(d_output + ((size_t)table * B + rowidx[I[j].x]) * D))[rem];
+      }
+    } else {
+      for (int e = tid; e < len * D; e += kThreads) {
+        unsigned rem;
+        const unsigned j = fdivmod((unsigned)e, L.fdD, rem);
+        Gb[e] = d_output[((size_t)table * B + rowidx[I[j].x]) * D + rem];
+      }
     }
-    // recompute the forward intermediates x_0 (.. x_{T-3})
-    gemm_x0(d, L, smem, len * q0);
+    // recompute the forward intermediate x_0 (rows up to rows32: zero A rows -> zero X0 rows)
+    STAMP(3);
+    if (!(L.dbg & 1)) gemm_x0(d, L, smem, rows32 / 16, nullptr, len);
     __syncthreads();
+    STAMP(4);
     if (T == 4) {
-      const int mt = d.m[1], kt = d.k[1], nt = d.n[1], per = mt * nt;
-      for (int e = tid; e < len * per; e += kThreads) {
-        const int j = e / per, rem = e % per, row = rem / nt, col = rem % nt;
-        const float* ct = C.c[2] + (size_t)I[3 * L.MC + j] * d.slice[2];
-        const float* xi = X0 + j * L.szX0 + row * kt;
-        float acc = 0.f;
-        for (int k = 0; k < kt; ++k) acc = fmaf(xi[k], ct[k * nt + col], acc);
-        X1[j * L.szX1 + rem] = acc;
+      // x_1 = x_0 * core_2[i_2]  (needed by the gradient of core 3)
+      const int k1 = d.k[1], n1 = d.n[1], m1 = d.m[1], q1 = d.q[1];
+      if (n1 <= 8) {
+#define CALL(NT) fwd_stage<NT>(len, m1, k1, q1, q0 * L.ld, L.ld, k1, X0, nullptr, 0, false, C.c[2], d.slice[2], I, 2, \
+                               X1, L.szX1, nullptr, D)
+        TTX_NT_SWITCH(n1, CALL)
+#undef CALL
+      } else {
+        fwd_stage_any(len, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, C.c[2], d.slice[2], I, 2, X1, L.szX1, nullptr, D);
+      }
+      __syncthreads();
+      // stage t = 2 on x_1 [m2 x k2] with G = bag gradient [m2 x n2]
+      const int m2 = d.m[2], k2 = d.k[2], n2 = d.n[2];
+      if (n2 <= 8) {
+#define CALL(NT) bwd_stage_fused<NT>(len, k2, 1, m2, L.szX1, 0, k2, X1, Gb, D, C.c[3], d.slice[3], I, 3, PC.pc[3])
+        TTX_NT_SWITCH(n2, CALL)
+#undef CALL
+      } else {
+        bwd_stage_any(len, m2, k2, n2, m2, L.szX1, 0, k2, X1, Gb, D, C.c[3], d.slice[3], I, 3, PC.pc[3]);
       }
       __syncthreads();
     }
-    // tail stages t = T-2 .. 1
-    for (int t = T - 2; t >= 1; --t) {
-      const int mt = d.m[t], kt = d.k[t], nt = d.n[t];
-      float* Xin = (t == 1) ? X0 : X1;           // x_{t-1}: [mt x kt] per lookup
-      const int szin = (t == 1) ? L.szX0 : L.szX1;
-      const float* Gin = (t == T - 2) ? Gb : X1;  // d x_t : [mt x nt] per lookup
-      const int szg = (t == T - 2) ? D : L.szX1;
-      // (a) d core_{t+1}[i_{t+1}] partial = x_{t-1}^T * G   -> HBM, per lookup
-      {
-        const int per = kt * nt;
-        float* pc = PC.pc[t + 1];
-        for (int e = tid; e < len * per; e += kThreads) {
-          const int j = e / per, rem = e % per, kk = rem / nt, col = rem % nt;
-          const float* xi = Xin + j * szin + kk;
-          const float* gi = Gin + j * szg + col;
-          float acc = 0.f;
-          for (int r = 0; r < mt; ++r) acc = fmaf(xi[r * kt], gi[r * nt], acc);
-          pc[(size_t)I[j] * d.slice[t + 1] + rem] = acc;
-        }
-      }
-      __syncthreads();
-      // (b) d x_{t-1} = G * core_{t+1}[i_{t+1}]^T, over x_{t-1} in place
-      {
-        const int per = mt * kt;
-        for (int e = tid; e < len * per; e += kThreads) {
-          const int j = e / per, rem = e % per, row = rem / kt, kk = rem % kt;
-          const float* ct = C.c[t + 1] + (size_t)I[(2 + t) * L.MC + j] * d.slice[t + 1] + kk * nt;
-          const float* gi = Gin + j * szg + row * nt;
-          float acc = 0.f;
-          for (int c = 0; c < nt; ++c) acc = fmaf(gi[c], ct[c], acc);
-          Xin[j * szin + rem] = acc;
-        }
+    // stage t = 1 on x_0 (row = a*q1 + b at a*ld + b*k1) with G1 = bag gradient (T == 3) or d x_1
+    if (!(L.dbg & 2)) {
+      const int m1 = d.m[1], k1 = d.k[1], n1 = d.n[1], q1 = d.q[1];
+      const float* Gin = (T == 3) ? Gb : X1;
+      const int gJ = (T == 3) ? D : L.szX1;
+      if (n1 <= 8) {
+#define CALL(NT) bwd_stage_fused<NT>(len, k1, q0, q1, q0 * L.ld, L.ld, k1, X0, Gin, gJ, C.c[2], d.slice[2], I, 2, PC.pc[2])
+        TTX_NT_SWITCH(n1, CALL)
+#undef CALL
+      } else {
+        bwd_stage_any(len, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, Gin, gJ, C.c[2], d.slice[2], I, 2, PC.pc[2]);
       }
       __syncthreads();
     }
   }
-  // chunk GEMMs on dX0 [rows x N1]
-  const int rowsM = len * q0;
-  const float* As = smem + L.oA;
-  const float* Bs = smem + L.oB;
-  {
-    // d core_1[slice] partial = As^T * dX0  -> HBM, per chunk
+
+  // ---- chunk GEMMs on dX0 [rows x N1] ---------------------------------------
+  STAMP(5);
+  const int w = tid / kWave;
+  if (!(L.dbg & 4)) {
+    // (2) d core_1[slice] partial [r1 x N1] = As^T * dX0   -> HBM, per chunk
     float* pc = PC.pc[1] + (size_t)chunk * d.slice[1];
-    for (int e = tid; e < K0 * N1; e += kThreads) {
-      const int kk = e / N1, col = e % N1;
-      float acc = 0.f;
-      for (int r = 0; r < rowsM; ++r) acc = fmaf(As[r * L.ldA + kk], X0[r * L.ldB + col], acc);
-      pc[e] = acc;
+    const int npairs = (L.N1t + 1) / 2;
+    for (int np = w; np < npairs; np += kWaves) {
+      const bool two = (np * 2 + 1) < L.N1t;
+      int k0t = 0;
+      while (k0t < L.K0t) {
+        const int rem = L.K0t - k0t;
+        if (rem >= 4) { if (two) db1_group<4, true>(d, L, smem, np, k0t, rows32, pc); else db1_group<4, false>(d, L, smem, np, k0t, rows32, pc); k0t += 4; }
+        else if (rem >= 2) { if (two) db1_group<2, true>(d, L, smem, np, k0t, rows32, pc); else db1_group<2, false>(d, L, smem, np, k0t, rows32, pc); k0t += 2; }
+        else { if (two) db1_group<1, true>(d, L, smem, np, k0t, rows32, pc); else db1_group<1, false>(d, L, smem, np, k0t, rows32, pc); k0t += 1; }
+      }
     }
   }
-  {
-    // d core_0[i_0] partial = dX0 * Bs^T  -> HBM, per lookup ([q0 x r1] rows)
+  STAMP(6);
+  if (!(L.dbg & 8)) {
+    // (3) d core_0[i_0] partials [rows x r1] = dX0 * Bs^T  -> HBM, per lookup
     float* pc = PC.pc[0];
-    const int sl0 = d.slice[0];
-    for (int e = tid; e < len * sl0; e += kThreads) {
-      const int j = e / sl0, rem = e % sl0, a = rem / K0, kk = rem % K0;
-      const float* xr = X0 + (j * q0 + a) * L.ldB;
-      const float* br = Bs + kk * L.ldB;
-      float acc = 0.f;
-      for (int c = 0; c < N1; ++c) acc = fmaf(xr[c], br[c], acc);
-      pc[(size_t)I[j] * sl0 + rem] = acc;
+    for (int mt = w; mt < mtiles; mt += kWaves) {
+      int k0t = 0;
+      while (k0t < L.K0t) {
+        const int rem = L.K0t - k0t;
+        if (rem >= 4) { da_group<4>(d, L, smem, mt, k0t, mrows, pc); k0t += 4; }
+        else if (rem >= 2) { da_group<2>(d, L, smem, mt, k0t, mrows, pc); k0t += 2; }
+        else { da_group<1>(d, L, smem, mt, k0t, mrows, pc); k0t += 1; }
+      }
     }
   }
+  STAMP(7);
+#undef STAMP
 }
 
-// one work-group per core slice: sum the slice's partials in index order and
+__device__ __forceinline__ float apply_one(int optim, float g, float w, float lr, float eps, float* st) {
+  if (optim == TTX_OPTIM_SGD) return w - lr * g;
+  const float s = *st + g * g;
+  *st = s;
+  return w - lr * g / (sqrtf(s) + eps);
+}
+
+// one work-group per core slice: sum the slice's partials in a fixed order and
 // apply.  DENSE writes the gradient (zeros for untouched slices: no memset of
 // d_tt_cores is needed); SGD / ADAGRAD skip untouched slices (g == 0).
+// Short slices with many partial rows: the 256 threads form G = 256/V groups
+// (V = lanes covering the slice, 4 floats per lane); group g sums partials g,
+// g+G, .. in index order, the G group sums are then added in group order
+// through LDS.  Long slices: 4 floats per thread, partials summed in order.
 __global__ __launch_bounds__(kThreads) void reduce_apply_kernel(Dims d, Plan P, Partials PC,
                                                                int optim, float lr, float eps,
                                                                CorePtrs W, CorePtrs St,
                                                                CorePtrs DW) {
+  __shared__ float4 red[kThreads];
   int b = blockIdx.x;
   int t = 0;
   while (t < d.T - 1 && b >= d.S[t]) { b -= d.S[t]; ++t; }
   const int s = b;
   const int sl = d.slice[t];
   int beg, end;
-  const int* list;
+  const int* __restrict__ list;
   if (t == 1) { beg = P.chunk_off[s]; end = P.chunk_off[s + 1]; list = nullptr; }
   else { beg = P.off[t][s]; end = P.off[t][s + 1]; list = P.perm[t]; }
   const size_t base = (size_t)s * sl;
+  const int tid = threadIdx.x;
+  float* __restrict__ dw = DW.c[t];
+  float* __restrict__ wt = W.c[t];
+  float* __restrict__ stt = St.c[t];
   if (beg == end) {
     if (optim == TTX_OPTIM_DENSE)
-      for (int e = threadIdx.x; e < sl; e += kThreads) DW.c[t][base + e] = 0.f;
+      for (int e = tid; e < sl; e += kThreads) dw[base + e] = 0.f;
     return;
   }
-  const float* pc = PC.pc[t];
-  for (int e = threadIdx.x; e < sl; e += kThreads) {
-    float g = 0.f;
-    if (t == 1) {
-      for (int i = beg; i < end; ++i) g += pc[(size_t)i * sl + e];
-    } else {
-      for (int i = beg; i < end; ++i) g += pc[(size_t)list[i] * sl + e];
+  const float* __restrict__ pc = PC.pc[t];
+  const int cnt = end - beg;
+  if ((sl & 3) == 0) {
+    const int V = sl / 4;  // float4 lanes per partial row
+    if (V <= kThreads / 2 && cnt >= 4) {
+      int G = kThreads / V;
+      if (G > cnt) G = cnt;
+      const int g = tid / V, v = tid - g * V;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g < G) {
+        for (int i = beg + g; i < end; i += G) {
+          const size_t row = list ? (size_t)list[i] : (size_t)i;
+          const float4 x = ((const float4*)(pc + row * sl))[v];
+          acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        red[tid] = acc;
+      }
+      __syncthreads();
+      if (g != 0) return;
+      for (int k = 1; k < G; ++k) {
+        const float4 x = red[k * V + v];
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+      }
+      const size_t o = base + (size_t)v * 4;
+      if (optim == TTX_OPTIM_DENSE) {
+        *(float4*)(dw + o) = acc;
+      } else {
+        float4 wv = *(const float4*)(wt + o);
+        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (optim == TTX_OPTIM_ADAGRAD) sv = *(const float4*)(stt + o);
+        wv.x = apply_one(optim, acc.x, wv.x, lr, eps, &sv.x);
+        wv.y = apply_one(optim, acc.y, wv.y, lr, eps, &sv.y);
+        wv.z = apply_one(optim, acc.z, wv.z, lr, eps, &sv.z);
+        wv.w = apply_one(optim, acc.w, wv.w, lr, eps, &sv.w);
+        *(float4*)(wt + o) = wv;
+        if (optim == TTX_OPTIM_ADAGRAD) *(float4*)(stt + o) = sv;
+      }
+      return;
     }
+    for (int v = tid; v < V; v += kThreads) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = beg; i < end; ++i) {
+        const size_t row = list ? (size_t)list[i] : (size_t)i;
+        const float4 x = ((const float4*)(pc + row * sl))[v];
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+      }
+      const size_t o = base + (size_t)v * 4;
+      if (optim == TTX_OPTIM_DENSE) {
+        *(float4*)(dw + o) = acc;
+      } else {
+        float4 wv = *(const float4*)(wt + o);
+        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (optim == TTX_OPTIM_ADAGRAD) sv = *(const float4*)(stt + o);
+        wv.x = apply_one(optim, acc.x, wv.x, lr, eps, &sv.x);
+        wv.y = apply_one(optim, acc.y, wv.y, lr, eps, &sv.y);
+        wv.z = apply_one(optim, acc.z, wv.z, lr, eps, &sv.z);
+        wv.w = apply_one(optim, acc.w, wv.w, lr, eps, &sv.w);
+        *(float4*)(wt + o) = wv;
+        if (optim == TTX_OPTIM_ADAGRAD) *(float4*)(stt + o) = sv;
+      }
+    }
+    return;
+  }
+  for (int e = tid; e < sl; e += kThreads) {
+    float g = 0.f;
+    for (int i = beg; i < end; ++i) g += pc[(list ? (size_t)list[i] : (size_t)i) * sl + e];
     if (optim == TTX_OPTIM_DENSE) {
-      DW.c[t][base + e] = g;
-    } else if (optim == TTX_OPTIM_SGD) {
-      W.c[t][base + e] -= lr * g;
+      dw[base + e] = g;
     } else {
-      const float st = St.c[t][base + e] + g * g;
-      St.c[t][base + e] = st;
-      W.c[t][base + e] -= lr * g / (sqrtf(st) + eps);
+      float sv = optim == TTX_OPTIM_ADAGRAD ? stt[base + e] : 0.f;
+      wt[base + e] = apply_one(optim, g, wt[base + e], lr, eps, &sv);
+      if (optim == TTX_OPTIM_ADAGRAD) stt[base + e] = sv;
     }
   }
 }
@@ -379,6 +949,18 @@ static int run_rows(const Dims& d, long long nnz, const Plan& P, const float* co
 using namespace ttx;
 
 extern "C" {
+
+// debug: device buffer of 16 int64 stamps per work-group (NULL = off), scripts/phase_times.py
+int ttx_debug_stamps(void* device_buffer) {
+  g_stamps = (long long*)device_buffer;
+  return TTX_OK;
+}
+
+// ablation knob for scripts/ablate.py: skip kernel phases (results become invalid)
+int ttx_debug_skip(int32_t mask) {
+  g_debug_skip = mask;
+  return TTX_OK;
+}
 
 int ttx_set_chunk(int32_t mc) {
   if (mc < 0 || mc > 64) TTX_FAIL(TTX_EINVAL, "chunk %d out of range 0..64", mc);

@@ -231,6 +231,12 @@ int ttx_profile_read(int which, int64_t* launches, double* total_ms);
 
 /* tuning knob (bench / tests): indices per work-group chunk; 0 = heuristic */
 int ttx_set_chunk(int32_t indices_per_chunk);
+/* ablation knob (scripts/ablate.py only): bit mask of kernel phases to skip;
+ * results are INVALID while it is non-zero.  0 = normal operation. */
+int ttx_debug_skip(int32_t mask);
+/* debug (scripts/phase_times.py only): device buffer receiving 16 int64 wall-clock
+ * stamps per backward work-group; NULL (default) = off. */
+int ttx_debug_stamps(void* device_buffer);
 
 #ifdef __cplusplus
 }

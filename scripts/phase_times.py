@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-phase wall-clock stamps of the backward contraction work-groups at cfg2
+(debug facility ttx_debug_stamps).  Prints, relative to the first work-group's
+entry, the distribution of each phase boundary and of each phase's duration."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "fbtt-embedding_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import gen_inputs as G, tt_embeddings as E, tt_embeddings_ops as ops
+
+dev = torch.device("cuda:0")
+p, q, r = [200, 220, 250], [4, 4, 4], [32, 32]
+E_, D = int(np.prod(p)), int(np.prod(q))
+m = ops.TTEmbeddingBag(E_, D, r, p, q, sparse=True, use_cache=False, weight_dist="uniform", device=dev)
+reqs = [(torch.from_numpy(i).to(dev), torch.from_numpy(o).to(dev)) for i, o in G.make_requests(1, 10, 512, 1, 20, E_)]
+grad = torch.from_numpy(G.make_grad(2, 1, 512, D)[0]).to(dev)
+for k in range(5):
+    m(*reqs[k]).backward(grad)
+buf = torch.zeros(1024 * 16, dtype=torch.int64, device=dev)
+torch.cuda.synchronize()
+E.lib().ttx_debug_stamps(E.C.c_void_p(buf.data_ptr()))
+m(*reqs[5]).backward(grad)
+torch.cuda.synchronize()
+E.lib().ttx_debug_stamps(None)
+st = buf.cpu().numpy().reshape(-1, 16)
+live = st[:, 7] > 0
+st = st[live][:, :8].astype(np.float64) / 100.0  # 100 MHz -> us
+t0 = st[:, 0].min()
+names = ["entry", "chunk_rec", "staged", "G loaded", "x0 recomputed", "tail done", "dB1 done", "dA done"]
+print(f"{live.sum()} work-groups; times in us relative to the first entry")
+for i, nm in enumerate(names):
+    v = st[:, i] - t0
+    print(f"  {nm:14s} min {v.min():6.2f}  med {np.median(v):6.2f}  max {v.max():6.2f}")
+print("phase durations (per work-group):")
+for i in range(1, 8):
+    v = st[:, i] - st[:, i - 1]
+    print(f"  {names[i-1]:>14s} -> {names[i]:14s} min {v.min():6.2f}  med {np.median(v):6.2f}  max {v.max():6.2f}")
