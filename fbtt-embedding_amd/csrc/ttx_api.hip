@@ -16,6 +16,18 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static UDiv make_udiv(unsigned long long dd) {
+  UDiv v;
+  const unsigned d = (unsigned)dd;
+  v.d = d;
+  int l = 0;
+  while ((1ull << l) < dd) ++l;  // ceil(log2 d)
+  v.m = (unsigned)(((1ull << 32) * ((1ull << l) - dd)) / dd + 1);
+  v.sh1 = l < 1 ? l : 1;
+  v.sh2 = l > 1 ? l - 1 : 0;
+  return v;
+}
+
 int make_dims(const ttx_geom* g, Dims* d) {
   if (!g) TTX_FAIL(TTX_EINVAL, "geometry is NULL");
   if (g->T < 2 || g->T > TTX_MAX_CORES)
@@ -44,6 +56,11 @@ int make_dims(const ttx_geom* g, Dims* d) {
     d->S[t] = (int)S;
   }
   for (int t = 0; t <= g->T; ++t) d->r[t] = g->r[t];
+  d->idx32 = Lv <= (1ll << 32);
+  for (int t = 0; t < g->T; ++t) {
+    d->dvL[t] = make_udiv(d->idx32 ? (unsigned long long)d->L[t] : 1ull);
+    d->dvP[t] = make_udiv((unsigned long long)g->p[t]);
+  }
   if (Dv > (1ll << 24)) TTX_FAIL(TTX_EINVAL, "embedding_dim %lld too large", Dv);
   d->D = (int)Dv;
   int m_ = g->q[0];

@@ -30,6 +30,12 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // ------------------------------------------------------------- geometry ----
 // Derived per-stage GEMM shapes of the TT chain:
 //   x_t[m_t x n_t] = x_{t-1}[m_t x k_t] * core_{t+1}[i_{t+1}][k_t x n_t]
+// unsigned 32-bit division by an invariant divisor (Granlund-Montgomery):
+//   q = (t + ((n - t) >> sh1)) >> sh2,  t = mulhi(m, n)   exact for all n < 2^32
+struct UDiv {
+  unsigned m, sh1, sh2, d;
+};
+
 struct Dims {
   int T, num_tables;
   int p[TTX_MAX_CORES], q[TTX_MAX_CORES], r[TTX_MAX_CORES + 1];
@@ -38,6 +44,8 @@ struct Dims {
   int S[TTX_MAX_CORES];      // num_tables * p_t  (slices of core t)
   int m[TTX_MAX_CORES], k[TTX_MAX_CORES], n[TTX_MAX_CORES];
   int D;
+  int idx32;                 // prod(p) <= 2^32: indices decode with 32-bit magic division
+  UDiv dvL[TTX_MAX_CORES], dvP[TTX_MAX_CORES];
 };
 
 int make_dims(const ttx_geom* g, Dims* d);  // TTX_OK or TTX_EINVAL (+message)
@@ -72,6 +80,8 @@ Plan carve_plan(const Dims& d, long long nnz, void* base);
 int plan_build(const Dims& d, long long nnz, const int64_t* indices,
                const int64_t* tableidx, const Plan& P, hipStream_t stream);
 
+long long* debug_stamps();  // debug stamp buffer (ttx_debug_stamps), or nullptr
+
 // ------------------------------------------------------------ profiling ----
 void prof_begin(int which, hipStream_t s);
 void prof_end(int which, hipStream_t s);
@@ -85,6 +95,11 @@ struct ProfScope {
 // ------------------------------------------------------- device helpers ----
 #ifdef __HIPCC__
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+__device__ __forceinline__ unsigned udiv(unsigned n, const UDiv dv) {
+  const unsigned t = __umulhi(dv.m, n);
+  return (t + ((n - t) >> dv.sh1)) >> dv.sh2;
+}
 
 // peers of this lane: valid lanes of the wave holding the same 8-bit digit.
 // Built from 9 wave ballots (the gfx950 replacement for a CUB rank pass).

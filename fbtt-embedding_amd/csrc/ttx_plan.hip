@@ -89,31 +89,47 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wtot, int* total) {
   return res;
 }
 
-// floor(n / dv) for 0 <= n < 2^31 via one fp64 multiply and a fix-up
-__device__ __forceinline__ unsigned div_small(unsigned n, unsigned dv, double rcp) {
-  unsigned q = (unsigned)((double)n * rcp);
-  const long long r = (long long)n - (long long)q * dv;
-  if (r < 0) q -= 1;
-  else if (r >= (long long)dv) q += 1;
-  return q;
+// i_t of lookup idx (reference decode: i_t = idx / L_t % p_t, cu:795-799; out-of-range
+// indices, which the reference reads out of bounds with, are clamped).  When
+// prod(p) <= 2^32 the int64 divisions become two 32-bit magic-number divisions.
+struct CoreDec {  // everything the decode of one core needs, fetched from the kernarg once
+  UDiv dl, dp;
+  long long L;
+  int p, first, idx32;
+};
+__device__ __forceinline__ CoreDec core_dec(const Dims& d, int t) {
+  CoreDec c;
+  c.dl = d.dvL[t];
+  c.dp = d.dvP[t];
+  c.L = d.L[t];
+  c.p = d.p[t];
+  c.first = (t == 0);
+  c.idx32 = d.idx32;
+  return c;
 }
-
-// i_t of lookup idx (reference decode: i_t = idx / L_t % p_t; out-of-range
-// indices, which the reference reads out of bounds with, are clamped)
-__device__ __forceinline__ int decode_core(const Dims& d, int t, long long idx, bool small,
-                                           double rcpL, double rcpP) {
+__device__ __forceinline__ int decode_core(const CoreDec& c, long long idx) {
   if (idx < 0) idx = 0;
-  long long a;
-  if (small && idx < (1ll << 31)) {
-    const unsigned q = div_small((unsigned)idx, (unsigned)d.L[t], rcpL);
-    if (t == 0) a = q;
-    else a = q - div_small(q, (unsigned)d.p[t], rcpP) * (unsigned)d.p[t];
-  } else {
-    a = idx / d.L[t];
-    if (t > 0) a = a % d.p[t];
+  if (c.idx32 && (unsigned long long)idx < (1ull << 32)) {
+    const unsigned q = udiv((unsigned)idx, c.dl);
+    const unsigned a = c.first ? q : q - udiv(q, c.dp) * c.dp.d;
+    return (int)min(a, (unsigned)(c.p - 1));
   }
-  if (a >= d.p[t]) a = d.p[t] - 1;
+  long long a = idx / c.L;
+  if (!c.first) a = a % c.p;
+  if (a >= c.p) a = c.p - 1;
   return (int)a;
+}
+__device__ __forceinline__ int decode_core(const Dims& d, int t, long long idx) {
+  return decode_core(core_dec(d, t), idx);
+}
+// branch-free 32-bit decode (prod(p) <= 2^32; idx already clamped to [0, 2^32))
+__device__ __forceinline__ int decode32(const CoreDec& c, unsigned idx) {
+  const unsigned q = udiv(idx, c.dl);
+  const unsigned a = c.first ? q : q - udiv(q, c.dp) * c.dp.d;
+  return (int)min(a, (unsigned)(c.p - 1));
+}
+__device__ __forceinline__ unsigned clamp_idx32(long long idx) {
+  return idx < 0 ? 0u : (idx > 0xffffffffll ? 0xffffffffu : (unsigned)idx);
 }
 
 __global__ __launch_bounds__(kPlanThreads) void plan_kernel(
@@ -124,16 +140,12 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(
   const int lane = lane_id();
   const int w = tid / kWave;
   const int t = blockIdx.x;  // the core this work-group plans
-  const bool small = d.L[0] * (long long)d.p[0] < (1ll << 31);
   int* key = P.sid[t];
 
   // ---- 1. decode ----------------------------------------------------------
-  {
-    const double rcpL = 1.0 / (double)d.L[t], rcpP = 1.0 / (double)d.p[t];
-    for (int n = tid; n < N; n += kPlanThreads) {
-      const long long tb = tableidx ? tableidx[n] : 0;
-      key[n] = (int)(tb * d.p[t]) + decode_core(d, t, indices[n], small, rcpL, rcpP);
-    }
+  for (int n = tid; n < N; n += kPlanThreads) {
+    const long long tb = tableidx ? tableidx[n] : 0;
+    key[n] = (int)(tb * d.p[t]) + decode_core(d, t, indices[n]);
   }
   __syncthreads();
 
@@ -242,32 +254,256 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(
       P.hdr[1] = MC;
       P.hdr[2] = N;
     }
-    double rcpL[TTX_MAX_CORES], rcpP[TTX_MAX_CORES];
-#pragma unroll
-    for (int u = 0; u < TTX_MAX_CORES; ++u) {
-      rcpL[u] = u < d.T ? 1.0 / (double)d.L[u] : 1.0;
-      rcpP[u] = u < d.T ? 1.0 / (double)d.p[u] : 1.0;
-    }
     for (int i = tid; i < N; i += kPlanThreads) {
       const int n = pm[i];
       const long long idx = indices[n];
       const int tb = tableidx ? (int)tableidx[n] : 0;
       int4 r;
       r.x = n;
-      r.y = tb * d.p[0] + decode_core(d, 0, idx, small, rcpL[0], rcpP[0]);
-      r.z = d.T > 2 ? tb * d.p[2] + decode_core(d, 2, idx, small, rcpL[2], rcpP[2]) : 0;
-      r.w = d.T > 3 ? tb * d.p[3] + decode_core(d, 3, idx, small, rcpL[3], rcpP[3]) : 0;
+      r.y = tb * d.p[0] + decode_core(d, 0, idx);
+      r.z = d.T > 2 ? tb * d.p[2] + decode_core(d, 2, idx) : 0;
+      r.w = d.T > 3 ? tb * d.p[3] + decode_core(d, 3, idx) : 0;
       P.lrec[i] = r;
     }
   }
+}
+
+// ---- small-batch fast path (nnz <= 16384): everything between the index load and
+// the final stores stays on chip.  Each thread keeps its (key, value, rank) triples in
+// registers (wave w owns the contiguous range [w*per, (w+1)*per) of the current
+// order, 64 per batch), passes exchange through LDS, and the pivot work-group emits the
+// flat lookup records at scatter time.  One global round trip in, one out.
+constexpr int kSmallMax = 16384;
+
+template <int kBPW>  // batches of 64 lookups per wave (register array extent)
+__global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
+    Dims d, int N, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx, Plan P,
+    long long* stamps) {
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+#define PSTAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(size_t)(1000 + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
+  PSTAMP(0);
+  int* hist = lds;                        // [256][kPlanWaves]
+  int* wtot = hist + 256 * kPlanWaves;    // [kPlanWaves + 1] (+pad)
+  int* keyL = wtot + 32;                  // [N]
+  int* valL = keyL + ((N + 63) / 64 * 64);  // [N]
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const int w = tid / kWave;
+  const int t = blockIdx.x;
+  const int per = ((N + kPlanWaves - 1) / kPlanWaves + kWave - 1) / kWave * kWave;
+  const int nb = per / kWave;  // <= kBPW
+  const int bits = 32 - __clz(max(d.S[t] - 1, 1));
+  const int passes = max((bits + 7) / 8, 1);
+  // single-pass pivot sort: the flat records go out straight from registers at scatter time
+  const bool direct = (t == 1) && (passes == 1);
+  const int wbeg = w * per;
+  const int wend = min(N, wbeg + per);
+
+  int k[kBPW], v[kBPW], r[kBPW];
+  // direct path: the other cores' slice ids wait in global scratch (written and read
+  // back by the same thread) so the register arrays stay within the 128-VGPR budget
+  int* sc0 = P.scratch[1][0];
+  int* sc2 = P.scratch[1][1];
+  int* sc3 = P.scratch[1][2];
+  // ---- 1. decode (coalesced).  All loads are issued before any dependent work:
+  // out-of-range lanes re-read element N-1 instead of branching around the load.
+  {
+    unsigned idx[kBPW];
+    int tbv[kBPW];
+    const int last_i = N > 0 ? N - 1 : 0;
+    const bool have_tb = tableidx != nullptr;
+#pragma unroll
+    for (int b = 0; b < kBPW; ++b) {
+      const int i = min(wbeg + b * kWave + lane, last_i);
+      idx[b] = (N > 0) ? clamp_idx32(indices[i]) : 0u;
+      tbv[b] = (N > 0 && have_tb) ? (int)tableidx[i] : 0;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep every load ahead of the arithmetic
+    const CoreDec ct = core_dec(d, t), c0 = core_dec(d, 0), c2 = core_dec(d, 2), c3 = core_dec(d, 3);
+#pragma unroll
+    for (int b = 0; b < kBPW; ++b) {
+      const int i = wbeg + b * kWave + lane;
+      v[b] = i;
+      k[b] = tbv[b] * ct.p + decode32(ct, idx[b]);
+      if (direct && b < nb && i < wend) {
+        sc0[i] = tbv[b] * c0.p + decode32(c0, idx[b]);
+        if (d.T > 2) sc2[i] = tbv[b] * c2.p + decode32(c2, idx[b]);
+        if (d.T > 3) sc3[i] = tbv[b] * c3.p + decode32(c3, idx[b]);
+      }
+    }
+  }
+  PSTAMP(1);
+  // ---- 2. stable LSD radix sort, 8 bits per pass ----------------------------
+  for (int ps = 0; ps < passes; ++ps) {
+    const int shift = ps * 8;
+    for (int e = tid; e < 256 * kPlanWaves; e += kPlanThreads) hist[e] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < kBPW; ++b) {
+      if (b < nb) {  // wave-uniform
+        const bool valid = wbeg + b * kWave + lane < wend;
+        const unsigned dg = ((unsigned)k[b] >> shift) & 255u;
+        const unsigned long long peers = wave_match8(dg, valid);
+        if (valid) {
+          const int before = hist[dg * kPlanWaves + w];
+          r[b] = before + __popcll(peers & lanemask_lt());
+          if ((peers & lanemask_lt()) == 0) hist[dg * kPlanWaves + w] = before + __popcll(peers);
+        }
+      }
+    }
+    PSTAMP(6);
+    __syncthreads();
+    {
+      int v0 = hist[tid * 4 + 0], v1 = hist[tid * 4 + 1], v2 = hist[tid * 4 + 2], v3 = hist[tid * 4 + 3];
+      int total;
+      int ex = block_excl_scan(v0 + v1 + v2 + v3, wtot, &total);
+      hist[tid * 4 + 0] = ex;
+      hist[tid * 4 + 1] = ex + v0;
+      hist[tid * 4 + 2] = ex + v0 + v1;
+      hist[tid * 4 + 3] = ex + v0 + v1 + v2;
+    }
+    __syncthreads();
+    PSTAMP(7);
+    const bool last = (ps == passes - 1);
+    if (direct) {
+      // single pass: v[b] is still this thread's own element; read its other slice ids
+      // back (all loads first), then scatter keys, values and the flat records
+      int a0[kBPW], a2[kBPW], a3[kBPW];
+      const int last_i = N > 0 ? N - 1 : 0;
+#pragma unroll
+      for (int b = 0; b < kBPW; ++b) {
+        const int i = min(v[b], last_i);
+        a0[b] = (b < nb) ? sc0[i] : 0;
+        a2[b] = (b < nb && d.T > 2) ? sc2[i] : 0;
+        a3[b] = (b < nb && d.T > 3) ? sc3[i] : 0;
+      }
+#pragma unroll
+      for (int b = 0; b < kBPW; ++b) {
+        if (b < nb && wbeg + b * kWave + lane < wend) {
+          const unsigned dg = ((unsigned)k[b] >> shift) & 255u;
+          const int pos = hist[dg * kPlanWaves + w] + r[b];
+          keyL[pos] = k[b];
+          valL[pos] = v[b];
+          P.lrec[pos] = make_int4(v[b], a0[b], a2[b], a3[b]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < kBPW; ++b) {
+        if (b < nb && wbeg + b * kWave + lane < wend) {
+          const unsigned dg = ((unsigned)k[b] >> shift) & 255u;
+          const int pos = hist[dg * kPlanWaves + w] + r[b];
+          keyL[pos] = k[b];
+          valL[pos] = v[b];
+        }
+      }
+    }
+    __syncthreads();
+    if (!last) {
+#pragma unroll
+      for (int b = 0; b < kBPW; ++b) {
+        const int i = wbeg + b * kWave + lane;
+        if (b < nb && i < wend) { k[b] = keyL[i]; v[b] = valL[i]; }
+      }
+      __syncthreads();
+    }
+  }
+  PSTAMP(2);
+  // ---- 3. stores: perm, slice offsets (run heads of the sorted keys) -----------
+  if (t != 1) {  // the pivot's consumers read lrec / chunk_rec / chunk_off only
+    int* pm = P.perm[t];
+    for (int i = tid; i < N; i += kPlanThreads) pm[i] = valL[i];
+    int* off = P.off[t];
+    const int S = d.S[t];
+    for (int i = tid; i <= N; i += kPlanThreads) {
+      const int kprev = (i == 0) ? -1 : keyL[i - 1];
+      const int kcur = (i == N) ? S : keyL[i];
+      for (int s = kprev + 1; s <= kcur; ++s) off[s] = i;
+    }
+  }
+  PSTAMP(3);
+  if (t != 1) return;
+  // ---- 4. pivot core: flat per-lookup records + chunk work-list ----------------
+  {
+    const CoreDec c0 = core_dec(d, 0), c2 = core_dec(d, 2), c3 = core_dec(d, 3);
+    for (int i = tid; i < N && !direct; i += kPlanThreads) {
+      const int n = valL[i];
+      const unsigned idx = clamp_idx32(indices[n]);
+      const int tb = tableidx ? (int)tableidx[n] : 0;
+      int4 rr;
+      rr.x = n;
+      rr.y = tb * c0.p + decode32(c0, idx);
+      rr.z = d.T > 2 ? tb * c2.p + decode32(c2, idx) : 0;
+      rr.w = d.T > 3 ? tb * c3.p + decode32(c3, idx) : 0;
+      P.lrec[i] = rr;
+    }
+    PSTAMP(4);
+    // chunk list from the sorted keys in LDS: slice s covers [lower_bound(s), lower_bound(s+1))
+    const int S1 = d.S[1];
+    const int MC = P.MC;
+    int carry = 0;
+    for (int s0 = 0; s0 < S1; s0 += kPlanThreads) {
+      const int s = s0 + tid;
+      int nch = 0, beg = 0, cnt = 0;
+      if (s < S1) {
+        int lo = 0, hi = N;  // first position with key >= s
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keyL[mid] < s) lo = mid + 1; else hi = mid; }
+        beg = lo;
+        hi = N;              // first position with key >= s + 1
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keyL[mid] <= s) lo = mid + 1; else hi = mid; }
+        cnt = lo - beg;
+        nch = (cnt + MC - 1) / MC;
+      }
+      int total;
+      const int ex = carry + block_excl_scan(nch, wtot, &total);
+      if (s < S1) {
+        P.chunk_off[s] = ex;
+        for (int j = 0; j < nch; ++j)
+          P.chunk_rec[ex + j] = make_int4(s, beg + j * MC, min(MC, cnt - j * MC), 0);
+      }
+      carry += total;
+    }
+    for (int c = carry + tid; c < P.max_chunks; c += kPlanThreads) P.chunk_rec[c] = make_int4(0, 0, 0, 0);
+    if (tid == 0) {
+      P.chunk_off[S1] = carry;
+      P.hdr[0] = carry;
+      P.hdr[1] = MC;
+      P.hdr[2] = N;
+    }
+    PSTAMP(5);
+  }
+#undef PSTAMP
 }
 
 int plan_build(const Dims& d, long long nnz, const int64_t* indices,
                const int64_t* tableidx, const Plan& P, hipStream_t stream) {
   if (nnz < 0 || nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz=%lld out of range", nnz);
   ProfScope ps(TTX_PROF_PLAN, stream);
-  hipLaunchKernelGGL(plan_kernel, dim3(d.T), dim3(kPlanThreads), 0, stream, d, (int)nnz,
-                     indices, tableidx, P);
+  if (nnz <= kSmallMax && d.idx32) {  // on-chip plan; 32-bit index decode only
+    const size_t lds = (256 * kPlanWaves + 32 + 2 * ((nnz + 63) / 64 * 64)) * sizeof(int);
+    const int per = (((int)nnz + kPlanWaves - 1) / kPlanWaves + kWave - 1) / kWave * kWave;
+    const int nb = per / kWave;
+#define TTX_PLAN_LAUNCH(BPW)                                                                          \
+  do {                                                                                                \
+    static bool attr_done = false;                                                                    \
+    if (!attr_done) {                                                                                 \
+      TTX_HIP(hipFuncSetAttribute((const void*)plan_small_kernel<BPW>,                                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+      attr_done = true;                                                                               \
+    }                                                                                                 \
+    hipLaunchKernelGGL(plan_small_kernel<BPW>, dim3(d.T), dim3(kPlanThreads), lds, stream, d,         \
+                       (int)nnz, indices, tableidx, P, debug_stamps());                               \
+  } while (0)
+    if (nb <= 2) TTX_PLAN_LAUNCH(2);
+    else if (nb <= 4) TTX_PLAN_LAUNCH(4);
+    else if (nb <= 8) TTX_PLAN_LAUNCH(8);
+    else if (nb <= 12) TTX_PLAN_LAUNCH(12);
+    else TTX_PLAN_LAUNCH(16);
+#undef TTX_PLAN_LAUNCH
+  } else {
+    hipLaunchKernelGGL(plan_kernel, dim3(d.T), dim3(kPlanThreads), 0, stream, d, (int)nnz,
+                       indices, tableidx, P);
+  }
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }

@@ -84,6 +84,8 @@ static int g_chunk_override = 0;
 static int g_debug_skip = 0;
 static long long* g_stamps = nullptr;
 
+long long* debug_stamps() { return g_stamps; }
+
 static int stride2(int n) {  // smallest s >= n with s % 32 == 2
   int s = (n + 29) / 32 * 32 + 2;
   return s;

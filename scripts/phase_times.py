@@ -17,7 +17,7 @@ reqs = [(torch.from_numpy(i).to(dev), torch.from_numpy(o).to(dev)) for i, o in G
 grad = torch.from_numpy(G.make_grad(2, 1, 512, D)[0]).to(dev)
 for k in range(5):
     m(*reqs[k]).backward(grad)
-buf = torch.zeros(1024 * 16, dtype=torch.int64, device=dev)
+buf = torch.zeros(1100 * 16, dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
 E.lib().ttx_debug_stamps(E.C.c_void_p(buf.data_ptr()))
 m(*reqs[5]).backward(grad)
@@ -36,3 +36,10 @@ print("phase durations (per work-group):")
 for i in range(1, 8):
     v = st[:, i] - st[:, i - 1]
     print(f"  {names[i-1]:>14s} -> {names[i]:14s} min {v.min():6.2f}  med {np.median(v):6.2f}  max {v.max():6.2f}")
+
+pl = buf.cpu().numpy().reshape(-1, 16)[1000:1003, :9].astype(np.float64) / 100.0
+pl = pl[:, [0, 8, 1, 6, 7, 2, 3, 4, 5]]
+pn = ["entry", "loads back", "decoded", "counted", "scanned", "sorted", "perm/off stored", "lrec stored", "chunk list"]
+print("plan kernel (one work-group per core), us since that block's entry:")
+for b in range(3):
+    print(f"  core {b}: " + "  ".join(f"{pn[i]}={pl[b, i] - pl[b, 0]:.2f}" for i in range(1, 9) if pl[b, i] > 0))

@@ -1,0 +1,122 @@
+"""world_size-2 gloo test (CPU, no GPU) of the table-sharded path: routing of
+lookups to table owners, pooled vectors back, gradients the opposite way, fused
+optimizer rank-local.  The local lookup engine is the oracle (test-only
+injection); the reference has no distributed code to compare with, so the check
+is against the single-process TableBatchedTTEmbeddingBag on the same tables."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+P, Q, R = [7, 9, 11], [3, 4, 5], [13, 12]
+NT, B_LOCAL, D = 5, 6, 60
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make_inputs(rank, fixed):
+    rs = np.random.RandomState(100 + rank)
+    E_ = int(np.prod(P))
+    if fixed:
+        lengths = np.full(NT * B_LOCAL, fixed, dtype=np.int64)
+    else:
+        lengths = rs.randint(0, 5, size=NT * B_LOCAL).astype(np.int64)
+    idx = rs.randint(0, E_, size=int(lengths.sum())).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    grad = (rs.rand(NT, B_LOCAL, D) * 0.1).astype(np.float32)
+    return idx, off, grad
+
+
+def _worker(rank, world, port, fixed, q):
+    try:
+        for p in (HERE, os.path.join(ROOT, "fbtt-embedding_amd")):
+            sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import gen_inputs as G
+        import oracle_engine
+        import tt_embeddings_ops as ops
+        import ttx_sharded
+
+        ops._engine = oracle_engine  # CPU stand-in for the HIP engine (test only)
+        cores_all = G.make_cores(5, NT, P, Q, R)
+        m = ttx_sharded.ShardedTableBatchedTTEmbeddingBag(
+            NT, int(np.prod(P)), D, R, tt_p_shapes=P, tt_q_shapes=Q, sparse=True, optimizer=ops.OptimType.SGD,
+            learning_rate=0.1, weight_dist="uniform", device="cpu")
+        mine = m.my_tables
+        with torch.no_grad():
+            for t, core in enumerate(m.local.tt_cores):
+                core.copy_(torch.from_numpy(cores_all[t][mine]))
+        idx, off, grad = _make_inputs(rank, fixed)
+        out = m(torch.from_numpy(idx), torch.from_numpy(off), fixed_pooling=fixed or None)
+        out.backward(torch.from_numpy(grad))
+        q.put((rank, out.detach().numpy(), mine, [c.detach().numpy() for c in m.local.tt_cores]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "ERROR", traceback.format_exc(), None))
+
+
+@pytest.mark.parametrize("fixed", [0, 3])
+def test_two_rank_table_sharding_matches_single_process(fixed):
+    sys.path.insert(0, HERE)
+    import gen_inputs as G
+    import oracle_lib as O
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fixed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=180)
+        assert r[1] is not None and not isinstance(r[1], str), f"rank {r[0]} failed:\n{r[2]}"
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+    # single-process expectation: all NT tables, global batch = ranks' batches side by side
+    cores = G.make_cores(5, NT, P, Q, R)
+    g = O.make_geom(NT, P, Q, R)
+    per_rank = [_make_inputs(r, fixed) for r in range(world)]
+    # global table-major order: table t -> [rank0 bags | rank1 bags]
+    idx_g, len_g = [], []
+    for t in range(NT):
+        for r in range(world):
+            idx, off, _ = per_rank[r]
+            lo, hi = off[t * B_LOCAL], off[(t + 1) * B_LOCAL]
+            idx_g.append(idx[lo:hi])
+            len_g.append(np.diff(off[t * B_LOCAL:(t + 1) * B_LOCAL + 1]))
+    idx_g = np.concatenate(idx_g)
+    off_g = np.concatenate([[0], np.cumsum(np.concatenate(len_g))]).astype(np.int64)
+    BG = world * B_LOCAL
+    rowidx, tableidx = O.rowidx_from_offsets(off_g, NT)
+    out_g = O.tt_forward(g, BG, D, idx_g, rowidx, tableidx, cores)
+    grad_g = np.concatenate([per_rank[r][2] for r in range(world)], axis=1)  # [NT, BG, D]
+    new_cores = [c.copy() for c in cores]
+    O.tt_backward(g, O.OPTIM_SGD, BG, D, 0.1, 0.0, idx_g, rowidx, tableidx, grad_g, new_cores)
+    for r in range(world):
+        _, out, mine, cr = res[r]
+        np.testing.assert_allclose(out, out_g[:, r * B_LOCAL:(r + 1) * B_LOCAL], rtol=1e-5, atol=1e-7)
+        assert mine == [t for t in range(NT) if t % world == r]
+        for t in range(3):
+            np.testing.assert_allclose(cr[t], new_cores[t][mine], rtol=1e-5, atol=1e-7)

@@ -155,6 +155,22 @@ def test_property_sweep_vs_oracle(T, tables):
                     assert_close(got["state"][k], orc["state"][k], f"T{T} tb{tables} it{it} state{k}")
 
 
+def test_large_batch_uses_the_global_memory_plan():
+    """nnz > 16384 takes the multi-pass global-memory plan kernel; nnz just below
+    takes the on-chip one.  Both against the oracle (dense grads + fused SGD)."""
+    for B, pf, tables in ((700, 9, 3), (500, 8, 4), (2000, 12, 1)):
+        c = _random_case(77 + B, 3, tables, B, pf, 2)
+        assert (c["indices"].size > 16384) == (B != 500)
+        for mode in ("dense", "sgd"):
+            got, orc = run_case(c, mode, plan_shared=True), oracle_case(c, mode)
+            assert_close(got["out"], orc["out"], f"B{B} out")
+            for k in range(3):
+                if mode == "dense":
+                    assert_close(got["grads"][k], orc["grads"][k], f"B{B} grad{k}")
+                else:
+                    assert_close(got["cores"][k], orc["cores"][k], f"B{B} sgd core{k}")
+
+
 def test_edge_cases():
     import tt_embeddings as E
 
