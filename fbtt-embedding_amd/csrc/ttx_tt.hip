@@ -63,21 +63,27 @@ __device__ __forceinline__ unsigned fdivmod(unsigned n, const FastDiv f, unsigne
   return q;
 }
 
-// LDS carve of the contraction kernels (float offsets) + padded GEMM extents
+// LDS carve of the contraction kernels (float offsets) + padded GEMM extents.
+// A CHUNK is <= MC lookups of one pivot slice: they share one staged B1 and one d core_1
+// partial.  A PASS is <= SC of those lookups: one X0 tile of rS rows (SC*q0 padded to 32).
+// Keeping X0 per pass small is what lets three work-groups share a CU at the benchmark shape.
 struct Lds {
-  int MC;
+  int MC, SC;
+  int rS;    // rows of one pass
+  int nsub;  // passes of a full chunk
   int K0p;   // r1 padded to a multiple of 32
   int K0t;   // 16-wide tiles covering r1
   int N1t;   // 16-wide tiles covering N1
   int ld;    // row stride of Bs and X0 (>= 16*N1t, == 2 mod 32)
   int ldA;   // row stride of As (>= K0p, == 2 mod 32)
-  int Mp;    // MC*q0 padded to a multiple of 32
-  int oB, oA, oX0, oX1, oG, oI;
+  int persist;  // d core_1 accumulates in registers across passes
+  int oB, oA, oX0, oX1, oG, oC, oI;
   int szX1;  // per-lookup floats of X1 (T == 4)
+  int cLds;  // forward: last-core slices of a pass are staged in LDS
   int bytes;
   int dbg;   // ablation mask (bench/ablate only): phases to skip, results invalid when != 0
   long long* stamps;  // debug: per work-group phase timestamps (100 MHz wall clock), or NULL
-  FastDiv fdD, fdD4, fdN1, fdN4, fdSl0, fdSl04, fdK0, fdK04, fdQ0, fdSl2;
+  FastDiv fdD, fdD4, fdN1, fdN4, fdSl0, fdSl04, fdK0, fdK04, fdQ0, fdSl2, fdSC;
 };
 
 static int g_chunk_override = 0;
@@ -94,22 +100,33 @@ static int stride2(int n) {  // smallest s >= n with s % 32 == 2
 static Lds make_lds(const Dims& d, int MC, bool bwd) {
   Lds L;
   memset(&L, 0, sizeof(L));
-  L.MC = MC;
   const int K0 = d.k[0], N1 = d.n[0], q0 = d.q[0];
+  L.MC = MC;
   L.K0p = (K0 + 31) / 32 * 32;
   L.K0t = (K0 + 15) / 16;
   L.N1t = (N1 + 15) / 16;
   L.ld = stride2(L.N1t * 16);
   L.ldA = stride2(L.K0p);
-  L.Mp = (MC * q0 + 31) / 32 * 32;
+  // register-resident d core_1 needs <= 2 (N-pair) jobs per wave and one group of <= 4 r1 tiles
+  const int npairs = (L.N1t + 1) / 2;
+  L.persist = (L.K0t <= 4 && npairs <= 2 * kWaves) ? 1 : 0;
+  int sc = 32 / q0;
+  if (sc < 1) sc = 1;
+  if (sc > MC || (bwd && !L.persist)) sc = MC;
+  L.SC = sc;
+  L.rS = (sc * q0 + 31) / 32 * 32;
+  L.nsub = (MC + sc - 1) / sc;
   L.szX1 = (d.T == 4) ? d.m[1] * d.n[1] : 0;
+  const int sl2 = d.T > 2 ? d.slice[2] : 0;
+  L.cLds = (!bwd && d.T > 2 && d.n[1] <= 8 && sc * sl2 <= 4096) ? 1 : 0;
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) / 4 * 4; return r; };
   L.oB = take(L.K0p * L.ld);
-  L.oA = take(L.Mp * L.ldA);
-  L.oX0 = take(L.Mp * L.ld);
-  L.oX1 = take(MC * L.szX1);
+  L.oA = take(L.nsub * L.rS * L.ldA);
+  L.oX0 = take(L.rS * L.ld);
+  L.oX1 = take(sc * L.szX1);
   L.oG = take(bwd && d.T >= 3 ? MC * d.D : 0);
+  L.oC = take(L.cLds ? sc * sl2 : 0);
   L.oI = take(MC * 4);  // int4 lookup records
   L.bytes = o * 4;
   L.fdD = make_fd(d.D);
@@ -121,18 +138,20 @@ static Lds make_lds(const Dims& d, int MC, bool bwd) {
   L.fdN4 = make_fd(N1 / 4 > 0 ? N1 / 4 : 1);
   L.fdSl04 = make_fd(d.slice[0] / 4 > 0 ? d.slice[0] / 4 : 1);
   L.fdK04 = make_fd(K0 / 4 > 0 ? K0 / 4 : 1);
-  L.fdSl2 = make_fd(d.T > 2 ? d.slice[2] : 1);
+  L.fdSl2 = make_fd(sl2 > 0 ? sl2 : 1);
+  L.fdSC = make_fd(sc);
   L.dbg = g_debug_skip;
   L.stamps = g_stamps;
   return L;
 }
 
-
 int choose_chunk(const Dims& d) {
   if (g_chunk_override > 0) return g_chunk_override;
-  // prefer <= 64 KiB (two work-groups per CU), else up to the full 160 KiB
+  // three, then two work-groups per CU (160 KiB of LDS), else whatever fits
+  for (int mc = 16; mc >= 8; mc >>= 1)
+    if (make_lds(d, mc, true).bytes <= 53 * 1024) return mc;
   for (int mc = 32; mc >= 8; mc >>= 1)
-    if (make_lds(d, mc, true).bytes <= 64 * 1024) return mc;
+    if (make_lds(d, mc, true).bytes <= 80 * 1024) return mc;
   for (int mc = 16; mc >= 1; mc >>= 1)
     if (make_lds(d, mc, true).bytes <= 160 * 1024) return mc;
   return 0;
@@ -144,19 +163,18 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// address of element e (< q0*N1) of lookup j's X0 block: rows are padded to ld
-__device__ __forceinline__ int x0_addr(const Lds& L, int q0, int j, unsigned e) {
-  unsigned col;
-  const unsigned a = fdivmod(e, L.fdN1, col);
-  return (j * q0 + (int)a) * L.ld + (int)col;
+// As row of (lookup j of the chunk, core-0 row a)
+__device__ __forceinline__ int a_row(const Lds& L, int q0, unsigned j, unsigned a) {
+  unsigned jl;
+  const unsigned h = fdivmod(j, L.fdSC, jl);
+  return h * L.rS + jl * q0 + a;
 }
 
-// chunk prologue shared by forward and backward: stage B1, the lookup records
-// and the stacked core-0 slices in LDS (zero padded to the MFMA tile extents).
+// chunk prologue shared by forward and backward: stage B1, the lookup records and the
+// stacked core-0 slices (pass-major, zero padded to the MFMA tile extents) in LDS.
 // Dependent global loads: chunk_rec -> lrec -> core-0 rows (B1 needs only chunk_rec).
 __device__ __forceinline__ void stage_chunk(const Dims& d, const Plan& P, const CorePtrs& C,
-                                            const Lds& L, float* smem, int s, int start, int len,
-                                            int rows32) {
+                                            const Lds& L, float* smem, int s, int start, int len) {
   const int tid = threadIdx.x;
   const int K0 = d.k[0], N1 = d.n[0], q0 = d.q[0];
   int4* I = (int4*)(smem + L.oI);
@@ -164,6 +182,7 @@ __device__ __forceinline__ void stage_chunk(const Dims& d, const Plan& P, const 
   float* As = smem + L.oA;
   const float* __restrict__ B1 = C.c[1] + (size_t)s * d.slice[1];
   const bool padB = (L.K0p != K0) || (L.N1t * 16 != N1);
+  if (tid < len) I[tid] = P.lrec[start + tid];
   if (padB) {
     for (int e = tid; e < L.K0p * L.ld; e += kThreads) Bs[e] = 0.f;
     __syncthreads();
@@ -185,26 +204,19 @@ __device__ __forceinline__ void stage_chunk(const Dims& d, const Plan& P, const 
       Bs[row * L.ld + col] = B1[e];
     }
   }
-  if (tid < len) I[tid] = P.lrec[start + tid];
-  // zero A where the MFMA reads beyond the data: whole tile if r1 is padded,
-  // else only the rows past the chunk
-  const int mrows = len * q0;
-  if (L.K0p != K0) {
-    for (int e = tid; e < rows32 * L.ldA; e += kThreads) As[e] = 0.f;
-  } else {
-    for (int e = mrows * L.ldA + tid; e < rows32 * L.ldA; e += kThreads) As[e] = 0.f;
-  }
+  // zero A: rows past the chunk / columns past r1 feed the MFMA as zeros
+  const int npass = (len + L.SC - 1) / L.SC;
+  for (int e = tid; e < npass * L.rS * L.ldA; e += kThreads) As[e] = 0.f;
   __syncthreads();
   const int sl0 = d.slice[0];  // q0 * r1
   if ((K0 & 3) == 0) {
-    const int k4 = K0 / 4, per = sl0 / 4;
+    const int per = sl0 / 4;
     for (int e = tid; e < len * per; e += kThreads) {
       unsigned rem, c4;
       const unsigned j = fdivmod((unsigned)e, L.fdSl04, rem);
       const unsigned a = fdivmod(rem, L.fdK04, c4);
-      (void)k4;
       const float4 v = ((const float4*)(C.c[0] + (size_t)I[j].y * sl0))[rem];
-      float2* dst = (float2*)(As + (j * q0 + a) * L.ldA + c4 * 4);
+      float2* dst = (float2*)(As + a_row(L, q0, j, a) * L.ldA + c4 * 4);
       dst[0] = make_float2(v.x, v.y);
       dst[1] = make_float2(v.z, v.w);
     }
@@ -213,19 +225,20 @@ __device__ __forceinline__ void stage_chunk(const Dims& d, const Plan& P, const 
       unsigned rem, k;
       const unsigned j = fdivmod((unsigned)e, L.fdSl0, rem);
       const unsigned a = fdivmod(rem, L.fdK0, k);
-      As[(j * q0 + a) * L.ldA + k] = (C.c[0] + (size_t)I[j].y * sl0)[rem];
+      As[a_row(L, q0, j, a) * L.ldA + k] = (C.c[0] + (size_t)I[j].y * sl0)[rem];
     }
   }
   __syncthreads();
 }
 
-// ---- GEMM 1:  X0[16 x NB*16] tile row = As * Bs, k-step {k, k+8, k+16, k+24} ----
+// ---- GEMM 1:  one 16-row tile of X0 x NB column tiles = As * Bs, k-step {k, k+8, k+16, k+24} ----
+// arow0: As row of the tile; xrow0: X0 row of the tile (within the pass)
 template <int NB>
-__device__ __forceinline__ void x0_group(const Dims& d, const Lds& L, float* smem, int mt, int n0,
-                                         float* rows_out, int len) {
+__device__ __forceinline__ void x0_group(const Dims& d, const Lds& L, float* smem, int arow0, int xrow0,
+                                         int n0, float* rows_out, int j0, int lenS) {
   const int lane = lane_id();
   const int i16 = lane & 15, kq = lane >> 4;
-  const float* arow = smem + L.oA + (mt * 16 + i16) * L.ldA + 8 * kq;
+  const float* arow = smem + L.oA + (arow0 + i16) * L.ldA + 8 * kq;
   const float* bbase = smem + L.oB + 8 * kq * L.ld + n0 * 16 + i16;
   f32x4 acc[NB];
 #pragma unroll
@@ -260,11 +273,11 @@ __device__ __forceinline__ void x0_group(const Dims& d, const Lds& L, float* sme
     const int4* I = (const int4*)(smem + L.oI);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = mt * 16 + kq * 4 + r;
+      const int row = xrow0 + kq * 4 + r;
       unsigned a_;
-      const unsigned j = fdivmod((unsigned)row, L.fdQ0, a_);
-      if ((int)j < len) {
-        float* o = rows_out + (size_t)I[j].x * d.D + a_ * d.n[0];
+      const unsigned jl = fdivmod((unsigned)row, L.fdQ0, a_);
+      if ((int)jl < lenS) {
+        float* o = rows_out + (size_t)I[j0 + jl].x * d.D + a_ * d.n[0];
 #pragma unroll
         for (int x = 0; x < NB; ++x) {
           const int col = (n0 + x) * 16 + i16;
@@ -273,7 +286,7 @@ __device__ __forceinline__ void x0_group(const Dims& d, const Lds& L, float* sme
       }
     }
   } else {
-    float* xo = smem + L.oX0 + (mt * 16 + kq * 4) * L.ld + n0 * 16 + i16;
+    float* xo = smem + L.oX0 + (xrow0 + kq * 4) * L.ld + n0 * 16 + i16;
 #pragma unroll
     for (int x = 0; x < NB; ++x)
 #pragma unroll
@@ -281,33 +294,45 @@ __device__ __forceinline__ void x0_group(const Dims& d, const Lds& L, float* sme
   }
 }
 
-__device__ __forceinline__ void gemm_x0(const Dims& d, const Lds& L, float* smem, int mtiles,
-                                        float* rows_out, int len) {
+// X0 of pass h (all rS rows: rows past the pass come out as zeros)
+__device__ __forceinline__ void gemm_x0(const Dims& d, const Lds& L, float* smem, int h,
+                                        float* rows_out, int j0, int lenS) {
   const int w = threadIdx.x / kWave;
-  for (int mt = w; mt < mtiles; mt += kWaves) {
-    int n0 = 0;
-    for (; n0 + 8 <= L.N1t; n0 += 8) x0_group<8>(d, L, smem, mt, n0, rows_out, len);
-    if (n0 + 4 <= L.N1t) { x0_group<4>(d, L, smem, mt, n0, rows_out, len); n0 += 4; }
-    if (n0 + 2 <= L.N1t) { x0_group<2>(d, L, smem, mt, n0, rows_out, len); n0 += 2; }
-    if (n0 < L.N1t) x0_group<1>(d, L, smem, mt, n0, rows_out, len);
+  const int mtiles = L.rS / 16;
+  // column-group width: the widest of 8/4/2/1 tiles that still gives every wave a job
+  int NB = 8;
+  while (NB > 1 && mtiles * ((L.N1t + NB - 1) / NB) < kWaves) NB >>= 1;
+  const int ngroups = (L.N1t + NB - 1) / NB;
+  for (int job = w; job < mtiles * ngroups; job += kWaves) {
+    const int mt = job / ngroups, g = job - mt * ngroups;
+    int n0 = g * NB;
+    int cnt = min(NB, L.N1t - n0);
+    const int ar = h * L.rS + mt * 16, xr = mt * 16;
+    while (cnt > 0) {
+      if (cnt >= 8) { x0_group<8>(d, L, smem, ar, xr, n0, rows_out, j0, lenS); n0 += 8; cnt -= 8; }
+      else if (cnt >= 4) { x0_group<4>(d, L, smem, ar, xr, n0, rows_out, j0, lenS); n0 += 4; cnt -= 4; }
+      else if (cnt >= 2) { x0_group<2>(d, L, smem, ar, xr, n0, rows_out, j0, lenS); n0 += 2; cnt -= 2; }
+      else { x0_group<1>(d, L, smem, ar, xr, n0, rows_out, j0, lenS); n0 += 1; cnt -= 1; }
+    }
   }
 }
 
 // ---- forward tail stage: out[m x NT] = x[m x k] * C[k x NT] per lookup, C from LDS or HBM ----
-// item = (lookup j, row); x addressing: row = a*nb + b -> xbase + a*sA + b*sB
+// item = (lookup jl of the pass, row); x addressing: row = a*nb + b -> X + jl*sJ + a*sA + b*sB
 template <int NT>
-__device__ __forceinline__ void fwd_stage(int len, int m, int k, int nb, int sJ, int sA, int sB,
+__device__ __forceinline__ void fwd_stage(int lenS, int j0, int m, int k, int nb, int sJ, int sA, int sB,
                                           const float* X, const float* Cs, int cJ, bool c_lds,
                                           const float* Cg, int slice, const int4* I, int which,
                                           float* out_lds, int oJ, float* __restrict__ rows, int D) {
   const FastDiv fm = make_fd(m), fnb = make_fd(nb);
-  for (int e = threadIdx.x; e < len * m; e += kThreads) {
+  for (int e = threadIdx.x; e < lenS * m; e += kThreads) {
     unsigned row, b;
-    const unsigned j = fdivmod((unsigned)e, fm, row);
+    const unsigned jl = fdivmod((unsigned)e, fm, row);
     const unsigned a = fdivmod(row, fnb, b);
-    const float* xi = X + j * sJ + a * sA + b * sB;
-    const int sid = which == 2 ? I[j].z : I[j].w;
-    const float* c = c_lds ? Cs + j * cJ : Cg + (size_t)sid * slice;
+    const float* xi = X + jl * sJ + a * sA + b * sB;
+    const int4 rec = I[j0 + jl];
+    const int sid = which == 2 ? rec.z : rec.w;
+    const float* c = c_lds ? Cs + jl * cJ : Cg + (size_t)sid * slice;
     float acc[NT];
 #pragma unroll
     for (int x = 0; x < NT; ++x) acc[x] = 0.f;
@@ -317,36 +342,31 @@ __device__ __forceinline__ void fwd_stage(int len, int m, int k, int nb, int sJ,
 #pragma unroll
       for (int x = 0; x < NT; ++x) acc[x] = fmaf(xv, c[kk * NT + x], acc[x]);
     }
-    if (rows) {
-      float* o = rows + (size_t)I[j].x * D + row * NT;
+    float* o = rows ? rows + (size_t)rec.x * D + row * NT : out_lds + jl * oJ + row * NT;
 #pragma unroll
-      for (int x = 0; x < NT; ++x) o[x] = acc[x];
-    } else {
-      float* o = out_lds + j * oJ + row * NT;
-#pragma unroll
-      for (int x = 0; x < NT; ++x) o[x] = acc[x];
-    }
+    for (int x = 0; x < NT; ++x) o[x] = acc[x];
   }
 }
 
-// generic (any n) version: item = (j, row, col), C from HBM
-__device__ __forceinline__ void fwd_stage_any(int len, int m, int k, int n, int nb, int sJ, int sA,
+// generic (any n) version: item = (jl, row, col), C from HBM
+__device__ __forceinline__ void fwd_stage_any(int lenS, int j0, int m, int k, int n, int nb, int sJ, int sA,
                                               int sB, const float* X, const float* Cg, int slice,
                                               const int4* I, int which, float* out_lds, int oJ,
                                               float* __restrict__ rows, int D) {
   const FastDiv fper = make_fd(m * n), fn = make_fd(n), fnb = make_fd(nb);
-  for (int e = threadIdx.x; e < len * m * n; e += kThreads) {
+  for (int e = threadIdx.x; e < lenS * m * n; e += kThreads) {
     unsigned rem, col, b;
-    const unsigned j = fdivmod((unsigned)e, fper, rem);
+    const unsigned jl = fdivmod((unsigned)e, fper, rem);
     const unsigned row = fdivmod(rem, fn, col);
     const unsigned a = fdivmod(row, fnb, b);
-    const float* xi = X + j * sJ + a * sA + b * sB;
-    const int sid = which == 2 ? I[j].z : I[j].w;
+    const float* xi = X + jl * sJ + a * sA + b * sB;
+    const int4 rec = I[j0 + jl];
+    const int sid = which == 2 ? rec.z : rec.w;
     const float* c = Cg + (size_t)sid * slice + col;
     float acc = 0.f;
     for (int kk = 0; kk < k; ++kk) acc = fmaf(xi[kk], c[kk * n], acc);
-    if (rows) rows[(size_t)I[j].x * D + rem] = acc;
-    else out_lds[j * oJ + rem] = acc;
+    if (rows) rows[(size_t)rec.x * D + rem] = acc;
+    else out_lds[jl * oJ + rem] = acc;
   }
 }
 
@@ -363,7 +383,7 @@ __device__ __forceinline__ void fwd_stage_any(int len, int m, int k, int n, int 
     default: break;                      \
   }
 
-__global__ __launch_bounds__(kThreads, 2) void fwd_kernel(Dims d, Plan P, CorePtrs C,
+__global__ __launch_bounds__(kThreads, 3) void fwd_kernel(Dims d, Plan P, CorePtrs C,
                                                          float* __restrict__ rows, Lds L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int chunk = blockIdx.x;
@@ -372,56 +392,58 @@ __global__ __launch_bounds__(kThreads, 2) void fwd_kernel(Dims d, Plan P, CorePt
   if (len == 0) return;
   const int tid = threadIdx.x;
   const int q0 = d.q[0];
-  const int mrows = len * q0;
-  const int mtiles = (mrows + 15) / 16;
-  stage_chunk(d, P, C, L, smem, s, start, len, mtiles * 16);
-  if (d.T == 2) {
-    gemm_x0(d, L, smem, mtiles, rows, len);
-    return;
-  }
-  if (!(L.dbg & 1)) gemm_x0(d, L, smem, mtiles, nullptr, len);
-  __syncthreads();
-  if (L.dbg & 2) return;
+  stage_chunk(d, P, C, L, smem, s, start, len);
   const int4* I = (const int4*)(smem + L.oI);
   const float* X0 = smem + L.oX0;
   float* X1 = smem + L.oX1;
-  float* Cs = smem + L.oB;  // Bs / As are dead after the GEMM: stage core slices there
-  const int cs_cap = L.oX0 - L.oB;
-  // tail stage t = 1: x_1[m1 x n1] = x_0[m1 x k1] * core_2[i_2][k1 x n1]
-  {
-    const int k1 = d.k[1], n1 = d.n[1], m1 = d.m[1], q1 = d.q[1];
-    const bool last = (d.T == 3);
-    const int sl2 = d.slice[2];
-    if (n1 <= 8) {
-      const bool c_lds = len * sl2 <= cs_cap;
-      if (c_lds) {
-        for (int e = tid; e < len * sl2; e += kThreads) {
-          unsigned rem;
-          const unsigned j = fdivmod((unsigned)e, L.fdSl2, rem);
-          Cs[e] = (C.c[2] + (size_t)I[j].z * sl2)[rem];
-        }
-        __syncthreads();
-      }
-#define CALL(NT) fwd_stage<NT>(len, m1, k1, q1, q0 * L.ld, L.ld, k1, X0, Cs, sl2, c_lds, C.c[2], sl2, I, 2, \
-                               X1, L.szX1, last ? rows : nullptr, d.D)
-      TTX_NT_SWITCH(n1, CALL)
-#undef CALL
-    } else {
-      fwd_stage_any(len, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, C.c[2], sl2, I, 2, X1, L.szX1,
-                    last ? rows : nullptr, d.D);
+  float* Cs = smem + L.oC;
+  const int npass = (len + L.SC - 1) / L.SC;
+  for (int h = 0; h < npass; ++h) {
+    const int j0 = h * L.SC;
+    const int lenS = min(L.SC, len - j0);
+    if (d.T == 2) {
+      gemm_x0(d, L, smem, h, rows, j0, lenS);
+      continue;
     }
-  }
-  if (d.T == 4) {
+    if (h > 0) __syncthreads();  // the previous pass is done with X0 / X1 / Cs
+    if (L.cLds) {  // last-core slices of this pass -> LDS (overlaps the GEMM)
+      const int sl2 = d.slice[2];
+      for (int e = tid; e < lenS * sl2; e += kThreads) {
+        unsigned rem;
+        const unsigned jl = fdivmod((unsigned)e, L.fdSl2, rem);
+        Cs[e] = (C.c[2] + (size_t)I[j0 + jl].z * sl2)[rem];
+      }
+    }
+    if (!(L.dbg & 1)) gemm_x0(d, L, smem, h, nullptr, j0, lenS);
     __syncthreads();
-    // tail stage t = 2: row[m2 x n2] = x_1[m2 x k2] * core_3[i_3][k2 x n2]
-    const int k2 = d.k[2], n2 = d.n[2], m2 = d.m[2];
-    if (n2 <= 8) {
-#define CALL(NT) fwd_stage<NT>(len, m2, k2, m2, L.szX1, 0, k2, X1, nullptr, 0, false, C.c[3], d.slice[3], I, 3, \
-                               nullptr, 0, rows, d.D)
-      TTX_NT_SWITCH(n2, CALL)
+    if (L.dbg & 2) continue;
+    // tail stage t = 1: x_1[m1 x n1] = x_0[m1 x k1] * core_2[i_2][k1 x n1]
+    {
+      const int k1 = d.k[1], n1 = d.n[1], m1 = d.m[1], q1 = d.q[1];
+      const bool last = (d.T == 3);
+      const int sl2 = d.slice[2];
+      if (n1 <= 8) {
+#define CALL(NT) fwd_stage<NT>(lenS, j0, m1, k1, q1, q0 * L.ld, L.ld, k1, X0, Cs, sl2, L.cLds != 0, C.c[2], sl2, I, 2, \
+                               X1, L.szX1, last ? rows : nullptr, d.D)
+        TTX_NT_SWITCH(n1, CALL)
 #undef CALL
-    } else {
-      fwd_stage_any(len, m2, k2, n2, m2, L.szX1, 0, k2, X1, C.c[3], d.slice[3], I, 3, nullptr, 0, rows, d.D);
+      } else {
+        fwd_stage_any(lenS, j0, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, C.c[2], sl2, I, 2, X1, L.szX1,
+                      last ? rows : nullptr, d.D);
+      }
+    }
+    if (d.T == 4) {
+      __syncthreads();
+      // tail stage t = 2: row[m2 x n2] = x_1[m2 x k2] * core_3[i_3][k2 x n2]
+      const int k2 = d.k[2], n2 = d.n[2], m2 = d.m[2];
+      if (n2 <= 8) {
+#define CALL(NT) fwd_stage<NT>(lenS, j0, m2, k2, m2, L.szX1, 0, k2, X1, nullptr, 0, false, C.c[3], d.slice[3], I, 3, \
+                               nullptr, 0, rows, d.D)
+        TTX_NT_SWITCH(n2, CALL)
+#undef CALL
+      } else {
+        fwd_stage_any(lenS, j0, m2, k2, n2, m2, L.szX1, 0, k2, X1, C.c[3], d.slice[3], I, 3, nullptr, 0, rows, d.D);
+      }
     }
   }
 }
@@ -469,26 +491,27 @@ struct Partials {
   float* pc[TTX_MAX_CORES];  // pc[1] is per CHUNK, the others per lookup
 };
 
-// ---- backward tail stage, fused: for one (lookup j, column kk) pair walk the rows once,
+// ---- backward tail stage, fused: for one (lookup, column kk) pair walk the rows once,
 //   d core partial[kk][0..NT) = sum_row x[row][kk] * G[row][0..NT)     -> HBM
 //   d x[row][kk]              = sum_c   G[row][c]  * C[kk][c]          -> over x in place
-// (only this thread ever reads x[.][kk] of lookup j, so in place is safe without a barrier)
+// (only this thread ever reads x[.][kk] of that lookup, so in place is safe without a barrier)
 template <int NT>
-__device__ __forceinline__ void bwd_stage_fused(int len, int k, int na, int nb, int sJ, int sA,
-                                                int sB, float* X, const float* G, int gJ,
+__device__ __forceinline__ void bwd_stage_fused(int lenS, int j0, int k, int na, int nb, int sJ, int sA,
+                                                int sB, float* X, const float* G, int gJ, int gBase,
                                                 const float* Cg, int slice, const int4* I, int which,
                                                 float* __restrict__ pc) {
   const FastDiv fk = make_fd(k);
-  for (int e = threadIdx.x; e < len * k; e += kThreads) {
+  for (int e = threadIdx.x; e < lenS * k; e += kThreads) {
     unsigned kk;
-    const unsigned j = fdivmod((unsigned)e, fk, kk);
-    const int sid = which == 2 ? I[j].z : I[j].w;
+    const unsigned jl = fdivmod((unsigned)e, fk, kk);
+    const int4 rec = I[j0 + jl];
+    const int sid = which == 2 ? rec.z : rec.w;
     const float* cg = Cg + (size_t)sid * slice + kk * NT;
     float c[NT], acc[NT];
 #pragma unroll
     for (int x = 0; x < NT; ++x) { c[x] = cg[x]; acc[x] = 0.f; }
-    float* xb = X + j * sJ + kk;
-    const float* g = G + j * gJ;
+    float* xb = X + jl * sJ + kk;
+    const float* g = G + (gBase + jl) * gJ;
     for (int a = 0; a < na; ++a) {
       float* xa = xb + a * sA;
 #pragma unroll 4
@@ -505,73 +528,70 @@ __device__ __forceinline__ void bwd_stage_fused(int len, int k, int na, int nb, 
         g += NT;
       }
     }
-    float* o = pc + (size_t)I[j].x * slice + kk * NT;
+    float* o = pc + (size_t)rec.x * slice + kk * NT;
 #pragma unroll
     for (int x = 0; x < NT; ++x) o[x] = acc[x];
   }
 }
 
 // generic two-phase version (any n): (a) partial, barrier, (b) d x in place
-__device__ __forceinline__ void bwd_stage_any(int len, int m, int k, int n, int nb, int sJ, int sA,
-                                              int sB, float* X, const float* G, int gJ,
+__device__ __forceinline__ void bwd_stage_any(int lenS, int j0, int m, int k, int n, int nb, int sJ, int sA,
+                                              int sB, float* X, const float* G, int gJ, int gBase,
                                               const float* Cg, int slice, const int4* I, int which,
                                               float* __restrict__ pc) {
   const FastDiv fn = make_fd(n), fnb = make_fd(nb);
   {
     const FastDiv fp = make_fd(k * n);
-    for (int e = threadIdx.x; e < len * k * n; e += kThreads) {
+    for (int e = threadIdx.x; e < lenS * k * n; e += kThreads) {
       unsigned rem, col;
-      const unsigned j = fdivmod((unsigned)e, fp, rem);
+      const unsigned jl = fdivmod((unsigned)e, fp, rem);
       const unsigned kk = fdivmod(rem, fn, col);
-      const float* gi = G + j * gJ + col;
-      const float* xj = X + j * sJ + kk;
+      const float* gi = G + (gBase + jl) * gJ + col;
+      const float* xj = X + jl * sJ + kk;
       float acc = 0.f;
       int row = 0;
       for (int a = 0; a * nb < m; ++a)
         for (int b = 0; b < nb; ++b, ++row) acc = fmaf(xj[a * sA + b * sB], gi[row * n], acc);
-      pc[(size_t)I[j].x * slice + rem] = acc;
+      pc[(size_t)I[j0 + jl].x * slice + rem] = acc;
     }
   }
   __syncthreads();
   {
     const FastDiv fp = make_fd(m * k), fk = make_fd(k);
-    for (int e = threadIdx.x; e < len * m * k; e += kThreads) {
+    for (int e = threadIdx.x; e < lenS * m * k; e += kThreads) {
       unsigned rem, kk, b;
-      const unsigned j = fdivmod((unsigned)e, fp, rem);
+      const unsigned jl = fdivmod((unsigned)e, fp, rem);
       const unsigned row = fdivmod(rem, fk, kk);
       const unsigned a = fdivmod(row, fnb, b);
-      const int sid = which == 2 ? I[j].z : I[j].w;
+      const int4 rec = I[j0 + jl];
+      const int sid = which == 2 ? rec.z : rec.w;
       const float* ct = Cg + (size_t)sid * slice + kk * n;
-      const float* gi = G + j * gJ + row * n;
+      const float* gi = G + (gBase + jl) * gJ + row * n;
       float acc = 0.f;
       for (int c = 0; c < n; ++c) acc = fmaf(gi[c], ct[c], acc);
-      X[j * sJ + a * sA + b * sB + kk] = acc;
+      X[jl * sJ + a * sA + b * sB + kk] = acc;
     }
   }
 }
 
-// ---- GEMM 2: d core_1 partial tile(s) = As^T * dX0, k-step rows {m, m+8, m+16, m+24} ----
+// ---- GEMM 2: d core_1 tiles += As^T * dX0 over one pass, k-step rows {m, m+8, m+16, m+24} ----
+// acc[x][y]: x = column tile of the pair (np*2 + x), y = r1 tile k0t + y
 template <int KB, bool TWO>
-__device__ __forceinline__ void db1_group(const Dims& d, const Lds& L, const float* smem, int np,
-                                          int k0t, int rows32, float* __restrict__ pc) {
+__device__ __forceinline__ void db1_accum(const Lds& L, const float* smem, int h, int np, int k0t,
+                                          f32x4 (&acc)[2][KB]) {
   const int lane = lane_id();
   const int i16 = lane & 15, kq = lane >> 4;
   const float* xr = smem + L.oX0 + 8 * kq * L.ld + np * 32 + i16;
-  const float* ar = smem + L.oA + 8 * kq * L.ldA + k0t * 16 + i16;
-  f32x4 acc[2][KB];
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < KB; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* ar = smem + L.oA + (h * L.rS + 8 * kq) * L.ldA + k0t * 16 + i16;
   // software pipeline: operands of k-step t+1 are read while the MFMAs of step t issue
   float bc0 = xr[0], bc1 = TWO ? xr[16] : 0.f, ac[KB];
 #pragma unroll
   for (int y = 0; y < KB; ++y) ac[y] = ar[y * 16];
-  for (int mb = 0; mb < rows32; mb += 32) {
+  for (int mb = 0; mb < L.rS; mb += 32) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int mx = (t < 7) ? mb + t + 1 : mb + 32;  // row steps of a block are mb+0..7 (+8*kq)
-      const int mn = (mx < rows32) ? mx : 0;          // last prefetch wraps (unused)
+      const int mn = (mx < L.rS) ? mx : 0;            // last prefetch wraps (unused)
       const float bn0 = xr[mn * L.ld];
       const float bn1 = TWO ? xr[mn * L.ld + 16] : 0.f;
       float an[KB];
@@ -586,13 +606,20 @@ __device__ __forceinline__ void db1_group(const Dims& d, const Lds& L, const flo
       bc1 = bn1;
 #pragma unroll
       for (int y = 0; y < KB; ++y) ac[y] = an[y];
-      __builtin_amdgcn_sched_group_barrier(0x100, (TWO ? 1 : 1) + (KB + 1) / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1 + (KB + 1) / 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, (TWO ? 2 : 1) * KB, 0);
     }
   }
+}
+
+template <int KB>
+__device__ __forceinline__ void db1_store(const Dims& d, const Lds& L, int np, int k0t,
+                                          const f32x4 (&acc)[2][KB], float* __restrict__ pc) {
+  const int lane = lane_id();
+  const int i16 = lane & 15, kq = lane >> 4;
   const int K0 = d.k[0], N1 = d.n[0];
 #pragma unroll
-  for (int x = 0; x < (TWO ? 2 : 1); ++x) {
+  for (int x = 0; x < 2; ++x) {
     const int col = (np * 2 + x) * 16 + i16;
 #pragma unroll
     for (int y = 0; y < KB; ++y)
@@ -604,10 +631,18 @@ __device__ __forceinline__ void db1_group(const Dims& d, const Lds& L, const flo
   }
 }
 
+template <int KB>
+__device__ __forceinline__ void db1_zero(f32x4 (&acc)[2][KB]) {
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < KB; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
 // ---- GEMM 3: d core_0 partial rows = dX0 * Bs^T, k-step columns {c, c+1, c+2, c+3} ----
 template <int KB>
 __device__ __forceinline__ void da_group(const Dims& d, const Lds& L, const float* smem, int mt,
-                                         int k0t, int mrows, float* __restrict__ pc) {
+                                         int k0t, int j0, int lenS, float* __restrict__ pc) {
   const int lane = lane_id();
   const int i16 = lane & 15, kq = lane >> 4;
   const float* xr = smem + L.oX0 + (mt * 16 + i16) * L.ld + kq;
@@ -652,10 +687,10 @@ __device__ __forceinline__ void da_group(const Dims& d, const Lds& L, const floa
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = mt * 16 + kq * 4 + r;
-    if (row < mrows) {
-      unsigned a_;
-      const unsigned j = fdivmod((unsigned)row, L.fdQ0, a_);
-      float* o = pc + (size_t)I[j].x * sl0 + a_ * K0;
+    unsigned a_;
+    const unsigned jl = fdivmod((unsigned)row, L.fdQ0, a_);
+    if ((int)jl < lenS) {
+      float* o = pc + (size_t)I[j0 + jl].x * sl0 + a_ * K0;
 #pragma unroll
       for (int y = 0; y < KB; ++y) {
         const int kk = (k0t + y) * 16 + i16;
@@ -665,7 +700,130 @@ __device__ __forceinline__ void da_group(const Dims& d, const Lds& L, const floa
   }
 }
 
-__global__ __launch_bounds__(kThreads, 2) void bwd_kernel(Dims d, Plan P, CorePtrs C, int B,
+// all d core_0 tiles of one pass, spread over the waves
+__device__ __forceinline__ void gemm_da(const Dims& d, const Lds& L, const float* smem, int j0, int lenS,
+                                        float* __restrict__ pc) {
+  const int w = threadIdx.x / kWave;
+  const int mtiles = (lenS * d.q[0] + 15) / 16;
+  int KB = 4;
+  while (KB > 1 && mtiles * ((L.K0t + KB - 1) / KB) < kWaves) KB >>= 1;
+  const int ngroups = (L.K0t + KB - 1) / KB;
+  for (int job = w; job < mtiles * ngroups; job += kWaves) {
+    const int mt = job / ngroups, g = job - mt * ngroups;
+    int k0t = g * KB;
+    int cnt = min(KB, L.K0t - k0t);
+    while (cnt > 0) {
+      if (cnt >= 4) { da_group<4>(d, L, smem, mt, k0t, j0, lenS, pc); k0t += 4; cnt -= 4; }
+      else if (cnt >= 2) { da_group<2>(d, L, smem, mt, k0t, j0, lenS, pc); k0t += 2; cnt -= 2; }
+      else { da_group<1>(d, L, smem, mt, k0t, j0, lenS, pc); k0t += 1; cnt -= 1; }
+    }
+  }
+}
+
+// everything of one pass up to and including the per-lookup tail: leaves dX0 in LDS
+__device__ __forceinline__ void bwd_pass_front(const Dims& d, const CorePtrs& C, const Lds& L, float* smem,
+                                               int B, int table, const int64_t* __restrict__ rowidx,
+                                               const float* __restrict__ d_output, const Partials& PC,
+                                               int h, int j0, int lenS) {
+  const int tid = threadIdx.x;
+  const int T = d.T, q0 = d.q[0], D = d.D;
+  const int4* I = (const int4*)(smem + L.oI);
+  float* X0 = smem + L.oX0;
+  float* X1 = smem + L.oX1;
+  float* Gb = smem + L.oG;
+  if (T == 2) {
+    // dX0 is the bag gradient itself: [q0 x q1]; zero the MFMA padding
+    for (int e = tid; e < L.rS * L.ld; e += kThreads) X0[e] = 0.f;
+    __syncthreads();
+    for (int e = tid; e < lenS * D; e += kThreads) {
+      unsigned rem, col;
+      const unsigned jl = fdivmod((unsigned)e, L.fdD, rem);
+      const unsigned a = fdivmod(rem, L.fdN1, col);
+      X0[(jl * q0 + a) * L.ld + col] = d_output[((size_t)table * B + rowidx[I[j0 + jl].x]) * D + rem];
+    }
+    __syncthreads();
+    return;
+  }
+  // recompute the forward intermediate x_0 of this pass
+  if (!(L.dbg & 1)) gemm_x0(d, L, smem, h, nullptr, j0, lenS);
+  __syncthreads();
+  if (L.dbg & 2) return;
+  if (T == 4) {
+    // x_1 = x_0 * core_2[i_2]  (needed by the gradient of core 3)
+    const int k1 = d.k[1], n1 = d.n[1], m1 = d.m[1], q1 = d.q[1];
+    if (n1 <= 8) {
+#define CALL(NT) fwd_stage<NT>(lenS, j0, m1, k1, q1, q0 * L.ld, L.ld, k1, X0, nullptr, 0, false, C.c[2], d.slice[2], I, 2, \
+                               X1, L.szX1, nullptr, D)
+      TTX_NT_SWITCH(n1, CALL)
+#undef CALL
+    } else {
+      fwd_stage_any(lenS, j0, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, C.c[2], d.slice[2], I, 2, X1, L.szX1, nullptr, D);
+    }
+    __syncthreads();
+    // stage t = 2 on x_1 [m2 x k2] with G = bag gradient [m2 x n2]
+    const int m2 = d.m[2], k2 = d.k[2], n2 = d.n[2];
+    if (n2 <= 8) {
+#define CALL(NT) bwd_stage_fused<NT>(lenS, j0, k2, 1, m2, L.szX1, 0, k2, X1, Gb, D, j0, C.c[3], d.slice[3], I, 3, PC.pc[3])
+      TTX_NT_SWITCH(n2, CALL)
+#undef CALL
+    } else {
+      bwd_stage_any(lenS, j0, m2, k2, n2, m2, L.szX1, 0, k2, X1, Gb, D, j0, C.c[3], d.slice[3], I, 3, PC.pc[3]);
+    }
+    __syncthreads();
+  }
+  // stage t = 1 on x_0 (row = a*q1 + b at a*ld + b*k1) with G1 = bag gradient (T == 3) or d x_1
+  {
+    const int m1 = d.m[1], k1 = d.k[1], n1 = d.n[1], q1 = d.q[1];
+    const float* Gin = (T == 3) ? Gb : X1;
+    const int gJ = (T == 3) ? D : L.szX1;
+    const int gBase = (T == 3) ? j0 : 0;
+    if (n1 <= 8) {
+#define CALL(NT) bwd_stage_fused<NT>(lenS, j0, k1, q0, q1, q0 * L.ld, L.ld, k1, X0, Gin, gJ, gBase, C.c[2], d.slice[2], I, 2, PC.pc[2])
+      TTX_NT_SWITCH(n1, CALL)
+#undef CALL
+    } else {
+      bwd_stage_any(lenS, j0, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, Gin, gJ, gBase, C.c[2], d.slice[2], I, 2, PC.pc[2]);
+    }
+    __syncthreads();
+  }
+}
+
+// the chunk loop with d core_1 held in registers across passes (KB = r1 tiles, <= 2 jobs/wave)
+template <int KB>
+__device__ __forceinline__ void bwd_passes(const Dims& d, const CorePtrs& C, const Lds& L, float* smem, int B,
+                                           int table, const int64_t* __restrict__ rowidx,
+                                           const float* __restrict__ d_output, const Partials& PC, int chunk,
+                                           int len) {
+  const int w = threadIdx.x / kWave;
+  const int npairs = (L.N1t + 1) / 2;
+  f32x4 acc0[2][KB], acc1[2][KB];
+  db1_zero<KB>(acc0);
+  db1_zero<KB>(acc1);
+  const int np0 = w, np1 = w + kWaves;
+  const int npass = (len + L.SC - 1) / L.SC;
+  for (int h = 0; h < npass; ++h) {
+    const int j0 = h * L.SC;
+    const int lenS = min(L.SC, len - j0);
+    if (h > 0) __syncthreads();  // the previous pass is done with X0 / X1
+    bwd_pass_front(d, C, L, smem, B, table, rowidx, d_output, PC, h, j0, lenS);
+    if (!(L.dbg & 4)) {
+      if (np0 < npairs) {
+        if (np0 * 2 + 1 < L.N1t) db1_accum<KB, true>(L, smem, h, np0, 0, acc0);
+        else db1_accum<KB, false>(L, smem, h, np0, 0, acc0);
+      }
+      if (np1 < npairs) {
+        if (np1 * 2 + 1 < L.N1t) db1_accum<KB, true>(L, smem, h, np1, 0, acc1);
+        else db1_accum<KB, false>(L, smem, h, np1, 0, acc1);
+      }
+    }
+    if (!(L.dbg & 8)) gemm_da(d, L, smem, j0, lenS, PC.pc[0]);
+  }
+  float* pc = PC.pc[1] + (size_t)chunk * d.slice[1];
+  if (np0 < npairs) db1_store<KB>(d, L, np0, 0, acc0, pc);
+  if (np1 < npairs) db1_store<KB>(d, L, np1, 0, acc1, pc);
+}
+
+__global__ __launch_bounds__(kThreads, 3) void bwd_kernel(Dims d, Plan P, CorePtrs C, int B,
                                                          const int64_t* __restrict__ rowidx,
                                                          const float* __restrict__ d_output,
                                                          Partials PC, Lds L) {
@@ -678,31 +836,15 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_kernel(Dims d, Plan P, CorePt
   if (len == 0) return;
   STAMP(1);
   const int tid = threadIdx.x;
-  const int T = d.T, q0 = d.q[0], D = d.D;
-  const int mrows = len * q0;
-  const int rows32 = (mrows + 31) / 32 * 32;  // K extent of the dB1 GEMM
-  const int mtiles = (mrows + 15) / 16;
-  stage_chunk(d, P, C, L, smem, s, start, len, rows32);
+  const int D = d.D;
+  stage_chunk(d, P, C, L, smem, s, start, len);
   STAMP(2);
   if (L.dbg & 16) return;
   const int4* I = (const int4*)(smem + L.oI);
-  float* X0 = smem + L.oX0;
-  float* X1 = smem + L.oX1;
-  float* Gb = smem + L.oG;
   const int table = s / d.p[1];
-
-  if (T == 2) {
-    // dX0 is the bag gradient itself: [q0 x q1]; zero the MFMA padding
-    for (int e = tid; e < rows32 * L.ld; e += kThreads) X0[e] = 0.f;
-    __syncthreads();
-    for (int e = tid; e < len * D; e += kThreads) {
-      unsigned rem;
-      const unsigned j = fdivmod((unsigned)e, L.fdD, rem);
-      X0[x0_addr(L, q0, j, rem)] = d_output[((size_t)table * B + rowidx[I[j].x]) * D + rem];
-    }
-    __syncthreads();
-  } else {
+  if (d.T >= 3) {
     // bag gradients of the chunk's lookups
+    float* Gb = smem + L.oG;
     if ((D & 3) == 0) {
       const int d4 = D / 4;
       for (int e = tid; e < len * d4; e += kThreads) {
@@ -717,81 +859,31 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_kernel(Dims d, Plan P, CorePt
         Gb[e] = d_output[((size_t)table * B + rowidx[I[j].x]) * D + rem];
       }
     }
-    // recompute the forward intermediate x_0 (rows up to rows32: zero A rows -> zero X0 rows)
-    STAMP(3);
-    if (!(L.dbg & 1)) gemm_x0(d, L, smem, rows32 / 16, nullptr, len);
-    __syncthreads();
-    STAMP(4);
-    if (T == 4) {
-      // x_1 = x_0 * core_2[i_2]  (needed by the gradient of core 3)
-      const int k1 = d.k[1], n1 = d.n[1], m1 = d.m[1], q1 = d.q[1];
-      if (n1 <= 8) {
-#define CALL(NT) fwd_stage<NT>(len, m1, k1, q1, q0 * L.ld, L.ld, k1, X0, nullptr, 0, false, C.c[2], d.slice[2], I, 2, \
-                               X1, L.szX1, nullptr, D)
-        TTX_NT_SWITCH(n1, CALL)
-#undef CALL
-      } else {
-        fwd_stage_any(len, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, C.c[2], d.slice[2], I, 2, X1, L.szX1, nullptr, D);
-      }
-      __syncthreads();
-      // stage t = 2 on x_1 [m2 x k2] with G = bag gradient [m2 x n2]
-      const int m2 = d.m[2], k2 = d.k[2], n2 = d.n[2];
-      if (n2 <= 8) {
-#define CALL(NT) bwd_stage_fused<NT>(len, k2, 1, m2, L.szX1, 0, k2, X1, Gb, D, C.c[3], d.slice[3], I, 3, PC.pc[3])
-        TTX_NT_SWITCH(n2, CALL)
-#undef CALL
-      } else {
-        bwd_stage_any(len, m2, k2, n2, m2, L.szX1, 0, k2, X1, Gb, D, C.c[3], d.slice[3], I, 3, PC.pc[3]);
-      }
-      __syncthreads();
-    }
-    // stage t = 1 on x_0 (row = a*q1 + b at a*ld + b*k1) with G1 = bag gradient (T == 3) or d x_1
-    if (!(L.dbg & 2)) {
-      const int m1 = d.m[1], k1 = d.k[1], n1 = d.n[1], q1 = d.q[1];
-      const float* Gin = (T == 3) ? Gb : X1;
-      const int gJ = (T == 3) ? D : L.szX1;
-      if (n1 <= 8) {
-#define CALL(NT) bwd_stage_fused<NT>(len, k1, q0, q1, q0 * L.ld, L.ld, k1, X0, Gin, gJ, C.c[2], d.slice[2], I, 2, PC.pc[2])
-        TTX_NT_SWITCH(n1, CALL)
-#undef CALL
-      } else {
-        bwd_stage_any(len, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, Gin, gJ, C.c[2], d.slice[2], I, 2, PC.pc[2]);
-      }
-      __syncthreads();
-    }
+    // (visible to the tail after the barrier that follows the first GEMM)
   }
-
-  // ---- chunk GEMMs on dX0 [rows x N1] ---------------------------------------
-  STAMP(5);
-  const int w = tid / kWave;
-  if (!(L.dbg & 4)) {
-    // (2) d core_1[slice] partial [r1 x N1] = As^T * dX0   -> HBM, per chunk
-    float* pc = PC.pc[1] + (size_t)chunk * d.slice[1];
+  STAMP(3);
+  if (L.persist) {
+    const int kb = L.K0t <= 1 ? 1 : (L.K0t <= 2 ? 2 : 4);
+    if (kb == 1) bwd_passes<1>(d, C, L, smem, B, table, rowidx, d_output, PC, chunk, len);
+    else if (kb == 2) bwd_passes<2>(d, C, L, smem, B, table, rowidx, d_output, PC, chunk, len);
+    else bwd_passes<4>(d, C, L, smem, B, table, rowidx, d_output, PC, chunk, len);
+  } else {
+    // single pass (SC == MC); d core_1 tiles computed and stored group by group
+    bwd_pass_front(d, C, L, smem, B, table, rowidx, d_output, PC, 0, 0, len);
+    const int w = tid / kWave;
     const int npairs = (L.N1t + 1) / 2;
+    float* pc = PC.pc[1] + (size_t)chunk * d.slice[1];
     for (int np = w; np < npairs; np += kWaves) {
       const bool two = (np * 2 + 1) < L.N1t;
-      int k0t = 0;
-      while (k0t < L.K0t) {
-        const int rem = L.K0t - k0t;
-        if (rem >= 4) { if (two) db1_group<4, true>(d, L, smem, np, k0t, rows32, pc); else db1_group<4, false>(d, L, smem, np, k0t, rows32, pc); k0t += 4; }
-        else if (rem >= 2) { if (two) db1_group<2, true>(d, L, smem, np, k0t, rows32, pc); else db1_group<2, false>(d, L, smem, np, k0t, rows32, pc); k0t += 2; }
-        else { if (two) db1_group<1, true>(d, L, smem, np, k0t, rows32, pc); else db1_group<1, false>(d, L, smem, np, k0t, rows32, pc); k0t += 1; }
+      for (int k0t = 0; k0t < L.K0t; k0t += 4) {
+        f32x4 acc[2][4];
+        db1_zero<4>(acc);
+        if (two) db1_accum<4, true>(L, smem, 0, np, k0t, acc);
+        else db1_accum<4, false>(L, smem, 0, np, k0t, acc);
+        db1_store<4>(d, L, np, k0t, acc, pc);
       }
     }
-  }
-  STAMP(6);
-  if (!(L.dbg & 8)) {
-    // (3) d core_0[i_0] partials [rows x r1] = dX0 * Bs^T  -> HBM, per lookup
-    float* pc = PC.pc[0];
-    for (int mt = w; mt < mtiles; mt += kWaves) {
-      int k0t = 0;
-      while (k0t < L.K0t) {
-        const int rem = L.K0t - k0t;
-        if (rem >= 4) { da_group<4>(d, L, smem, mt, k0t, mrows, pc); k0t += 4; }
-        else if (rem >= 2) { da_group<2>(d, L, smem, mt, k0t, mrows, pc); k0t += 2; }
-        else { da_group<1>(d, L, smem, mt, k0t, mrows, pc); k0t += 1; }
-      }
-    }
+    gemm_da(d, L, smem, 0, len, PC.pc[0]);
   }
   STAMP(7);
 #undef STAMP

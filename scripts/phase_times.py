@@ -27,15 +27,17 @@ st = buf.cpu().numpy().reshape(-1, 16)
 live = st[:, 7] > 0
 st = st[live][:, :8].astype(np.float64) / 100.0  # 100 MHz -> us
 t0 = st[:, 0].min()
-names = ["entry", "chunk_rec", "staged", "G loaded", "x0 recomputed", "tail done", "dB1 done", "dA done"]
+names = ["entry", "chunk_rec", "staged", "G issued", "-", "-", "-", "done"]
 print(f"{live.sum()} work-groups; times in us relative to the first entry")
 for i, nm in enumerate(names):
+    if nm == "-":
+        continue
     v = st[:, i] - t0
     print(f"  {nm:14s} min {v.min():6.2f}  med {np.median(v):6.2f}  max {v.max():6.2f}")
 print("phase durations (per work-group):")
-for i in range(1, 8):
-    v = st[:, i] - st[:, i - 1]
-    print(f"  {names[i-1]:>14s} -> {names[i]:14s} min {v.min():6.2f}  med {np.median(v):6.2f}  max {v.max():6.2f}")
+for a, b in ((0, 1), (1, 2), (2, 3), (3, 7), (0, 7)):
+    v = st[:, b] - st[:, a]
+    print(f"  {names[a]:>14s} -> {names[b]:14s} min {v.min():6.2f}  med {np.median(v):6.2f}  max {v.max():6.2f}")
 
 pl = buf.cpu().numpy().reshape(-1, 16)[1000:1003, :9].astype(np.float64) / 100.0
 pl = pl[:, [0, 8, 1, 6, 7, 2, 3, 4, 5]]
