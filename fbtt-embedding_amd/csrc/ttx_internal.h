@@ -59,14 +59,16 @@ int make_dims(const ttx_geom* g, Dims* d);  // TTX_OK or TTX_EINVAL (+message)
 //                 list of the pivot core (core 1), each slice's run of lookups
 //                 cut into chunks of <= MC lookups; chunk_off[s] = first chunk of s
 //   lrec[i]     = {n, sid_0, sid_2, sid_3} of the i-th lookup in pivot order
+//   lrow[i]     = bag row (rowidx[n]) of that lookup; valid iff hdr[3] != 0
 struct Plan {
-  int* hdr;  // [0] = number of chunks, [1] = MC, [2] = nnz
+  int* hdr;  // [0] = number of chunks, [1] = MC, [2] = nnz, [3] = lrow valid
   int* sid[TTX_MAX_CORES];
   int* perm[TTX_MAX_CORES];
   int* off[TTX_MAX_CORES];
   int* chunk_off;    // [S_1 + 1]
   int4* chunk_rec;   // [max_chunks]
   int4* lrec;        // [nnz]
+  int* lrow;         // [nnz]
   int* scratch[TTX_MAX_CORES][3];  // rank / ping / pong per core, [nnz] each
   int max_chunks;
   int MC;
@@ -78,7 +80,7 @@ size_t plan_bytes(const Dims& d, long long nnz);
 // carve `base` into the plan arrays (same function for builder and consumers)
 Plan carve_plan(const Dims& d, long long nnz, void* base);
 int plan_build(const Dims& d, long long nnz, const int64_t* indices,
-               const int64_t* tableidx, const Plan& P, hipStream_t stream);
+               const int64_t* tableidx, const int64_t* rowidx, const Plan& P, hipStream_t stream);
 
 long long* debug_stamps();  // debug stamp buffer (ttx_debug_stamps), or nullptr
 

@@ -42,6 +42,7 @@ static size_t plan_ints(const Dims& d, long long nnz, int MC) {
   n += r64((size_t)d.S[1] + 1);                                     // chunk_off
   n += r64((size_t)max_chunks(d, nnz, MC) * 4);                     // chunk_rec
   n += r64((size_t)nnz * 4);                                        // lrec
+  n += r64((size_t)nnz);                                            // lrow
   return n;
 }
 
@@ -59,6 +60,7 @@ Plan carve_plan(const Dims& d, long long nnz, void* base) {
   P.hdr = take(64);
   P.chunk_rec = (int4*)take((size_t)P.max_chunks * 4);
   P.lrec = (int4*)take((size_t)nnz * 4);
+  P.lrow = take(nnz);
   for (int t = 0; t < d.T; ++t) {
     P.sid[t] = take(nnz);
     P.perm[t] = take(nnz);
@@ -133,7 +135,8 @@ __device__ __forceinline__ unsigned clamp_idx32(long long idx) {
 }
 
 __global__ __launch_bounds__(kPlanThreads) void plan_kernel(
-    Dims d, int N, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx, Plan P) {
+    Dims d, int N, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx,
+    const int64_t* __restrict__ rowidx, Plan P) {
   __shared__ int hist[256 * kPlanWaves];  // [digit][wave]
   __shared__ int wtot[kPlanWaves + 1];
   const int tid = threadIdx.x;
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(
       P.hdr[0] = carry;
       P.hdr[1] = MC;
       P.hdr[2] = N;
+      P.hdr[3] = rowidx ? 1 : 0;
     }
     for (int i = tid; i < N; i += kPlanThreads) {
       const int n = pm[i];
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_kernel(
       r.z = d.T > 2 ? tb * d.p[2] + decode_core(d, 2, idx) : 0;
       r.w = d.T > 3 ? tb * d.p[3] + decode_core(d, 3, idx) : 0;
       P.lrec[i] = r;
+      if (rowidx) P.lrow[i] = (int)rowidx[n];
     }
   }
 }
@@ -277,8 +282,8 @@ constexpr int kSmallMax = 16384;
 
 template <int kBPW>  // batches of 64 lookups per wave (register array extent)
 __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
-    Dims d, int N, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx, Plan P,
-    long long* stamps) {
+    Dims d, int N, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx,
+    const int64_t* __restrict__ rowidx, Plan P, long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) int lds[];
 #define PSTAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(size_t)(1000 + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
   PSTAMP(0);
@@ -368,11 +373,12 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
     if (direct) {
       // single pass: v[b] is still this thread's own element; read its other slice ids
       // back (all loads first), then scatter keys, values and the flat records
-      int a0[kBPW], a2[kBPW], a3[kBPW];
+      int a0[kBPW], a2[kBPW], a3[kBPW], rw[kBPW];
       const int last_i = N > 0 ? N - 1 : 0;
 #pragma unroll
       for (int b = 0; b < kBPW; ++b) {
         const int i = min(v[b], last_i);
+        rw[b] = (b < nb && rowidx) ? (int)rowidx[i] : 0;
         a0[b] = (b < nb) ? sc0[i] : 0;
         a2[b] = (b < nb && d.T > 2) ? sc2[i] : 0;
         a3[b] = (b < nb && d.T > 3) ? sc3[i] : 0;
@@ -385,6 +391,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
           keyL[pos] = k[b];
           valL[pos] = v[b];
           P.lrec[pos] = make_int4(v[b], a0[b], a2[b], a3[b]);
+          if (rowidx) P.lrow[pos] = rw[b];
         }
       }
     } else {
@@ -436,6 +443,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
       rr.z = d.T > 2 ? tb * c2.p + decode32(c2, idx) : 0;
       rr.w = d.T > 3 ? tb * c3.p + decode32(c3, idx) : 0;
       P.lrec[i] = rr;
+      if (rowidx) P.lrow[i] = (int)rowidx[n];
     }
     PSTAMP(4);
     // chunk list from the sorted keys in LDS: slice s covers [lower_bound(s), lower_bound(s+1))
@@ -469,6 +477,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
       P.hdr[0] = carry;
       P.hdr[1] = MC;
       P.hdr[2] = N;
+      P.hdr[3] = rowidx ? 1 : 0;
     }
     PSTAMP(5);
   }
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
 }
 
 int plan_build(const Dims& d, long long nnz, const int64_t* indices,
-               const int64_t* tableidx, const Plan& P, hipStream_t stream) {
+               const int64_t* tableidx, const int64_t* rowidx, const Plan& P, hipStream_t stream) {
   if (nnz < 0 || nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz=%lld out of range", nnz);
   ProfScope ps(TTX_PROF_PLAN, stream);
   if (nnz <= kSmallMax && d.idx32) {  // on-chip plan; 32-bit index decode only
@@ -492,7 +501,7 @@ int plan_build(const Dims& d, long long nnz, const int64_t* indices,
       attr_done = true;                                                                               \
     }                                                                                                 \
     hipLaunchKernelGGL(plan_small_kernel<BPW>, dim3(d.T), dim3(kPlanThreads), lds, stream, d,         \
-                       (int)nnz, indices, tableidx, P, debug_stamps());                               \
+                       (int)nnz, indices, tableidx, rowidx, P, debug_stamps());                               \
   } while (0)
     if (nb <= 2) TTX_PLAN_LAUNCH(2);
     else if (nb <= 4) TTX_PLAN_LAUNCH(4);
@@ -502,7 +511,7 @@ int plan_build(const Dims& d, long long nnz, const int64_t* indices,
 #undef TTX_PLAN_LAUNCH
   } else {
     hipLaunchKernelGGL(plan_kernel, dim3(d.T), dim3(kPlanThreads), 0, stream, d, (int)nnz,
-                       indices, tableidx, P);
+                       indices, tableidx, rowidx, P);
   }
   TTX_HIP(hipGetLastError());
   return TTX_OK;
@@ -519,7 +528,7 @@ size_t ttx_plan_bytes(const ttx_geom* g, int64_t nnz) {
 }
 
 int ttx_plan_build(const ttx_geom* g, int64_t nnz, const int64_t* indices,
-                   const int64_t* tableidx, void* plan, size_t plan_bytes,
+                   const int64_t* tableidx, const int64_t* rowidx, void* plan, size_t plan_bytes,
                    ttx_stream_t stream) {
   ttx::Dims d;
   int rc = ttx::make_dims(g, &d);
@@ -528,7 +537,7 @@ int ttx_plan_build(const ttx_geom* g, int64_t nnz, const int64_t* indices,
     TTX_FAIL(TTX_EWORKSPACE, "plan buffer too small: %zu < %zu", plan_bytes, ttx::plan_bytes(d, nnz));
   if (nnz > 0 && !indices) TTX_FAIL(TTX_EINVAL, "indices is NULL");
   ttx::Plan P = ttx::carve_plan(d, nnz, plan);
-  return ttx::plan_build(d, nnz, indices, tableidx, P, (hipStream_t)stream);
+  return ttx::plan_build(d, nnz, indices, tableidx, rowidx, P, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -88,6 +88,8 @@ struct Lds {
 
 static int g_chunk_override = 0;
 static int g_debug_skip = 0;
+static int g_disable_spec = 0;
+static bool spec_shape(const Dims& d);  // ttx_tt_spec.inc covers this geometry
 static long long* g_stamps = nullptr;
 
 long long* debug_stamps() { return g_stamps; }
@@ -146,6 +148,7 @@ static Lds make_lds(const Dims& d, int MC, bool bwd) {
 }
 
 int choose_chunk(const Dims& d) {
+  if (spec_shape(d)) return 32;  // wave-independent kernels: 8 groups of 4 lookups per chunk (kSpecMC)
   if (g_chunk_override > 0) return g_chunk_override;
   // three, then two work-groups per CU (160 KiB of LDS), else whatever fits
   for (int mc = 16; mc >= 8; mc >>= 1)
@@ -1003,6 +1006,10 @@ __global__ __launch_bounds__(kThreads) void reduce_apply_kernel(Dims d, Plan P, 
   }
 }
 
+#include "ttx_tt_spec.inc"
+
+static bool spec_shape(const Dims& d) { return spec_match(d) != SPEC_NONE; }
+
 // ---------------------------------------------------------- host side ------
 
 static int check_lds(const Dims& d, const Lds& L) {
@@ -1023,8 +1030,29 @@ static int allow_lds(K kernel, int bytes) {
 
 static size_t rows_bytes(const Dims& d, long long nnz) { return align_up((size_t)nnz * d.D * 4); }
 
+static int run_rows_spec(SpecId id, const Plan& P, const CorePtrs& C, float* rows, hipStream_t st) {
+#define CALLF(S) spec_launch_fwd<S>(P, C, rows, st)
+  TTX_SPEC_DISPATCH(id, CALLF)
+#undef CALLF
+  TTX_FAIL(TTX_EUNSUPPORTED, "no specialised forward kernel");
+}
+
+static int run_bwd_spec(SpecId id, const Dims& d, const Plan& P, const CorePtrs& C, int B,
+                        const int64_t* rowidx, const float* d_output, const Partials& PC, hipStream_t st) {
+#define CALLB(S) spec_launch_bwd<S>(d, P, C, B, rowidx, d_output, PC, st)
+  TTX_SPEC_DISPATCH(id, CALLB)
+#undef CALLB
+  TTX_FAIL(TTX_EUNSUPPORTED, "no specialised backward kernel");
+}
+
 static int run_rows(const Dims& d, long long nnz, const Plan& P, const float* const* cores,
                     float* rows, hipStream_t st) {
+  if (const SpecId id = spec_match(d)) {
+    CorePtrs C;
+    for (int t = 0; t < TTX_MAX_CORES; ++t) C.c[t] = t < d.T ? (float*)cores[t] : nullptr;
+    ProfScope ps(TTX_PROF_FWD, st);
+    return run_rows_spec(id, P, C, rows, st);
+  }
   Lds L = make_lds(d, P.MC, false);
   int rc = check_lds(d, L);
   if (rc) return rc;
@@ -1052,6 +1080,8 @@ int ttx_debug_stamps(void* device_buffer) {
 
 // ablation knob for scripts/ablate.py: skip kernel phases (results become invalid)
 int ttx_debug_skip(int32_t mask) {
+  g_disable_spec = (mask & 256) ? 1 : 0;  // bit 8: force the generic kernels (A/B tests)
+  mask &= 255;
   g_debug_skip = mask;
   return TTX_OK;
 }
@@ -1102,7 +1132,7 @@ int ttx_tt_forward(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const i
     P = carve_plan(d, nnz, (void*)plan);
   } else {
     P = carve_plan(d, nnz, ws);
-    rc = plan_build(d, nnz, indices, tableidx, P, st);
+    rc = plan_build(d, nnz, indices, tableidx, rowidx, P, st);
     if (rc) return rc;
     ws += pb;
   }
@@ -1132,7 +1162,7 @@ int ttx_tt_rows(const ttx_geom* g, int32_t D, int64_t nnz, const int64_t* indice
   if (!workspace || workspace_bytes < plan_bytes(d, nnz))
     TTX_FAIL(TTX_EWORKSPACE, "rows workspace too small: %zu < %zu", workspace_bytes, plan_bytes(d, nnz));
   Plan P = carve_plan(d, nnz, workspace);
-  rc = plan_build(d, nnz, indices, tableidx, P, (hipStream_t)stream);
+  rc = plan_build(d, nnz, indices, tableidx, nullptr, P, (hipStream_t)stream);
   if (rc) return rc;
   return run_rows(d, nnz, P, tt_cores, rows, (hipStream_t)stream);
 }
@@ -1191,24 +1221,28 @@ int ttx_tt_backward(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, floa
     P = carve_plan(d, nnz, (void*)plan);
   } else {
     P = carve_plan(d, nnz, ws);
-    rc = plan_build(d, nnz, indices, tableidx, P, st);
+    rc = plan_build(d, nnz, indices, tableidx, rowidx, P, st);
     if (rc) return rc;
     ws += pb;
   }
   Partials PC;
   for (int t = 0; t < TTX_MAX_CORES; ++t) PC.pc[t] = t < d.T ? (float*)(ws + offs[t]) : nullptr;
-  Lds L = make_lds(d, P.MC, true);
-  rc = check_lds(d, L);
-  if (rc) return rc;
-  rc = allow_lds(bwd_kernel, L.bytes);
-  if (rc) return rc;
   CorePtrs C, S, DW;
   for (int t = 0; t < TTX_MAX_CORES; ++t) {
     C.c[t] = t < d.T ? tt_cores[t] : nullptr;
     S.c[t] = (t < d.T && optim == TTX_OPTIM_ADAGRAD) ? optimizer_state[t] : nullptr;
     DW.c[t] = (t < d.T && optim == TTX_OPTIM_DENSE) ? d_tt_cores[t] : nullptr;
   }
-  {
+  if (const SpecId id = spec_match(d)) {
+    ProfScope ps(TTX_PROF_BWD, st);
+    rc = run_bwd_spec(id, d, P, C, B, rowidx, d_output, PC, st);
+    if (rc) return rc;
+  } else {
+    Lds L = make_lds(d, P.MC, true);
+    rc = check_lds(d, L);
+    if (rc) return rc;
+    rc = allow_lds(bwd_kernel, L.bytes);
+    if (rc) return rc;
     ProfScope ps(TTX_PROF_BWD, st);
     hipLaunchKernelGGL(bwd_kernel, dim3(P.max_chunks), dim3(kThreads), L.bytes, st, d, P, C, B,
                        rowidx, d_output, PC, L);

@@ -66,7 +66,7 @@ def lib():
     vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
     G = C.POINTER(_Geom)
     L.ttx_plan_bytes.argtypes = [G, i64]
-    L.ttx_plan_build.argtypes = [G, i64, vp, vp, vp, sz, vp]
+    L.ttx_plan_build.argtypes = [G, i64, vp, vp, vp, vp, sz, vp]
     L.ttx_tt_forward_workspace_bytes.argtypes = [G, i32, i32, i64]
     L.ttx_tt_forward.argtypes = [G, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.ttx_tt_rows.argtypes = [G, i32, i64, vp, vp, vp, vp, vp, sz, vp]
@@ -201,7 +201,7 @@ class Plan:
         self.buf, self.nnz, self.key = buf, nnz, key
 
 
-def make_plan(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, tableidx) -> Optional[Plan]:
+def make_plan(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, tableidx, rowidx=None) -> Optional[Plan]:
     if nnz == 0:
         return None
     g = _geom(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks)
@@ -211,7 +211,8 @@ def make_plan(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, tabl
     nb = L.ttx_plan_bytes(C.byref(g), nnz)
     buf = torch.empty(nb, dtype=torch.uint8, device=dev)
     with _guard(dev):
-        _check(L.ttx_plan_build(C.byref(g), nnz, indices.data_ptr(), tableidx.data_ptr(), buf.data_ptr(), nb, _stream(dev)))
+        _check(L.ttx_plan_build(C.byref(g), nnz, indices.data_ptr(), tableidx.data_ptr(),
+                                None if rowidx is None else _i64(rowidx, "rowidx").data_ptr(), buf.data_ptr(), nb, _stream(dev)))
     return Plan(buf, nnz, (num_tables, tuple(tt_p_shapes), tuple(tt_q_shapes), tuple(tt_ranks)))
 
 

@@ -142,7 +142,7 @@ class TTLookupFunction(torch.autograd.Function):
         num_tables = tt_cores[0].size(0)
         # one lookup plan serves forward and backward of this batch
         mk = getattr(_engine, "make_plan", None)
-        ctx.plan = mk(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz_tt, indices, tableidx) if mk else None
+        ctx.plan = mk(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz_tt, indices, tableidx, rowidx) if mk else None
         extra = {"plan": ctx.plan} if ctx.plan is not None else {}
         output = _engine.tt_forward(1000, num_tables, B, D, tt_p_shapes, tt_q_shapes, tt_ranks, L, nnz_tt, indices,
                                     rowidx, tableidx, list(tt_cores), **extra)

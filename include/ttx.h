@@ -75,13 +75,14 @@ int ttx_version(void);
  * tt_embeddings_cuda.cu:79-360, :754-918): index decode, a stable radix sort of
  * the lookups by (table, i_t) for every core and the work-list of index groups
  * that share a middle-core slice.  It depends only on (geometry, indices,
- * tableidx); forward and backward of the same batch can share one plan.
+ * tableidx, rowidx); forward and backward of the same batch can share one plan.
+ * rowidx may be NULL (the backward kernel then gathers the bag row per lookup).
  * Passing plan == NULL to ttx_tt_forward / ttx_tt_backward builds it inside
  * their workspace. */
 size_t ttx_plan_bytes(const ttx_geom* g, int64_t nnz);
 int ttx_plan_build(const ttx_geom* g, int64_t nnz, const int64_t* indices,
-                   const int64_t* tableidx, void* plan, size_t plan_bytes,
-                   ttx_stream_t stream);
+                   const int64_t* tableidx, const int64_t* rowidx, void* plan,
+                   size_t plan_bytes, ttx_stream_t stream);
 
 /* --------------------------------------------------------------- forward ---
  * replaces tt_embeddings_forward_cuda (tt_embeddings.cpp:13-26,

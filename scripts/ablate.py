@@ -40,7 +40,7 @@ def run(mask, chunk=0, steps=30):
 for chunk in (0, 8, 32):
     base = run(0, chunk)
     print(f"chunk={chunk}: " + "  ".join(f"{k}={v:.1f}us" for k, v in base.items()))
-print("bwd ablation (mask: 1=no recompute GEMM, 2=no tail, 4=no dB1 GEMM, 8=no dA GEMM, 16=stage only)")
-for mask in (1, 2, 4, 8, 1 | 2 | 4 | 8, 16):
+print("spec bwd cut points (16=after chunk_rec, 32=after records, 64=after all loads+B1 staged, 12=+LDS puts, 6=+GEMM1+tail, 7=no stores/no dB1 red., 1=no pc0/pc2 stores, 4=no dB1 reduction)")
+for mask in (16, 32, 64, 8 | 4, 2 | 4, 1 | 2 | 4, 1, 4):
     r = run(mask)
     print(f"  mask={mask:2d}: bwd={r['bwd']:.1f}us fwd={r['fwd']:.1f}us")

@@ -23,22 +23,22 @@ E.lib().ttx_debug_stamps(E.C.c_void_p(buf.data_ptr()))
 m(*reqs[5]).backward(grad)
 torch.cuda.synchronize()
 E.lib().ttx_debug_stamps(None)
-st = buf.cpu().numpy().reshape(-1, 16)
-live = st[:, 7] > 0
-st = st[live][:, :8].astype(np.float64) / 100.0  # 100 MHz -> us
+st = buf.cpu().numpy().reshape(-1, 16)[:1000]
+live = st[:, 9] > 0
+st = st[live][:, :10].astype(np.float64) / 100.0  # 100 MHz -> us
 t0 = st[:, 0].min()
-names = ["entry", "chunk_rec", "staged", "G issued", "-", "-", "-", "done"]
-print(f"{live.sum()} work-groups; times in us relative to the first entry")
+names = ["entry", "chunk_rec", "B1 staged+sync", "group recs", "A staged", "G/c2 issued", "x0 in regs", "tail+dX0 stored", "groups done", "dB1 reduced (end)"]
+print(f"{live.sum()} work-groups (wave 0's first group); us relative to the first entry")
 for i, nm in enumerate(names):
-    if nm == "-":
-        continue
     v = st[:, i] - t0
-    print(f"  {nm:14s} min {v.min():6.2f}  med {np.median(v):6.2f}  max {v.max():6.2f}")
+    print(f"  {nm:20s} min {v.min():6.2f}  med {np.median(v):6.2f}  max {v.max():6.2f}")
+raw = buf.cpu().numpy().reshape(-1, 16)[:1000][live].astype(np.float64) / 100.0
+print(f"probe: lrec vector load latency  min {(raw[:,11]-raw[:,10]).min():.2f} med {np.median(raw[:,11]-raw[:,10]):.2f} max {(raw[:,11]-raw[:,10]).max():.2f} us")
+print(f"probe: B1   vector load latency  min {(raw[:,12]-raw[:,11]).min():.2f} med {np.median(raw[:,12]-raw[:,11]):.2f} max {(raw[:,12]-raw[:,11]).max():.2f} us")
 print("phase durations (per work-group):")
-for a, b in ((0, 1), (1, 2), (2, 3), (3, 7), (0, 7)):
-    v = st[:, b] - st[:, a]
-    print(f"  {names[a]:>14s} -> {names[b]:14s} min {v.min():6.2f}  med {np.median(v):6.2f}  max {v.max():6.2f}")
-
+for i in range(1, 10):
+    v = st[:, i] - st[:, i - 1]
+    print(f"  {names[i-1]:>20s} -> {names[i]:20s} min {v.min():6.2f}  med {np.median(v):6.2f}  max {v.max():6.2f}")
 pl = buf.cpu().numpy().reshape(-1, 16)[1000:1003, :9].astype(np.float64) / 100.0
 pl = pl[:, [0, 8, 1, 6, 7, 2, 3, 4, 5]]
 pn = ["entry", "loads back", "decoded", "counted", "scanned", "sorted", "perm/off stored", "lrec stored", "chunk list"]

@@ -34,7 +34,7 @@ def run_case(c, mode, plan_shared=False):
     nnz = idx.numel()
     assert ntt == nnz and loc is None
     cores = [t(x) for x in c["cores"]]
-    plan = E.make_plan(tables, p, q, r, nnz, colidx, tableidx) if plan_shared else None
+    plan = E.make_plan(tables, p, q, r, nnz, colidx, tableidx, rowidx if (nnz % 2 == 0) else None) if plan_shared else None
     out = E.tt_forward(1000, tables, B, D, p, q, r, Lt, nnz, colidx, rowidx, tableidx, cores, plan=plan)
     res = {"out": out.cpu().numpy(), "rowidx": rowidx.cpu().numpy(), "tableidx": tableidx.cpu().numpy()}
     d_out = t(c["d_out"])
@@ -169,6 +169,42 @@ def test_large_batch_uses_the_global_memory_plan():
                     assert_close(got["grads"][k], orc["grads"][k], f"B{B} grad{k}")
                 else:
                     assert_close(got["cores"][k], orc["cores"][k], f"B{B} sgd core{k}")
+
+
+@pytest.mark.parametrize("ranks,q", [([32, 32], [4, 4, 4]), ([16, 16], [4, 4, 4]), ([32, 32], [4, 4, 8]), ([16, 16], [4, 4, 8])])
+def test_specialised_shapes_vs_oracle_and_generic(ranks, q):
+    """the shape-specialised wave-independent kernels (ttx_tt_spec.inc): against the oracle,
+    and against the generic kernels (forced with the debug knob) on the same inputs;
+    slices with 1..70 lookups exercise partial groups of 4 and chunks of 32"""
+    import tt_embeddings as E
+
+    p = [6, 5, 7]
+    r = [1] + ranks + [1]
+    E_, D = int(np.prod(p)), int(np.prod(q))
+    for tables, B, pf, std in ((1, 90, 3, 2), (3, 40, 5, 4), (1, 7, 1, 0)):
+        idx, off = G.make_bags(11 + B, B, E_, pf, std, tables)
+        c = dict(tables=tables, T=3, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+                 cores=G.make_cores(12 + B, tables, p, q, r, "signed"), d_out=G.make_grad(13, tables, B, D))
+        for mode in ("dense", "sgd", "adagrad"):
+            got = run_case(c, mode, plan_shared=True)
+            orc = oracle_case(c, mode)
+            E.lib().ttx_debug_skip(256)  # generic kernels
+            try:
+                gen = run_case(c, mode, plan_shared=False)
+            finally:
+                E.lib().ttx_debug_skip(0)
+            assert_close(got["out"], orc["out"], f"spec {ranks}{q} out vs oracle")
+            assert_close(got["out"], gen["out"], f"spec {ranks}{q} out vs generic")
+            gref = oracle_case(c, "dense")["grads"] if mode == "adagrad" else None
+            for k in range(3):
+                if mode == "dense":
+                    assert_close(got["grads"][k], orc["grads"][k], f"spec {ranks}{q} grad{k} vs oracle")
+                    assert_close(got["grads"][k], gen["grads"][k], f"spec {ranks}{q} grad{k} vs generic")
+                elif mode == "sgd":
+                    assert_close(got["cores"][k], orc["cores"][k], f"spec {ranks}{q} sgd core{k}")
+                else:
+                    assert_close(got["state"][k], orc["state"][k], f"spec {ranks}{q} state{k}")
+                    assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"spec {ranks}{q} adagrad core{k}")
 
 
 def test_edge_cases():
