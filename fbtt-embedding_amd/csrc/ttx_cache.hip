@@ -65,6 +65,38 @@ __global__ __launch_bounds__(kCT) void update_cache_state_kernel(
   }
 }
 
+// rowidx/tableidx of every bag AND the frequency update of every index in one launch
+// (tiny kernels cost ~4 us each on this chip whatever they do): threads [0, 8*nb) walk the
+// bags 8 lanes per bag, threads [0, N) each insert one index.
+__global__ __launch_bounds__(kCT) void rowidx_update_kernel(int64_t nb, int32_t B,
+                                                           const int64_t* __restrict__ offsets,
+                                                           int64_t* rowidx, int64_t* tableidx, int64_t N,
+                                                           const int64_t* __restrict__ colidx, int32_t H,
+                                                           int64_t* hashtbl, int64_t* cache_freq) {
+  const int64_t gt = (int64_t)blockIdx.x * kCT + threadIdx.x;
+  const int64_t b = gt >> 3;
+  if (b < nb) {
+    const int64_t beg = offsets[b], end = offsets[b + 1];
+    for (int64_t l = beg + (threadIdx.x & 7); l < end; l += 8) {
+      rowidx[l] = b % B;
+      tableidx[l] = b / B;
+    }
+  }
+  if (gt < N) {
+    const int64_t key = colidx[gt];
+    int32_t idx = (int32_t)hash64(key, H);
+    for (int c = 0; c < kMaxProbes; ++c) {
+      const unsigned long long old = atomicCAS((unsigned long long*)&hashtbl[idx],
+                                               (unsigned long long)(-1ll), (unsigned long long)key);
+      if ((int64_t)old == -1 || (int64_t)old == key) {
+        atomicAdd((unsigned long long*)&cache_freq[idx], 1ull);
+        break;
+      }
+      idx = (idx + 1) % H;
+    }
+  }
+}
+
 // compute_rowidx_kernel, cu:1338-1354: one 8-lane group per bag
 __global__ __launch_bounds__(kCT) void compute_rowidx_kernel(int64_t nb, int32_t B,
                                                             const int64_t* __restrict__ offsets,
@@ -377,6 +409,18 @@ int ttx_preprocess_indices_sync(int64_t nnz, const int64_t* colidx, int64_t nb,
                                 int64_t* rowidx, int64_t* tableidx, int64_t* pcol, int64_t* prow,
                                 int32_t* ploc, int32_t* num_tt_host, int32_t* partitioned_host,
                                 void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
+  return ttx_preprocess_indices_sync_fused(nnz, colidx, nb, offsets, num_tables, warmup, H, hashtbl, cache_state,
+                                           rowidx, tableidx, pcol, prow, ploc, num_tt_host, partitioned_host,
+                                           nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+int ttx_preprocess_indices_sync_fused(int64_t nnz, const int64_t* colidx, int64_t nb,
+                                      const int64_t* offsets, int32_t num_tables, int32_t warmup,
+                                      int64_t H, const int64_t* hashtbl, const int32_t* cache_state,
+                                      int64_t* rowidx, int64_t* tableidx, int64_t* pcol, int64_t* prow,
+                                      int32_t* ploc, int32_t* num_tt_host, int32_t* partitioned_host,
+                                      int64_t* upd_hashtbl, int64_t* upd_cache_freq,
+                                      void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!num_tt_host || !partitioned_host) TTX_FAIL(TTX_EINVAL, "NULL output");
   *num_tt_host = (int32_t)nnz;
@@ -387,8 +431,15 @@ int ttx_preprocess_indices_sync(int64_t nnz, const int64_t* colidx, int64_t nb,
     TTX_FAIL(TTX_EINVAL, "offsets has %lld bags, not a multiple of num_tables=%d", (long long)nb, num_tables);
   if (!colidx || !offsets || !rowidx || !tableidx) TTX_FAIL(TTX_EINVAL, "NULL input");
   const int32_t B = (int32_t)(nb / num_tables);
-  hipLaunchKernelGGL(compute_rowidx_kernel, dim3((unsigned)((nb + kCT / 8 - 1) / (kCT / 8))), dim3(kCT), 0,
-                     st, nb, B, offsets, rowidx, tableidx);
+  if (upd_hashtbl && upd_cache_freq) {  // fused update_cache_state (cu:1077-1113) + compute_rowidx
+    if (H <= 0 || H >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
+    const int64_t threads = nb * 8 > nnz ? nb * 8 : nnz;
+    hipLaunchKernelGGL(rowidx_update_kernel, dim3((unsigned)((threads + kCT - 1) / kCT)), dim3(kCT), 0, st, nb, B,
+                       offsets, rowidx, tableidx, nnz, colidx, (int32_t)H, upd_hashtbl, upd_cache_freq);
+  } else {
+    hipLaunchKernelGGL(compute_rowidx_kernel, dim3((unsigned)((nb + kCT / 8 - 1) / (kCT / 8))), dim3(kCT), 0,
+                       st, nb, B, offsets, rowidx, tableidx);
+  }
   TTX_HIP(hipGetLastError());
   if (warmup || num_tables != 1) return TTX_OK;  // cu:1410-1412
   if (H <= 0 || H >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);

@@ -69,6 +69,7 @@ struct Plan {
   int4* chunk_rec;   // [max_chunks]
   int4* lrec;        // [nnz]
   int* lrow;         // [nnz]
+  int* cnt;          // multi-block sort: [T][256][units]
   int* scratch[TTX_MAX_CORES][3];  // rank / ping / pong per core, [nnz] each
   int max_chunks;
   int MC;

@@ -43,6 +43,7 @@ static size_t plan_ints(const Dims& d, long long nnz, int MC) {
   n += r64((size_t)max_chunks(d, nnz, MC) * 4);                     // chunk_rec
   n += r64((size_t)nnz * 4);                                        // lrec
   n += r64((size_t)nnz);                                            // lrow
+  n += r64((size_t)d.T * 256 * ((nnz + 255) / 256 + 1));            // multi-block digit counts
   return n;
 }
 
@@ -61,6 +62,7 @@ Plan carve_plan(const Dims& d, long long nnz, void* base) {
   P.chunk_rec = (int4*)take((size_t)P.max_chunks * 4);
   P.lrec = (int4*)take((size_t)nnz * 4);
   P.lrow = take(nnz);
+  P.cnt = take((size_t)d.T * 256 * ((nnz + 255) / 256 + 1));
   for (int t = 0; t < d.T; ++t) {
     P.sid[t] = take(nnz);
     P.perm[t] = take(nnz);
@@ -484,11 +486,250 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
 #undef PSTAMP
 }
 
+// ---- multi-work-group plan (any nnz): the same stable LSD radix sort spread over the chip ----
+// A "unit" is one wavefront walking kUnit consecutive positions of the current order in batches
+// of 64 (ranking by wave_match8, running digit counters in LDS).  Per 8-bit pass:
+//   mb_count   : per-unit digit counts            -> cnt[t][digit][unit]   (pass 0 also decodes
+//                                                    idx -> sid[t][n] and stores it)
+//   mb_scan    : exclusive scan over (digit major, unit minor), one work-group per core
+//   mb_scatter : position = base[digit][unit] + rank; writes the next order; on a core's last
+//                pass also perm[t], the sorted keys and (pivot) the flat lookup records
+// then mb_finish: slice offsets by binary search on the sorted keys + the pivot chunk list.
+constexpr int kUnit = 256;                 // positions per wave unit
+constexpr int kMbThreads = 256;            // 4 units per work-group
+constexpr int kMbUnits = kMbThreads / kWave;
+
+struct MbArgs {
+  int N, U;            // lookups, units per core
+  int pass;            // current pass
+  int fused_scan;      // scatter derives its bases itself (few units): no scan launch
+  int passes[TTX_MAX_CORES];
+  int* cnt;            // [T][256][U]
+};
+
+__device__ __forceinline__ int mb_passes(int S) {
+  const int bits = 32 - __clz(max(S - 1, 1));
+  return max((bits + 7) / 8, 1);
+}
+
+__global__ __launch_bounds__(kMbThreads) void mb_count_kernel(
+    Dims d, MbArgs A, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx, Plan P) {
+  __shared__ int hist[kMbUnits][256];
+  const int t = blockIdx.y;
+  if (A.pass >= A.passes[t]) return;
+  const int lane = lane_id(), w = threadIdx.x / kWave;
+  const int u = blockIdx.x * kMbUnits + w;
+  for (int e = lane; e < 256; e += kWave) hist[w][e] = 0;
+  const int beg = u * kUnit, end = min(A.N, beg + kUnit);
+  int* key = P.sid[t];
+  const int* src = (A.pass == 0) ? nullptr : ((A.pass & 1) ? P.scratch[t][1] : P.scratch[t][2]);
+  const int shift = A.pass * 8;
+  const CoreDec ct = core_dec(d, t);
+  for (int base = beg; base < end; base += kWave) {
+    const int i = base + lane;
+    const bool valid = i < end;
+    unsigned dg = 0;
+    if (valid) {
+      int kv;
+      if (A.pass == 0) {
+        const int tb = tableidx ? (int)tableidx[i] : 0;
+        kv = tb * ct.p + decode_core(ct, indices[i]);
+        key[i] = kv;
+      } else {
+        kv = key[src[i]];
+      }
+      dg = ((unsigned)kv >> shift) & 255u;
+    }
+    const unsigned long long peers = wave_match8(dg, valid);
+    if (valid && (peers & lanemask_lt()) == 0) hist[w][dg] += __popcll(peers);
+  }
+  if (u < A.U)
+    for (int e = lane; e < 256; e += kWave) A.cnt[((size_t)t * 256 + e) * A.U + u] = hist[w][e];
+}
+
+__global__ __launch_bounds__(1024) void mb_scan_kernel(MbArgs A) {
+  __shared__ int wt[17];
+  const int t = blockIdx.x;
+  if (A.pass >= A.passes[t]) return;
+  int* c = A.cnt + (size_t)t * 256 * A.U;
+  const int total = 256 * A.U;
+  const int per = (total + 1023) / 1024;
+  const int beg = threadIdx.x * per, end = min(total, beg + per);
+  int s = 0;
+  for (int i = beg; i < end; ++i) s += c[i];
+  const int inc = wave_incl_scan(s);
+  const int w = threadIdx.x / kWave;
+  if (lane_id() == kWave - 1) wt[w] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 0; k < 16; ++k) { const int v = wt[k]; wt[k] = run; run += v; }
+  }
+  __syncthreads();
+  int run = wt[w] + inc - s;
+  for (int i = beg; i < end; ++i) { const int v = c[i]; c[i] = run; run += v; }
+}
+
+__global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
+    Dims d, MbArgs A, const int64_t* __restrict__ rowidx, Plan P) {
+  __shared__ int run[kMbUnits][256];
+  __shared__ int dtot[256];
+  __shared__ int wt5[kMbUnits + 1];
+  const int t = blockIdx.y;
+  if (A.pass >= A.passes[t]) return;
+  const int lane = lane_id(), w = threadIdx.x / kWave;
+  const int u = blockIdx.x * kMbUnits + w;
+  if (A.fused_scan) {
+    // few units: every work-group derives its own bases from the raw counts (no scan launch).
+    // thread = digit: total of the digit, exclusive prefix over digits, prefix over earlier units
+    const int dg = threadIdx.x;
+    const int* c = A.cnt + ((size_t)t * 256 + dg) * A.U;
+    const int u0 = blockIdx.x * kMbUnits;
+    int tot = 0, before = 0, mine[kMbUnits];
+#pragma unroll
+    for (int k = 0; k < kMbUnits; ++k) mine[k] = 0;
+    for (int uu = 0; uu < A.U; ++uu) {
+      const int v = c[uu];
+      if (uu < u0) before += v;
+#pragma unroll
+      for (int k = 0; k < kMbUnits; ++k) if (uu == u0 + k) mine[k] = v;
+      tot += v;
+    }
+    const int inc = wave_incl_scan(tot);
+    if (lane == kWave - 1) wt5[w] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int k = 0; k < w; ++k) wbase += wt5[k];
+    int b = wbase + inc - tot + before;  // first position of (digit dg, unit u0)
+#pragma unroll
+    for (int k = 0; k < kMbUnits; ++k) { run[k][dg] = b; b += mine[k]; }
+    __syncthreads();
+    (void)dtot;
+  } else if (u < A.U) {
+    for (int e = lane; e < 256; e += kWave) run[w][e] = A.cnt[((size_t)t * 256 + e) * A.U + u];
+  }
+  const int beg = u * kUnit, end = min(A.N, beg + kUnit);
+  const int* key = P.sid[t];
+  const int* src = (A.pass == 0) ? nullptr : ((A.pass & 1) ? P.scratch[t][1] : P.scratch[t][2]);
+  const bool last = (A.pass == A.passes[t] - 1);
+  int* dst = last ? P.perm[t] : ((A.pass & 1) ? P.scratch[t][2] : P.scratch[t][1]);
+  int* sk = P.scratch[t][0];  // sorted keys (last pass)
+  const int shift = A.pass * 8;
+  const bool pivot = (t == 1);
+  for (int base = beg; base < end; base += kWave) {
+    const int i = base + lane;
+    const bool valid = i < end;
+    int val = 0, kv = 0;
+    unsigned dg = 0;
+    if (valid) {
+      val = src ? src[i] : i;
+      kv = key[val];
+      dg = ((unsigned)kv >> shift) & 255u;
+    }
+    const unsigned long long peers = wave_match8(dg, valid);
+    if (valid) {
+      const int before = run[w][dg];
+      const int pos = before + __popcll(peers & lanemask_lt());
+      dst[pos] = val;
+      if (last) {
+        sk[pos] = kv;
+        if (pivot) {
+          P.lrec[pos] = make_int4(val, P.sid[0][val], d.T > 2 ? P.sid[2][val] : 0, d.T > 3 ? P.sid[3][val] : 0);
+          if (rowidx) P.lrow[pos] = (int)rowidx[val];
+        }
+      }
+      if ((peers & lanemask_lt()) == 0) run[w][dg] = before + __popcll(peers);
+    }
+  }
+}
+
+// first position of the sorted keys with key >= s
+__device__ __forceinline__ int lower_bound_key(const int* sk, int N, int s) {
+  int lo = 0, hi = N;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (sk[mid] < s) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// blockIdx.y = core: slice offsets of the thin cores; the pivot's work-group(s) build the chunk list
+__global__ __launch_bounds__(1024) void mb_finish_kernel(Dims d, int N, int has_row, Plan P) {
+  __shared__ int wtot[kPlanWaves + 1];
+  const int t = blockIdx.y, tid = threadIdx.x;
+  const int* sk = P.scratch[t][0];
+  if (t != 1) {
+    const int S = d.S[t];
+    for (int s = blockIdx.x * 1024 + tid; s <= S; s += gridDim.x * 1024) P.off[t][s] = (s == S) ? N : lower_bound_key(sk, N, s);
+    return;
+  }
+  if (blockIdx.x != 0) return;
+  const int S1 = d.S[1], MC = P.MC;
+  int carry = 0;
+  for (int s0 = 0; s0 < S1; s0 += 1024) {
+    const int s = s0 + tid;
+    int nch = 0, beg = 0, cnt = 0;
+    if (s < S1) {
+      beg = lower_bound_key(sk, N, s);
+      cnt = lower_bound_key(sk, N, s + 1) - beg;
+      nch = (cnt + MC - 1) / MC;
+    }
+    int total;
+    const int ex = carry + block_excl_scan(nch, wtot, &total);
+    if (s < S1) {
+      P.chunk_off[s] = ex;
+      for (int j = 0; j < nch; ++j) P.chunk_rec[ex + j] = make_int4(s, beg + j * MC, min(MC, cnt - j * MC), 0);
+    }
+    carry += total;
+  }
+  for (int c = carry + tid; c < P.max_chunks; c += 1024) P.chunk_rec[c] = make_int4(0, 0, 0, 0);
+  if (tid == 0) {
+    P.chunk_off[S1] = carry;
+    P.hdr[0] = carry;
+    P.hdr[1] = MC;
+    P.hdr[2] = N;
+    P.hdr[3] = has_row;
+  }
+}
+
+static int plan_build_mb(const Dims& d, int N, const int64_t* indices, const int64_t* tableidx,
+                         const int64_t* rowidx, const Plan& P, hipStream_t stream) {
+  MbArgs A;
+  A.N = N;
+  A.U = (N + kUnit - 1) / kUnit;
+  A.cnt = P.cnt;
+  int maxp = 1;
+  for (int t = 0; t < TTX_MAX_CORES; ++t) {
+    A.passes[t] = 0;
+    if (t < d.T) {
+      int bits = 0;
+      while ((1ll << bits) < d.S[t]) ++bits;
+      A.passes[t] = (bits + 7) / 8 > 0 ? (bits + 7) / 8 : 1;
+      if (A.passes[t] > maxp) maxp = A.passes[t];
+    }
+  }
+  const dim3 gu((A.U + kMbUnits - 1) / kMbUnits, d.T);
+  A.fused_scan = A.U <= 96 ? 1 : 0;
+  for (int ps = 0; ps < maxp; ++ps) {
+    A.pass = ps;
+    hipLaunchKernelGGL(mb_count_kernel, gu, dim3(kMbThreads), 0, stream, d, A, indices, tableidx, P);
+    if (!A.fused_scan) hipLaunchKernelGGL(mb_scan_kernel, dim3(d.T), dim3(1024), 0, stream, A);
+    hipLaunchKernelGGL(mb_scatter_kernel, gu, dim3(kMbThreads), 0, stream, d, A, rowidx, P);
+  }
+  int smax = 1;
+  for (int t = 0; t < d.T; ++t) if (t != 1 && d.S[t] + 1 > smax) smax = d.S[t] + 1;
+  hipLaunchKernelGGL(mb_finish_kernel, dim3((smax + 1023) / 1024, d.T), dim3(1024), 0, stream, d, N,
+                     rowidx ? 1 : 0, P);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
 int plan_build(const Dims& d, long long nnz, const int64_t* indices,
                const int64_t* tableidx, const int64_t* rowidx, const Plan& P, hipStream_t stream) {
   if (nnz < 0 || nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz=%lld out of range", nnz);
   ProfScope ps(TTX_PROF_PLAN, stream);
-  if (nnz <= kSmallMax && d.idx32) {  // on-chip plan; 32-bit index decode only
+  if (nnz > 1024 || !d.idx32) return plan_build_mb(d, (int)nnz, indices, tableidx, rowidx, P, stream);
+  if (nnz <= kSmallMax && d.idx32) {  // tiny batch: one launch, everything on chip
     const size_t lds = (256 * kPlanWaves + 32 + 2 * ((nnz + 63) / 64 * 64)) * sizeof(int);
     const int per = (((int)nnz + kPlanWaves - 1) / kPlanWaves + kWave - 1) / kWave * kWave;
     const int nb = per / kWave;

@@ -386,9 +386,18 @@ __device__ __forceinline__ void fwd_stage_any(int lenS, int j0, int m, int k, in
     default: break;                      \
   }
 
+// the grid also zeroes the pooled output (the bag-pooling kernel that follows accumulates
+// onto it): saves a memset launch
+__device__ __forceinline__ void zero_output(float* __restrict__ out, long long n) {
+  if (!out) return;
+  for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < n; e += (long long)gridDim.x * kThreads) out[e] = 0.f;
+}
+
 __global__ __launch_bounds__(kThreads, 3) void fwd_kernel(Dims d, Plan P, CorePtrs C,
-                                                         float* __restrict__ rows, Lds L) {
+                                                         float* __restrict__ rows, Lds L,
+                                                         float* __restrict__ zout, long long nzero) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  zero_output(zout, nzero);
   const int chunk = blockIdx.x;
   const int4 cr = P.chunk_rec[chunk];
   const int s = cr.x, start = cr.y, len = cr.z;
@@ -1030,8 +1039,9 @@ static int allow_lds(K kernel, int bytes) {
 
 static size_t rows_bytes(const Dims& d, long long nnz) { return align_up((size_t)nnz * d.D * 4); }
 
-static int run_rows_spec(SpecId id, const Plan& P, const CorePtrs& C, float* rows, hipStream_t st) {
-#define CALLF(S) spec_launch_fwd<S>(P, C, rows, st)
+static int run_rows_spec(SpecId id, const Plan& P, const CorePtrs& C, float* rows, float* zout,
+                         long long nzero, hipStream_t st) {
+#define CALLF(S) spec_launch_fwd<S>(P, C, rows, zout, nzero, st)
   TTX_SPEC_DISPATCH(id, CALLF)
 #undef CALLF
   TTX_FAIL(TTX_EUNSUPPORTED, "no specialised forward kernel");
@@ -1046,12 +1056,12 @@ static int run_bwd_spec(SpecId id, const Dims& d, const Plan& P, const CorePtrs&
 }
 
 static int run_rows(const Dims& d, long long nnz, const Plan& P, const float* const* cores,
-                    float* rows, hipStream_t st) {
+                    float* rows, float* zout, long long nzero, hipStream_t st) {
   if (const SpecId id = spec_match(d)) {
     CorePtrs C;
     for (int t = 0; t < TTX_MAX_CORES; ++t) C.c[t] = t < d.T ? (float*)cores[t] : nullptr;
     ProfScope ps(TTX_PROF_FWD, st);
-    return run_rows_spec(id, P, C, rows, st);
+    return run_rows_spec(id, P, C, rows, zout, nzero, st);
   }
   Lds L = make_lds(d, P.MC, false);
   int rc = check_lds(d, L);
@@ -1061,7 +1071,7 @@ static int run_rows(const Dims& d, long long nnz, const Plan& P, const float* co
   CorePtrs C;
   for (int t = 0; t < TTX_MAX_CORES; ++t) C.c[t] = t < d.T ? (float*)cores[t] : nullptr;
   ProfScope ps(TTX_PROF_FWD, st);
-  hipLaunchKernelGGL(fwd_kernel, dim3(P.max_chunks), dim3(kThreads), L.bytes, st, d, P, C, rows, L);
+  hipLaunchKernelGGL(fwd_kernel, dim3(P.max_chunks), dim3(kThreads), L.bytes, st, d, P, C, rows, L, zout, nzero);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }
@@ -1117,9 +1127,11 @@ int ttx_tt_forward(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const i
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (B < 0 || !output) TTX_FAIL(TTX_EINVAL, "bad B/output");
-  if ((size_t)d.num_tables * B * d.D > 0)
-    TTX_HIP(hipMemsetAsync(output, 0, (size_t)d.num_tables * B * d.D * sizeof(float), st));
-  if (nnz == 0) return TTX_OK;  // zeros, like cu:981-985
+  const long long nout = (long long)d.num_tables * B * d.D;
+  if (nnz == 0) {  // zeros, like cu:981-985
+    if (nout > 0) TTX_HIP(hipMemsetAsync(output, 0, (size_t)nout * sizeof(float), st));
+    return TTX_OK;
+  }
   rc = common_checks(d, D, nnz);
   if (rc) return rc;
   if (!indices || !rowidx || !tableidx || !tt_cores) TTX_FAIL(TTX_EINVAL, "NULL input");
@@ -1137,7 +1149,7 @@ int ttx_tt_forward(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const i
     ws += pb;
   }
   float* rows = (float*)ws;
-  rc = run_rows(d, nnz, P, tt_cores, rows, st);
+  rc = run_rows(d, nnz, P, tt_cores, rows, output, nout, st);  // also zeroes `output`
   if (rc) return rc;
   {
     ProfScope ps(TTX_PROF_POOL, st);
@@ -1164,7 +1176,7 @@ int ttx_tt_rows(const ttx_geom* g, int32_t D, int64_t nnz, const int64_t* indice
   Plan P = carve_plan(d, nnz, workspace);
   rc = plan_build(d, nnz, indices, tableidx, nullptr, P, (hipStream_t)stream);
   if (rc) return rc;
-  return run_rows(d, nnz, P, tt_cores, rows, (hipStream_t)stream);
+  return run_rows(d, nnz, P, tt_cores, rows, nullptr, 0, (hipStream_t)stream);
 }
 
 static size_t partial_bytes(const Dims& d, long long nnz, int MC, size_t* offs) {

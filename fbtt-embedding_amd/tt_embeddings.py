@@ -27,6 +27,7 @@ _SO = os.path.join(_HERE, "libttx.so")
 MAX_CORES = 4
 OPTIM_SGD, OPTIM_ADAGRAD, OPTIM_DENSE = 0, 1, 2
 PROF_FWD, PROF_BWD, PROF_APPLY, PROF_PLAN, PROF_POOL, PROF_CACHE_FWD = range(6)
+FUSED_CACHE_UPDATE = True  # preprocess_indices_sync(..., update_cache_freq=) exists
 
 
 class _Geom(C.Structure):
@@ -76,6 +77,8 @@ def lib():
     L.ttx_preprocess_workspace_bytes.argtypes = [i64]
     L.ttx_preprocess_indices_sync.argtypes = [i64, vp, i64, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp,
                                               C.POINTER(i32), C.POINTER(i32), vp, sz, vp]
+    L.ttx_preprocess_indices_sync_fused.argtypes = [i64, vp, i64, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp,
+                                                    C.POINTER(i32), C.POINTER(i32), vp, vp, vp, sz, vp]
     L.ttx_cache_populate_workspace_bytes.argtypes = [G, i64, i64, i32]
     L.ttx_cache_populate.argtypes = [G, vp, i64, vp, vp, vp, i64, i32, vp, vp, sz, vp]
     L.ttx_cache_forward.argtypes = [i32, i64, vp, vp, i32, vp, vp, vp]
@@ -344,9 +347,12 @@ def cache_populate(num_embeddings: int, tt_p_shapes, tt_q_shapes, tt_ranks, tt_c
 
 
 def preprocess_indices_sync(colidx: torch.Tensor, offsets: torch.Tensor, num_tables: int, warmup: bool,
-                            hashtbl: torch.Tensor, cache_state: torch.Tensor
+                            hashtbl: torch.Tensor, cache_state: torch.Tensor,
+                            update_cache_freq: Optional[torch.Tensor] = None
                             ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int, Optional[torch.Tensor]]:
-    """tt_embeddings.cpp:88-95.  Host-synchronous iff not warmup and num_tables == 1."""
+    """tt_embeddings.cpp:88-95.  Host-synchronous iff not warmup and num_tables == 1.
+    Extra (not in the reference): `update_cache_freq` folds update_cache_state(colidx, hashtbl,
+    update_cache_freq) into the same launch."""
     dev = _dev(colidx)
     colidx, offsets = _i64(colidx, "colidx"), _i64(offsets, "offsets")
     nnz = colidx.numel()
@@ -365,13 +371,17 @@ def preprocess_indices_sync(colidx: torch.Tensor, offsets: torch.Tensor, num_tab
         ws = _workspace(dev, st, lb.ttx_preprocess_workspace_bytes(nnz))
         wsp, wsn = ws.data_ptr(), ws.numel()
     num_tt, part = C.c_int32(0), C.c_int32(0)
+    fuse = update_cache_freq is not None and hashtbl.numel() > 0
+    if fuse and hashtbl.numel() != update_cache_freq.numel():
+        raise RuntimeError("tt_embeddings: hashtbl must match cache_freq")
     with _guard(dev):
-        _check(lb.ttx_preprocess_indices_sync(
+        _check(lb.ttx_preprocess_indices_sync_fused(
             nnz, colidx.data_ptr(), offsets.numel() - 1, offsets.data_ptr(), num_tables, int(bool(warmup)),
-            hashtbl.numel(), hashtbl.data_ptr() if live else None, cache_state.data_ptr() if live else None,
+            hashtbl.numel(), hashtbl.data_ptr() if (live or fuse) else None, cache_state.data_ptr() if live else None,
             rowidx.data_ptr(), tableidx.data_ptr(), pcol.data_ptr() if live else None,
             prow.data_ptr() if live else None, ploc.data_ptr() if live else None,
-            C.byref(num_tt), C.byref(part), wsp, wsn, st))
+            C.byref(num_tt), C.byref(part), hashtbl.data_ptr() if fuse else None,
+            update_cache_freq.data_ptr() if fuse else None, wsp, wsn, st))
     if part.value:
         return pcol, prow, tableidx, int(num_tt.value), ploc
     return colidx, rowidx, tableidx, nnz, None

@@ -423,9 +423,15 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         """-> [num_tables, B, D].  (`warmup` is ignored like in the reference,
         which uses self.warmup, :822,:841.)"""
         indices, offsets = indices.long(), offsets.long()
-        self.update_cache(indices)
-        indices, rowidx, tableidx, n_tt, cache_locations = _engine.preprocess_indices_sync(
-            indices, offsets, self.num_tables, self.warmup, self.hashtbl, self.cache_state)
+        if self.use_cache and getattr(_engine, "FUSED_CACHE_UPDATE", False) and indices.numel() > 0:
+            # frequency update folded into the preprocessing launch (same order as the reference:
+            # count the batch's indices, then look them up)
+            indices, rowidx, tableidx, n_tt, cache_locations = _engine.preprocess_indices_sync(
+                indices, offsets, self.num_tables, self.warmup, self.hashtbl, self.cache_state, self.cache_freq)
+        else:
+            self.update_cache(indices)
+            indices, rowidx, tableidx, n_tt, cache_locations = _engine.preprocess_indices_sync(
+                indices, offsets, self.num_tables, self.warmup, self.hashtbl, self.cache_state)
         n_cached = indices.numel() - n_tt
         return TTLookupFunction.apply(
             (offsets.numel() - 1) // self.num_tables, self.embedding_dim, self.tt_p_shapes, self.tt_q_shapes,
@@ -457,4 +463,6 @@ class TTEmbeddingBag(TableBatchedTTEmbeddingBag):
                          enforce_embedding_dim, device)
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True) -> torch.Tensor:
-        return super().forward(indices, offsets, warmup)[0]
+        # squeeze is a view both ways: `[0]` would make autograd materialise a zero [1,B,D] buffer
+        # and copy the gradient into it (two extra kernels per step)
+        return super().forward(indices, offsets, warmup).squeeze(0)

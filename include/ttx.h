@@ -162,6 +162,21 @@ int ttx_preprocess_indices_sync(int64_t nnz, const int64_t* colidx,
                                 void* workspace, size_t workspace_bytes,
                                 ttx_stream_t stream);
 
+/* The same, with update_cache_state folded into the first kernel when upd_hashtbl /
+ * upd_cache_freq are non-NULL (one launch instead of two; the order "count the batch's
+ * indices, then look them up" of tt_embeddings_ops.py:827-846 is kept). */
+int ttx_preprocess_indices_sync_fused(int64_t nnz, const int64_t* colidx,
+                                      int64_t num_bags_total, const int64_t* offsets,
+                                      int32_t num_tables, int32_t warmup,
+                                      int64_t hashtbl_size, const int64_t* hashtbl,
+                                      const int32_t* cache_state, int64_t* rowidx,
+                                      int64_t* tableidx, int64_t* part_colidx,
+                                      int64_t* part_rowidx, int32_t* part_cache_locations,
+                                      int32_t* num_tt_host, int32_t* partitioned_host,
+                                      int64_t* upd_hashtbl, int64_t* upd_cache_freq,
+                                      void* workspace, size_t workspace_bytes,
+                                      ttx_stream_t stream);
+
 /* replaces cache_populate_cuda (tt_embeddings.cpp:76-86,
  * tt_embeddings_cuda.cu:1260-1336): stable descending radix sort of the slots
  * by frequency, the top cache_size keys get cache rows (cache_state[slot] =
