@@ -6,21 +6,27 @@
 // (:362-377): after this kernel every core slice knows, in index order, the
 // lookups that touch it, so gradients are reduced by one owner per slice.
 //
-// One launch, T work-groups of 1024 threads (16 waves); work-group t plans core t:
-//   1. decode idx -> i_t exactly as the reference (idx / L_t % p_t, cu:795-799;
-//      the int64 divisions are done as a double-reciprocal multiply + fix-up
-//      when prod(p) < 2^31) and form the slice id  sid[t][n] = table*p_t + i_t;
-//   2. a stable LSD radix sort (8-bit digits) of the lookups by sid[t].  Ranking
-//      inside a wave uses 9 ballots per 64 keys (wave_match8); per-wave digit
-//      counters live in LDS and are combined by one block-wide exclusive scan
-//      per pass -- no atomics, deterministic;
-//   3. slice offsets by run-head detection on the sorted keys;
-//   4. (pivot core 1 only) the chunk work-list and one flat record per sorted
-//      lookup {n, sid_0, sid_2, sid_3}, so a contraction work-group reaches its
-//      operands with two dependent loads instead of a five-deep pointer chase.
-// The plan is HBM-resident integer work: ~ (8 + 8*passes) bytes per lookup per
-// core; at the benchmark shape (nnz 10240, 200/220/250 slices) every sort is a
-// single 8-bit pass.
+// What a plan holds, per core t:
+//   1. the slice id of every lookup, sid = table*p_t + i_t, with i_t decoded exactly as
+//      the reference does (idx / L_t % p_t, cu:795-799; when prod(p) <= 2^32 the two int64
+//      divisions become 32-bit magic-number multiplies);
+//   2. a stable LSD radix sort (8-bit digits) of the lookups by sid.  Ranking inside a wave
+//      uses 9 ballots per 64 keys (wave_match8); no float or ordering-dependent atomics, so
+//      the order -- and every sum that follows it -- is deterministic;
+//   3. slice offsets (thin cores) / the chunk work-list (pivot core 1);
+//   4. (pivot only) one flat record per sorted lookup {n, sid_0, sid_2, sid_3} and its bag
+//      row, so a contraction wave reaches its operands with two dependent loads.
+// Three routes, all producing the same plan:
+//   * mb_single_kernel  -- every sort is one 8-bit pass and nnz <= 16384 (the benchmark
+//     shape): ONE launch; each work-group histograms its core's keys itself in LDS, then
+//     ranks and scatters its own 256 positions; work-group 0 of each core also emits the
+//     offset table / chunk list from the digit totals.
+//   * mb_count / (mb_scan) / mb_scatter per pass + mb_finish -- any size, any slice count;
+//     the scan launch is folded into the scatter pass while there are <= 96 wave units and
+//     the finish launch into it when every sort is a single pass.
+//   * plan_small_kernel -- nnz <= 1024: one work-group per core, keys stay in registers/LDS.
+// The plan is integer work of ~ (8 + 8*passes) bytes per lookup per core; its cost is launch
+// latency and dependent-load chains, not bandwidth -- hence the effort to keep it to one launch.
 #include "ttx_internal.h"
 
 namespace ttx {
@@ -136,146 +142,7 @@ __device__ __forceinline__ unsigned clamp_idx32(long long idx) {
   return idx < 0 ? 0u : (idx > 0xffffffffll ? 0xffffffffu : (unsigned)idx);
 }
 
-__global__ __launch_bounds__(kPlanThreads) void plan_kernel(
-    Dims d, int N, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx,
-    const int64_t* __restrict__ rowidx, Plan P) {
-  __shared__ int hist[256 * kPlanWaves];  // [digit][wave]
-  __shared__ int wtot[kPlanWaves + 1];
-  const int tid = threadIdx.x;
-  const int lane = lane_id();
-  const int w = tid / kWave;
-  const int t = blockIdx.x;  // the core this work-group plans
-  int* key = P.sid[t];
-
-  // ---- 1. decode ----------------------------------------------------------
-  for (int n = tid; n < N; n += kPlanThreads) {
-    const long long tb = tableidx ? tableidx[n] : 0;
-    key[n] = (int)(tb * d.p[t]) + decode_core(d, t, indices[n]);
-  }
-  __syncthreads();
-
-  // per-wave contiguous range of the current order
-  const int per = ((N + kPlanWaves - 1) / kPlanWaves + kWave - 1) / kWave * kWave;
-  const int wbeg = w * per;
-  const int wend = min(N, wbeg + per);
-
-  // ---- 2. stable LSD radix sort by sid[t] ----------------------------------
-  {
-    int bits = 32 - __clz(max(d.S[t] - 1, 1));
-    int passes = (bits + 7) / 8;
-    if (passes < 1) passes = 1;
-    int* rk = P.scratch[t][0];
-    for (int ps = 0; ps < passes; ++ps) {
-      const int shift = ps * 8;
-      const int* src = (ps == 0) ? nullptr : ((ps & 1) ? P.scratch[t][1] : P.scratch[t][2]);
-      int* dst = (ps == passes - 1) ? P.perm[t] : ((ps & 1) ? P.scratch[t][2] : P.scratch[t][1]);
-      for (int e = tid; e < 256 * kPlanWaves; e += kPlanThreads) hist[e] = 0;
-      __syncthreads();
-      // count + rank inside the wave's range
-      for (int base = wbeg; base < wend; base += kWave) {
-        const int i = base + lane;
-        const bool valid = i < wend;
-        int val = 0;
-        unsigned dg = 0;
-        if (valid) {
-          val = src ? src[i] : i;
-          dg = ((unsigned)key[val] >> shift) & 255u;
-        }
-        const unsigned long long peers = wave_match8(dg, valid);
-        if (valid) {
-          const int before = hist[dg * kPlanWaves + w];
-          rk[i] = before + __popcll(peers & lanemask_lt());
-          // the lowest peer publishes the new count (LDS ops of one wave are
-          // executed in program order: every peer read `before` already)
-          if ((peers & lanemask_lt()) == 0) hist[dg * kPlanWaves + w] = before + __popcll(peers);
-        }
-      }
-      __syncthreads();
-      // exclusive scan over (digit major, wave minor): 4 entries per thread
-      {
-        int v0 = hist[tid * 4 + 0], v1 = hist[tid * 4 + 1], v2 = hist[tid * 4 + 2], v3 = hist[tid * 4 + 3];
-        int total;
-        int ex = block_excl_scan(v0 + v1 + v2 + v3, wtot, &total);
-        hist[tid * 4 + 0] = ex;
-        hist[tid * 4 + 1] = ex + v0;
-        hist[tid * 4 + 2] = ex + v0 + v1;
-        hist[tid * 4 + 3] = ex + v0 + v1 + v2;
-      }
-      __syncthreads();
-      // scatter
-      for (int base = wbeg; base < wend; base += kWave) {
-        const int i = base + lane;
-        if (i < wend) {
-          const int val = src ? src[i] : i;
-          const unsigned dg = ((unsigned)key[val] >> shift) & 255u;
-          dst[hist[dg * kPlanWaves + w] + rk[i]] = val;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // ---- 3. slice offsets by run-head detection -------------------------------
-  const int* pm = P.perm[t];
-  {
-    int* off = P.off[t];
-    const int S = d.S[t];
-    for (int i = tid; i <= N; i += kPlanThreads) {
-      const int kprev = (i == 0) ? -1 : key[pm[i - 1]];
-      const int kcur = (i == N) ? S : key[pm[i]];
-      for (int s = kprev + 1; s <= kcur; ++s) off[s] = i;
-    }
-  }
-  if (t != 1) return;
-  __syncthreads();
-
-  // ---- 4. pivot core: chunk work-list + flat per-lookup records ------------
-  {
-    const int S1 = d.S[1];
-    const int MC = P.MC;
-    const int* off = P.off[1];
-    int carry = 0;
-    for (int s0 = 0; s0 < S1; s0 += kPlanThreads) {
-      const int s = s0 + tid;
-      int nch = 0, beg = 0, cnt = 0;
-      if (s < S1) {
-        beg = off[s];
-        cnt = off[s + 1] - beg;
-        nch = (cnt + MC - 1) / MC;
-      }
-      int total;
-      const int ex = carry + block_excl_scan(nch, wtot, &total);
-      if (s < S1) {
-        P.chunk_off[s] = ex;
-        for (int j = 0; j < nch; ++j)
-          P.chunk_rec[ex + j] = make_int4(s, beg + j * MC, min(MC, cnt - j * MC), 0);
-      }
-      carry += total;
-    }
-    // unused tail of the work list: len = 0 -> the contraction work-group exits
-    for (int c = carry + tid; c < P.max_chunks; c += kPlanThreads) P.chunk_rec[c] = make_int4(0, 0, 0, 0);
-    if (tid == 0) {
-      P.chunk_off[S1] = carry;
-      P.hdr[0] = carry;
-      P.hdr[1] = MC;
-      P.hdr[2] = N;
-      P.hdr[3] = rowidx ? 1 : 0;
-    }
-    for (int i = tid; i < N; i += kPlanThreads) {
-      const int n = pm[i];
-      const long long idx = indices[n];
-      const int tb = tableidx ? (int)tableidx[n] : 0;
-      int4 r;
-      r.x = n;
-      r.y = tb * d.p[0] + decode_core(d, 0, idx);
-      r.z = d.T > 2 ? tb * d.p[2] + decode_core(d, 2, idx) : 0;
-      r.w = d.T > 3 ? tb * d.p[3] + decode_core(d, 3, idx) : 0;
-      P.lrec[i] = r;
-      if (rowidx) P.lrow[i] = (int)rowidx[n];
-    }
-  }
-}
-
-// ---- small-batch fast path (nnz <= 16384): everything between the index load and
+// ---- tiny-batch path (nnz <= 1024; the template extents still allow 16384): everything between the index load and
 // the final stores stays on chip.  Each thread keeps its (key, value, rank) triples in
 // registers (wave w owns the contiguous range [w*per, (w+1)*per) of the current
 // order, 64 per batch), passes exchange through LDS, and the pivot work-group emits the
@@ -503,6 +370,7 @@ struct MbArgs {
   int N, U;            // lookups, units per core
   int pass;            // current pass
   int fused_scan;      // scatter derives its bases itself (few units): no scan launch
+  int fused_finish;    // ... and, single-pass sorts, the offset tables / chunk list: no finish launch
   int passes[TTX_MAX_CORES];
   int* cnt;            // [T][256][U]
 };
@@ -570,10 +438,127 @@ __global__ __launch_bounds__(1024) void mb_scan_kernel(MbArgs A) {
   for (int i = beg; i < end; ++i) { const int v = c[i]; c[i] = run; run += v; }
 }
 
+// Single 8-bit pass (every S[t] <= 256): digit == slice id, so the digit prefix IS the slice
+// offset table and the pivot's chunk list follows from the digit totals -- what mb_finish would
+// recompute from the sorted keys.  One 256-thread work-group per core, thread = digit dg;
+// tot = lookups of the slice, dbase = its first position.  wt5: LDS int[kMbUnits + 1].
+__device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg, int tot, int dbase, int N,
+                                                   bool has_row, const Plan& P, int* wt5) {
+  const int lane = lane_id(), w = threadIdx.x / kWave;
+  const int S = d.S[t];
+  if (t != 1) {
+    if (dg <= S) P.off[t][dg] = (dg == S) ? N : dbase;
+    if (dg == 0 && S == 256) P.off[t][256] = N;
+    return;
+  }
+  const int MC = P.MC;
+  const int nch = dg < S ? (tot + MC - 1) / MC : 0;
+  const int cinc = wave_incl_scan(nch);
+  __syncthreads();
+  if (lane == kWave - 1) wt5[w] = cinc;
+  __syncthreads();
+  int cb = 0, ctot = 0;
+  for (int k = 0; k < kMbUnits; ++k) { const int v = wt5[k]; if (k < w) cb += v; ctot += v; }
+  const int ex = cb + cinc - nch;
+  if (dg < S) {
+    P.chunk_off[dg] = ex;
+    for (int j = 0; j < nch; ++j) P.chunk_rec[ex + j] = make_int4(dg, dbase + j * MC, min(MC, tot - j * MC), 0);
+  }
+  for (int cc = ctot + dg; cc < P.max_chunks; cc += kMbThreads) P.chunk_rec[cc] = make_int4(0, 0, 0, 0);
+  if (dg == 0) {
+    P.chunk_off[S] = ctot;
+    P.hdr[0] = ctot;
+    P.hdr[1] = MC;
+    P.hdr[2] = N;
+    P.hdr[3] = has_row ? 1 : 0;
+  }
+}
+
+// Small batches whose sorts are all single-pass: ONE launch builds the whole plan.  Every
+// work-group histograms all N keys of its core itself (LDS integer atomics -- N/256 decodes per
+// thread is cheaper than a count launch), then ranks and scatters its own 4 x kOneUnit positions.
+constexpr int kOneUnit = 64;      // positions per wave
+constexpr int kOneMaxN = 16384;
+__global__ __launch_bounds__(kMbThreads) void mb_single_kernel(
+    Dims d, int N, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx,
+    const int64_t* __restrict__ rowidx, Plan P) {
+  __shared__ int htot[256], hbef[256], hrun[kMbUnits][256];
+  __shared__ int wt5[kMbUnits + 1];
+  const int t = blockIdx.y, tid = threadIdx.x;
+  const int lane = lane_id(), w = tid / kWave;
+  const CoreDec ct = core_dec(d, t);
+  htot[tid] = 0;
+  hbef[tid] = 0;
+#pragma unroll
+  for (int k = 0; k < kMbUnits; ++k) hrun[k][tid] = 0;
+  __syncthreads();
+  const int bbeg = blockIdx.x * (kMbUnits * kOneUnit), bend = min(N, bbeg + kMbUnits * kOneUnit);
+  constexpr int kU = 4;  // loads in flight per thread
+  for (int i0 = tid; i0 < N; i0 += kMbThreads * kU) {
+    long long ix[kU];
+    int tb[kU];
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      const int i = i0 + j * kMbThreads;
+      ix[j] = i < N ? indices[i] : 0;
+      tb[j] = (i < N && tableidx) ? (int)tableidx[i] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      const int i = i0 + j * kMbThreads;
+      if (i < N) {
+        const int kv = min(tb[j] * ct.p + decode_core(ct, ix[j]), 255);  // tableidx is not validated
+        atomicAdd(&htot[kv], 1);
+        if (i < bbeg) atomicAdd(&hbef[kv], 1);
+        else if (i < bend) atomicAdd(&hrun[(i - bbeg) / kOneUnit][kv], 1);
+      }
+    }
+  }
+  __syncthreads();
+  const int dg = tid;
+  const int tot = htot[dg];
+  const int inc = wave_incl_scan(tot);
+  if (lane == kWave - 1) wt5[w] = inc;
+  int mine[kMbUnits];
+#pragma unroll
+  for (int k = 0; k < kMbUnits; ++k) mine[k] = hrun[k][dg];
+  __syncthreads();
+  int wbase = 0;
+  for (int k = 0; k < w; ++k) wbase += wt5[k];
+  const int dbase = wbase + inc - tot;
+  int b = dbase + hbef[dg];
+#pragma unroll
+  for (int k = 0; k < kMbUnits; ++k) { hrun[k][dg] = b; b += mine[k]; }
+  __syncthreads();
+  if (blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, N, rowidx != nullptr, P, wt5);
+  // rank + scatter this wave's 64 positions
+  const int i = bbeg + w * kOneUnit + lane;
+  const bool valid = i < bend;
+  int kv = 0, tbv = 0;
+  long long idx = 0;
+  if (valid) {
+    idx = indices[i];
+    tbv = tableidx ? (int)tableidx[i] : 0;
+    kv = min(tbv * ct.p + decode_core(ct, idx), 255);
+  }
+  const unsigned long long peers = wave_match8((unsigned)kv, valid);
+  if (valid) {
+    const int pos = hrun[w][kv] + __popcll(peers & lanemask_lt());
+    if (t != 1) {
+      P.perm[t][pos] = i;
+    } else {
+      const int s0 = tbv * d.p[0] + decode_core(d, 0, idx);
+      const int s2 = d.T > 2 ? tbv * d.p[2] + decode_core(d, 2, idx) : 0;
+      const int s3 = d.T > 3 ? tbv * d.p[3] + decode_core(d, 3, idx) : 0;
+      P.lrec[pos] = make_int4(i, s0, s2, s3);
+      if (rowidx) P.lrow[pos] = (int)rowidx[i];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
     Dims d, MbArgs A, const int64_t* __restrict__ rowidx, Plan P) {
   __shared__ int run[kMbUnits][256];
-  __shared__ int dtot[256];
   __shared__ int wt5[kMbUnits + 1];
   const int t = blockIdx.y;
   if (A.pass >= A.passes[t]) return;
@@ -600,11 +585,12 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
     __syncthreads();
     int wbase = 0;
     for (int k = 0; k < w; ++k) wbase += wt5[k];
-    int b = wbase + inc - tot + before;  // first position of (digit dg, unit u0)
+    const int dbase = wbase + inc - tot;  // first position of digit dg
+    int b = dbase + before;               // first position of (digit dg, unit u0)
 #pragma unroll
     for (int k = 0; k < kMbUnits; ++k) { run[k][dg] = b; b += mine[k]; }
     __syncthreads();
-    (void)dtot;
+    if (A.fused_finish && blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, A.N, rowidx != nullptr, P, wt5);
   } else if (u < A.U) {
     for (int e = lane; e < 256; e += kWave) run[w][e] = A.cnt[((size_t)t * 256 + e) * A.U + u];
   }
@@ -708,14 +694,22 @@ static int plan_build_mb(const Dims& d, int N, const int64_t* indices, const int
       if (A.passes[t] > maxp) maxp = A.passes[t];
     }
   }
+  if (maxp == 1 && N <= kOneMaxN) {
+    hipLaunchKernelGGL(mb_single_kernel, dim3((N + kMbUnits * kOneUnit - 1) / (kMbUnits * kOneUnit), d.T),
+                       dim3(kMbThreads), 0, stream, d, N, indices, tableidx, rowidx, P);
+    TTX_HIP(hipGetLastError());
+    return TTX_OK;
+  }
   const dim3 gu((A.U + kMbUnits - 1) / kMbUnits, d.T);
   A.fused_scan = A.U <= 96 ? 1 : 0;
+  A.fused_finish = (A.fused_scan && maxp == 1) ? 1 : 0;
   for (int ps = 0; ps < maxp; ++ps) {
     A.pass = ps;
     hipLaunchKernelGGL(mb_count_kernel, gu, dim3(kMbThreads), 0, stream, d, A, indices, tableidx, P);
     if (!A.fused_scan) hipLaunchKernelGGL(mb_scan_kernel, dim3(d.T), dim3(1024), 0, stream, A);
     hipLaunchKernelGGL(mb_scatter_kernel, gu, dim3(kMbThreads), 0, stream, d, A, rowidx, P);
   }
+  if (A.fused_finish) { TTX_HIP(hipGetLastError()); return TTX_OK; }
   int smax = 1;
   for (int t = 0; t < d.T; ++t) if (t != 1 && d.S[t] + 1 > smax) smax = d.S[t] + 1;
   hipLaunchKernelGGL(mb_finish_kernel, dim3((smax + 1023) / 1024, d.T), dim3(1024), 0, stream, d, N,
@@ -729,7 +723,7 @@ int plan_build(const Dims& d, long long nnz, const int64_t* indices,
   if (nnz < 0 || nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz=%lld out of range", nnz);
   ProfScope ps(TTX_PROF_PLAN, stream);
   if (nnz > 1024 || !d.idx32) return plan_build_mb(d, (int)nnz, indices, tableidx, rowidx, P, stream);
-  if (nnz <= kSmallMax && d.idx32) {  // tiny batch: one launch, everything on chip
+  {  // tiny batch: one launch, one work-group per core, everything on chip
     const size_t lds = (256 * kPlanWaves + 32 + 2 * ((nnz + 63) / 64 * 64)) * sizeof(int);
     const int per = (((int)nnz + kPlanWaves - 1) / kPlanWaves + kWave - 1) / kWave * kWave;
     const int nb = per / kWave;
@@ -750,9 +744,6 @@ int plan_build(const Dims& d, long long nnz, const int64_t* indices,
     else if (nb <= 12) TTX_PLAN_LAUNCH(12);
     else TTX_PLAN_LAUNCH(16);
 #undef TTX_PLAN_LAUNCH
-  } else {
-    hipLaunchKernelGGL(plan_kernel, dim3(d.T), dim3(kPlanThreads), 0, stream, d, (int)nnz,
-                       indices, tableidx, rowidx, P);
   }
   TTX_HIP(hipGetLastError());
   return TTX_OK;

@@ -156,8 +156,8 @@ def test_property_sweep_vs_oracle(T, tables):
 
 
 def test_large_batch_uses_the_global_memory_plan():
-    """nnz > 16384 takes the multi-pass global-memory plan kernel; nnz just below
-    takes the on-chip one.  Both against the oracle (dense grads + fused SGD)."""
+    """nnz > 16384 takes the count / scatter launches of the multi-work-group plan; nnz below
+    takes the single-launch one.  Both against the oracle (dense grads + fused SGD)."""
     for B, pf, tables in ((700, 9, 3), (500, 8, 4), (2000, 12, 1)):
         c = _random_case(77 + B, 3, tables, B, pf, 2)
         assert (c["indices"].size > 16384) == (B != 500)
@@ -169,6 +169,32 @@ def test_large_batch_uses_the_global_memory_plan():
                     assert_close(got["grads"][k], orc["grads"][k], f"B{B} grad{k}")
                 else:
                     assert_close(got["cores"][k], orc["cores"][k], f"B{B} sgd core{k}")
+
+
+@pytest.mark.parametrize("tables,p,B,pf", [
+    (1, [300, 290, 310], 300, 10),    # two 8-bit passes per core, bases derived in the scatter pass, finish launch
+    (1, [300, 290, 310], 3000, 10),   # > 96 wave units: scan launch between count and scatter
+    (3, [100, 120, 90], 400, 6),      # slice id = table * p + i_t exceeds one digit because of the table
+    (2, [20, 600, 15], 350, 7),       # only the pivot core needs a second pass
+    (1, [256, 255, 257], 500, 30),    # digit-boundary slice counts, single/multi pass mixed, N < 16384
+])
+def test_plan_paths_vs_oracle(tables, p, B, pf):
+    """every route through the lookup plan (ttx_plan.hip): single launch (all sorts one 8-bit pass,
+    N <= 16384) is what the other tests take; here multi-pass sorts, the separate scan launch and
+    the finish launch.  Forward, dense grads and fused SGD against the oracle."""
+    q, r = [2, 3, 2], [1, 4, 5, 1]
+    E_, D = int(np.prod(np.array(p, dtype=np.int64))), int(np.prod(q))
+    idx, off = G.make_bags(5 + B, B, E_, pf, 1, tables)
+    c = dict(tables=tables, T=3, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+             cores=G.make_cores(6 + B, tables, p, q, r, "signed"), d_out=G.make_grad(7, tables, B, D))
+    for mode in ("dense", "sgd"):
+        got, orc = run_case(c, mode, plan_shared=True), oracle_case(c, mode)
+        assert_close(got["out"], orc["out"], f"plan {p} out")
+        for k in range(3):
+            if mode == "dense":
+                assert_close(got["grads"][k], orc["grads"][k], f"plan {p} grad{k}")
+            else:
+                assert_close(got["cores"][k], orc["cores"][k], f"plan {p} sgd core{k}")
 
 
 @pytest.mark.parametrize("ranks,q", [([32, 32], [4, 4, 4]), ([16, 16], [4, 4, 4]), ([32, 32], [4, 4, 8]), ([16, 16], [4, 4, 8])])
