@@ -43,6 +43,16 @@ P_SHAPES, Q_SHAPES, RANKS = [200, 220, 250], [4, 4, 4], [32, 32]
 B_GLOBAL, POOL = 512, 20
 PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 MFMA/VALU dense peak (MI355X_MICROARCH.md)
 
+# --workload: cfg2 is the bench line (BASELINE.json configs[1]); the others are the rest of
+# SURVEY.md section 8(d)'s measurement list, for profiles/ -- never the driver's default.
+WORKLOADS = {
+    "cfg2": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    "cfg3": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.2, populate=True),
+    "cfg4": dict(q=[4, 4, 8], ranks=[64, 64], tables=1, B=512, optimizer="adagrad", alpha=1.0, populate=False),
+    # one rank's share of cfg5 at 8 GPUs: 4 of the 26 tables, the whole 4096-bag batch
+    "cfg5shard": dict(q=[4, 4, 4], ranks=[32, 32], tables=4, B=4096, optimizer="sgd", alpha=1.0, populate=False),
+}
+
 
 def flop_per_nnz_fwd(q, r):
     return 2.0 * (q[0] * r[0] * q[1] * r[1] + q[0] * q[1] * r[1] * q[2])
@@ -69,7 +79,7 @@ def cpu_baseline(requests, cores, d_out, budget_s=12.0):
             break
     gflops = 3.0 * flop_per_nnz_fwd(Q_SHAPES, RANKS) * nnz / el / 1e9
     return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": 1, "kind": "port",
-            "sample": f"{done} fwd+bwd(SGD) steps of the same cfg2 requests ({nnz} lookups) in {el:.1f} s, "
+            "sample": f"{done} fwd+bwd(SGD) steps of the same requests ({nnz} lookups) in {el:.1f} s, "
                       f"oracle/ttx_oracle.c single thread; {el / nnz * 1e6:.2f} us/nnz"}
 
 
@@ -81,8 +91,17 @@ def main():
     ap.add_argument("--no-cache", action="store_true", help="use_cache=False (skip the hash-table frequency update)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager Python path only (no hipGraph replay)")
-    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adagrad"])
+    ap.add_argument("--optimizer", default=None, choices=["sgd", "adagrad"])
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     args = ap.parse_args()
+    global Q_SHAPES, RANKS, B_GLOBAL
+    wl = WORKLOADS[args.workload]
+    Q_SHAPES, RANKS, B_GLOBAL = wl["q"], wl["ranks"], wl["B"]
+    if args.optimizer is None:
+        args.optimizer = wl["optimizer"]
+    ntab = wl["tables"]
+    if args.gpus > 1 and args.workload != "cfg2":
+        raise SystemExit("--gpus N > 1 runs the cfg2-per-rank sharded workload only")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -105,22 +124,35 @@ def main():
     E_, D = int(np.prod(P_SHAPES)), int(np.prod(Q_SHAPES))
     opt = ops.OptimType.SGD if args.optimizer == "sgd" else ops.OptimType.EXACT_ADAGRAD
     iters = 10  # request batches, like the reference's --iters
+    hit_rate = None
     B_local = B_GLOBAL // world
     assert B_local * world == B_GLOBAL
     torch.manual_seed(1234 + rank)
     if world == 1:
-        mod = ops.TTEmbeddingBag(E_, D, RANKS, P_SHAPES, Q_SHAPES, sparse=True, optimizer=opt, learning_rate=0.1,
-                                 use_cache=not args.no_cache, weight_dist="uniform", device=dev)
-        cores_np = G.make_cores(1234, 1, P_SHAPES, Q_SHAPES, RANKS, "uniform")
+        use_cache = (not args.no_cache) and ntab == 1
+        kw = dict(sparse=True, optimizer=opt, learning_rate=0.1, use_cache=use_cache, weight_dist="uniform", device=dev)
+        if wl["populate"]:  # cfg3: 256Ki-row cache behind a 1Mi-slot table
+            kw.update(cache_size=1 << 18, hashtbl_size=1 << 20)
+        if ntab == 1:
+            mod = ops.TTEmbeddingBag(E_, D, RANKS, P_SHAPES, Q_SHAPES, **kw)
+        else:
+            mod = ops.TableBatchedTTEmbeddingBag(ntab, E_, D, RANKS, P_SHAPES, Q_SHAPES, **kw)
+        cores_np = G.make_cores(1234, ntab, P_SHAPES, Q_SHAPES, RANKS, "uniform")
         with torch.no_grad():
             for dst, src in zip(mod.tt_cores, cores_np):
                 dst.copy_(torch.from_numpy(src))
-        reqs_np = G.make_requests(1235, iters, B_GLOBAL, 1, POOL, E_)
+        reqs_np = G.make_requests(1235, iters, B_GLOBAL, ntab, POOL, E_, alpha=wl["alpha"])
         reqs = [(torch.from_numpy(i).to(dev), torch.from_numpy(o).to(dev)) for i, o in reqs_np]
-        d_out_np = G.make_grad(1236, 1, B_GLOBAL, D)
-        grad = torch.from_numpy(d_out_np[0]).to(dev)
+        d_out_np = G.make_grad(1236, ntab, B_GLOBAL, D)
+        grad = torch.from_numpy(d_out_np[0] if ntab == 1 else d_out_np).to(dev)
         step = lambda i, o: mod(i, o).backward(grad)  # noqa: E731
-        nnz_step_total = B_GLOBAL * POOL
+        nnz_step_total = ntab * B_GLOBAL * POOL
+        if wl["populate"]:
+            for k in range(iters):
+                step(*reqs[k])
+            mod.cache_populate()
+            n_tt = sum(E.preprocess_indices_sync(i, o, 1, False, mod.hashtbl, mod.cache_state)[3] for i, o in reqs)
+            hit_rate = 1.0 - n_tt / float(iters * nnz_step_total)
     else:
         mod = ttx_sharded.ShardedTableBatchedTTEmbeddingBag(
             world, E_, D, RANKS, tt_p_shapes=P_SHAPES, tt_q_shapes=Q_SHAPES, sparse=True, optimizer=opt,
@@ -160,7 +192,7 @@ def main():
     # replayed; every replay runs the full plan/forward/pool/backward/apply kernel sequence
     # on inputs resident in HBM.  Falls back to the eager timing if capture is unavailable.
     mode, elapsed = "eager", eager_elapsed
-    if not args.no_graph and world == 1:
+    if not args.no_graph and world == 1 and not wl["populate"]:  # cache-live lookups read a count back: no capture
         try:
             cap = torch.cuda.Stream()
             cap.wait_stream(torch.cuda.current_stream())
@@ -221,12 +253,16 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "fwd+bwd GFLOPS (true algorithmic: 3 x fwd FLOP / time), TT-EmbeddingBag E=11M D=64 ranks=[32,32] nnz=10240",
+            "metric": ("fwd+bwd GFLOPS (true algorithmic: 3 x fwd FLOP / time), TT-EmbeddingBag E=11M "
+                       f"D={D} ranks={RANKS} nnz={per_rank_nnz}"),
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("cfg2: TTEmbeddingBag E=11000000 D=64 p=[200,220,250] q=[4,4,4] ranks=[32,32] B=512 L=20 "
-                                    f"nnz=10240 sparse {args.optimizer.upper()}, use_cache={'False' if (args.no_cache or world > 1) else 'True(unpopulated)'}"
+            "config": {"workload": (f"{args.workload}: {'TTEmbeddingBag' if ntab == 1 else f'TableBatchedTTEmbeddingBag x{ntab} tables'} "
+                                    f"E=11000000 D={D} p=[200,220,250] q={Q_SHAPES} ranks={RANKS} B={B_GLOBAL} L=20 "
+                                    f"nnz={per_rank_nnz} sparse {args.optimizer.upper()}, use_cache="
+                                    + ("False" if (args.no_cache or world > 1 or ntab > 1) else
+                                       (f"True(populated, 256Ki rows, Zipf a={wl['alpha']}, hit rate {hit_rate:.3f})" if wl["populate"] else "True(unpopulated)"))
                                     + ("" if world == 1 else f"; {world} such tables, one per rank, table-sharded, RCCL all-to-all; B_local={B_local}")),
                        "nnz_per_step_total": nnz_step_total, "flop_per_nnz_fwd_bwd": 3.0 * fl_fwd,
                        "path": "Python module -> ctypes -> C ABI -> HIP" + ("; timed as hipGraph replay of the captured module fwd+bwd step" if mode == "hipgraph" else "; eager")},
@@ -237,12 +273,12 @@ def main():
             "ref_formula_gflops_x_iters": round(gflops * 10, 1),
             "reference_readme_true_gflops": 265.8,
             "kernel_us": breakdown,
-            "roofline": {"bound": "mfma", "kernel": "bwd_kernel (backward contraction)", "achieved": round(achieved, 3),
+            "roofline": {"bound": "mfma", "kernel": "spec_bwd_kernel / bwd_kernel (backward contraction)", "achieved": round(achieved, 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 5),
                          "traffic": traffic, "launches": n_bwd, "avg_us": round(bwd_us, 2),
                          "flop_per_launch": bwd_flop_per_launch},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and ntab == 1:
             line["cpu_baseline"] = cpu_baseline(reqs_np, cores_np, d_out_np)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -147,7 +147,6 @@ __device__ __forceinline__ unsigned clamp_idx32(long long idx) {
 // registers (wave w owns the contiguous range [w*per, (w+1)*per) of the current
 // order, 64 per batch), passes exchange through LDS, and the pivot work-group emits the
 // flat lookup records at scatter time.  One global round trip in, one out.
-constexpr int kSmallMax = 16384;
 
 template <int kBPW>  // batches of 64 lookups per wave (register array extent)
 __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
@@ -362,22 +361,38 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
 //   mb_scatter : position = base[digit][unit] + rank; writes the next order; on a core's last
 //                pass also perm[t], the sorted keys and (pivot) the flat lookup records
 // then mb_finish: slice offsets by binary search on the sorted keys + the pivot chunk list.
-constexpr int kUnit = 256;                 // positions per wave unit
-constexpr int kMbThreads = 256;            // 4 units per work-group
+constexpr int kMbThreads = 256;            // 4 wave units per work-group
 constexpr int kMbUnits = kMbThreads / kWave;
+constexpr int kMbFuseU = 256;              // up to this many units the scatter pass scans the counts itself
 
 struct MbArgs {
   int N, U;            // lookups, units per core
+  int unit;            // positions per wave unit (multiple of 64)
   int pass;            // current pass
   int fused_scan;      // scatter derives its bases itself (few units): no scan launch
   int fused_finish;    // ... and, single-pass sorts, the offset tables / chunk list: no finish launch
   int passes[TTX_MAX_CORES];
-  int* cnt;            // [T][256][U]
+  int* cnt;            // [T][U][256]  (unit-major: a unit's 256 digit counts are one 1 KiB row)
 };
 
-__device__ __forceinline__ int mb_passes(int S) {
-  const int bits = 32 - __clz(max(S - 1, 1));
-  return max((bits + 7) / 8, 1);
+// what one lane holds of one batch of 64 positions
+struct MbItem { int val, kv; };
+
+// pass 0 reads (and decodes) the indices; later passes chase order -> key
+__device__ __forceinline__ MbItem mb_load(int i, bool valid, int pass, const CoreDec& ct,
+                                          const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx,
+                                          const int* __restrict__ src, const int* __restrict__ key) {
+  MbItem it{0, 0};
+  if (!valid) return it;
+  if (pass == 0) {
+    const int tb = tableidx ? (int)tableidx[i] : 0;
+    it.val = i;
+    it.kv = tb * ct.p + decode_core(ct, indices[i]);
+  } else {
+    it.val = src[i];
+    it.kv = key[it.val];
+  }
+  return it;
 }
 
 __global__ __launch_bounds__(kMbThreads) void mb_count_kernel(
@@ -388,54 +403,50 @@ __global__ __launch_bounds__(kMbThreads) void mb_count_kernel(
   const int lane = lane_id(), w = threadIdx.x / kWave;
   const int u = blockIdx.x * kMbUnits + w;
   for (int e = lane; e < 256; e += kWave) hist[w][e] = 0;
-  const int beg = u * kUnit, end = min(A.N, beg + kUnit);
+  const int beg = min(A.N, u * A.unit), end = min(A.N, beg + A.unit);
   int* key = P.sid[t];
   const int* src = (A.pass == 0) ? nullptr : ((A.pass & 1) ? P.scratch[t][1] : P.scratch[t][2]);
   const int shift = A.pass * 8;
   const CoreDec ct = core_dec(d, t);
+  MbItem nx = mb_load(beg + lane, beg + lane < end, A.pass, ct, indices, tableidx, src, key);
   for (int base = beg; base < end; base += kWave) {
+    const MbItem it = nx;
     const int i = base + lane;
     const bool valid = i < end;
-    unsigned dg = 0;
-    if (valid) {
-      int kv;
-      if (A.pass == 0) {
-        const int tb = tableidx ? (int)tableidx[i] : 0;
-        kv = tb * ct.p + decode_core(ct, indices[i]);
-        key[i] = kv;
-      } else {
-        kv = key[src[i]];
-      }
-      dg = ((unsigned)kv >> shift) & 255u;
-    }
+    nx = mb_load(i + kWave, i + kWave < end, A.pass, ct, indices, tableidx, src, key);  // next batch in flight
+    if (valid && A.pass == 0) key[i] = it.kv;
+    const unsigned dg = ((unsigned)it.kv >> shift) & 255u;
     const unsigned long long peers = wave_match8(dg, valid);
     if (valid && (peers & lanemask_lt()) == 0) hist[w][dg] += __popcll(peers);
   }
   if (u < A.U)
-    for (int e = lane; e < 256; e += kWave) A.cnt[((size_t)t * 256 + e) * A.U + u] = hist[w][e];
+    for (int e = lane; e < 256; e += kWave) A.cnt[((size_t)t * A.U + u) * 256 + e] = hist[w][e];
 }
 
-__global__ __launch_bounds__(1024) void mb_scan_kernel(MbArgs A) {
-  __shared__ int wt[17];
-  const int t = blockIdx.x;
+// many units (> kMbFuseU): counts -> first positions, in place.  One work-group per core,
+// thread = digit, walking the unit rows (coalesced 1 KiB each).
+__global__ __launch_bounds__(256) void mb_scan_kernel(MbArgs A) {
+  __shared__ int wt[kMbUnits];
+  const int t = blockIdx.x, dg = threadIdx.x;
   if (A.pass >= A.passes[t]) return;
-  int* c = A.cnt + (size_t)t * 256 * A.U;
-  const int total = 256 * A.U;
-  const int per = (total + 1023) / 1024;
-  const int beg = threadIdx.x * per, end = min(total, beg + per);
-  int s = 0;
-  for (int i = beg; i < end; ++i) s += c[i];
-  const int inc = wave_incl_scan(s);
-  const int w = threadIdx.x / kWave;
-  if (lane_id() == kWave - 1) wt[w] = inc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int k = 0; k < 16; ++k) { const int v = wt[k]; wt[k] = run; run += v; }
+  int* c = A.cnt + (size_t)t * A.U * 256 + dg;
+  int tot = 0;
+  for (int u0 = 0; u0 < A.U; u0 += 8) {
+    int v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (u0 + j < A.U) ? c[(size_t)(u0 + j) * 256] : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (u0 + j < A.U) c[(size_t)(u0 + j) * 256] = tot;
+      tot += v[j];
+    }
   }
+  const int inc = wave_incl_scan(tot);
+  if (lane_id() == kWave - 1) wt[dg / kWave] = inc;
   __syncthreads();
-  int run = wt[w] + inc - s;
-  for (int i = beg; i < end; ++i) { const int v = c[i]; c[i] = run; run += v; }
+  int dbase = inc - tot;
+  for (int k = 0; k < dg / kWave; ++k) dbase += wt[k];
+  for (int u = 0; u < A.U; ++u) c[(size_t)u * 256] += dbase;
 }
 
 // Single 8-bit pass (every S[t] <= 256): digit == slice id, so the digit prefix IS the slice
@@ -557,7 +568,8 @@ __global__ __launch_bounds__(kMbThreads) void mb_single_kernel(
 }
 
 __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
-    Dims d, MbArgs A, const int64_t* __restrict__ rowidx, Plan P) {
+    Dims d, MbArgs A, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx,
+    const int64_t* __restrict__ rowidx, Plan P) {
   __shared__ int run[kMbUnits][256];
   __shared__ int wt5[kMbUnits + 1];
   const int t = blockIdx.y;
@@ -568,17 +580,23 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
     // few units: every work-group derives its own bases from the raw counts (no scan launch).
     // thread = digit: total of the digit, exclusive prefix over digits, prefix over earlier units
     const int dg = threadIdx.x;
-    const int* c = A.cnt + ((size_t)t * 256 + dg) * A.U;
+    const int* c = A.cnt + (size_t)t * A.U * 256 + dg;
     const int u0 = blockIdx.x * kMbUnits;
     int tot = 0, before = 0, mine[kMbUnits];
 #pragma unroll
     for (int k = 0; k < kMbUnits; ++k) mine[k] = 0;
-    for (int uu = 0; uu < A.U; ++uu) {
-      const int v = c[uu];
-      if (uu < u0) before += v;
+    for (int ub = 0; ub < A.U; ub += 8) {
+      int v[8];
 #pragma unroll
-      for (int k = 0; k < kMbUnits; ++k) if (uu == u0 + k) mine[k] = v;
-      tot += v;
+      for (int j = 0; j < 8; ++j) v[j] = (ub + j < A.U) ? c[(size_t)(ub + j) * 256] : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int uu = ub + j;
+        if (uu < u0) before += v[j];
+#pragma unroll
+        for (int k = 0; k < kMbUnits; ++k) if (uu == u0 + k) mine[k] = v[j];
+        tot += v[j];
+      }
     }
     const int inc = wave_incl_scan(tot);
     if (lane == kWave - 1) wt5[w] = inc;
@@ -592,9 +610,9 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
     __syncthreads();
     if (A.fused_finish && blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, A.N, rowidx != nullptr, P, wt5);
   } else if (u < A.U) {
-    for (int e = lane; e < 256; e += kWave) run[w][e] = A.cnt[((size_t)t * 256 + e) * A.U + u];
+    for (int e = lane; e < 256; e += kWave) run[w][e] = A.cnt[((size_t)t * A.U + u) * 256 + e];
   }
-  const int beg = u * kUnit, end = min(A.N, beg + kUnit);
+  const int beg = min(A.N, u * A.unit), end = min(A.N, beg + A.unit);
   const int* key = P.sid[t];
   const int* src = (A.pass == 0) ? nullptr : ((A.pass & 1) ? P.scratch[t][1] : P.scratch[t][2]);
   const bool last = (A.pass == A.passes[t] - 1);
@@ -602,26 +620,25 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
   int* sk = P.scratch[t][0];  // sorted keys (last pass)
   const int shift = A.pass * 8;
   const bool pivot = (t == 1);
+  const CoreDec ct = core_dec(d, t);
+  // pass 0 re-derives the key from the index (cheaper than chasing key[i] behind the count launch's store)
+  MbItem nx = mb_load(beg + lane, beg + lane < end, A.pass, ct, indices, tableidx, src, key);
   for (int base = beg; base < end; base += kWave) {
+    const MbItem it = nx;
     const int i = base + lane;
     const bool valid = i < end;
-    int val = 0, kv = 0;
-    unsigned dg = 0;
-    if (valid) {
-      val = src ? src[i] : i;
-      kv = key[val];
-      dg = ((unsigned)kv >> shift) & 255u;
-    }
+    nx = mb_load(i + kWave, i + kWave < end, A.pass, ct, indices, tableidx, src, key);
+    const unsigned dg = ((unsigned)it.kv >> shift) & 255u;
     const unsigned long long peers = wave_match8(dg, valid);
     if (valid) {
       const int before = run[w][dg];
       const int pos = before + __popcll(peers & lanemask_lt());
-      dst[pos] = val;
+      if (!(last && pivot)) dst[pos] = it.val;  // the pivot's final order lives in lrec.x
       if (last) {
-        sk[pos] = kv;
+        sk[pos] = it.kv;
         if (pivot) {
-          P.lrec[pos] = make_int4(val, P.sid[0][val], d.T > 2 ? P.sid[2][val] : 0, d.T > 3 ? P.sid[3][val] : 0);
-          if (rowidx) P.lrow[pos] = (int)rowidx[val];
+          P.lrec[pos] = make_int4(it.val, P.sid[0][it.val], d.T > 2 ? P.sid[2][it.val] : 0, d.T > 3 ? P.sid[3][it.val] : 0);
+          if (rowidx) P.lrow[pos] = (int)rowidx[it.val];
         }
       }
       if ((peers & lanemask_lt()) == 0) run[w][dg] = before + __popcll(peers);
@@ -682,8 +699,6 @@ static int plan_build_mb(const Dims& d, int N, const int64_t* indices, const int
                          const int64_t* rowidx, const Plan& P, hipStream_t stream) {
   MbArgs A;
   A.N = N;
-  A.U = (N + kUnit - 1) / kUnit;
-  A.cnt = P.cnt;
   int maxp = 1;
   for (int t = 0; t < TTX_MAX_CORES; ++t) {
     A.passes[t] = 0;
@@ -700,14 +715,24 @@ static int plan_build_mb(const Dims& d, int N, const int64_t* indices, const int
     TTX_HIP(hipGetLastError());
     return TTX_OK;
   }
-  const dim3 gu((A.U + kMbUnits - 1) / kMbUnits, d.T);
-  A.fused_scan = A.U <= 96 ? 1 : 0;
+  // unit size: 256 positions per wave while that keeps the unit count small enough for the
+  // scatter pass to scan the counts itself; longer walks (<= 4096) before falling back to the
+  // scan launch.  cnt was sized for units of 256 (carve_plan), any larger unit fits.
+  A.unit = 256;
+  if ((N + 255) / 256 > kMbFuseU) {
+    A.unit = ((N + kMbFuseU - 1) / kMbFuseU + 63) / 64 * 64;
+    if (A.unit > 4096) A.unit = 4096;
+  }
+  A.U = (N + A.unit - 1) / A.unit;
+  A.cnt = P.cnt;
+  A.fused_scan = A.U <= kMbFuseU ? 1 : 0;
   A.fused_finish = (A.fused_scan && maxp == 1) ? 1 : 0;
+  const dim3 gu((A.U + kMbUnits - 1) / kMbUnits, d.T);
   for (int ps = 0; ps < maxp; ++ps) {
     A.pass = ps;
     hipLaunchKernelGGL(mb_count_kernel, gu, dim3(kMbThreads), 0, stream, d, A, indices, tableidx, P);
-    if (!A.fused_scan) hipLaunchKernelGGL(mb_scan_kernel, dim3(d.T), dim3(1024), 0, stream, A);
-    hipLaunchKernelGGL(mb_scatter_kernel, gu, dim3(kMbThreads), 0, stream, d, A, rowidx, P);
+    if (!A.fused_scan) hipLaunchKernelGGL(mb_scan_kernel, dim3(d.T), dim3(256), 0, stream, A);
+    hipLaunchKernelGGL(mb_scatter_kernel, gu, dim3(kMbThreads), 0, stream, d, A, indices, tableidx, rowidx, P);
   }
   if (A.fused_finish) { TTX_HIP(hipGetLastError()); return TTX_OK; }
   int smax = 1;

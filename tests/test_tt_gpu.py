@@ -173,7 +173,9 @@ def test_large_batch_uses_the_global_memory_plan():
 
 @pytest.mark.parametrize("tables,p,B,pf", [
     (1, [300, 290, 310], 300, 10),    # two 8-bit passes per core, bases derived in the scatter pass, finish launch
-    (1, [300, 290, 310], 3000, 10),   # > 96 wave units: scan launch between count and scatter
+    (1, [300, 290, 310], 3000, 10),   # 118 wave units of 256
+    (2, [300, 29, 310], 5000, 20),    # ~200k lookups: longer wave units, still scanned inside the scatter pass
+    (1, [40, 300, 50], 40000, 30),    # ~1.2M lookups: more than 256 units of 4096 -> the scan launch
     (3, [100, 120, 90], 400, 6),      # slice id = table * p + i_t exceeds one digit because of the table
     (2, [20, 600, 15], 350, 7),       # only the pivot core needs a second pass
     (1, [256, 255, 257], 500, 30),    # digit-boundary slice counts, single/multi pass mixed, N < 16384
