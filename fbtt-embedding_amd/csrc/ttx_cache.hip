@@ -13,26 +13,7 @@
 
 namespace ttx {
 
-constexpr int kMaxProbes = 3;  // tt_embeddings_cuda.cu:29
 constexpr int kCT = 256;
-
-// hashtbl_cuda_utils.cuh:48-76 (bit-exact restatement; KATs in tests/golden)
-__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
-
-__device__ __forceinline__ uint32_t hash64(int64_t key, int32_t C) {
-  const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u;
-  const uint64_t u = (uint64_t)key;
-  uint32_t h = 0;
-  uint32_t k1 = (uint32_t)u;
-  k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2;
-  h ^= k1; h = rotl32(h, 13); h = h * 5 + 0xe6546b64u;
-  uint32_t k2 = (uint32_t)(u >> 32);
-  k2 *= c1; k2 = rotl32(k2, 15); k2 *= c2;
-  h ^= k2; h = rotl32(h, 13); h = h * 5 + 0xe6546b64u;
-  h ^= 2;
-  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-  return (uint32_t)(((uint64_t)h * (uint64_t)(uint32_t)C) >> 32);
-}
 
 // hashtbl_cuda_utils.cuh:135-154 (incl. the early-out on the SEARCH key, :146)
 __device__ __forceinline__ int32_t hashtbl_find(int64_t key, int32_t size, const int64_t* keys) {
@@ -52,17 +33,7 @@ __global__ __launch_bounds__(kCT) void update_cache_state_kernel(
     int64_t N, const int64_t* __restrict__ colidx, int32_t H, int64_t* hashtbl, int64_t* cache_freq) {
   const int64_t n = (int64_t)blockIdx.x * kCT + threadIdx.x;
   if (n >= N) return;
-  const int64_t key = colidx[n];
-  int32_t idx = (int32_t)hash64(key, H);
-  for (int c = 0; c < kMaxProbes; ++c) {
-    const unsigned long long old = atomicCAS((unsigned long long*)&hashtbl[idx],
-                                             (unsigned long long)(-1ll), (unsigned long long)key);
-    if ((int64_t)old == -1 || (int64_t)old == key) {
-      atomicAdd((unsigned long long*)&cache_freq[idx], 1ull);
-      return;
-    }
-    idx = (idx + 1) % H;
-  }
+  hashtbl_count(colidx[n], H, hashtbl, cache_freq);
 }
 
 // rowidx/tableidx of every bag AND the frequency update of every index in one launch
@@ -83,17 +54,7 @@ __global__ __launch_bounds__(kCT) void rowidx_update_kernel(int64_t nb, int32_t 
     }
   }
   if (gt < N) {
-    const int64_t key = colidx[gt];
-    int32_t idx = (int32_t)hash64(key, H);
-    for (int c = 0; c < kMaxProbes; ++c) {
-      const unsigned long long old = atomicCAS((unsigned long long*)&hashtbl[idx],
-                                               (unsigned long long)(-1ll), (unsigned long long)key);
-      if ((int64_t)old == -1 || (int64_t)old == key) {
-        atomicAdd((unsigned long long*)&cache_freq[idx], 1ull);
-        break;
-      }
-      idx = (idx + 1) % H;
-    }
+    hashtbl_count(colidx[gt], H, hashtbl, cache_freq);
   }
 }
 

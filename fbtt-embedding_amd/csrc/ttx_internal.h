@@ -55,7 +55,7 @@ int make_dims(const ttx_geom* g, Dims* d);  // TTX_OK or TTX_EINVAL (+message)
 //   sid[t][n]   = table*p_t + i_t                      (original order)
 //   perm[t][*]  = lookups n sorted (stably) by sid[t]
 //   off[t][s]   = first position in perm[t] of slice s  (S_t + 1 entries)
-//   chunk_rec[c]= {pivot slice, start in perm[1], lookups in chunk, 0}: the work
+//   chunk_rec[c]= {pivot slice, start in the sorted order, lookups in chunk, partial slot}: the work
 //                 list of the pivot core (core 1), each slice's run of lookups
 //                 cut into chunks of <= MC lookups; chunk_off[s] = first chunk of s
 //   lrec[i]     = {n, sid_0, sid_2, sid_3} of the i-th lookup in pivot order
@@ -130,6 +130,40 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     if (lane_id() >= o) v += u;
   }
   return v;
+}
+constexpr int kMaxProbes = 3;  // tt_embeddings_cuda.cu:29
+
+// hashtbl_cuda_utils.cuh:48-76 (bit-exact restatement; KATs in tests/golden)
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+__device__ __forceinline__ uint32_t hash64(int64_t key, int32_t C) {
+  const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u;
+  const uint64_t u = (uint64_t)key;
+  uint32_t h = 0;
+  uint32_t k1 = (uint32_t)u;
+  k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2;
+  h ^= k1; h = rotl32(h, 13); h = h * 5 + 0xe6546b64u;
+  uint32_t k2 = (uint32_t)(u >> 32);
+  k2 *= c1; k2 = rotl32(k2, 15); k2 *= c2;
+  h ^= k2; h = rotl32(h, 13); h = h * 5 + 0xe6546b64u;
+  h ^= 2;
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return (uint32_t)(((uint64_t)h * (uint64_t)(uint32_t)C) >> 32);
+}
+
+// hashtbl_cuda_utils.cuh:102-133 with accumulate == true: a 64-bit CAS claims the slot (or finds
+// the key already there), a 64-bit atomic add bumps its frequency; dropped after kMaxProbes.
+__device__ __forceinline__ void hashtbl_count(int64_t key, int32_t H, int64_t* hashtbl, int64_t* cache_freq) {
+  int32_t idx = (int32_t)hash64(key, H);
+  for (int c = 0; c < kMaxProbes; ++c) {
+    const unsigned long long old = atomicCAS((unsigned long long*)&hashtbl[idx],
+                                             (unsigned long long)(-1ll), (unsigned long long)key);
+    if ((int64_t)old == -1 || (int64_t)old == key) {
+      atomicAdd((unsigned long long*)&cache_freq[idx], 1ull);
+      return;
+    }
+    idx = (idx + 1) % H;
+  }
 }
 #endif
 

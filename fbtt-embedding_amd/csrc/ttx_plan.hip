@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
       if (s < S1) {
         P.chunk_off[s] = ex;
         for (int j = 0; j < nch; ++j)
-          P.chunk_rec[ex + j] = make_int4(s, beg + j * MC, min(MC, cnt - j * MC), 0);
+          P.chunk_rec[ex + j] = make_int4(s, beg + j * MC, min(MC, cnt - j * MC), ex + j);
       }
       carry += total;
     }
@@ -462,18 +462,31 @@ __device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg,
     if (dg == 0 && S == 256) P.off[t][256] = N;
     return;
   }
+  // chunk SLOTS (where a chunk's d core_1 partial lives) are contiguous per slice; the DISPATCH
+  // order (index into chunk_rec = blockIdx of the contraction kernels) puts all full chunks
+  // first and the partial ones after: work-groups go round-robin over the 8 XCDs, and a
+  // slice-major list (full, partial, full, partial, ..) would hand every full chunk to the
+  // even XCDs.  Largest-first is also the order a greedy dispatcher balances best.
   const int MC = P.MC;
-  const int nch = dg < S ? (tot + MC - 1) / MC : 0;
-  const int cinc = wave_incl_scan(nch);
+  const int nf = dg < S ? tot / MC : 0;            // full chunks
+  const int pr = dg < S ? tot - nf * MC : 0;       // lookups in the partial chunk
+  const int np = pr ? 1 : 0;
+  const int packed = (nf << 12) | np;              // slices <= 256: np sums stay < 4096
+  const int cinc = wave_incl_scan(packed);
   __syncthreads();
   if (lane == kWave - 1) wt5[w] = cinc;
   __syncthreads();
-  int cb = 0, ctot = 0;
-  for (int k = 0; k < kMbUnits; ++k) { const int v = wt5[k]; if (k < w) cb += v; ctot += v; }
-  const int ex = cb + cinc - nch;
+  int cb = 0, call = 0;
+  for (int k = 0; k < kMbUnits; ++k) { const int v = wt5[k]; if (k < w) cb += v; call += v; }
+  const int exq = cb + cinc - packed;
+  const int fbase = exq >> 12, pbase = exq & 4095;  // full / partial chunks of earlier slices
+  const int ftot = call >> 12, ptot = call & 4095;
+  const int ctot = ftot + ptot;
+  const int ex = fbase + pbase;                     // first slot of this slice
   if (dg < S) {
     P.chunk_off[dg] = ex;
-    for (int j = 0; j < nch; ++j) P.chunk_rec[ex + j] = make_int4(dg, dbase + j * MC, min(MC, tot - j * MC), 0);
+    for (int j = 0; j < nf; ++j) P.chunk_rec[fbase + j] = make_int4(dg, dbase + j * MC, MC, ex + j);
+    if (np) P.chunk_rec[ftot + pbase] = make_int4(dg, dbase + nf * MC, pr, ex + nf);
   }
   for (int cc = ctot + dg; cc < P.max_chunks; cc += kMbThreads) P.chunk_rec[cc] = make_int4(0, 0, 0, 0);
   if (dg == 0) {
@@ -490,14 +503,35 @@ __device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg,
 // thread is cheaper than a count launch), then ranks and scatters its own 4 x kOneUnit positions.
 constexpr int kOneUnit = 64;      // positions per wave
 constexpr int kOneMaxN = 16384;
+// PRO: the launch is also the lookup PROLOGUE of a one-table module (tableidx == 0): bag rows
+// from the offsets (compute_rowidx_kernel, cu:1338-1354, as a binary search over an LDS copy of
+// the offsets) and the hash-table frequency update (update_cache_state, cu:1077-1113), both done
+// by the work-groups of core 0 for their own positions.
+constexpr int kProMaxBags = 4096;
+struct Prologue {
+  const int64_t* offsets;  // [nb + 1]
+  int nb;
+  int64_t* rowidx;         // out [N]
+  int64_t* tableidx;       // out [N] (zeros)
+  int H;                   // 0: no frequency update
+  int64_t* hashtbl;
+  int64_t* cache_freq;
+};
+template <bool PRO>
 __global__ __launch_bounds__(kMbThreads) void mb_single_kernel(
     Dims d, int N, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx,
-    const int64_t* __restrict__ rowidx, Plan P) {
+    const int64_t* __restrict__ rowidx, Plan P, Prologue pg) {
   __shared__ int htot[256], hbef[256], hrun[kMbUnits][256];
   __shared__ int wt5[kMbUnits + 1];
+  __shared__ int offs[PRO ? kProMaxBags + 1 : 1];
   const int t = blockIdx.y, tid = threadIdx.x;
   const int lane = lane_id(), w = tid / kWave;
   const CoreDec ct = core_dec(d, t);
+  if (PRO) {
+    tableidx = nullptr;
+    if (t <= 1)  // only core 0 (rowidx out) and the pivot (lrow) need bag rows
+      for (int e = tid; e <= pg.nb; e += kMbThreads) offs[e] = (int)min(pg.offsets[e], (int64_t)0x7fffffff);
+  }
   htot[tid] = 0;
   hbef[tid] = 0;
 #pragma unroll
@@ -541,16 +575,29 @@ __global__ __launch_bounds__(kMbThreads) void mb_single_kernel(
 #pragma unroll
   for (int k = 0; k < kMbUnits; ++k) { hrun[k][dg] = b; b += mine[k]; }
   __syncthreads();
-  if (blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, N, rowidx != nullptr, P, wt5);
+  if (blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, N, PRO || rowidx != nullptr, P, wt5);
   // rank + scatter this wave's 64 positions
   const int i = bbeg + w * kOneUnit + lane;
   const bool valid = i < bend;
-  int kv = 0, tbv = 0;
+  int kv = 0, tbv = 0, row = 0;
   long long idx = 0;
   if (valid) {
     idx = indices[i];
     tbv = tableidx ? (int)tableidx[i] : 0;
     kv = min(tbv * ct.p + decode_core(ct, idx), 255);
+    if (PRO && t <= 1) {  // bag of position i: the last b with offsets[b] <= i (empty bags skipped)
+      int lo = 0, hi = pg.nb;  // answer in [lo, hi)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offs[mid] <= i) lo = mid; else hi = mid;
+      }
+      row = lo;
+      if (t == 0) {
+        pg.rowidx[i] = row;
+        pg.tableidx[i] = 0;
+        if (pg.H) hashtbl_count(idx, pg.H, pg.hashtbl, pg.cache_freq);
+      }
+    }
   }
   const unsigned long long peers = wave_match8((unsigned)kv, valid);
   if (valid) {
@@ -562,7 +609,8 @@ __global__ __launch_bounds__(kMbThreads) void mb_single_kernel(
       const int s2 = d.T > 2 ? tbv * d.p[2] + decode_core(d, 2, idx) : 0;
       const int s3 = d.T > 3 ? tbv * d.p[3] + decode_core(d, 3, idx) : 0;
       P.lrec[pos] = make_int4(i, s0, s2, s3);
-      if (rowidx) P.lrow[pos] = (int)rowidx[i];
+      if (PRO) P.lrow[pos] = row;
+      else if (rowidx) P.lrow[pos] = (int)rowidx[i];
     }
   }
 }
@@ -681,7 +729,7 @@ __global__ __launch_bounds__(1024) void mb_finish_kernel(Dims d, int N, int has_
     const int ex = carry + block_excl_scan(nch, wtot, &total);
     if (s < S1) {
       P.chunk_off[s] = ex;
-      for (int j = 0; j < nch; ++j) P.chunk_rec[ex + j] = make_int4(s, beg + j * MC, min(MC, cnt - j * MC), 0);
+      for (int j = 0; j < nch; ++j) P.chunk_rec[ex + j] = make_int4(s, beg + j * MC, min(MC, cnt - j * MC), ex + j);
     }
     carry += total;
   }
@@ -710,8 +758,8 @@ static int plan_build_mb(const Dims& d, int N, const int64_t* indices, const int
     }
   }
   if (maxp == 1 && N <= kOneMaxN) {
-    hipLaunchKernelGGL(mb_single_kernel, dim3((N + kMbUnits * kOneUnit - 1) / (kMbUnits * kOneUnit), d.T),
-                       dim3(kMbThreads), 0, stream, d, N, indices, tableidx, rowidx, P);
+    hipLaunchKernelGGL(mb_single_kernel<false>, dim3((N + kMbUnits * kOneUnit - 1) / (kMbUnits * kOneUnit), d.T),
+                       dim3(kMbThreads), 0, stream, d, N, indices, tableidx, rowidx, P, Prologue{});
     TTX_HIP(hipGetLastError());
     return TTX_OK;
   }
@@ -774,9 +822,51 @@ int plan_build(const Dims& d, long long nnz, const int64_t* indices,
   return TTX_OK;
 }
 
+// one launch for "offsets -> bag rows (+ frequency update) + plan" when the batch qualifies
+bool prologue_fusable(const Dims& d, long long nnz, long long nb) {
+  if (d.num_tables != 1 || !(nnz > 1024 && nnz <= kOneMaxN) || nb < 1 || nb > kProMaxBags) return false;
+  for (int t = 0; t < d.T; ++t) if (d.S[t] > 256) return false;
+  return true;
+}
+
+int prologue_launch(const Dims& d, int N, const int64_t* indices, const Prologue& pg, const Plan& P, hipStream_t stream) {
+  ProfScope ps(TTX_PROF_PLAN, stream);
+  hipLaunchKernelGGL(mb_single_kernel<true>, dim3((N + kMbUnits * kOneUnit - 1) / (kMbUnits * kOneUnit), d.T),
+                     dim3(kMbThreads), 0, stream, d, N, indices, nullptr, nullptr, P, pg);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
 }  // namespace ttx
 
 extern "C" {
+
+int ttx_lookup_prologue(const ttx_geom* g, int64_t nnz, const int64_t* colidx, int64_t nb, const int64_t* offsets,
+                        int64_t H, int64_t* upd_hashtbl, int64_t* upd_cache_freq, int64_t* rowidx,
+                        int64_t* tableidx, void* plan, size_t plan_bytes, ttx_stream_t stream) {
+  ttx::Dims d;
+  int rc = ttx::make_dims(g, &d);
+  if (rc != TTX_OK) return rc;
+  if (nnz == 0) return TTX_OK;
+  if (!colidx || !offsets || !rowidx || !tableidx) TTX_FAIL(TTX_EINVAL, "NULL input");
+  if (nb <= 0 || nb % d.num_tables != 0) TTX_FAIL(TTX_EINVAL, "offsets must hold num_tables * B + 1 entries");
+  if (!plan || plan_bytes < ttx::plan_bytes(d, nnz))
+    TTX_FAIL(TTX_EWORKSPACE, "plan buffer too small: %zu < %zu", plan_bytes, ttx::plan_bytes(d, nnz));
+  const bool upd = upd_hashtbl && upd_cache_freq;
+  if (upd && (H <= 0 || H >= (1ll << 31))) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
+  ttx::Plan P = ttx::carve_plan(d, nnz, plan);
+  if (ttx::prologue_fusable(d, nnz, nb)) {
+    ttx::Prologue pg{offsets, (int)nb, rowidx, tableidx, upd ? (int)H : 0, upd_hashtbl, upd_cache_freq};
+    return ttx::prologue_launch(d, (int)nnz, colidx, pg, P, (hipStream_t)stream);
+  }
+  // general shape: the separate launches, same results
+  int32_t ntt = 0, part = 0;
+  rc = ttx_preprocess_indices_sync_fused(nnz, colidx, nb, offsets, d.num_tables, /*warmup=*/1, H, nullptr, nullptr,
+                                         rowidx, tableidx, nullptr, nullptr, nullptr, &ntt, &part, upd_hashtbl,
+                                         upd_cache_freq, nullptr, 0, stream);
+  if (rc != TTX_OK) return rc;
+  return ttx::plan_build(d, nnz, colidx, tableidx, rowidx, P, (hipStream_t)stream);
+}
 
 size_t ttx_plan_bytes(const ttx_geom* g, int64_t nnz) {
   ttx::Dims d;

@@ -876,15 +876,15 @@ __global__ __launch_bounds__(kThreads, 3) void bwd_kernel(Dims d, Plan P, CorePt
   STAMP(3);
   if (L.persist) {
     const int kb = L.K0t <= 1 ? 1 : (L.K0t <= 2 ? 2 : 4);
-    if (kb == 1) bwd_passes<1>(d, C, L, smem, B, table, rowidx, d_output, PC, chunk, len);
-    else if (kb == 2) bwd_passes<2>(d, C, L, smem, B, table, rowidx, d_output, PC, chunk, len);
-    else bwd_passes<4>(d, C, L, smem, B, table, rowidx, d_output, PC, chunk, len);
+    if (kb == 1) bwd_passes<1>(d, C, L, smem, B, table, rowidx, d_output, PC, cr.w, len);
+    else if (kb == 2) bwd_passes<2>(d, C, L, smem, B, table, rowidx, d_output, PC, cr.w, len);
+    else bwd_passes<4>(d, C, L, smem, B, table, rowidx, d_output, PC, cr.w, len);
   } else {
     // single pass (SC == MC); d core_1 tiles computed and stored group by group
     bwd_pass_front(d, C, L, smem, B, table, rowidx, d_output, PC, 0, 0, len);
     const int w = tid / kWave;
     const int npairs = (L.N1t + 1) / 2;
-    float* pc = PC.pc[1] + (size_t)chunk * d.slice[1];
+    float* pc = PC.pc[1] + (size_t)cr.w * d.slice[1];  // .w = the chunk's partial slot
     for (int np = w; np < npairs; np += kWaves) {
       const bool two = (np * 2 + 1) < L.N1t;
       for (int k0t = 0; k0t < L.K0t; k0t += 4) {

@@ -22,7 +22,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libttx.so")
+_SO = os.environ.get("TTX_LIB") or os.path.join(_HERE, "libttx.so")  # TTX_LIB: try another build of the same library
 
 MAX_CORES = 4
 OPTIM_SGD, OPTIM_ADAGRAD, OPTIM_DENSE = 0, 1, 2
@@ -79,6 +79,7 @@ def lib():
                                               C.POINTER(i32), C.POINTER(i32), vp, sz, vp]
     L.ttx_preprocess_indices_sync_fused.argtypes = [i64, vp, i64, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp,
                                                     C.POINTER(i32), C.POINTER(i32), vp, vp, vp, sz, vp]
+    L.ttx_lookup_prologue.argtypes = [C.POINTER(_Geom), i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, sz, vp]
     L.ttx_cache_populate_workspace_bytes.argtypes = [G, i64, i64, i32]
     L.ttx_cache_populate.argtypes = [G, vp, i64, vp, vp, vp, i64, i32, vp, vp, sz, vp]
     L.ttx_cache_forward.argtypes = [i32, i64, vp, vp, i32, vp, vp, vp]
@@ -125,7 +126,14 @@ def _dev(t: torch.Tensor) -> torch.device:
     return t.device
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(dev: torch.device) -> int:
+    """the current HIP stream of `dev` as an integer handle (the raw getter skips building a
+    torch.cuda.Stream object: ~8 us per call on the lookup path)"""
+    if _raw_stream is not None:
+        return _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(dev).cuda_stream
 
 
@@ -217,6 +225,34 @@ def make_plan(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, tabl
         _check(L.ttx_plan_build(C.byref(g), nnz, indices.data_ptr(), tableidx.data_ptr(),
                                 None if rowidx is None else _i64(rowidx, "rowidx").data_ptr(), buf.data_ptr(), nb, _stream(dev)))
     return Plan(buf, nnz, (num_tables, tuple(tt_p_shapes), tuple(tt_q_shapes), tuple(tt_ranks)))
+
+
+def lookup_prologue(colidx: torch.Tensor, offsets: torch.Tensor, num_tables: int, tt_p_shapes, tt_q_shapes, tt_ranks,
+                    hashtbl: Optional[torch.Tensor] = None, cache_freq: Optional[torch.Tensor] = None
+                    ) -> Tuple[torch.Tensor, torch.Tensor, Optional[Plan]]:
+    """Not in the reference: update_cache_state (when hashtbl / cache_freq are given) +
+    preprocess_indices_sync(warmup=True) + make_plan of one batch in ONE native call (one launch
+    when the batch qualifies, include/ttx.h).  -> (rowidx, tableidx, plan)."""
+    dev = _dev(colidx)
+    colidx, offsets = _i64(colidx, "colidx"), _i64(offsets, "offsets")
+    nnz = colidx.numel()
+    rowidx = torch.empty_like(colidx)
+    tableidx = torch.empty_like(colidx)
+    if nnz == 0:
+        return rowidx, tableidx, None
+    g = _geom(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks)
+    upd = hashtbl is not None and cache_freq is not None and hashtbl.numel() > 0
+    if upd and hashtbl.numel() != cache_freq.numel():
+        raise RuntimeError("tt_embeddings: hashtbl must match cache_freq")
+    L = lib()
+    nb = L.ttx_plan_bytes(C.byref(g), nnz)
+    buf = torch.empty(nb, dtype=torch.uint8, device=dev)
+    with _guard(dev):
+        _check(L.ttx_lookup_prologue(C.byref(g), nnz, colidx.data_ptr(), offsets.numel() - 1, offsets.data_ptr(),
+                                     hashtbl.numel() if upd else 0, hashtbl.data_ptr() if upd else None,
+                                     cache_freq.data_ptr() if upd else None, rowidx.data_ptr(), tableidx.data_ptr(),
+                                     buf.data_ptr(), nb, _stream(dev)))
+    return rowidx, tableidx, Plan(buf, nnz, (num_tables, tuple(tt_p_shapes), tuple(tt_q_shapes), tuple(tt_ranks)))
 
 
 def _plan_ptr(plan: Optional[Plan], nnz: int):

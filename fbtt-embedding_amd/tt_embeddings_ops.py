@@ -142,7 +142,9 @@ class TTLookupFunction(torch.autograd.Function):
         num_tables = tt_cores[0].size(0)
         # one lookup plan serves forward and backward of this batch
         mk = getattr(_engine, "make_plan", None)
-        ctx.plan = mk(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz_tt, indices, tableidx, rowidx) if mk else None
+        ctx.plan = getattr(rowidx, "_ttx_plan", None)  # built by the module's lookup prologue
+        if ctx.plan is None and mk is not None:
+            ctx.plan = mk(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz_tt, indices, tableidx, rowidx)
         extra = {"plan": ctx.plan} if ctx.plan is not None else {}
         output = _engine.tt_forward(1000, num_tables, B, D, tt_p_shapes, tt_q_shapes, tt_ranks, L, nnz_tt, indices,
                                     rowidx, tableidx, list(tt_cores), **extra)
@@ -423,7 +425,15 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         """-> [num_tables, B, D].  (`warmup` is ignored like in the reference,
         which uses self.warmup, :822,:841.)"""
         indices, offsets = indices.long(), offsets.long()
-        if self.use_cache and getattr(_engine, "FUSED_CACHE_UPDATE", False) and indices.numel() > 0:
+        prologue = getattr(_engine, "lookup_prologue", None)
+        if prologue is not None and self.warmup and indices.numel() > 0:
+            # cache not live: frequency update, offsets -> bag rows and the lookup plan in one native call
+            rowidx, tableidx, plan = prologue(indices, offsets, self.num_tables, self.tt_p_shapes, self.tt_q_shapes,
+                                              self.tt_ranks, self.hashtbl if self.use_cache else None,
+                                              self.cache_freq if self.use_cache else None)
+            rowidx._ttx_plan = plan  # picked up by TTLookupFunction.forward
+            n_tt, cache_locations = indices.numel(), None
+        elif self.use_cache and getattr(_engine, "FUSED_CACHE_UPDATE", False) and indices.numel() > 0:
             # frequency update folded into the preprocessing launch (same order as the reference:
             # count the batch's indices, then look them up)
             indices, rowidx, tableidx, n_tt, cache_locations = _engine.preprocess_indices_sync(

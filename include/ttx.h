@@ -177,6 +177,17 @@ int ttx_preprocess_indices_sync_fused(int64_t nnz, const int64_t* colidx,
                                       void* workspace, size_t workspace_bytes,
                                       ttx_stream_t stream);
 
+/* Lookup prologue of a batch while the cache is not live (warmup): what the module does
+ * before the contraction -- update_cache_state (tt_embeddings_ops.py:827-833) when
+ * upd_hashtbl / upd_cache_freq are non-NULL, preprocess_indices_sync with warmup = true
+ * (:834-846: rowidx / tableidx from the offsets) and ttx_plan_build -- as ONE launch when the
+ * batch qualifies (one table, every tables*p_t <= 256, 1024 < nnz <= 16384, <= 4096 bags),
+ * otherwise as the separate launches; results are identical either way. */
+int ttx_lookup_prologue(const ttx_geom* g, int64_t nnz, const int64_t* colidx,
+                        int64_t num_bags_total, const int64_t* offsets, int64_t hashtbl_size,
+                        int64_t* upd_hashtbl, int64_t* upd_cache_freq, int64_t* rowidx,
+                        int64_t* tableidx, void* plan, size_t plan_bytes, ttx_stream_t stream);
+
 /* replaces cache_populate_cuda (tt_embeddings.cpp:76-86,
  * tt_embeddings_cuda.cu:1260-1336): stable descending radix sort of the slots
  * by frequency, the top cache_size keys get cache rows (cache_state[slot] =

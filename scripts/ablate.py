@@ -44,3 +44,8 @@ print("spec bwd cut points (16=after chunk_rec, 32=after records, 64=after all l
 for mask in (16, 32, 64, 8 | 4, 2 | 4, 1 | 2 | 4, 1, 4):
     r = run(mask)
     print(f"  mask={mask:2d}: bwd={r['bwd']:.1f}us fwd={r['fwd']:.1f}us")
+
+print("non-temporal partial stores (512 = thin cores, 1024 = pivot): bwd + apply")
+for mask in (0, 512, 1024, 1536, 0, 1536):
+    r = run(mask, steps=100)
+    print(f"  mask={mask:4d}: bwd={r['bwd']:.1f}us apply={r['apply']:.1f}us sum={r['bwd'] + r['apply']:.1f}us")

@@ -183,3 +183,56 @@ def test_cache_gather_forward_backward():
         O.cache_backward_rowwise_adagrad_approx(grad, loc, rowidx, 0.1, 1e-4, st2, w.copy())
         E.cache_backward_rowwise_adagrad_approx(n, t(grad), t(loc), t(rowidx), 0.1, 1e-4, dst2, t(w))
         assert_close(dst2.cpu().numpy(), st2, f"rowwise adagrad state total D={D}", rtol=2e-5, atol_scale=4e-6)
+
+
+@pytest.mark.parametrize("tables,p,B,pf,std,H", [
+    (1, [20, 22, 25], 300, 10, 3, 1 << 19),     # one launch: rows by binary search over the offsets, fused update
+    (1, [20, 22, 25], 400, 8, 4, 0),            # one launch, no frequency table
+    (1, [200, 220, 250], 512, 20, 0, 1 << 20),  # the benchmark shape
+    (3, [20, 22, 25], 200, 6, 2, 0),            # several tables: separate launches
+    (1, [20, 22, 25], 60, 5, 2, 1 << 16),       # nnz <= 1024: separate launches
+    (1, [300, 22, 25], 300, 10, 2, 1 << 19),    # a two-pass sort: separate launches
+    (1, [20, 22, 25], 5000, 2, 1, 1 << 20),     # more bags than the LDS copy of the offsets holds
+])
+def test_lookup_prologue_equals_separate_calls(tables, p, B, pf, std, H):
+    """ttx_lookup_prologue == update_cache_state + preprocess_indices_sync(warmup) + make_plan:
+    rowidx / tableidx and the hash table bit-exact (keys whose home slot is contended are only
+    compared as a multiset), and the forward output through either plan identical."""
+    import tt_embeddings as E
+
+    q, r = [2, 2, 2], [1, 4, 4, 1]
+    E_ = int(np.prod(np.array(p, dtype=np.int64)))
+    idx, off = G.make_bags(17 + B, B, E_, pf, std, tables)
+    off[1:3] = off[1]  # an empty bag near the front (idx beyond stays valid: offsets only move boundaries)
+    cores = [t(c) for c in G.make_cores(3, tables, p, q, r, "signed")]
+    ix, of = t(idx), t(off)
+    empty64, empty32 = torch.empty(0, dtype=torch.int64, device=DEV), torch.empty(0, dtype=torch.int32, device=DEV)
+
+    def table():
+        return (torch.full((H,), -1, dtype=torch.int64, device=DEV), torch.zeros(H, dtype=torch.int64, device=DEV)) if H else (None, None)
+
+    ht1, fr1 = table()
+    row1, tab1, plan1 = E.lookup_prologue(ix, of, tables, p, q, r, ht1, fr1)
+    ht2, fr2 = table()
+    if H:
+        E.update_cache_state(ix, ht2, fr2)
+    _, row2, tab2, ntt, _ = E.preprocess_indices_sync(ix, of, tables, True, empty64, empty32)
+    plan2 = E.make_plan(tables, p, q, r, idx.size, ix, tab2, row2)
+    assert ntt == idx.size
+    assert torch.equal(row1, row2) and torch.equal(tab1, tab2)
+    # oracle for the rows as well
+    orow, otab = O.rowidx_from_offsets(off, tables)
+    assert np.array_equal(row1.cpu().numpy(), orow) and np.array_equal(tab1.cpu().numpy(), otab)
+    if H:  # tables are sparse enough that no key runs out of probes: the stored (key, count) sets must agree
+        assert int(fr1.sum()) == int(fr2.sum()) == idx.size
+        k1, k2 = ht1.cpu().numpy(), ht2.cpu().numpy()
+        f1, f2 = fr1.cpu().numpy(), fr2.cpu().numpy()
+        assert sorted(zip(k1[k1 >= 0].tolist(), f1[k1 >= 0].tolist())) == sorted(zip(k2[k2 >= 0].tolist(), f2[k2 >= 0].tolist()))
+    Bq, D = B, int(np.prod(q))
+    Lt = torch.tensor([int(np.prod(p[i + 1:])) for i in range(3)], dtype=torch.int64, device=DEV)
+    o1 = E.tt_forward(1000, tables, Bq, D, p, q, r, Lt, idx.size, ix, row1, tab1, cores, plan=plan1)
+    o2 = E.tt_forward(1000, tables, Bq, D, p, q, r, Lt, idx.size, ix, row2, tab2, cores, plan=plan2)
+    assert torch.equal(o1, o2)
+    g = O.make_geom(tables, p, q, r)
+    ref = O.tt_forward(g, Bq, D, idx, orow, otab, [c.cpu().numpy() for c in cores])
+    assert_close(o1.cpu().numpy(), ref, "prologue plan forward vs oracle")
