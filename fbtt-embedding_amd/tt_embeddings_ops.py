@@ -266,8 +266,11 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                  optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
                  sparse: bool = True, use_cache: bool = False, cache_size: int = 0, hashtbl_size: int = 0,
                  weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
-                 device: Optional[torch.device] = None) -> None:
+                 device: Optional[torch.device] = None, include_last_offset: bool = True) -> None:
         super().__init__()
+        # nn.EmbeddingBag call form: False = offsets hold only the bag starts (PyTorch's default,
+        # what DLRM passes); True = the reference's form, num_tables*B + 1 entries (:851)
+        self.include_last_offset = bool(include_last_offset)
         if device is None:
             if not torch.cuda.is_available():
                 raise RuntimeError("TTEmbeddingBag needs a GPU (the reference asserts torch.cuda.is_available(), :454)")
@@ -421,10 +424,21 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             _engine.update_cache_state(indices, self.hashtbl, self.cache_freq)
 
     # --------------------------------------------------------------- forward
-    def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True) -> torch.Tensor:
+    def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True,
+                per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
         """-> [num_tables, B, D].  (`warmup` is ignored like in the reference,
-        which uses self.warmup, :822,:841.)"""
+        which uses self.warmup, :822,:841.)  int32 indices / offsets are accepted; with
+        include_last_offset=False the closing offset (nnz) is appended here."""
+        if per_sample_weights is not None:
+            raise NotImplementedError("TT embedding bags pool with plain sums (mode='sum' without per_sample_weights)")
+        if indices.dim() != 1 or offsets.dim() != 1:
+            raise ValueError("indices and offsets must be 1-D (the 2-D fixed-length form of nn.EmbeddingBag is not supported)")
         indices, offsets = indices.long(), offsets.long()
+        if not self.include_last_offset:
+            offsets = torch.cat([offsets, offsets.new_full((1,), indices.numel())])
+        if (offsets.numel() - 1) % self.num_tables != 0:
+            raise ValueError(f"offsets must describe num_tables * B bags, got {offsets.numel() - 1} bags for "
+                             f"{self.num_tables} tables")
         prologue = getattr(_engine, "lookup_prologue", None)
         if prologue is not None and self.warmup and indices.numel() > 0:
             # cache not live: frequency update, offsets -> bag rows and the lookup plan in one native call
@@ -467,12 +481,13 @@ class TTEmbeddingBag(TableBatchedTTEmbeddingBag):
                  optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
                  sparse: bool = True, use_cache: bool = True, cache_size: int = 0, hashtbl_size: int = 0,
                  weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
-                 device: Optional[torch.device] = None) -> None:
+                 device: Optional[torch.device] = None, include_last_offset: bool = True) -> None:
         super().__init__(1, num_embeddings, embedding_dim, tt_ranks, tt_p_shapes, tt_q_shapes, optimizer,
                          learning_rate, eps, sparse, use_cache, cache_size, hashtbl_size, weight_dist,
-                         enforce_embedding_dim, device)
+                         enforce_embedding_dim, device, include_last_offset)
 
-    def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True) -> torch.Tensor:
+    def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True,
+                per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
         # squeeze is a view both ways: `[0]` would make autograd materialise a zero [1,B,D] buffer
         # and copy the gradient into it (two extra kernels per step)
-        return super().forward(indices, offsets, warmup).squeeze(0)
+        return super().forward(indices, offsets, warmup, per_sample_weights).squeeze(0)

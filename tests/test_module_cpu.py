@@ -160,6 +160,33 @@ def test_single_table_module_and_tt_matrix_to_full(ops, small_cases):
     assert_close(out.detach().numpy(), c["out"][0], "vs golden")
 
 
+def test_embedding_bag_call_forms(ops, small_cases):
+    """offsets without the closing entry (nn.EmbeddingBag's default, what DLRM
+    passes), int32 indices / offsets; per_sample_weights and 2-D input are refused, not ignored"""
+    c = small_cases["t3_tb1_s0"]
+    kw = dict(sparse=False, use_cache=False, weight_dist="uniform", device="cpu")
+    m = ops.TTEmbeddingBag(int(np.prod(c["p"])), c["D"], c["r"][1:-1], c["p"], c["q"], include_last_offset=False, **kw)
+    with torch.no_grad():
+        for dst, src in zip(m.tt_cores, c["cores"]):
+            dst.copy_(torch.from_numpy(src))
+    idx, off = torch.from_numpy(c["indices"]), torch.from_numpy(c["offsets"])
+    out = m(idx.int(), off[:-1].int())
+    assert_close(out.detach().numpy(), c["out"][0], "offsets without the last entry, int32")
+    ref = torch.nn.EmbeddingBag.from_pretrained(m.full_weight().detach(), mode="sum")(idx, off[:-1])
+    assert_close(out.detach().numpy(), ref.numpy(), "vs nn.EmbeddingBag(mode=sum) defaults")
+    out.backward(torch.from_numpy(c["d_out"][0]))
+    for k in range(3):
+        assert_close(m.tt_cores[k].grad.numpy(), c["grads"][k], f"grad{k}")
+    with pytest.raises(NotImplementedError):
+        m(idx, off[:-1], per_sample_weights=torch.ones(idx.numel()))
+    with pytest.raises(ValueError):
+        m(idx[:116].reshape(2, -1), off[:-1])
+    c3 = small_cases["t2_tb3_s0"]
+    mt = _module_for(ops, c3, sparse=False)
+    with pytest.raises(ValueError):
+        mt(torch.from_numpy(c3["indices"]), torch.from_numpy(c3["offsets"][:-1]))  # bags not a multiple of the tables
+
+
 def test_cache_life_cycle(ops):
     """warm-up -> cache_populate -> steady state: outputs with a live cache equal
     the TT-only outputs; hit rows come from cache_weight; fused SGD updates both."""
