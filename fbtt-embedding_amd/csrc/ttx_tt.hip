@@ -90,6 +90,7 @@ static int g_chunk_override = 0;
 static int g_debug_skip = 0;
 static int g_disable_spec = 0;
 static bool spec_shape(const Dims& d);  // ttx_tt_spec.inc covers this geometry
+static int spec_mc(const Dims& d);      // ... with this many lookups per chunk
 static long long* g_stamps = nullptr;
 
 long long* debug_stamps() { return g_stamps; }
@@ -148,7 +149,7 @@ static Lds make_lds(const Dims& d, int MC, bool bwd) {
 }
 
 int choose_chunk(const Dims& d) {
-  if (spec_shape(d)) return 32;  // wave-independent kernels: 8 groups of 4 lookups per chunk (kSpecMC)
+  if (spec_shape(d)) return spec_mc(d);  // wave-independent kernels: Shape3::MC (32; 16 for r = 64)
   if (g_chunk_override > 0) return g_chunk_override;
   // three, then two work-groups per CU (160 KiB of LDS), else whatever fits
   for (int mc = 16; mc >= 8; mc >>= 1)
@@ -1018,6 +1019,10 @@ __global__ __launch_bounds__(kThreads) void reduce_apply_kernel(Dims d, Plan P, 
 #include "ttx_tt_spec.inc"
 
 static bool spec_shape(const Dims& d) { return spec_match(d) != SPEC_NONE; }
+static int spec_mc(const Dims& d) {
+  const SpecId id = spec_match(d);
+  return (id == SPEC_64_4_64_8 || id == SPEC_64_4_64_4) ? S_64_4_64_8::MC : S_32_4_32_4::MC;
+}
 
 // ---------------------------------------------------------- host side ------
 

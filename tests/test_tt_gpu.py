@@ -199,11 +199,13 @@ def test_plan_paths_vs_oracle(tables, p, B, pf):
                 assert_close(got["cores"][k], orc["cores"][k], f"plan {p} sgd core{k}")
 
 
-@pytest.mark.parametrize("ranks,q", [([32, 32], [4, 4, 4]), ([16, 16], [4, 4, 4]), ([32, 32], [4, 4, 8]), ([16, 16], [4, 4, 8])])
+@pytest.mark.parametrize("ranks,q", [([32, 32], [4, 4, 4]), ([16, 16], [4, 4, 4]), ([32, 32], [4, 4, 8]), ([16, 16], [4, 4, 8]),
+                                      ([64, 64], [4, 4, 8]), ([64, 64], [4, 4, 4])])
 def test_specialised_shapes_vs_oracle_and_generic(ranks, q):
     """the shape-specialised wave-independent kernels (ttx_tt_spec.inc): against the oracle,
     and against the generic kernels (forced with the debug knob) on the same inputs;
-    slices with 1..70 lookups exercise partial groups of 4 and chunks of 32"""
+    slices with 1..70 lookups exercise partial groups of 4 and chunks of 32 (16 for r = 64, which
+    also walks core 1 in four column passes)"""
     import tt_embeddings as E
 
     p = [6, 5, 7]
