@@ -1,0 +1,187 @@
+// ttx_torch.cpp -- native (C++) autograd node of one TT lookup while the cache is not live.
+//
+// The reference's binding layer is C++ too (tt_embeddings.cpp, pybind11 over at::Tensor); its
+// Python autograd.Function (tt_embeddings_ops.py:130-356) then costs ~200 us of interpreter,
+// ctypes and autograd-engine time per training step here, three times the GPU time of the step
+// (DESIGN.md section 6).  This file is the same node written against the C ABI of libttx.so:
+// forward = ttx_lookup_prologue + ttx_tt_forward, backward = ttx_tt_backward (fused SGD / Adagrad
+// in place, or dense core gradients), one lookup plan shared by both.  No compute happens here:
+// torch supplies device memory (caching allocator), the current HIP stream and the autograd graph.
+// The cache-live path (host-synchronous partition, cache gather / scatter) stays in
+// tt_embeddings_ops.py, which also remains the fallback when this extension was not built.
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <torch/extension.h>
+
+#include <vector>
+
+#include "ttx.h"
+
+namespace {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+void check(int rc) { TORCH_CHECK(rc == TTX_OK, "tt_embeddings (libttx): ", ttx_last_error()); }
+
+ttx_geom make_geom(int64_t num_tables, const std::vector<int64_t>& p, const std::vector<int64_t>& q,
+                   const std::vector<int64_t>& r) {
+  const size_t T = p.size();
+  TORCH_CHECK(T >= 2 && T <= TTX_MAX_CORES && q.size() == T && r.size() == T + 1,
+              "tt_embeddings: need 2..4 cores with len(q) == len(p) and len(ranks) == len(p)+1");
+  ttx_geom g{};
+  g.T = (int32_t)T;
+  g.num_tables = (int32_t)num_tables;
+  for (size_t t = 0; t < T; ++t) { g.p[t] = (int32_t)p[t]; g.q[t] = (int32_t)q[t]; }
+  for (size_t t = 0; t <= T; ++t) g.r[t] = (int32_t)r[t];
+  return g;
+}
+
+void check_cores(const ttx_geom& g, at::TensorList cores, const char* what) {
+  TORCH_CHECK((int64_t)cores.size() == g.T, "tt_embeddings: expected ", g.T, " ", what);
+  for (int t = 0; t < g.T; ++t) {
+    const Tensor& c = cores[t];
+    TORCH_CHECK(c.is_cuda() && c.scalar_type() == at::kFloat && c.is_contiguous() && c.dim() == 3 &&
+                    c.size(0) == g.num_tables && c.size(1) == g.p[t] &&
+                    c.size(2) == (int64_t)g.r[t] * g.q[t] * g.r[t + 1],
+                "tt_embeddings: ", what, "[", t, "] must be a contiguous float32 GPU tensor of shape [",
+                g.num_tables, ", ", g.p[t], ", ", (int64_t)g.r[t] * g.q[t] * g.r[t + 1], "]");
+  }
+}
+
+Tensor bytes_on(const Tensor& like, size_t n) {
+  return at::empty({(int64_t)(n ? n : 1)}, like.options().dtype(at::kByte));
+}
+
+struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
+  // inputs: indices, offsets, hashtbl, cache_freq (the last two may be undefined), then
+  // T optimizer-state tensors (empty list unless Adagrad), then the T cores.
+  static Tensor forward(AutogradContext* ctx, const Tensor& indices, const Tensor& offsets, int64_t num_tables,
+                        std::vector<int64_t> p, std::vector<int64_t> q, std::vector<int64_t> r, int64_t optim,
+                        double lr, double eps, const c10::optional<Tensor>& hashtbl,
+                        const c10::optional<Tensor>& cache_freq, at::TensorList state, at::TensorList cores) {
+    const ttx_geom g = make_geom(num_tables, p, q, r);
+    check_cores(g, cores, "tt_cores");
+    TORCH_CHECK(indices.is_cuda() && indices.scalar_type() == at::kLong && indices.is_contiguous() &&
+                    offsets.is_cuda() && offsets.scalar_type() == at::kLong && offsets.is_contiguous(),
+                "tt_embeddings: indices / offsets must be contiguous int64 GPU tensors");
+    if (optim == TTX_OPTIM_ADAGRAD) check_cores(g, state, "optimizer_state");
+    const int64_t nnz = indices.numel(), nb = offsets.numel() - 1;
+    TORCH_CHECK(nb > 0 && nb % num_tables == 0, "tt_embeddings: offsets must hold num_tables * B + 1 entries");
+    const int64_t B = nb / num_tables;
+    int64_t D = 1;
+    for (auto v : q) D *= v;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(indices.device());  // (torch-ROCm calls its HIP devices "cuda")
+    auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+
+    Tensor out = at::empty({num_tables, B, D}, cores[0].options());
+    Tensor rowidx = at::empty_like(indices), tableidx = at::empty_like(indices);
+    Tensor plan;
+    if (nnz > 0) {
+      const size_t pb = ttx_plan_bytes(&g, nnz);
+      plan = bytes_on(indices, pb);
+      const bool upd = hashtbl.has_value() && hashtbl->defined() && hashtbl->numel() > 0 && cache_freq.has_value() &&
+                       cache_freq->defined();
+      if (upd) TORCH_CHECK(hashtbl->numel() == cache_freq->numel(), "tt_embeddings: hashtbl must match cache_freq");
+      check(ttx_lookup_prologue(&g, nnz, indices.data_ptr<int64_t>(), nb, offsets.data_ptr<int64_t>(),
+                                upd ? hashtbl->numel() : 0, upd ? hashtbl->data_ptr<int64_t>() : nullptr,
+                                upd ? cache_freq->data_ptr<int64_t>() : nullptr, rowidx.data_ptr<int64_t>(),
+                                tableidx.data_ptr<int64_t>(), plan.data_ptr(), pb, stream));
+    }
+    const float* cp[TTX_MAX_CORES] = {};
+    for (int t = 0; t < g.T; ++t) cp[t] = cores[t].data_ptr<float>();
+    const size_t wb = ttx_tt_forward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
+    Tensor ws = bytes_on(indices, wb);
+    check(ttx_tt_forward(&g, (int32_t)B, (int32_t)D, nnz, indices.data_ptr<int64_t>(), rowidx.data_ptr<int64_t>(),
+                         tableidx.data_ptr<int64_t>(), cp, out.data_ptr<float>(), nnz > 0 ? plan.data_ptr() : nullptr,
+                         ws.data_ptr(), wb, stream));
+
+    ctx->saved_data["p"] = p;
+    ctx->saved_data["q"] = q;
+    ctx->saved_data["r"] = r;
+    ctx->saved_data["num_tables"] = num_tables;
+    ctx->saved_data["optim"] = optim;
+    ctx->saved_data["lr"] = lr;
+    ctx->saved_data["eps"] = eps;
+    ctx->saved_data["T"] = (int64_t)g.T;
+    ctx->saved_data["nstate"] = (int64_t)state.size();
+    // integer tensors and the in-place-updated cores / state are kept out of the version-counter
+    // check on purpose (the fused optimizer mutates the cores between forward and the next backward)
+    std::vector<Tensor> keep = {indices, rowidx, tableidx};
+    if (plan.defined()) keep.push_back(plan);
+    ctx->saved_data["keep"] = keep;
+    ctx->saved_data["cores"] = std::vector<Tensor>(cores.begin(), cores.end());
+    ctx->saved_data["state"] = std::vector<Tensor>(state.begin(), state.end());
+    return out;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grad_outputs) {
+    const auto p = ctx->saved_data["p"].toIntVector();
+    const auto q = ctx->saved_data["q"].toIntVector();
+    const auto r = ctx->saved_data["r"].toIntVector();
+    const int64_t num_tables = ctx->saved_data["num_tables"].toInt();
+    const int64_t optim = ctx->saved_data["optim"].toInt();
+    const double lr = ctx->saved_data["lr"].toDouble(), eps = ctx->saved_data["eps"].toDouble();
+    const int64_t T = ctx->saved_data["T"].toInt(), nstate = ctx->saved_data["nstate"].toInt();
+    auto keep = ctx->saved_data["keep"].toTensorVector();
+    auto cores = ctx->saved_data["cores"].toTensorVector();
+    auto state = ctx->saved_data["state"].toTensorVector();
+    const ttx_geom g = make_geom(num_tables, p, q, r);
+    const Tensor &indices = keep[0], &rowidx = keep[1], &tableidx = keep[2];
+    const int64_t nnz = indices.numel();
+
+    // one slot per forward argument (lists expanded): indices, offsets, num_tables, p, q, r, optim, lr, eps,
+    // hashtbl, cache_freq, state.., cores..
+    constexpr int64_t kHead = 11;
+    variable_list grads(kHead + nstate + T);
+    Tensor go = grad_outputs[0];
+    TORCH_CHECK(go.defined(), "tt_embeddings: backward needs the output gradient");
+    go = go.contiguous();
+    TORCH_CHECK(go.scalar_type() == at::kFloat && go.dim() == 3 && go.size(0) == num_tables,
+                "tt_embeddings: d_output must be float32 [num_tables, B, D]");
+    const int64_t B = go.size(1), D = go.size(2);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(go.device());
+    auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+
+    float* cp[TTX_MAX_CORES] = {};
+    float* sp[TTX_MAX_CORES] = {};
+    float* gp[TTX_MAX_CORES] = {};
+    std::vector<Tensor> dense;
+    for (int t = 0; t < T; ++t) {
+      cp[t] = cores[t].data_ptr<float>();
+      if (optim == TTX_OPTIM_ADAGRAD) sp[t] = state[t].data_ptr<float>();
+      if (optim == TTX_OPTIM_DENSE) {
+        dense.push_back(at::empty_like(cores[t]));
+        gp[t] = dense.back().data_ptr<float>();
+      }
+    }
+    const size_t wb = ttx_tt_backward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
+    Tensor ws = bytes_on(indices, wb);
+    check(ttx_tt_backward(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz,
+                          indices.data_ptr<int64_t>(), rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
+                          go.data_ptr<float>(), cp, optim == TTX_OPTIM_ADAGRAD ? sp : nullptr,
+                          optim == TTX_OPTIM_DENSE ? gp : nullptr, keep.size() > 3 ? keep[3].data_ptr() : nullptr,
+                          ws.data_ptr(), wb, stream));
+    if (optim == TTX_OPTIM_DENSE)
+      for (int t = 0; t < T; ++t) grads[kHead + nstate + t] = dense[t];
+    return grads;
+  }
+};
+
+Tensor lookup(const Tensor& indices, const Tensor& offsets, int64_t num_tables, std::vector<int64_t> p,
+              std::vector<int64_t> q, std::vector<int64_t> r, int64_t optim, double lr, double eps,
+              c10::optional<Tensor> hashtbl, c10::optional<Tensor> cache_freq, std::vector<Tensor> state,
+              std::vector<Tensor> cores) {
+  // autograd.Function::apply wants every tensor it tracks as a plain argument: undefined stands for "none"
+  return TTLookupOp::apply(indices, offsets, num_tables, std::move(p), std::move(q), std::move(r), optim, lr, eps,
+                           hashtbl, cache_freq, at::TensorList(state), at::TensorList(cores));
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "native autograd node of the TT lookup (cache not live) over the C ABI of libttx.so";
+  m.def("lookup", &lookup, "prologue + forward; backward = fused optimizer step or dense core gradients");
+  m.def("abi_version", []() { return ttx_version(); });
+}

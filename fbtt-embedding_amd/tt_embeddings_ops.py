@@ -25,6 +25,7 @@ Deliberate differences (each is a superset or a fix):
 import itertools
 import logging
 import math
+import os
 import random
 from enum import Enum, unique
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
@@ -34,6 +35,25 @@ import torch
 from torch import nn
 
 import tt_embeddings as _engine  # the 11-function native-module surface
+
+_native = None  # ttx_torch (csrc/ttx_torch.cpp), False once an import attempt failed
+
+
+def _native_node():
+    """The C++ autograd node of the lookup, when it was built (__graft_entry__.build()) and the engine is
+    the HIP shim (tests swap `_engine` for the oracle-backed stand-in on CPU).  It is an optional,
+    faster route through the SAME C ABI -- TTLookupFunction below stays the reference-shaped path."""
+    global _native
+    if getattr(_engine, "__name__", "") != "tt_embeddings" or os.environ.get("TTX_NO_NATIVE_NODE"):
+        return None
+    if _native is None:
+        try:
+            import ttx_torch as _m
+
+            _native = _m
+        except ImportError:
+            _native = False
+    return _native or None
 
 
 @unique
@@ -439,6 +459,16 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         if (offsets.numel() - 1) % self.num_tables != 0:
             raise ValueError(f"offsets must describe num_tables * B bags, got {offsets.numel() - 1} bags for "
                              f"{self.num_tables} tables")
+        fast = _native_node()
+        if fast is not None and self.warmup and indices.is_cuda and indices.numel() > 0:
+            # cache not live: the whole lookup (prologue, forward, and the backward / fused optimizer node)
+            # is the C++ autograd node of csrc/ttx_torch.cpp -- same C ABI calls, no interpreter in between
+            use_state = self.sparse and self.optimizer not in _SGD_LIKE
+            optim = 2 if not self.sparse else (1 if use_state else 0)
+            return fast.lookup(indices.contiguous(), offsets.contiguous(), self.num_tables, self.tt_p_shapes,
+                               self.tt_q_shapes, self.tt_ranks, optim, self.learning_rate, self.eps,
+                               self.hashtbl if self.use_cache else None, self.cache_freq if self.use_cache else None,
+                               list(self.optimizer_state) if use_state else [], list(self.tt_cores))
         prologue = getattr(_engine, "lookup_prologue", None)
         if prologue is not None and self.warmup and indices.numel() > 0:
             # cache not live: frequency update, offsets -> bag rows and the lookup plan in one native call

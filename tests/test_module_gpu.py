@@ -15,6 +15,21 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True, params=["native", "python"])
+def node(request, monkeypatch):
+    """every module test runs twice: through the C++ autograd node (csrc/ttx_torch.cpp) and through
+    the reference-shaped Python TTLookupFunction (ctypes) -- both end in the same C ABI"""
+    import tt_embeddings_ops as ops
+
+    if request.param == "python":
+        monkeypatch.setenv("TTX_NO_NATIVE_NODE", "1")
+        assert ops._native_node() is None
+    else:
+        monkeypatch.delenv("TTX_NO_NATIVE_NODE", raising=False)
+        assert ops._native_node() is not None, "ttx_torch.so not built / not importable on this box"
+    return request.param
+
+
 def t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
