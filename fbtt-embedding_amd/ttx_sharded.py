@@ -66,6 +66,8 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         for pos, t in enumerate(order):
             inv[t] = pos
         self._order, self._inv = order, inv
+        self._identity = order == list(range(num_tables))  # e.g. one table per rank: no reordering on the wire
+        self._dev_cache = {}  # device tensors that only depend on the batch shape (built once, not per step)
         assert not kw.get("use_cache", False), "cache is single-table only (reference :458)"
         self.local = None
         if self.my_tables:
@@ -83,18 +85,19 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         dev = indices.device
         n_own = [len(o) for o in self.owned]
         n_me = n_own[self.rank]
-        order = torch.tensor(self._order, device=dev)
+        order = self._cached(("order", dev), lambda: torch.tensor(self._order, device=dev))
         # ---- 1. lookups in -------------------------------------------------
         if fixed_pooling is not None:
             Lp = int(fixed_pooling)
-            send_idx = indices.view(NT, B * Lp)[order].contiguous().view(-1)
+            send_idx = indices if self._identity else indices.view(NT, B * Lp)[order].contiguous().view(-1)
             in_splits = [k * B * Lp for k in n_own]
             out_splits = [n_me * B * Lp] * W
             recv_idx = indices.new_empty(sum(out_splits))
             self._a2a(recv_idx, send_idx, out_splits, in_splits)
             # wire order [src][k][b][l] -> table-major [k][src][b][l]
             loc_idx = recv_idx.view(W, n_me, B * Lp).permute(1, 0, 2).contiguous().view(-1)
-            loc_off = torch.arange(0, n_me * W * B * Lp + 1, Lp, device=dev, dtype=torch.int64)
+            loc_off = self._cached(("off", dev, n_me * W * B, Lp), lambda: torch.arange(
+                0, n_me * W * B * Lp + 1, Lp, device=dev, dtype=torch.int64))
         else:
             lengths = (offsets[1:] - offsets[:-1]).view(NT, B)
             send_len = lengths[order].contiguous()                       # owner-major
@@ -129,7 +132,16 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
             send = torch.zeros((0, D), device=dev, dtype=torch.float32)
         # ---- 3. pooled out ---------------------------------------------------
         got = _PooledAllToAll.apply(self.group, send, [n_me * B] * W, [k * B for k in n_own])
-        return got.view(NT, B, D)[torch.tensor(self._inv, device=dev)]
+        out = got.view(NT, B, D)
+        if self._identity:
+            return out
+        return out[self._cached(("inv", dev), lambda: torch.tensor(self._inv, device=dev))]
+
+    def _cached(self, key, make):
+        v = self._dev_cache.get(key)
+        if v is None:
+            v = self._dev_cache[key] = make()
+        return v
 
     def set_learning_rate(self, lr: float) -> None:
         if self.local is not None:

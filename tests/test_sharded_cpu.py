@@ -28,7 +28,7 @@ def _free_port():
     return port
 
 
-def _make_inputs(rank, fixed):
+def _make_inputs(rank, fixed, NT=NT):
     rs = np.random.RandomState(100 + rank)
     E_ = int(np.prod(P))
     if fixed:
@@ -41,7 +41,7 @@ def _make_inputs(rank, fixed):
     return idx, off, grad
 
 
-def _worker(rank, world, port, fixed, q):
+def _worker(rank, world, port, fixed, q, NT=NT):
     try:
         for p in (HERE, os.path.join(ROOT, "fbtt-embedding_amd")):
             sys.path.insert(0, p)
@@ -62,7 +62,7 @@ def _worker(rank, world, port, fixed, q):
         with torch.no_grad():
             for t, core in enumerate(m.local.tt_cores):
                 core.copy_(torch.from_numpy(cores_all[t][mine]))
-        idx, off, grad = _make_inputs(rank, fixed)
+        idx, off, grad = _make_inputs(rank, fixed, NT)
         out = m(torch.from_numpy(idx), torch.from_numpy(off), fixed_pooling=fixed or None)
         out.backward(torch.from_numpy(grad))
         q.put((rank, out.detach().numpy(), mine, [c.detach().numpy() for c in m.local.tt_cores]))
@@ -74,8 +74,8 @@ def _worker(rank, world, port, fixed, q):
         q.put((rank, "ERROR", traceback.format_exc(), None))
 
 
-@pytest.mark.parametrize("fixed", [0, 3])
-def test_two_rank_table_sharding_matches_single_process(fixed):
+@pytest.mark.parametrize("fixed,NT", [(0, 5), (3, 5), (3, 2)])  # NT == world: one table per rank (the bench shape)
+def test_two_rank_table_sharding_matches_single_process(fixed, NT):
     sys.path.insert(0, HERE)
     import gen_inputs as G
     import oracle_lib as O
@@ -84,7 +84,7 @@ def test_two_rank_table_sharding_matches_single_process(fixed):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, fixed, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fixed, q, NT)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -97,7 +97,7 @@ def test_two_rank_table_sharding_matches_single_process(fixed):
     # single-process expectation: all NT tables, global batch = ranks' batches side by side
     cores = G.make_cores(5, NT, P, Q, R)
     g = O.make_geom(NT, P, Q, R)
-    per_rank = [_make_inputs(r, fixed) for r in range(world)]
+    per_rank = [_make_inputs(r, fixed, NT) for r in range(world)]
     # global table-major order: table t -> [rank0 bags | rank1 bags]
     idx_g, len_g = [], []
     for t in range(NT):
