@@ -538,7 +538,7 @@ __global__ __launch_bounds__(kMbThreads) void mb_single_kernel(
   for (int k = 0; k < kMbUnits; ++k) hrun[k][tid] = 0;
   __syncthreads();
   const int bbeg = blockIdx.x * (kMbUnits * kOneUnit), bend = min(N, bbeg + kMbUnits * kOneUnit);
-  constexpr int kU = 4;  // loads in flight per thread
+  constexpr int kU = 16;  // loads in flight per thread (every work-group reads all N indices: latency, not bandwidth)
   for (int i0 = tid; i0 < N; i0 += kMbThreads * kU) {
     long long ix[kU];
     int tb[kU];
@@ -595,9 +595,11 @@ __global__ __launch_bounds__(kMbThreads) void mb_single_kernel(
       if (t == 0) {
         pg.rowidx[i] = row;
         pg.tableidx[i] = 0;
-        if (pg.H) hashtbl_count(idx, pg.H, pg.hashtbl, pg.cache_freq);
       }
     }
+    // the frequency update (a CAS round trip + an add) rides on the work-groups of the last core,
+    // which have no bag rows to find
+    if (PRO && pg.H && t == (d.T >= 3 ? 2 : 0)) hashtbl_count(idx, pg.H, pg.hashtbl, pg.cache_freq);
   }
   const unsigned long long peers = wave_match8((unsigned)kv, valid);
   if (valid) {
