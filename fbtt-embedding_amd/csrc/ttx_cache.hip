@@ -152,7 +152,37 @@ __global__ __launch_bounds__(kCT) void partition_scatter_kernel(
 
 // ---- cache row gather / scatter --------------------------------------------
 // cache_forward_kernel cu:1498-1538: run heads add their run's cache rows, in
-// index order, onto the current output value.  32 lanes per lookup.
+// index order, onto the current output value.  32 lanes per lookup.  HBM/latency bound
+// (268 B per cached lookup): the rows of a run are fetched 8 at a time -- 8 cache locations,
+// then 8 x EPL independent row loads in flight per lane -- and added in index order.
+template <int EPL>  // elements per lane = ceil(D / 32), 1..4
+__device__ __forceinline__ void gather_run(int n, int sl, int D, int l, const int32_t* __restrict__ loc,
+                                           const float* __restrict__ w, float* o) {
+  float acc[EPL];
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) acc[k] = (l + 32 * k < D) ? o[l + 32 * k] : 0.f;
+  for (int j0 = 0; j0 < sl; j0 += 8) {
+    int lc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) lc[u] = (j0 + u < sl) ? loc[n + j0 + u] : -1;
+    float v[8][EPL];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int k = 0; k < EPL; ++k)
+        v[u][k] = (lc[u] >= 0 && l + 32 * k < D) ? w[(size_t)lc[u] * D + l + 32 * k] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (j0 + u < sl) {
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) acc[k] += v[u][k];
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < EPL; ++k)
+    if (l + 32 * k < D) o[l + 32 * k] = acc[k];
+}
+
 __global__ __launch_bounds__(kCT) void cache_forward_kernel(int N, int D,
                                                            const int64_t* __restrict__ rowidx,
                                                            const int32_t* __restrict__ loc,
@@ -162,9 +192,20 @@ __global__ __launch_bounds__(kCT) void cache_forward_kernel(int N, int D,
   if (n >= N) return;
   const int64_t r = rowidx[n];
   if (n > 0 && rowidx[n - 1] == r) return;
+  // run length: the 32 lanes test 32 candidates per step (one ballot) instead of walking them
+  const unsigned long long half = (threadIdx.x & 32) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
   int sl = 1;
-  while (n + sl < N && rowidx[n + sl] == r) ++sl;
+  for (;;) {
+    const int c = n + sl + l;
+    const bool same = c < N && rowidx[c] == r;
+    const unsigned long long m = (__ballot(!same) & half) >> (threadIdx.x & 32);
+    if (m) { sl += __builtin_ctzll(m); break; }
+    sl += 32;
+  }
   float* o = out + (size_t)r * D;
+  if (D <= 32) return gather_run<1>(n, sl, D, l, loc, w, o);
+  if (D <= 64) return gather_run<2>(n, sl, D, l, loc, w, o);
+  if (D <= 128) return gather_run<4>(n, sl, D, l, loc, w, o);
   for (int e = l; e < D; e += 32) {
     float acc = o[e];
     for (int j = 0; j < sl; ++j) acc += w[(size_t)loc[n + j] * D + e];

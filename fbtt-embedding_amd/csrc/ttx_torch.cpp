@@ -7,8 +7,11 @@
 // forward = ttx_lookup_prologue + ttx_tt_forward, backward = ttx_tt_backward (fused SGD / Adagrad
 // in place, or dense core gradients), one lookup plan shared by both.  No compute happens here:
 // torch supplies device memory (caching allocator), the current HIP stream and the autograd graph.
-// The cache-live path (host-synchronous partition, cache gather / scatter) stays in
-// tt_embeddings_ops.py, which also remains the fallback when this extension was not built.
+// TTCachedLookupOp is the cache-live variant (one table): hash lookup + stable partition (one host
+// read-back of the split point, as in the reference, tt_embeddings_cuda.cu:1481-1488), contraction of
+// the misses, gather of the hits; backward = fused TT update + cache-row update (or dense gradients).
+// tt_embeddings_ops.py keeps the reference-shaped Python route and is the fallback when this
+// extension was not built.
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
@@ -178,10 +181,170 @@ Tensor lookup(const Tensor& indices, const Tensor& offsets, int64_t num_tables, 
                            hashtbl, cache_freq, at::TensorList(state), at::TensorList(cores));
 }
 
+// ---- cache live (one table): tt_embeddings_ops.py:821-874 with self.warmup == False ----------------
+struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
+  // args: indices, offsets, p, q, r, optim, lr, eps, hashtbl, cache_freq, cache_state,
+  //       cache_optimizer_state (undefined unless Adagrad), cache_weight, state.., cores..
+  static constexpr int64_t kHead = 13;
+  static Tensor forward(AutogradContext* ctx, const Tensor& indices, const Tensor& offsets, std::vector<int64_t> p,
+                        std::vector<int64_t> q, std::vector<int64_t> r, int64_t optim, double lr, double eps,
+                        const Tensor& hashtbl, const Tensor& cache_freq, const Tensor& cache_state,
+                        const c10::optional<Tensor>& cache_opt_state, const Tensor& cache_weight,
+                        at::TensorList state, at::TensorList cores) {
+    const ttx_geom g = make_geom(1, p, q, r);
+    check_cores(g, cores, "tt_cores");
+    if (optim == TTX_OPTIM_ADAGRAD) check_cores(g, state, "optimizer_state");
+    TORCH_CHECK(indices.is_cuda() && indices.scalar_type() == at::kLong && indices.is_contiguous() &&
+                    offsets.is_cuda() && offsets.scalar_type() == at::kLong && offsets.is_contiguous(),
+                "tt_embeddings: indices / offsets must be contiguous int64 GPU tensors");
+    const int64_t H = hashtbl.numel();
+    TORCH_CHECK(H > 0 && cache_freq.numel() == H && cache_state.numel() == H && hashtbl.scalar_type() == at::kLong &&
+                    cache_freq.scalar_type() == at::kLong && cache_state.scalar_type() == at::kInt,
+                "tt_embeddings: hashtbl / cache_freq (int64) and cache_state (int32) must have hashtbl_size entries");
+    TORCH_CHECK(cache_weight.is_cuda() && cache_weight.scalar_type() == at::kFloat && cache_weight.is_contiguous() &&
+                    cache_weight.dim() == 2, "tt_embeddings: cache_weight must be contiguous float32 [cache_size, D]");
+    const int64_t nnz = indices.numel(), B = offsets.numel() - 1, D = cache_weight.size(1);
+    TORCH_CHECK(B > 0 && nnz > 0, "tt_embeddings: empty batch");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(indices.device());
+    auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+
+    Tensor rowidx = at::empty_like(indices), tableidx = at::empty_like(indices);
+    Tensor pcol = at::empty_like(indices), prow = at::empty_like(indices);
+    Tensor ploc = at::empty({nnz}, indices.options().dtype(at::kInt));
+    const size_t pwb = ttx_preprocess_workspace_bytes(nnz);
+    Tensor pws = bytes_on(indices, pwb);
+    int32_t n_tt = 0, part = 0;
+    check(ttx_preprocess_indices_sync_fused(nnz, indices.data_ptr<int64_t>(), B, offsets.data_ptr<int64_t>(), 1, 0, H,
+                                            hashtbl.data_ptr<int64_t>(), cache_state.data_ptr<int32_t>(),
+                                            rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
+                                            pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(), ploc.data_ptr<int32_t>(),
+                                            &n_tt, &part, hashtbl.data_ptr<int64_t>(), cache_freq.data_ptr<int64_t>(),
+                                            pws.data_ptr(), pwb, stream));
+    TORCH_CHECK(part == 1, "tt_embeddings: the cache-live preprocessing did not partition");
+    const int64_t n_c = nnz - n_tt;
+
+    Tensor out = at::empty({1, B, D}, cores[0].options());
+    Tensor plan;
+    if (n_tt > 0) {
+      const size_t pb = ttx_plan_bytes(&g, n_tt);
+      plan = bytes_on(indices, pb);
+      check(ttx_plan_build(&g, n_tt, pcol.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(), prow.data_ptr<int64_t>(),
+                           plan.data_ptr(), pb, stream));
+    }
+    const float* cp[TTX_MAX_CORES] = {};
+    for (int t = 0; t < g.T; ++t) cp[t] = cores[t].data_ptr<float>();
+    const size_t wb = ttx_tt_forward_workspace_bytes(&g, (int32_t)B, (int32_t)D, n_tt);
+    Tensor ws = bytes_on(indices, wb);
+    check(ttx_tt_forward(&g, (int32_t)B, (int32_t)D, n_tt, pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(),
+                         tableidx.data_ptr<int64_t>(), cp, out.data_ptr<float>(), n_tt > 0 ? plan.data_ptr() : nullptr,
+                         ws.data_ptr(), wb, stream));
+    if (n_c > 0)
+      check(ttx_cache_forward((int32_t)B, n_c, ploc.data_ptr<int32_t>() + n_tt, prow.data_ptr<int64_t>() + n_tt,
+                              (int32_t)D, cache_weight.data_ptr<float>(), out.data_ptr<float>(), stream));
+
+    ctx->saved_data["p"] = p;
+    ctx->saved_data["q"] = q;
+    ctx->saved_data["r"] = r;
+    ctx->saved_data["optim"] = optim;
+    ctx->saved_data["lr"] = lr;
+    ctx->saved_data["eps"] = eps;
+    ctx->saved_data["T"] = (int64_t)g.T;
+    ctx->saved_data["nstate"] = (int64_t)state.size();
+    ctx->saved_data["n_tt"] = (int64_t)n_tt;
+    std::vector<Tensor> keep = {pcol, prow, tableidx, ploc, cache_weight};
+    ctx->saved_data["keep"] = keep;
+    if (cache_opt_state.has_value() && cache_opt_state->defined()) ctx->saved_data["copt"] = *cache_opt_state;
+    if (plan.defined()) ctx->saved_data["plan"] = plan;
+    ctx->saved_data["cores"] = std::vector<Tensor>(cores.begin(), cores.end());
+    ctx->saved_data["state"] = std::vector<Tensor>(state.begin(), state.end());
+    return out;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grad_outputs) {
+    const auto p = ctx->saved_data["p"].toIntVector();
+    const auto q = ctx->saved_data["q"].toIntVector();
+    const auto r = ctx->saved_data["r"].toIntVector();
+    const int64_t optim = ctx->saved_data["optim"].toInt();
+    const double lr = ctx->saved_data["lr"].toDouble(), eps = ctx->saved_data["eps"].toDouble();
+    const int64_t T = ctx->saved_data["T"].toInt(), nstate = ctx->saved_data["nstate"].toInt();
+    const int64_t n_tt = ctx->saved_data["n_tt"].toInt();
+    auto keep = ctx->saved_data["keep"].toTensorVector();
+    auto cores = ctx->saved_data["cores"].toTensorVector();
+    auto state = ctx->saved_data["state"].toTensorVector();
+    const ttx_geom g = make_geom(1, p, q, r);
+    const Tensor &pcol = keep[0], &prow = keep[1], &tableidx = keep[2], &ploc = keep[3], &cache_weight = keep[4];
+    const Tensor cache_opt_state = ctx->saved_data.count("copt") ? ctx->saved_data["copt"].toTensor() : Tensor();
+    const Tensor plan = ctx->saved_data.count("plan") ? ctx->saved_data["plan"].toTensor() : Tensor();
+    const int64_t nnz = pcol.numel(), n_c = nnz - n_tt;
+
+    variable_list grads(kHead + nstate + T);
+    Tensor go = grad_outputs[0];
+    TORCH_CHECK(go.defined(), "tt_embeddings: backward needs the output gradient");
+    go = go.contiguous();
+    TORCH_CHECK(go.scalar_type() == at::kFloat && go.dim() == 3 && go.size(0) == 1,
+                "tt_embeddings: d_output must be float32 [1, B, D]");
+    const int64_t B = go.size(1), D = go.size(2);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(go.device());
+    auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+
+    float* cp[TTX_MAX_CORES] = {};
+    float* sp[TTX_MAX_CORES] = {};
+    float* gp[TTX_MAX_CORES] = {};
+    std::vector<Tensor> dense;
+    for (int t = 0; t < T; ++t) {
+      cp[t] = cores[t].data_ptr<float>();
+      if (optim == TTX_OPTIM_ADAGRAD) sp[t] = state[t].data_ptr<float>();
+      if (optim == TTX_OPTIM_DENSE) {
+        dense.push_back(at::empty_like(cores[t]));
+        gp[t] = dense.back().data_ptr<float>();
+      }
+    }
+    const size_t wb = ttx_tt_backward_workspace_bytes(&g, (int32_t)B, (int32_t)D, n_tt);
+    Tensor ws = bytes_on(pcol, wb);
+    check(ttx_tt_backward(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, n_tt,
+                          pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
+                          go.data_ptr<float>(), cp, optim == TTX_OPTIM_ADAGRAD ? sp : nullptr,
+                          optim == TTX_OPTIM_DENSE ? gp : nullptr, plan.defined() ? plan.data_ptr() : nullptr,
+                          ws.data_ptr(), wb, stream));
+    const int32_t* loc = ploc.data_ptr<int32_t>() + n_tt;
+    const int64_t* rows = prow.data_ptr<int64_t>() + n_tt;
+    if (optim == TTX_OPTIM_SGD) {
+      if (n_c > 0)
+        check(ttx_cache_backward_sgd(n_c, (int32_t)D, go.data_ptr<float>(), loc, rows, (float)lr,
+                                     cache_weight.data_ptr<float>(), stream));
+    } else if (optim == TTX_OPTIM_ADAGRAD) {
+      TORCH_CHECK(cache_opt_state.defined(), "tt_embeddings: Adagrad with a live cache needs cache_optimizer_state");
+      if (n_c > 0)
+        check(ttx_cache_backward_rowwise_adagrad_approx(n_c, (int32_t)D, go.data_ptr<float>(), loc, rows, (float)lr,
+                                                        (float)eps, cache_opt_state.data_ptr<float>(),
+                                                        cache_weight.data_ptr<float>(), stream));
+    } else {
+      for (int t = 0; t < T; ++t) grads[kHead + nstate + t] = dense[t];
+      if (n_c > 0) {  // (tt_embeddings_ops.py:349-353: the cache gradient exists only when rows were hit)
+        Tensor gcw = at::empty_like(cache_weight);
+        check(ttx_cache_backward_dense(n_c, (int32_t)D, go.data_ptr<float>(), loc, rows, cache_weight.size(0),
+                                       gcw.data_ptr<float>(), stream));
+        grads[12] = gcw;  // cache_weight
+      }
+    }
+    return grads;
+  }
+};
+
+Tensor lookup_cached(const Tensor& indices, const Tensor& offsets, std::vector<int64_t> p, std::vector<int64_t> q,
+                     std::vector<int64_t> r, int64_t optim, double lr, double eps, const Tensor& hashtbl,
+                     const Tensor& cache_freq, const Tensor& cache_state, c10::optional<Tensor> cache_opt_state,
+                     const Tensor& cache_weight, std::vector<Tensor> state, std::vector<Tensor> cores) {
+  return TTCachedLookupOp::apply(indices, offsets, std::move(p), std::move(q), std::move(r), optim, lr, eps, hashtbl,
+                                 cache_freq, cache_state, cache_opt_state, cache_weight, at::TensorList(state),
+                                 at::TensorList(cores));
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "native autograd node of the TT lookup (cache not live) over the C ABI of libttx.so";
   m.def("lookup", &lookup, "prologue + forward; backward = fused optimizer step or dense core gradients");
+  m.def("lookup_cached", &lookup_cached, "cache-live lookup of one table: partition, contraction of the misses, gather of the hits");
   m.def("abi_version", []() { return ttx_version(); });
 }

@@ -469,6 +469,17 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                                self.tt_q_shapes, self.tt_ranks, optim, self.learning_rate, self.eps,
                                self.hashtbl if self.use_cache else None, self.cache_freq if self.use_cache else None,
                                list(self.optimizer_state) if use_state else [], list(self.tt_cores))
+        if (fast is not None and not self.warmup and self.use_cache and self.num_tables == 1 and indices.is_cuda
+                and indices.numel() > 0):
+            # cache live: frequency update + hash lookup + stable partition (one host read-back), contraction of
+            # the misses, gather of the hits, and the matching backward -- the C++ node again
+            use_state = self.sparse and self.optimizer not in _SGD_LIKE
+            optim = 2 if not self.sparse else (1 if use_state else 0)
+            return fast.lookup_cached(indices.contiguous(), offsets.contiguous(), self.tt_p_shapes, self.tt_q_shapes,
+                                      self.tt_ranks, optim, self.learning_rate, self.eps, self.hashtbl, self.cache_freq,
+                                      self.cache_state, self.cache_optimizer_state if use_state else None,
+                                      self.cache_weight, list(self.optimizer_state) if use_state else [],
+                                      list(self.tt_cores))
         prologue = getattr(_engine, "lookup_prologue", None)
         if prologue is not None and self.warmup and indices.numel() > 0:
             # cache not live: frequency update, offsets -> bag rows and the lookup plan in one native call
