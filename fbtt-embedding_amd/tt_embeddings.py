@@ -423,6 +423,13 @@ def preprocess_indices_sync(colidx: torch.Tensor, offsets: torch.Tensor, num_tab
     return colidx, rowidx, tableidx, nnz, None
 
 
+def _check_cached_args(nnz: int, cache_locations: torch.Tensor, rowidx: torch.Tensor) -> None:
+    if cache_locations.dtype != torch.int32 or not cache_locations.is_contiguous():
+        raise RuntimeError("tt_embeddings: cache_locations must be contiguous int32")
+    if nnz > cache_locations.numel() or nnz > rowidx.numel():
+        raise RuntimeError("tt_embeddings: nnz exceeds cache_locations / rowidx")
+
+
 def cache_forward(B: int, nnz: int, cache_locations: torch.Tensor, rowidx: torch.Tensor, cache_weight: torch.Tensor,
                   output: torch.Tensor) -> None:
     """tt_embeddings.cpp:97-103: output[rowidx[n], :] += cache_weight[cache_locations[n], :]."""
@@ -431,6 +438,7 @@ def cache_forward(B: int, nnz: int, cache_locations: torch.Tensor, rowidx: torch
         raise RuntimeError("tt_embeddings: B must be > 0")  # cu:1549
     if nnz == 0:
         return
+    _check_cached_args(nnz, cache_locations, rowidx)
     cw = cache_weight.detach()
     with _guard(dev):
         _check(lib().ttx_cache_forward(B, nnz, cache_locations.data_ptr(), _i64(rowidx, "rowidx").data_ptr(), cw.size(1),
@@ -445,6 +453,7 @@ def cache_backward_sgd(nnz: int, grad_output: torch.Tensor, cache_locations: tor
     dev = _dev(cache_weight)
     cw = cache_weight.detach()
     go = _f32(grad_output, "grad_output")
+    _check_cached_args(nnz, cache_locations, rowidx)
     with _guard(dev):
         _check(lib().ttx_cache_backward_sgd(nnz, cw.size(1), go.data_ptr(), cache_locations.data_ptr(),
                                             _i64(rowidx, "rowidx").data_ptr(), learning_rate, cw.data_ptr(), _stream(dev)))
@@ -457,6 +466,7 @@ def cache_backward_dense(nnz: int, grad_output: torch.Tensor, cache_locations: t
     cw = cache_weight.detach()
     out = torch.empty_like(cw)
     go = _f32(grad_output, "grad_output")
+    _check_cached_args(nnz, cache_locations, rowidx)
     with _guard(dev):
         _check(lib().ttx_cache_backward_dense(nnz, cw.size(1), go.data_ptr(),
                                               cache_locations.data_ptr() if nnz else None,
@@ -475,6 +485,7 @@ def cache_backward_rowwise_adagrad_approx(nnz: int, grad_output: torch.Tensor, c
     cw = cache_weight.detach()
     go = _f32(grad_output, "grad_output")
     _dev(cache_optimizer_state)
+    _check_cached_args(nnz, cache_locations, rowidx)
     with _guard(dev):
         _check(lib().ttx_cache_backward_rowwise_adagrad_approx(
             nnz, cw.size(1), go.data_ptr(), cache_locations.data_ptr(), _i64(rowidx, "rowidx").data_ptr(),
