@@ -225,6 +225,31 @@ def main():
             print(f"[bench] graph capture unavailable ({type(ex).__name__}: {ex}); reporting the eager path", file=sys.stderr)
             torch.cuda.synchronize()
 
+    # N > 1: the two exchanges of a step in isolation (xGMI all-to-all bandwidth vs the link roofline)
+    a2a = None
+    if world > 1:
+        try:
+            a2a = {}
+            for name, numel, dtype in (("indices_in", B_local * POOL * world, torch.int64),
+                                       ("pooled_out", B_local * D * world, torch.float32)):
+                src = torch.zeros(numel, dtype=dtype, device=dev)
+                dst = torch.empty_like(src)
+                for _ in range(5):
+                    dist.all_to_all_single(dst, src)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    dist.all_to_all_single(dst, src)
+                sync()
+                dt = (time.perf_counter() - t0) / 50
+                sent = src.element_size() * numel * (world - 1) // world  # bytes this rank puts on the links
+                a2a[name] = {"bytes_per_rank": sent, "us": round(dt * 1e6, 1), "GB/s_per_rank": round(sent / dt / 1e9, 2),
+                             "frac_of_xgmi": round(sent / dt / 1e9 / (153.0 * min(world - 1, 7)), 4)}
+            a2a["note"] = ("eager all_to_all_single over RCCL, barrier-synchronised loop of 50; link roofline = 153 GB/s x "
+                           "peers (MI355X_MICROARCH.md); messages this small are latency-bound")
+        except Exception as ex:  # noqa: BLE001
+            a2a = {"error": f"{type(ex).__name__}: {ex}"}
+
     # second, untimed pass: per-kernel breakdown (all kernel slots bracketed)
     E.profile_reset()
     E.profile_enable(0x3F)
@@ -281,6 +306,8 @@ def main():
                          "traffic": traffic, "launches": n_bwd, "avg_us": round(bwd_us, 2),
                          "flop_per_launch": bwd_flop_per_launch},
         }
+        if a2a is not None:
+            line["all_to_all"] = a2a
         if world == 1 and not args.no_cpu_baseline and ntab == 1:
             line["cpu_baseline"] = cpu_baseline(reqs_np, cores_np, d_out_np)
         print(json.dumps(line), flush=True)
