@@ -950,7 +950,21 @@ __global__ __launch_bounds__(kThreads) void reduce_apply_kernel(Dims d, Plan P, 
       const int g = tid / V, v = tid - g * V;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       if (g < G) {
-        for (int i = beg + g; i < end; i += G) {
+        // 4 partial rows in flight per lane (a hot slice under a skewed index stream holds
+        // thousands of partials: one dependent load at a time made that the step's tail)
+        int i = beg + g;
+        for (; i + 3 * G < end; i += 4 * G) {
+          size_t r0, r1, r2, r3;
+          if (list) { r0 = list[i]; r1 = list[i + G]; r2 = list[i + 2 * G]; r3 = list[i + 3 * G]; }
+          else { r0 = i; r1 = i + G; r2 = i + 2 * G; r3 = i + 3 * G; }
+          const float4 x0 = ((const float4*)(pc + r0 * sl))[v], x1 = ((const float4*)(pc + r1 * sl))[v];
+          const float4 x2 = ((const float4*)(pc + r2 * sl))[v], x3 = ((const float4*)(pc + r3 * sl))[v];
+          acc.x += x0.x; acc.y += x0.y; acc.z += x0.z; acc.w += x0.w;
+          acc.x += x1.x; acc.y += x1.y; acc.z += x1.z; acc.w += x1.w;
+          acc.x += x2.x; acc.y += x2.y; acc.z += x2.z; acc.w += x2.w;
+          acc.x += x3.x; acc.y += x3.y; acc.z += x3.z; acc.w += x3.w;
+        }
+        for (; i < end; i += G) {
           const size_t row = list ? (size_t)list[i] : (size_t)i;
           const float4 x = ((const float4*)(pc + row * sl))[v];
           acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
