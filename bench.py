@@ -195,7 +195,9 @@ def main():
     # replayed; every replay runs the full plan/forward/pool/backward/apply kernel sequence
     # on inputs resident in HBM.  Falls back to the eager timing if capture is unavailable.
     mode, elapsed = "eager", eager_elapsed
-    if not args.no_graph and world == 1 and not wl["populate"]:  # cache-live lookups read a count back: no capture
+    # (cache live: capturable only through the C++ node, which keeps the partition's split point on the device;
+    # the reference-shaped Python route reads it back to the host every step)
+    if not args.no_graph and world == 1 and (not wl["populate"] or ops._native_node() is not None):
         try:
             cap = torch.cuda.Stream()
             cap.wait_stream(torch.cuda.current_stream())

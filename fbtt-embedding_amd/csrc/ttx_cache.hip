@@ -32,8 +32,7 @@ __device__ __forceinline__ int32_t hashtbl_find(int64_t key, int32_t size, const
 __global__ __launch_bounds__(kCT) void update_cache_state_kernel(
     int64_t N, const int64_t* __restrict__ colidx, int32_t H, int64_t* hashtbl, int64_t* cache_freq) {
   const int64_t n = (int64_t)blockIdx.x * kCT + threadIdx.x;
-  if (n >= N) return;
-  hashtbl_count(colidx[n], H, hashtbl, cache_freq);
+  hashtbl_count_wave(n < N ? colidx[n] : 0, n < N, H, hashtbl, cache_freq);
 }
 
 // rowidx/tableidx of every bag AND the frequency update of every index in one launch
@@ -53,10 +52,10 @@ __global__ __launch_bounds__(kCT) void rowidx_update_kernel(int64_t nb, int32_t 
       tableidx[l] = b / B;
     }
   }
-  if (gt < N) {
-    hashtbl_count(colidx[gt], H, hashtbl, cache_freq);
-  }
+  hashtbl_count_wave(gt < N ? colidx[gt] : 0, gt < N, H, hashtbl, cache_freq);
 }
+
+__global__ void set_int_kernel(int32_t* p, int32_t v) { *p = v; }
 
 // compute_rowidx_kernel, cu:1338-1354: one 8-lane group per bag
 __global__ __launch_bounds__(kCT) void compute_rowidx_kernel(int64_t nb, int32_t B,
@@ -183,12 +182,15 @@ __device__ __forceinline__ void gather_run(int n, int sl, int D, int l, const in
     if (l + 32 * k < D) o[l + 32 * k] = acc[k];
 }
 
-__global__ __launch_bounds__(kCT) void cache_forward_kernel(int N, int D,
+// (skip_dev, all three cache kernels: device-side count of leading entries that are NOT cached --
+// the split point of the partition -- so that no host read-back is needed; NULL = 0)
+__global__ __launch_bounds__(kCT) void cache_forward_kernel(int N, int D, const int* __restrict__ skip_dev,
                                                            const int64_t* __restrict__ rowidx,
                                                            const int32_t* __restrict__ loc,
                                                            const float* __restrict__ w, float* out) {
   const int n = blockIdx.x * (kCT / 32) + threadIdx.x / 32;
   const int l = threadIdx.x & 31;
+  if (skip_dev) { const int k = max(0, min(N, *skip_dev)); N -= k; rowidx += k; loc += k; }
   if (n >= N) return;
   const int64_t r = rowidx[n];
   if (n > 0 && rowidx[n - 1] == r) return;
@@ -217,16 +219,42 @@ __global__ __launch_bounds__(kCT) void cache_forward_kernel(int N, int D,
 // atomic add (the same row can be hit from several bags).  scale = -lr (SGD)
 // or +1 (dense gradient).
 __global__ __launch_bounds__(kCT) void cache_scatter_add_kernel(int N, int D, float scale,
+                                                               const int* __restrict__ skip_dev,
                                                                const float* __restrict__ grad,
                                                                const int32_t* __restrict__ loc,
                                                                const int64_t* __restrict__ rowidx,
                                                                float* dst) {
   const int n = blockIdx.x * (kCT / 32) + threadIdx.x / 32;
   const int l = threadIdx.x & 31;
+  if (skip_dev) { const int k = max(0, min(N, *skip_dev)); N -= k; rowidx += k; loc += k; }
   if (n >= N) return;
-  const float* g = grad + (size_t)rowidx[n] * D;
-  float* w = dst + (size_t)loc[n] * D;
-  for (int e = l; e < D; e += 32) unsafeAtomicAdd(&w[e], g[e] * scale);
+  // A bag that hits the same cache row m times adds m * g once instead of g m times: its lookups
+  // are contiguous, so the 32 lanes scan the run for earlier copies (-> nothing to do) and count
+  // the later ones.  Under a skewed stream a hot row takes thousands of atomic row adds per step;
+  // this removes the within-bag share of them (and is exact up to the rounding of m * g).
+  const int64_t r = rowidx[n];
+  const int32_t c = loc[n];
+  const int sh = threadIdx.x & 32;
+  const unsigned long long half = sh ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+  for (int base = 1;; base += 32) {  // an earlier copy in this bag?
+    const int j = n - base - l;
+    const bool in_run = j >= 0 && rowidx[j] == r;
+    const bool hit = in_run && loc[j] == c;
+    if (__ballot(hit) & half) return;
+    if (__ballot(!in_run) & half) break;
+  }
+  int m = 1;
+  for (int base = 1;; base += 32) {  // later copies in this bag
+    const int j = n + base + l;
+    const bool in_run = j < N && rowidx[j] == r;
+    const bool hit = in_run && loc[j] == c;
+    m += __popcll(__ballot(hit) & half);
+    if (__ballot(!in_run) & half) break;
+  }
+  const float* g = grad + (size_t)r * D;
+  float* w = dst + (size_t)c * D;
+  const float sc = scale * (float)m;
+  for (int e = l; e < D; e += 32) unsafeAtomicAdd(&w[e], g[e] * sc);
 }
 
 // cache_backward_rowwise_adagrad_approx_kernel cu:1735-1795.  One wave per
@@ -235,10 +263,11 @@ __global__ __launch_bounds__(kCT) void cache_scatter_add_kernel(int N, int D, fl
 // w[loc,:] -= g * mult (atomic: the sum over lookups is order independent; only
 // the `old` each lookup observes depends on arrival order, as in the reference).
 __global__ __launch_bounds__(kCT) void cache_rowwise_adagrad_kernel(
-    int N, int D, const float* __restrict__ grad, const int32_t* __restrict__ loc,
+    int N, int D, const int* __restrict__ skip_dev, const float* __restrict__ grad, const int32_t* __restrict__ loc,
     const int64_t* __restrict__ rowidx, float lr, float eps, float* state, float* wgt) {
   const int n = blockIdx.x * (kCT / kWave) + threadIdx.x / kWave;
   const int l = lane_id();
+  if (skip_dev) { const int k = max(0, min(N, *skip_dev)); N -= k; rowidx += k; loc += k; }
   if (n >= N) return;
   const float* g = grad + (size_t)rowidx[n] * D;
   float s = 0.f;
@@ -423,6 +452,18 @@ int ttx_preprocess_indices_sync_fused(int64_t nnz, const int64_t* colidx, int64_
                                       int32_t* ploc, int32_t* num_tt_host, int32_t* partitioned_host,
                                       int64_t* upd_hashtbl, int64_t* upd_cache_freq,
                                       void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
+  return ttx_preprocess_indices_async(nnz, colidx, nb, offsets, num_tables, warmup, H, hashtbl, cache_state, rowidx,
+                                      tableidx, pcol, prow, ploc, num_tt_host, partitioned_host, nullptr, upd_hashtbl,
+                                      upd_cache_freq, workspace, workspace_bytes, stream);
+}
+
+int ttx_preprocess_indices_async(int64_t nnz, const int64_t* colidx, int64_t nb,
+                                 const int64_t* offsets, int32_t num_tables, int32_t warmup,
+                                 int64_t H, const int64_t* hashtbl, const int32_t* cache_state,
+                                 int64_t* rowidx, int64_t* tableidx, int64_t* pcol, int64_t* prow,
+                                 int32_t* ploc, int32_t* num_tt_host, int32_t* partitioned_host,
+                                 int32_t* num_tt_dev, int64_t* upd_hashtbl, int64_t* upd_cache_freq,
+                                 void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!num_tt_host || !partitioned_host) TTX_FAIL(TTX_EINVAL, "NULL output");
   *num_tt_host = (int32_t)nnz;
@@ -443,7 +484,13 @@ int ttx_preprocess_indices_sync_fused(int64_t nnz, const int64_t* colidx, int64_
                        st, nb, B, offsets, rowidx, tableidx);
   }
   TTX_HIP(hipGetLastError());
-  if (warmup || num_tables != 1) return TTX_OK;  // cu:1410-1412
+  if (warmup || num_tables != 1) {  // cu:1410-1412
+    if (num_tt_dev) {  // every lookup is a TT lookup
+      hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, st, num_tt_dev, (int32_t)nnz);
+      TTX_HIP(hipGetLastError());
+    }
+    return TTX_OK;
+  }
   if (H <= 0 || H >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
   if (!hashtbl || !cache_state || !pcol || !prow || !ploc) TTX_FAIL(TTX_EINVAL, "NULL cache input");
   if (!workspace || workspace_bytes < ttx_preprocess_workspace_bytes(nnz))
@@ -461,39 +508,59 @@ int ttx_preprocess_indices_sync_fused(int64_t nnz, const int64_t* colidx, int64_
   hipLaunchKernelGGL(partition_scatter_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, colidx, rowidx,
                      loc, unit_cnt, pcol, prow, ploc);
   TTX_HIP(hipGetLastError());
+  *partitioned_host = 1;
+  if (num_tt_dev) {  // the split point stays on the device: no host synchronisation at all
+    TTX_HIP(hipMemcpyAsync(num_tt_dev, total, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return TTX_OK;  // (*num_tt_host keeps the upper bound nnz)
+  }
   // the one host synchronisation of the hot path (cu:1481-1488)
   TTX_HIP(hipMemcpyAsync(num_tt_host, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   TTX_HIP(hipStreamSynchronize(st));
-  *partitioned_host = 1;
   return TTX_OK;
 }
 
 int ttx_cache_forward(int32_t B, int64_t nnz, const int32_t* loc, const int64_t* rowidx, int32_t D,
                       const float* cache_weight, float* output, ttx_stream_t stream) {
+  return ttx_cache_forward_n(B, nnz, nullptr, loc, rowidx, D, cache_weight, output, stream);
+}
+
+int ttx_cache_forward_n(int32_t B, int64_t nnz, const int32_t* skip_dev, const int32_t* loc,
+                        const int64_t* rowidx, int32_t D, const float* cache_weight, float* output,
+                        ttx_stream_t stream) {
   if (B <= 0) TTX_FAIL(TTX_EINVAL, "B=%d must be > 0", B);  // cu:1549
   if (D <= 0) TTX_FAIL(TTX_EINVAL, "D=%d must be > 0", D);
   if (nnz == 0) return TTX_OK;
   if (!loc || !rowidx || !cache_weight || !output) TTX_FAIL(TTX_EINVAL, "NULL input");
   ProfScope ps(TTX_PROF_CACHE_FWD, (hipStream_t)stream);
   hipLaunchKernelGGL(cache_forward_kernel, dim3((unsigned)((nnz + kCT / 32 - 1) / (kCT / 32))), dim3(kCT), 0,
-                     (hipStream_t)stream, (int)nnz, D, rowidx, loc, cache_weight, output);
+                     (hipStream_t)stream, (int)nnz, D, skip_dev, rowidx, loc, cache_weight, output);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }
 
 int ttx_cache_backward_sgd(int64_t nnz, int32_t D, const float* grad, const int32_t* loc,
                            const int64_t* rowidx, float lr, float* cache_weight, ttx_stream_t stream) {
+  return ttx_cache_backward_sgd_n(nnz, nullptr, D, grad, loc, rowidx, lr, cache_weight, stream);
+}
+
+int ttx_cache_backward_sgd_n(int64_t nnz, const int32_t* skip_dev, int32_t D, const float* grad, const int32_t* loc,
+                             const int64_t* rowidx, float lr, float* cache_weight, ttx_stream_t stream) {
   if (nnz == 0) return TTX_OK;
   if (D <= 0) TTX_FAIL(TTX_EINVAL, "D=%d must be > 0", D);
   if (!grad || !loc || !rowidx || !cache_weight) TTX_FAIL(TTX_EINVAL, "NULL input");
   hipLaunchKernelGGL(cache_scatter_add_kernel, dim3((unsigned)((nnz + kCT / 32 - 1) / (kCT / 32))), dim3(kCT),
-                     0, (hipStream_t)stream, (int)nnz, D, -lr, grad, loc, rowidx, cache_weight);
+                     0, (hipStream_t)stream, (int)nnz, D, -lr, skip_dev, grad, loc, rowidx, cache_weight);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }
 
 int ttx_cache_backward_dense(int64_t nnz, int32_t D, const float* grad, const int32_t* loc,
                              const int64_t* rowidx, int64_t cache_size, float* gcw, ttx_stream_t stream) {
+  return ttx_cache_backward_dense_n(nnz, nullptr, D, grad, loc, rowidx, cache_size, gcw, stream);
+}
+
+int ttx_cache_backward_dense_n(int64_t nnz, const int32_t* skip_dev, int32_t D, const float* grad, const int32_t* loc,
+                               const int64_t* rowidx, int64_t cache_size, float* gcw, ttx_stream_t stream) {
   if (D <= 0 || cache_size < 0) TTX_FAIL(TTX_EINVAL, "bad D / cache_size");
   if (!gcw) TTX_FAIL(TTX_EINVAL, "NULL output");
   if (cache_size > 0)
@@ -501,7 +568,7 @@ int ttx_cache_backward_dense(int64_t nnz, int32_t D, const float* grad, const in
   if (nnz == 0) return TTX_OK;
   if (!grad || !loc || !rowidx) TTX_FAIL(TTX_EINVAL, "NULL input");
   hipLaunchKernelGGL(cache_scatter_add_kernel, dim3((unsigned)((nnz + kCT / 32 - 1) / (kCT / 32))), dim3(kCT),
-                     0, (hipStream_t)stream, (int)nnz, D, 1.0f, grad, loc, rowidx, gcw);
+                     0, (hipStream_t)stream, (int)nnz, D, 1.0f, skip_dev, grad, loc, rowidx, gcw);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }
@@ -510,11 +577,18 @@ int ttx_cache_backward_rowwise_adagrad_approx(int64_t nnz, int32_t D, const floa
                                               const int32_t* loc, const int64_t* rowidx, float lr,
                                               float eps, float* state, float* cache_weight,
                                               ttx_stream_t stream) {
+  return ttx_cache_backward_rowwise_adagrad_approx_n(nnz, nullptr, D, grad, loc, rowidx, lr, eps, state, cache_weight,
+                                                     stream);
+}
+
+int ttx_cache_backward_rowwise_adagrad_approx_n(int64_t nnz, const int32_t* skip_dev, int32_t D, const float* grad,
+                                                const int32_t* loc, const int64_t* rowidx, float lr, float eps,
+                                                float* state, float* cache_weight, ttx_stream_t stream) {
   if (nnz == 0) return TTX_OK;
   if (D <= 0) TTX_FAIL(TTX_EINVAL, "D=%d must be > 0", D);
   if (!grad || !loc || !rowidx || !state || !cache_weight) TTX_FAIL(TTX_EINVAL, "NULL input");
   hipLaunchKernelGGL(cache_rowwise_adagrad_kernel, dim3((unsigned)((nnz + kCT / kWave - 1) / (kCT / kWave))),
-                     dim3(kCT), 0, (hipStream_t)stream, (int)nnz, D, grad, loc, rowidx, lr, eps, state,
+                     dim3(kCT), 0, (hipStream_t)stream, (int)nnz, D, skip_dev, grad, loc, rowidx, lr, eps, state,
                      cache_weight);
   TTX_HIP(hipGetLastError());
   return TTX_OK;

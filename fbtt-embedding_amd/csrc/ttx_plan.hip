@@ -366,7 +366,8 @@ constexpr int kMbUnits = kMbThreads / kWave;
 constexpr int kMbFuseU = 256;              // up to this many units the scatter pass scans the counts itself
 
 struct MbArgs {
-  int N, U;            // lookups, units per core
+  int N, U;            // lookups (upper bound when n_dev is set), units per core
+  const int* n_dev;    // device-side lookup count (<= N), or NULL: N is exact
   int unit;            // positions per wave unit (multiple of 64)
   int pass;            // current pass
   int fused_scan;      // scatter derives its bases itself (few units): no scan launch
@@ -374,6 +375,13 @@ struct MbArgs {
   int passes[TTX_MAX_CORES];
   int* cnt;            // [T][U][256]  (unit-major: a unit's 256 digit counts are one 1 KiB row)
 };
+
+// the number of lookups a kernel works on: the host value, or the device-side count clamped to it
+__device__ __forceinline__ int live_n(int n_host, const int* n_dev) {
+  if (!n_dev) return n_host;
+  const int v = *n_dev;
+  return v < 0 ? 0 : (v < n_host ? v : n_host);
+}
 
 // what one lane holds of one batch of 64 positions
 struct MbItem { int val, kv; };
@@ -403,7 +411,8 @@ __global__ __launch_bounds__(kMbThreads) void mb_count_kernel(
   const int lane = lane_id(), w = threadIdx.x / kWave;
   const int u = blockIdx.x * kMbUnits + w;
   for (int e = lane; e < 256; e += kWave) hist[w][e] = 0;
-  const int beg = min(A.N, u * A.unit), end = min(A.N, beg + A.unit);
+  const int N = live_n(A.N, A.n_dev);
+  const int beg = min(N, u * A.unit), end = min(N, beg + A.unit);
   int* key = P.sid[t];
   const int* src = (A.pass == 0) ? nullptr : ((A.pass & 1) ? P.scratch[t][1] : P.scratch[t][2]);
   const int shift = A.pass * 8;
@@ -519,9 +528,10 @@ struct Prologue {
 };
 template <bool PRO>
 __global__ __launch_bounds__(kMbThreads) void mb_single_kernel(
-    Dims d, int N, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx,
-    const int64_t* __restrict__ rowidx, Plan P, Prologue pg) {
+    Dims d, int Nmax, const int* __restrict__ n_dev, const int64_t* __restrict__ indices,
+    const int64_t* __restrict__ tableidx, const int64_t* __restrict__ rowidx, Plan P, Prologue pg) {
   __shared__ int htot[256], hbef[256], hrun[kMbUnits][256];
+  const int N = live_n(Nmax, n_dev);
   __shared__ int wt5[kMbUnits + 1];
   __shared__ int offs[PRO ? kProMaxBags + 1 : 1];
   const int t = blockIdx.y, tid = threadIdx.x;
@@ -597,10 +607,10 @@ __global__ __launch_bounds__(kMbThreads) void mb_single_kernel(
         pg.tableidx[i] = 0;
       }
     }
-    // the frequency update (a CAS round trip + an add) rides on the work-groups of the last core,
-    // which have no bag rows to find
-    if (PRO && pg.H && t == (d.T >= 3 ? 2 : 0)) hashtbl_count(idx, pg.H, pg.hashtbl, pg.cache_freq);
   }
+  // the frequency update (a CAS round trip + an add) rides on the work-groups of the last core,
+  // which have no bag rows to find; equal keys of a wave are combined first
+  if (PRO && pg.H && t == (d.T >= 3 ? 2 : 0)) hashtbl_count_wave(idx, valid, pg.H, pg.hashtbl, pg.cache_freq);
   const unsigned long long peers = wave_match8((unsigned)kv, valid);
   if (valid) {
     const int pos = hrun[w][kv] + __popcll(peers & lanemask_lt());
@@ -658,11 +668,12 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
 #pragma unroll
     for (int k = 0; k < kMbUnits; ++k) { run[k][dg] = b; b += mine[k]; }
     __syncthreads();
-    if (A.fused_finish && blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, A.N, rowidx != nullptr, P, wt5);
+    if (A.fused_finish && blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, live_n(A.N, A.n_dev), rowidx != nullptr, P, wt5);
   } else if (u < A.U) {
     for (int e = lane; e < 256; e += kWave) run[w][e] = A.cnt[((size_t)t * A.U + u) * 256 + e];
   }
-  const int beg = min(A.N, u * A.unit), end = min(A.N, beg + A.unit);
+  const int N = live_n(A.N, A.n_dev);
+  const int beg = min(N, u * A.unit), end = min(N, beg + A.unit);
   const int* key = P.sid[t];
   const int* src = (A.pass == 0) ? nullptr : ((A.pass & 1) ? P.scratch[t][1] : P.scratch[t][2]);
   const bool last = (A.pass == A.passes[t] - 1);
@@ -707,7 +718,8 @@ __device__ __forceinline__ int lower_bound_key(const int* sk, int N, int s) {
 }
 
 // blockIdx.y = core: slice offsets of the thin cores; the pivot's work-group(s) build the chunk list
-__global__ __launch_bounds__(1024) void mb_finish_kernel(Dims d, int N, int has_row, Plan P) {
+__global__ __launch_bounds__(1024) void mb_finish_kernel(Dims d, int Nmax, const int* __restrict__ n_dev, int has_row, Plan P) {
+  const int N = live_n(Nmax, n_dev);
   __shared__ int wtot[kPlanWaves + 1];
   const int t = blockIdx.y, tid = threadIdx.x;
   const int* sk = P.scratch[t][0];
@@ -745,10 +757,11 @@ __global__ __launch_bounds__(1024) void mb_finish_kernel(Dims d, int N, int has_
   }
 }
 
-static int plan_build_mb(const Dims& d, int N, const int64_t* indices, const int64_t* tableidx,
+static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* indices, const int64_t* tableidx,
                          const int64_t* rowidx, const Plan& P, hipStream_t stream) {
   MbArgs A;
   A.N = N;
+  A.n_dev = n_dev;
   int maxp = 1;
   for (int t = 0; t < TTX_MAX_CORES; ++t) {
     A.passes[t] = 0;
@@ -761,7 +774,7 @@ static int plan_build_mb(const Dims& d, int N, const int64_t* indices, const int
   }
   if (maxp == 1 && N <= kOneMaxN) {
     hipLaunchKernelGGL(mb_single_kernel<false>, dim3((N + kMbUnits * kOneUnit - 1) / (kMbUnits * kOneUnit), d.T),
-                       dim3(kMbThreads), 0, stream, d, N, indices, tableidx, rowidx, P, Prologue{});
+                       dim3(kMbThreads), 0, stream, d, N, n_dev, indices, tableidx, rowidx, P, Prologue{});
     TTX_HIP(hipGetLastError());
     return TTX_OK;
   }
@@ -787,17 +800,18 @@ static int plan_build_mb(const Dims& d, int N, const int64_t* indices, const int
   if (A.fused_finish) { TTX_HIP(hipGetLastError()); return TTX_OK; }
   int smax = 1;
   for (int t = 0; t < d.T; ++t) if (t != 1 && d.S[t] + 1 > smax) smax = d.S[t] + 1;
-  hipLaunchKernelGGL(mb_finish_kernel, dim3((smax + 1023) / 1024, d.T), dim3(1024), 0, stream, d, N,
+  hipLaunchKernelGGL(mb_finish_kernel, dim3((smax + 1023) / 1024, d.T), dim3(1024), 0, stream, d, N, n_dev,
                      rowidx ? 1 : 0, P);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }
 
 int plan_build(const Dims& d, long long nnz, const int64_t* indices,
-               const int64_t* tableidx, const int64_t* rowidx, const Plan& P, hipStream_t stream) {
+               const int64_t* tableidx, const int64_t* rowidx, const Plan& P, hipStream_t stream,
+               const int* n_dev) {
   if (nnz < 0 || nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz=%lld out of range", nnz);
   ProfScope ps(TTX_PROF_PLAN, stream);
-  if (nnz > 1024 || !d.idx32) return plan_build_mb(d, (int)nnz, indices, tableidx, rowidx, P, stream);
+  if (nnz > 1024 || !d.idx32 || n_dev) return plan_build_mb(d, (int)nnz, n_dev, indices, tableidx, rowidx, P, stream);
   {  // tiny batch: one launch, one work-group per core, everything on chip
     const size_t lds = (256 * kPlanWaves + 32 + 2 * ((nnz + 63) / 64 * 64)) * sizeof(int);
     const int per = (((int)nnz + kPlanWaves - 1) / kPlanWaves + kWave - 1) / kWave * kWave;
@@ -834,7 +848,7 @@ bool prologue_fusable(const Dims& d, long long nnz, long long nb) {
 int prologue_launch(const Dims& d, int N, const int64_t* indices, const Prologue& pg, const Plan& P, hipStream_t stream) {
   ProfScope ps(TTX_PROF_PLAN, stream);
   hipLaunchKernelGGL(mb_single_kernel<true>, dim3((N + kMbUnits * kOneUnit - 1) / (kMbUnits * kOneUnit), d.T),
-                     dim3(kMbThreads), 0, stream, d, N, indices, nullptr, nullptr, P, pg);
+                     dim3(kMbThreads), 0, stream, d, N, (const int*)nullptr, indices, nullptr, nullptr, P, pg);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }
@@ -879,6 +893,12 @@ size_t ttx_plan_bytes(const ttx_geom* g, int64_t nnz) {
 int ttx_plan_build(const ttx_geom* g, int64_t nnz, const int64_t* indices,
                    const int64_t* tableidx, const int64_t* rowidx, void* plan, size_t plan_bytes,
                    ttx_stream_t stream) {
+  return ttx_plan_build_n(g, nnz, nullptr, indices, tableidx, rowidx, plan, plan_bytes, stream);
+}
+
+int ttx_plan_build_n(const ttx_geom* g, int64_t nnz, const int32_t* nnz_dev, const int64_t* indices,
+                     const int64_t* tableidx, const int64_t* rowidx, void* plan, size_t plan_bytes,
+                     ttx_stream_t stream) {
   ttx::Dims d;
   int rc = ttx::make_dims(g, &d);
   if (rc != TTX_OK) return rc;
@@ -886,7 +906,7 @@ int ttx_plan_build(const ttx_geom* g, int64_t nnz, const int64_t* indices,
     TTX_FAIL(TTX_EWORKSPACE, "plan buffer too small: %zu < %zu", plan_bytes, ttx::plan_bytes(d, nnz));
   if (nnz > 0 && !indices) TTX_FAIL(TTX_EINVAL, "indices is NULL");
   ttx::Plan P = ttx::carve_plan(d, nnz, plan);
-  return ttx::plan_build(d, nnz, indices, tableidx, rowidx, P, (hipStream_t)stream);
+  return ttx::plan_build(d, nnz, indices, tableidx, rowidx, P, (hipStream_t)stream, nnz_dev);
 }
 
 }  // extern "C"

@@ -7,9 +7,9 @@
 // forward = ttx_lookup_prologue + ttx_tt_forward, backward = ttx_tt_backward (fused SGD / Adagrad
 // in place, or dense core gradients), one lookup plan shared by both.  No compute happens here:
 // torch supplies device memory (caching allocator), the current HIP stream and the autograd graph.
-// TTCachedLookupOp is the cache-live variant (one table): hash lookup + stable partition (one host
-// read-back of the split point, as in the reference, tt_embeddings_cuda.cu:1481-1488), contraction of
-// the misses, gather of the hits; backward = fused TT update + cache-row update (or dense gradients).
+// TTCachedLookupOp is the cache-live variant (one table): hash lookup + stable partition, contraction of
+// the misses, gather of the hits -- with the split point kept on the device (the reference reads it back
+// and synchronises, tt_embeddings_cuda.cu:1481-1488; here the kernels read it from HBM); backward = fused TT update + cache-row update (or dense gradients).
 // tt_embeddings_ops.py keeps the reference-shaped Python route and is the fallback when this
 // extension was not built.
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
@@ -213,34 +213,33 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     Tensor ploc = at::empty({nnz}, indices.options().dtype(at::kInt));
     const size_t pwb = ttx_preprocess_workspace_bytes(nnz);
     Tensor pws = bytes_on(indices, pwb);
-    int32_t n_tt = 0, part = 0;
-    check(ttx_preprocess_indices_sync_fused(nnz, indices.data_ptr<int64_t>(), B, offsets.data_ptr<int64_t>(), 1, 0, H,
-                                            hashtbl.data_ptr<int64_t>(), cache_state.data_ptr<int32_t>(),
-                                            rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
-                                            pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(), ploc.data_ptr<int32_t>(),
-                                            &n_tt, &part, hashtbl.data_ptr<int64_t>(), cache_freq.data_ptr<int64_t>(),
-                                            pws.data_ptr(), pwb, stream));
+    // the split point (number of TT entries) stays on the device: the kernels below read it there,
+    // nnz only sizes grids and workspaces -- no host synchronisation, the step can be graph-captured
+    Tensor n_tt = at::empty({1}, indices.options().dtype(at::kInt));
+    int32_t n_host = 0, part = 0;
+    check(ttx_preprocess_indices_async(nnz, indices.data_ptr<int64_t>(), B, offsets.data_ptr<int64_t>(), 1, 0, H,
+                                       hashtbl.data_ptr<int64_t>(), cache_state.data_ptr<int32_t>(),
+                                       rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(), pcol.data_ptr<int64_t>(),
+                                       prow.data_ptr<int64_t>(), ploc.data_ptr<int32_t>(), &n_host, &part,
+                                       n_tt.data_ptr<int32_t>(), hashtbl.data_ptr<int64_t>(),
+                                       cache_freq.data_ptr<int64_t>(), pws.data_ptr(), pwb, stream));
     TORCH_CHECK(part == 1, "tt_embeddings: the cache-live preprocessing did not partition");
-    const int64_t n_c = nnz - n_tt;
 
     Tensor out = at::empty({1, B, D}, cores[0].options());
-    Tensor plan;
-    if (n_tt > 0) {
-      const size_t pb = ttx_plan_bytes(&g, n_tt);
-      plan = bytes_on(indices, pb);
-      check(ttx_plan_build(&g, n_tt, pcol.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(), prow.data_ptr<int64_t>(),
-                           plan.data_ptr(), pb, stream));
-    }
+    const size_t pb = ttx_plan_bytes(&g, nnz);
+    Tensor plan = bytes_on(indices, pb);
+    check(ttx_plan_build_n(&g, nnz, n_tt.data_ptr<int32_t>(), pcol.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
+                           prow.data_ptr<int64_t>(), plan.data_ptr(), pb, stream));
     const float* cp[TTX_MAX_CORES] = {};
     for (int t = 0; t < g.T; ++t) cp[t] = cores[t].data_ptr<float>();
-    const size_t wb = ttx_tt_forward_workspace_bytes(&g, (int32_t)B, (int32_t)D, n_tt);
+    const size_t wb = ttx_tt_forward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
     Tensor ws = bytes_on(indices, wb);
-    check(ttx_tt_forward(&g, (int32_t)B, (int32_t)D, n_tt, pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(),
-                         tableidx.data_ptr<int64_t>(), cp, out.data_ptr<float>(), n_tt > 0 ? plan.data_ptr() : nullptr,
-                         ws.data_ptr(), wb, stream));
-    if (n_c > 0)
-      check(ttx_cache_forward((int32_t)B, n_c, ploc.data_ptr<int32_t>() + n_tt, prow.data_ptr<int64_t>() + n_tt,
-                              (int32_t)D, cache_weight.data_ptr<float>(), out.data_ptr<float>(), stream));
+    check(ttx_tt_forward(&g, (int32_t)B, (int32_t)D, nnz, pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(),
+                         tableidx.data_ptr<int64_t>(), cp, out.data_ptr<float>(), plan.data_ptr(), ws.data_ptr(), wb,
+                         stream));
+    check(ttx_cache_forward_n((int32_t)B, nnz, n_tt.data_ptr<int32_t>(), ploc.data_ptr<int32_t>(),
+                              prow.data_ptr<int64_t>(), (int32_t)D, cache_weight.data_ptr<float>(), out.data_ptr<float>(),
+                              stream));
 
     ctx->saved_data["p"] = p;
     ctx->saved_data["q"] = q;
@@ -250,8 +249,7 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     ctx->saved_data["eps"] = eps;
     ctx->saved_data["T"] = (int64_t)g.T;
     ctx->saved_data["nstate"] = (int64_t)state.size();
-    ctx->saved_data["n_tt"] = (int64_t)n_tt;
-    std::vector<Tensor> keep = {pcol, prow, tableidx, ploc, cache_weight};
+    std::vector<Tensor> keep = {pcol, prow, tableidx, ploc, cache_weight, n_tt};
     ctx->saved_data["keep"] = keep;
     if (cache_opt_state.has_value() && cache_opt_state->defined()) ctx->saved_data["copt"] = *cache_opt_state;
     if (plan.defined()) ctx->saved_data["plan"] = plan;
@@ -267,15 +265,15 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     const int64_t optim = ctx->saved_data["optim"].toInt();
     const double lr = ctx->saved_data["lr"].toDouble(), eps = ctx->saved_data["eps"].toDouble();
     const int64_t T = ctx->saved_data["T"].toInt(), nstate = ctx->saved_data["nstate"].toInt();
-    const int64_t n_tt = ctx->saved_data["n_tt"].toInt();
     auto keep = ctx->saved_data["keep"].toTensorVector();
     auto cores = ctx->saved_data["cores"].toTensorVector();
     auto state = ctx->saved_data["state"].toTensorVector();
     const ttx_geom g = make_geom(1, p, q, r);
     const Tensor &pcol = keep[0], &prow = keep[1], &tableidx = keep[2], &ploc = keep[3], &cache_weight = keep[4];
+    const int32_t* n_tt = keep[5].data_ptr<int32_t>();  // device-side split point
     const Tensor cache_opt_state = ctx->saved_data.count("copt") ? ctx->saved_data["copt"].toTensor() : Tensor();
     const Tensor plan = ctx->saved_data.count("plan") ? ctx->saved_data["plan"].toTensor() : Tensor();
-    const int64_t nnz = pcol.numel(), n_c = nnz - n_tt;
+    const int64_t nnz = pcol.numel();
 
     variable_list grads(kHead + nstate + T);
     Tensor go = grad_outputs[0];
@@ -299,33 +297,31 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
         gp[t] = dense.back().data_ptr<float>();
       }
     }
-    const size_t wb = ttx_tt_backward_workspace_bytes(&g, (int32_t)B, (int32_t)D, n_tt);
+    const size_t wb = ttx_tt_backward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
     Tensor ws = bytes_on(pcol, wb);
-    check(ttx_tt_backward(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, n_tt,
+    check(ttx_tt_backward(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz,
                           pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
                           go.data_ptr<float>(), cp, optim == TTX_OPTIM_ADAGRAD ? sp : nullptr,
                           optim == TTX_OPTIM_DENSE ? gp : nullptr, plan.defined() ? plan.data_ptr() : nullptr,
                           ws.data_ptr(), wb, stream));
-    const int32_t* loc = ploc.data_ptr<int32_t>() + n_tt;
-    const int64_t* rows = prow.data_ptr<int64_t>() + n_tt;
+    const int32_t* loc = ploc.data_ptr<int32_t>();
+    const int64_t* rows = prow.data_ptr<int64_t>();
     if (optim == TTX_OPTIM_SGD) {
-      if (n_c > 0)
-        check(ttx_cache_backward_sgd(n_c, (int32_t)D, go.data_ptr<float>(), loc, rows, (float)lr,
+      check(ttx_cache_backward_sgd_n(nnz, n_tt, (int32_t)D, go.data_ptr<float>(), loc, rows, (float)lr,
                                      cache_weight.data_ptr<float>(), stream));
     } else if (optim == TTX_OPTIM_ADAGRAD) {
       TORCH_CHECK(cache_opt_state.defined(), "tt_embeddings: Adagrad with a live cache needs cache_optimizer_state");
-      if (n_c > 0)
-        check(ttx_cache_backward_rowwise_adagrad_approx(n_c, (int32_t)D, go.data_ptr<float>(), loc, rows, (float)lr,
+      check(ttx_cache_backward_rowwise_adagrad_approx_n(nnz, n_tt, (int32_t)D, go.data_ptr<float>(), loc, rows, (float)lr,
                                                         (float)eps, cache_opt_state.data_ptr<float>(),
                                                         cache_weight.data_ptr<float>(), stream));
     } else {
       for (int t = 0; t < T; ++t) grads[kHead + nstate + t] = dense[t];
-      if (n_c > 0) {  // (tt_embeddings_ops.py:349-353: the cache gradient exists only when rows were hit)
-        Tensor gcw = at::empty_like(cache_weight);
-        check(ttx_cache_backward_dense(n_c, (int32_t)D, go.data_ptr<float>(), loc, rows, cache_weight.size(0),
+      // (the reference returns no cache gradient when nothing was hit, tt_embeddings_ops.py:349-353;
+      // with the split point on the device this node always returns one -- zeros in that case)
+      Tensor gcw = at::empty_like(cache_weight);
+      check(ttx_cache_backward_dense_n(nnz, n_tt, (int32_t)D, go.data_ptr<float>(), loc, rows, cache_weight.size(0),
                                        gcw.data_ptr<float>(), stream));
-        grads[12] = gcw;  // cache_weight
-      }
+      grads[12] = gcw;  // cache_weight
     }
     return grads;
   }

@@ -465,13 +465,14 @@ __global__ __launch_bounds__(kThreads, 3) void fwd_kernel(Dims d, Plan P, CorePt
 // lookups with equal (rowidx, tableidx); reference reduce_output_kernel
 // cu:920-962).  One 32-lane group per lookup; only run heads work.  The run
 // length is found with one ballot per 32 candidates.
-__global__ __launch_bounds__(kThreads) void pool_kernel(int N, int B, int D,
+__global__ __launch_bounds__(kThreads) void pool_kernel(int Nmax, const int* __restrict__ hdr, int B, int D,
                                                        const int64_t* __restrict__ rowidx,
                                                        const int64_t* __restrict__ tableidx,
                                                        const float* __restrict__ rows,
                                                        float* __restrict__ out) {
   const int n = blockIdx.x * (kThreads / 32) + threadIdx.x / 32;
   const int l = threadIdx.x & 31;
+  const int N = min(Nmax, hdr[2]);  // the plan knows how many lookups are live (device-side counts)
   if (n >= N) return;
   const int64_t r = rowidx[n], tb = tableidx[n];
   if (n > 0 && rowidx[n - 1] == r && tableidx[n - 1] == tb) return;
@@ -1174,7 +1175,7 @@ int ttx_tt_forward(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const i
     ProfScope ps(TTX_PROF_POOL, st);
     const int groups = kThreads / 32;
     hipLaunchKernelGGL(pool_kernel, dim3(((int)nnz + groups - 1) / groups), dim3(kThreads), 0, st,
-                       (int)nnz, B, d.D, rowidx, tableidx, rows, output);
+                       (int)nnz, P.hdr, B, d.D, rowidx, tableidx, rows, output);
     TTX_HIP(hipGetLastError());
   }
   return TTX_OK;

@@ -177,6 +177,48 @@ int ttx_preprocess_indices_sync_fused(int64_t nnz, const int64_t* colidx,
                                       void* workspace, size_t workspace_bytes,
                                       ttx_stream_t stream);
 
+/* ---- device-side counts: the cache-live path without its host read-back -------------------
+ * The reference copies the partition's split point to the host and synchronises
+ * (tt_embeddings_cuda.cu:1481-1488) because its launch grids depend on it.  Here every kernel
+ * can take its lookup count from device memory instead, with the host-side `nnz` an upper bound
+ * that only sizes grids and workspaces:
+ *  - ttx_preprocess_indices_async: as ttx_preprocess_indices_sync_fused, but when num_tt_dev
+ *    (a device int32) is non-NULL the count of TT entries is written there and nothing is read
+ *    back (*num_tt_host keeps nnz);
+ *  - ttx_plan_build_n: nnz_dev (device int32, <= nnz) is the number of leading entries of
+ *    indices / tableidx / rowidx to plan; a plan built this way may be handed to
+ *    ttx_tt_forward / ttx_tt_backward together with the same upper bound nnz (their kernels
+ *    are driven by the plan; workspaces are sized for nnz);
+ *  - ttx_cache_*_n: skip_dev (device int32) = number of leading entries of cache_locations /
+ *    rowidx that are NOT cached; the kernels work on [*skip_dev, nnz).
+ * Passing NULL for the device pointer gives exactly the plain entry point. */
+int ttx_preprocess_indices_async(int64_t nnz, const int64_t* colidx, int64_t num_bags_total,
+                                 const int64_t* offsets, int32_t num_tables, int32_t warmup,
+                                 int64_t hashtbl_size, const int64_t* hashtbl,
+                                 const int32_t* cache_state, int64_t* rowidx, int64_t* tableidx,
+                                 int64_t* part_colidx, int64_t* part_rowidx,
+                                 int32_t* part_cache_locations, int32_t* num_tt_host,
+                                 int32_t* partitioned_host, int32_t* num_tt_dev,
+                                 int64_t* upd_hashtbl, int64_t* upd_cache_freq, void* workspace,
+                                 size_t workspace_bytes, ttx_stream_t stream);
+int ttx_plan_build_n(const ttx_geom* g, int64_t nnz, const int32_t* nnz_dev, const int64_t* indices,
+                     const int64_t* tableidx, const int64_t* rowidx, void* plan, size_t plan_bytes,
+                     ttx_stream_t stream);
+int ttx_cache_forward_n(int32_t B, int64_t nnz, const int32_t* skip_dev, const int32_t* cache_locations,
+                        const int64_t* rowidx, int32_t D, const float* cache_weight, float* output,
+                        ttx_stream_t stream);
+int ttx_cache_backward_sgd_n(int64_t nnz, const int32_t* skip_dev, int32_t D, const float* grad_output,
+                             const int32_t* cache_locations, const int64_t* rowidx, float learning_rate,
+                             float* cache_weight, ttx_stream_t stream);
+int ttx_cache_backward_dense_n(int64_t nnz, const int32_t* skip_dev, int32_t D, const float* grad_output,
+                               const int32_t* cache_locations, const int64_t* rowidx, int64_t cache_size,
+                               float* grad_cache_weight, ttx_stream_t stream);
+int ttx_cache_backward_rowwise_adagrad_approx_n(int64_t nnz, const int32_t* skip_dev, int32_t D,
+                                                const float* grad_output, const int32_t* cache_locations,
+                                                const int64_t* rowidx, float learning_rate, float eps,
+                                                float* cache_optimizer_state, float* cache_weight,
+                                                ttx_stream_t stream);
+
 /* Lookup prologue of a batch while the cache is not live (warmup): what the module does
  * before the contraction -- update_cache_state (tt_embeddings_ops.py:827-833) when
  * upd_hashtbl / upd_cache_freq are non-NULL, preprocess_indices_sync with warmup = true
