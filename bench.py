@@ -50,6 +50,8 @@ WORKLOADS = {
     "cfg3": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.2, populate=True),
     "cfg4": dict(q=[4, 4, 8], ranks=[64, 64], tables=1, B=512, optimizer="adagrad", alpha=1.0, populate=False),
     # one rank's share of cfg5 at 8 GPUs: 4 of the 26 tables, the whole 4096-bag batch
+    # all 26 tables of cfg5 on ONE GPU (2.13 M lookups per step): the table-batched path at scale
+    "cfg5full": dict(q=[4, 4, 4], ranks=[32, 32], tables=26, B=4096, optimizer="sgd", alpha=1.0, populate=False),
     "cfg5shard": dict(q=[4, 4, 4], ranks=[32, 32], tables=4, B=4096, optimizer="sgd", alpha=1.0, populate=False),
 }
 

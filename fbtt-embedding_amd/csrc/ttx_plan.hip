@@ -363,6 +363,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
 // then mb_finish: slice offsets by binary search on the sorted keys + the pivot chunk list.
 constexpr int kMbThreads = 256;            // 4 wave units per work-group
 constexpr int kMbUnits = kMbThreads / kWave;
+constexpr int kSB = 4;                     // batches of 64 whose loads are in flight together
 constexpr int kMbFuseU = 256;              // up to this many units the scatter pass scans the counts itself
 
 struct MbArgs {
@@ -417,16 +418,24 @@ __global__ __launch_bounds__(kMbThreads) void mb_count_kernel(
   const int* src = (A.pass == 0) ? nullptr : ((A.pass & 1) ? P.scratch[t][1] : P.scratch[t][2]);
   const int shift = A.pass * 8;
   const CoreDec ct = core_dec(d, t);
-  MbItem nx = mb_load(beg + lane, beg + lane < end, A.pass, ct, indices, tableidx, src, key);
-  for (int base = beg; base < end; base += kWave) {
-    const MbItem it = nx;
-    const int i = base + lane;
-    const bool valid = i < end;
-    nx = mb_load(i + kWave, i + kWave < end, A.pass, ct, indices, tableidx, src, key);  // next batch in flight
-    if (valid && A.pass == 0) key[i] = it.kv;
-    const unsigned dg = ((unsigned)it.kv >> shift) & 255u;
-    const unsigned long long peers = wave_match8(dg, valid);
-    if (valid && (peers & lanemask_lt()) == 0) hist[w][dg] += __popcll(peers);
+  // super-batches of kSB x 64 positions: all their (dependent) loads are issued before any is used --
+  // a wave walks thousands of positions and one round trip per 64 was the whole cost of the pass
+  for (int base = beg; base < end; base += kSB * kWave) {
+    MbItem it[kSB];
+#pragma unroll
+    for (int k = 0; k < kSB; ++k) {
+      const int i = base + k * kWave + lane;
+      it[k] = mb_load(i, i < end, A.pass, ct, indices, tableidx, src, key);
+    }
+#pragma unroll
+    for (int k = 0; k < kSB; ++k) {
+      const int i = base + k * kWave + lane;
+      const bool valid = i < end;
+      if (valid && A.pass == 0) key[i] = it[k].kv;
+      const unsigned dg = ((unsigned)it[k].kv >> shift) & 255u;
+      const unsigned long long peers = wave_match8(dg, valid);
+      if (valid && (peers & lanemask_lt()) == 0) hist[w][dg] += __popcll(peers);
+    }
   }
   if (u < A.U)
     for (int e = lane; e < 256; e += kWave) A.cnt[((size_t)t * A.U + u) * 256 + e] = hist[w][e];
@@ -683,26 +692,49 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
   const bool pivot = (t == 1);
   const CoreDec ct = core_dec(d, t);
   // pass 0 re-derives the key from the index (cheaper than chasing key[i] behind the count launch's store)
-  MbItem nx = mb_load(beg + lane, beg + lane < end, A.pass, ct, indices, tableidx, src, key);
-  for (int base = beg; base < end; base += kWave) {
-    const MbItem it = nx;
-    const int i = base + lane;
-    const bool valid = i < end;
-    nx = mb_load(i + kWave, i + kWave < end, A.pass, ct, indices, tableidx, src, key);
-    const unsigned dg = ((unsigned)it.kv >> shift) & 255u;
-    const unsigned long long peers = wave_match8(dg, valid);
-    if (valid) {
-      const int before = run[w][dg];
-      const int pos = before + __popcll(peers & lanemask_lt());
-      if (!(last && pivot)) dst[pos] = it.val;  // the pivot's final order lives in lrec.x
-      if (last) {
-        sk[pos] = it.kv;
-        if (pivot) {
-          P.lrec[pos] = make_int4(it.val, P.sid[0][it.val], d.T > 2 ? P.sid[2][it.val] : 0, d.T > 3 ? P.sid[3][it.val] : 0);
-          if (rowidx) P.lrow[pos] = (int)rowidx[it.val];
+  for (int base = beg; base < end; base += kSB * kWave) {
+    MbItem it[kSB];
+    int4 rec[kSB];
+    int brow[kSB];
+#pragma unroll
+    for (int k = 0; k < kSB; ++k) {
+      const int i = base + k * kWave + lane;
+      it[k] = mb_load(i, i < end, A.pass, ct, indices, tableidx, src, key);
+    }
+    if (last && pivot) {  // the record gathers of the whole super-batch, in flight together
+#pragma unroll
+      for (int k = 0; k < kSB; ++k) {
+        const int i = base + k * kWave + lane;
+        const int v = it[k].val;
+        rec[k] = make_int4(v, 0, 0, 0);
+        brow[k] = 0;
+        if (i < end) {
+          rec[k].y = P.sid[0][v];
+          rec[k].z = d.T > 2 ? P.sid[2][v] : 0;
+          rec[k].w = d.T > 3 ? P.sid[3][v] : 0;
+          if (rowidx) brow[k] = (int)rowidx[v];
         }
       }
-      if ((peers & lanemask_lt()) == 0) run[w][dg] = before + __popcll(peers);
+    }
+#pragma unroll
+    for (int k = 0; k < kSB; ++k) {
+      const int i = base + k * kWave + lane;
+      const bool valid = i < end;
+      const unsigned dg = ((unsigned)it[k].kv >> shift) & 255u;
+      const unsigned long long peers = wave_match8(dg, valid);
+      if (valid) {
+        const int before = run[w][dg];
+        const int pos = before + __popcll(peers & lanemask_lt());
+        if (!(last && pivot)) dst[pos] = it[k].val;  // the pivot's final order lives in lrec.x
+        if (last) {
+          sk[pos] = it[k].kv;
+          if (pivot) {
+            P.lrec[pos] = rec[k];
+            if (rowidx) P.lrow[pos] = brow[k];
+          }
+        }
+        if ((peers & lanemask_lt()) == 0) run[w][dg] = before + __popcll(peers);
+      }
     }
   }
 }
