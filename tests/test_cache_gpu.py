@@ -236,3 +236,61 @@ def test_lookup_prologue_equals_separate_calls(tables, p, B, pf, std, H):
     g = O.make_geom(tables, p, q, r)
     ref = O.tt_forward(g, Bq, D, idx, orow, otab, [c.cpu().numpy() for c in cores])
     assert_close(o1.cpu().numpy(), ref, "prologue plan forward vs oracle")
+
+
+@pytest.mark.parametrize("n_live", [0, 1, 777, 3000])
+def test_device_side_counts_equal_exact_sizes(n_live):
+    """include/ttx.h 'device-side counts': a plan built by ttx_plan_build_n for nnz_dev = n_live out of an
+    upper bound nnz, and the cache kernels driven by skip_dev, give what the exact-size calls give."""
+    import ctypes as C
+
+    import tt_embeddings as E
+
+    L = E.lib()
+    vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
+    L.ttx_plan_build_n.argtypes = [C.POINTER(E._Geom), i64, vp, vp, vp, vp, vp, sz, vp]
+    L.ttx_cache_forward_n.argtypes = [i32, i64, vp, vp, vp, i32, vp, vp, vp]
+    L.ttx_cache_backward_sgd_n.argtypes = [i64, vp, i32, vp, vp, vp, C.c_float, vp, vp]
+    p, q, r = [20, 22, 25], [4, 4, 4], [1, 16, 16, 1]
+    E_, D, B, nnz = 20 * 22 * 25, 64, 150, 3000
+    rs = np.random.RandomState(n_live)
+    idx = t(rs.randint(0, E_, size=nnz).astype(np.int64))
+    rowidx = t(np.sort(rs.randint(0, B, size=nnz)).astype(np.int64))
+    tableidx = torch.zeros(nnz, dtype=torch.int64, device=DEV)
+    cores = [t(c) for c in G.make_cores(4, 1, p, q, r[1:-1], "signed")]
+    Lt = torch.tensor([22 * 25, 25, 1], dtype=torch.int64, device=DEV)
+    g = E._geom(1, p, q, r)
+    st = torch.cuda.current_stream().cuda_stream
+    n_dev = torch.tensor([n_live], dtype=torch.int32, device=DEV)
+    # forward through a plan built with the device-side count
+    pb = L.ttx_plan_bytes(C.byref(g), nnz)
+    buf = torch.empty(pb, dtype=torch.uint8, device=DEV)
+    assert L.ttx_plan_build_n(C.byref(g), nnz, n_dev.data_ptr(), idx.data_ptr(), tableidx.data_ptr(), rowidx.data_ptr(),
+                              buf.data_ptr(), pb, st) == 0, L.ttx_last_error()
+    plan = E.Plan(buf, nnz, None)
+    out_n = E.tt_forward(1000, 1, B, D, p, q, r, Lt, nnz, idx, rowidx, tableidx, cores, plan=plan)
+    out_x = E.tt_forward(1000, 1, B, D, p, q, r, Lt, n_live, idx, rowidx, tableidx, cores)
+    assert torch.equal(out_n, out_x)
+    # fused SGD through the same plan
+    d_out = t(G.make_grad(5, 1, B, D))
+    ca, cb = [c.clone() for c in cores], [c.clone() for c in cores]
+    E.tt_sgd_backward(1000, D, 0.1, p, q, r, Lt, nnz, idx, rowidx, tableidx, d_out, ca, plan=plan)
+    E.tt_sgd_backward(1000, D, 0.1, p, q, r, Lt, n_live, idx, rowidx, tableidx, d_out, cb)
+    for a, b in zip(ca, cb):
+        assert torch.equal(a, b)
+    # cache gather / SGD scatter on the entries behind the split point
+    rows = 500
+    loc = t(rs.randint(0, rows, size=nnz).astype(np.int32))
+    w = torch.rand(rows, D, device=DEV)
+    o1, o2 = torch.zeros(B, D, device=DEV), torch.zeros(B, D, device=DEV)
+    assert L.ttx_cache_forward_n(B, nnz, n_dev.data_ptr(), loc.data_ptr(), rowidx.data_ptr(), D, w.data_ptr(),
+                                 o1.data_ptr(), st) == 0
+    if nnz - n_live:
+        E.cache_forward(B, nnz - n_live, loc[n_live:], rowidx[n_live:], w, o2)
+    assert torch.equal(o1, o2)
+    w1, w2 = w.clone(), w.clone()
+    gr = t(G.make_grad(6, 1, B, D)[0])
+    assert L.ttx_cache_backward_sgd_n(nnz, n_dev.data_ptr(), D, gr.data_ptr(), loc.data_ptr(), rowidx.data_ptr(), 0.1,
+                                      w1.data_ptr(), st) == 0
+    E.cache_backward_sgd(nnz - n_live, gr, loc[n_live:], rowidx[n_live:], 0.1, w2)
+    assert_close(w1.cpu().numpy(), w2.cpu().numpy(), "cache SGD scatter behind a device-side split point")
