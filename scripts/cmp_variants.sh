@@ -1,6 +1,7 @@
 #!/bin/bash
-# scripts/cmp_variants.sh name1 name2 ... : bench each variant (hipGraph value + kernel breakdown)
+# scripts/cmp_variants.sh "<bench args>" name1 name2 ... : bench each variant build (variants/libttx_<name>.so)
+ARGS=$1; shift
 for v in "$@"; do
-  TTX_LIB=$(pwd)/variants/libttx_$v.so python bench.py --steps 300 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | \
+  TTX_NO_NATIVE_NODE=1 TTX_LIB=$(pwd)/variants/libttx_$v.so python bench.py $ARGS --no-cpu-baseline 2>&1 | tail -1 | \
     python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], d['kernel_us'])"
 done
