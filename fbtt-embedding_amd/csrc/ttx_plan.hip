@@ -492,7 +492,7 @@ __device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg,
   const int packed = (nf << 12) | np;              // slices <= 256: np sums stay < 4096
   const int cinc = wave_incl_scan(packed);
   __syncthreads();
-  if (lane == kWave - 1) wt5[w] = cinc;
+  if (lane == kWave - 1 && w < kMbUnits) wt5[w] = cinc;  // (digits live in the first 256 threads)
   __syncthreads();
   int cb = 0, call = 0;
   for (int k = 0; k < kMbUnits; ++k) { const int v = wt5[k]; if (k < w) cb += v; call += v; }
@@ -506,7 +506,7 @@ __device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg,
     for (int j = 0; j < nf; ++j) P.chunk_rec[fbase + j] = make_int4(dg, dbase + j * MC, MC, ex + j);
     if (np) P.chunk_rec[ftot + pbase] = make_int4(dg, dbase + nf * MC, pr, ex + nf);
   }
-  for (int cc = ctot + dg; cc < P.max_chunks; cc += kMbThreads) P.chunk_rec[cc] = make_int4(0, 0, 0, 0);
+  for (int cc = ctot + dg; cc < P.max_chunks; cc += blockDim.x) P.chunk_rec[cc] = make_int4(0, 0, 0, 0);
   if (dg == 0) {
     P.chunk_off[S] = ctot;
     P.hdr[0] = ctot;
@@ -535,11 +535,13 @@ struct Prologue {
   int64_t* hashtbl;
   int64_t* cache_freq;
 };
+constexpr int kOneThreads = 1024;                 // 16 waves: the histogram of all N keys is 4x shorter per thread
+constexpr int kOneWaves = kOneThreads / kWave;
 template <bool PRO>
-__global__ __launch_bounds__(kMbThreads) void mb_single_kernel(
+__global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
     Dims d, int Nmax, const int* __restrict__ n_dev, const int64_t* __restrict__ indices,
     const int64_t* __restrict__ tableidx, const int64_t* __restrict__ rowidx, Plan P, Prologue pg) {
-  __shared__ int htot[256], hbef[256], hrun[kMbUnits][256];
+  __shared__ int htot[256], hbef[256], hrun[kOneWaves][256];
   const int N = live_n(Nmax, n_dev);
   __shared__ int wt5[kMbUnits + 1];
   __shared__ int offs[PRO ? kProMaxBags + 1 : 1];
@@ -549,27 +551,25 @@ __global__ __launch_bounds__(kMbThreads) void mb_single_kernel(
   if (PRO) {
     tableidx = nullptr;
     if (t <= 1)  // only core 0 (rowidx out) and the pivot (lrow) need bag rows
-      for (int e = tid; e <= pg.nb; e += kMbThreads) offs[e] = (int)min(pg.offsets[e], (int64_t)0x7fffffff);
+      for (int e = tid; e <= pg.nb; e += kOneThreads) offs[e] = (int)min(pg.offsets[e], (int64_t)0x7fffffff);
   }
-  htot[tid] = 0;
-  hbef[tid] = 0;
-#pragma unroll
-  for (int k = 0; k < kMbUnits; ++k) hrun[k][tid] = 0;
+  if (tid < 256) { htot[tid] = 0; hbef[tid] = 0; }
+  for (int e = tid; e < kOneWaves * 256; e += kOneThreads) (&hrun[0][0])[e] = 0;
   __syncthreads();
-  const int bbeg = blockIdx.x * (kMbUnits * kOneUnit), bend = min(N, bbeg + kMbUnits * kOneUnit);
-  constexpr int kU = 16;  // loads in flight per thread (every work-group reads all N indices: latency, not bandwidth)
-  for (int i0 = tid; i0 < N; i0 += kMbThreads * kU) {
+  const int bbeg = blockIdx.x * (kOneWaves * kOneUnit), bend = min(N, bbeg + kOneWaves * kOneUnit);
+  constexpr int kU = 4;  // loads in flight per thread (every work-group reads all N indices: latency, not bandwidth)
+  for (int i0 = tid; i0 < N; i0 += kOneThreads * kU) {
     long long ix[kU];
     int tb[kU];
 #pragma unroll
     for (int j = 0; j < kU; ++j) {
-      const int i = i0 + j * kMbThreads;
+      const int i = i0 + j * kOneThreads;
       ix[j] = i < N ? indices[i] : 0;
       tb[j] = (i < N && tableidx) ? (int)tableidx[i] : 0;
     }
 #pragma unroll
     for (int j = 0; j < kU; ++j) {
-      const int i = i0 + j * kMbThreads;
+      const int i = i0 + j * kOneThreads;
       if (i < N) {
         const int kv = min(tb[j] * ct.p + decode_core(ct, ix[j]), 255);  // tableidx is not validated
         atomicAdd(&htot[kv], 1);
@@ -579,20 +579,25 @@ __global__ __launch_bounds__(kMbThreads) void mb_single_kernel(
     }
   }
   __syncthreads();
+  // digit dg = tid (first 256 threads): total, exclusive prefix over digits, first position per wave
   const int dg = tid;
-  const int tot = htot[dg];
+  const bool isd = tid < 256;
+  const int tot = isd ? htot[dg] : 0;
   const int inc = wave_incl_scan(tot);
-  if (lane == kWave - 1) wt5[w] = inc;
-  int mine[kMbUnits];
+  if (isd && lane == kWave - 1) wt5[w] = inc;
+  int mine[kOneWaves];
 #pragma unroll
-  for (int k = 0; k < kMbUnits; ++k) mine[k] = hrun[k][dg];
+  for (int k = 0; k < kOneWaves; ++k) mine[k] = isd ? hrun[k][dg] : 0;
   __syncthreads();
   int wbase = 0;
-  for (int k = 0; k < w; ++k) wbase += wt5[k];
+  if (isd)
+    for (int k = 0; k < w; ++k) wbase += wt5[k];
   const int dbase = wbase + inc - tot;
-  int b = dbase + hbef[dg];
+  if (isd) {
+    int b = dbase + hbef[dg];
 #pragma unroll
-  for (int k = 0; k < kMbUnits; ++k) { hrun[k][dg] = b; b += mine[k]; }
+    for (int k = 0; k < kOneWaves; ++k) { hrun[k][dg] = b; b += mine[k]; }
+  }
   __syncthreads();
   if (blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, N, PRO || rowidx != nullptr, P, wt5);
   // rank + scatter this wave's 64 positions
@@ -805,8 +810,8 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
     }
   }
   if (maxp == 1 && N <= kOneMaxN) {
-    hipLaunchKernelGGL(mb_single_kernel<false>, dim3((N + kMbUnits * kOneUnit - 1) / (kMbUnits * kOneUnit), d.T),
-                       dim3(kMbThreads), 0, stream, d, N, n_dev, indices, tableidx, rowidx, P, Prologue{});
+    hipLaunchKernelGGL(mb_single_kernel<false>, dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit), d.T),
+                       dim3(kOneThreads), 0, stream, d, N, n_dev, indices, tableidx, rowidx, P, Prologue{});
     TTX_HIP(hipGetLastError());
     return TTX_OK;
   }
@@ -879,8 +884,8 @@ bool prologue_fusable(const Dims& d, long long nnz, long long nb) {
 
 int prologue_launch(const Dims& d, int N, const int64_t* indices, const Prologue& pg, const Plan& P, hipStream_t stream) {
   ProfScope ps(TTX_PROF_PLAN, stream);
-  hipLaunchKernelGGL(mb_single_kernel<true>, dim3((N + kMbUnits * kOneUnit - 1) / (kMbUnits * kOneUnit), d.T),
-                     dim3(kMbThreads), 0, stream, d, N, (const int*)nullptr, indices, nullptr, nullptr, P, pg);
+  hipLaunchKernelGGL(mb_single_kernel<true>, dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit), d.T),
+                     dim3(kOneThreads), 0, stream, d, N, (const int*)nullptr, indices, nullptr, nullptr, P, pg);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }
