@@ -63,9 +63,15 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
   static Tensor forward(AutogradContext* ctx, const Tensor& indices, const Tensor& offsets, int64_t num_tables,
                         std::vector<int64_t> p, std::vector<int64_t> q, std::vector<int64_t> r, int64_t optim,
                         double lr, double eps, const c10::optional<Tensor>& hashtbl,
-                        const c10::optional<Tensor>& cache_freq, at::TensorList state, at::TensorList cores) {
+                        const c10::optional<Tensor>& cache_freq, const c10::optional<Tensor>& psw,
+                        at::TensorList state, at::TensorList cores) {
     const ttx_geom g = make_geom(num_tables, p, q, r);
     check_cores(g, cores, "tt_cores");
+    const bool weighted = psw.has_value() && psw->defined();
+    if (weighted)
+      TORCH_CHECK(psw->is_cuda() && psw->scalar_type() == at::kFloat && psw->is_contiguous() &&
+                      psw->numel() == indices.numel(),
+                  "tt_embeddings: per_sample_weights must be a contiguous float32 GPU tensor, one weight per index");
     TORCH_CHECK(indices.is_cuda() && indices.scalar_type() == at::kLong && indices.is_contiguous() &&
                     offsets.is_cuda() && offsets.scalar_type() == at::kLong && offsets.is_contiguous(),
                 "tt_embeddings: indices / offsets must be contiguous int64 GPU tensors");
@@ -96,10 +102,11 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
     for (int t = 0; t < g.T; ++t) cp[t] = cores[t].data_ptr<float>();
     const size_t wb = ttx_tt_forward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
     Tensor ws = bytes_on(indices, wb);
-    check(ttx_tt_forward(&g, (int32_t)B, (int32_t)D, nnz, indices.data_ptr<int64_t>(), rowidx.data_ptr<int64_t>(),
-                         tableidx.data_ptr<int64_t>(), cp, out.data_ptr<float>(), nnz > 0 ? plan.data_ptr() : nullptr,
-                         ws.data_ptr(), wb, stream));
+    check(ttx_tt_forward_w(&g, (int32_t)B, (int32_t)D, nnz, indices.data_ptr<int64_t>(), rowidx.data_ptr<int64_t>(),
+                           tableidx.data_ptr<int64_t>(), weighted ? psw->data_ptr<float>() : nullptr, cp,
+                           out.data_ptr<float>(), nnz > 0 ? plan.data_ptr() : nullptr, ws.data_ptr(), wb, stream));
 
+    if (weighted) ctx->saved_data["psw"] = psw->detach();
     ctx->saved_data["p"] = p;
     ctx->saved_data["q"] = q;
     ctx->saved_data["r"] = r;
@@ -135,8 +142,9 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
     const int64_t nnz = indices.numel();
 
     // one slot per forward argument (lists expanded): indices, offsets, num_tables, p, q, r, optim, lr, eps,
-    // hashtbl, cache_freq, state.., cores..
-    constexpr int64_t kHead = 11;
+    // hashtbl, cache_freq, per_sample_weights, state.., cores..
+    constexpr int64_t kHead = 12;
+    const Tensor psw = ctx->saved_data.count("psw") ? ctx->saved_data["psw"].toTensor() : Tensor();
     variable_list grads(kHead + nstate + T);
     Tensor go = grad_outputs[0];
     TORCH_CHECK(go.defined(), "tt_embeddings: backward needs the output gradient");
@@ -161,11 +169,11 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
     }
     const size_t wb = ttx_tt_backward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
     Tensor ws = bytes_on(indices, wb);
-    check(ttx_tt_backward(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz,
-                          indices.data_ptr<int64_t>(), rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
-                          go.data_ptr<float>(), cp, optim == TTX_OPTIM_ADAGRAD ? sp : nullptr,
-                          optim == TTX_OPTIM_DENSE ? gp : nullptr, keep.size() > 3 ? keep[3].data_ptr() : nullptr,
-                          ws.data_ptr(), wb, stream));
+    check(ttx_tt_backward_w(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz,
+                            indices.data_ptr<int64_t>(), rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
+                            psw.defined() ? psw.data_ptr<float>() : nullptr, go.data_ptr<float>(), cp,
+                            optim == TTX_OPTIM_ADAGRAD ? sp : nullptr, optim == TTX_OPTIM_DENSE ? gp : nullptr,
+                            keep.size() > 3 ? keep[3].data_ptr() : nullptr, ws.data_ptr(), wb, stream));
     if (optim == TTX_OPTIM_DENSE)
       for (int t = 0; t < T; ++t) grads[kHead + nstate + t] = dense[t];
     return grads;
@@ -175,10 +183,11 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
 Tensor lookup(const Tensor& indices, const Tensor& offsets, int64_t num_tables, std::vector<int64_t> p,
               std::vector<int64_t> q, std::vector<int64_t> r, int64_t optim, double lr, double eps,
               c10::optional<Tensor> hashtbl, c10::optional<Tensor> cache_freq, std::vector<Tensor> state,
-              std::vector<Tensor> cores) {
-  // autograd.Function::apply wants every tensor it tracks as a plain argument: undefined stands for "none"
+              std::vector<Tensor> cores, c10::optional<Tensor> per_sample_weights) {
+  // (the weights are detached: no gradient flows to them)
+  if (per_sample_weights.has_value() && per_sample_weights->defined()) per_sample_weights = per_sample_weights->detach();
   return TTLookupOp::apply(indices, offsets, num_tables, std::move(p), std::move(q), std::move(r), optim, lr, eps,
-                           hashtbl, cache_freq, at::TensorList(state), at::TensorList(cores));
+                           hashtbl, cache_freq, per_sample_weights, at::TensorList(state), at::TensorList(cores));
 }
 
 // ---- cache live (one table): tt_embeddings_ops.py:821-874 with self.warmup == False ----------------
@@ -340,7 +349,11 @@ Tensor lookup_cached(const Tensor& indices, const Tensor& offsets, std::vector<i
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "native autograd node of the TT lookup (cache not live) over the C ABI of libttx.so";
-  m.def("lookup", &lookup, "prologue + forward; backward = fused optimizer step or dense core gradients");
+  m.def("lookup", &lookup, "prologue + forward; backward = fused optimizer step or dense core gradients",
+        pybind11::arg("indices"), pybind11::arg("offsets"), pybind11::arg("num_tables"), pybind11::arg("p"),
+        pybind11::arg("q"), pybind11::arg("r"), pybind11::arg("optim"), pybind11::arg("lr"), pybind11::arg("eps"),
+        pybind11::arg("hashtbl"), pybind11::arg("cache_freq"), pybind11::arg("state"), pybind11::arg("cores"),
+        pybind11::arg("per_sample_weights") = pybind11::none());
   m.def("lookup_cached", &lookup_cached, "cache-live lookup of one table: partition, contraction of the misses, gather of the hits");
   m.def("abi_version", []() { return ttx_version(); });
 }

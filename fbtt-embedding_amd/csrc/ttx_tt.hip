@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kThreads) void pool_kernel(int Nmax, const int* __r
                                                        const int64_t* __restrict__ rowidx,
                                                        const int64_t* __restrict__ tableidx,
                                                        const float* __restrict__ rows,
-                                                       float* __restrict__ out) {
+                                                       const float* __restrict__ psw, float* __restrict__ out) {
   const int n = blockIdx.x * (kThreads / 32) + threadIdx.x / 32;
   const int l = threadIdx.x & 31;
   const int N = min(Nmax, hdr[2]);  // the plan knows how many lookups are live (device-side counts)
@@ -488,6 +488,14 @@ __global__ __launch_bounds__(kThreads) void pool_kernel(int Nmax, const int* __r
   }
   float* o = out + ((size_t)tb * B + r) * D;
   const float* src = rows + (size_t)n * D;
+  if (psw) {  // weighted sum (per_sample_weights), same order
+    for (int e = l; e < D; e += 32) {
+      float acc = o[e];
+      for (int j = 0; j < sl; ++j) acc = fmaf(psw[n + j], src[(size_t)j * D + e], acc);
+      o[e] = acc;
+    }
+    return;
+  }
   for (int e = l; e < D; e += 32) {
     float acc = o[e];
     int j = 0;
@@ -503,6 +511,8 @@ __global__ __launch_bounds__(kThreads) void pool_kernel(int Nmax, const int* __r
 
 struct Partials {
   float* pc[TTX_MAX_CORES];  // pc[1] is per CHUNK, the others per lookup
+  const float* psw;          // per_sample_weights by lookup (nn.EmbeddingBag), or NULL: the bag gradient of
+                             // lookup n enters the backward scaled by psw[n]
 };
 
 // ---- backward tail stage, fused: for one (lookup, column kk) pair walk the rows once,
@@ -753,7 +763,8 @@ __device__ __forceinline__ void bwd_pass_front(const Dims& d, const CorePtrs& C,
       unsigned rem, col;
       const unsigned jl = fdivmod((unsigned)e, L.fdD, rem);
       const unsigned a = fdivmod(rem, L.fdN1, col);
-      X0[(jl * q0 + a) * L.ld + col] = d_output[((size_t)table * B + rowidx[I[j0 + jl].x]) * D + rem];
+      X0[(jl * q0 + a) * L.ld + col] = d_output[((size_t)table * B + rowidx[I[j0 + jl].x]) * D + rem] *
+                                       (PC.psw ? PC.psw[I[j0 + jl].x] : 1.f);
     }
     __syncthreads();
     return;
@@ -864,13 +875,15 @@ __global__ __launch_bounds__(kThreads, 3) void bwd_kernel(Dims d, Plan P, CorePt
       for (int e = tid; e < len * d4; e += kThreads) {
         unsigned rem;
         const unsigned j = fdivmod((unsigned)e, L.fdD4, rem);
-        ((float4*)Gb)[e] = ((const float4*)(d_output + ((size_t)table * B + rowidx[I[j].x]) * D))[rem];
+        float4 gq = ((const float4*)(d_output + ((size_t)table * B + rowidx[I[j].x]) * D))[rem];
+        if (PC.psw) { const float sw = PC.psw[I[j].x]; gq.x *= sw; gq.y *= sw; gq.z *= sw; gq.w *= sw; }
+        ((float4*)Gb)[e] = gq;
       }
     } else {
       for (int e = tid; e < len * D; e += kThreads) {
         unsigned rem;
         const unsigned j = fdivmod((unsigned)e, L.fdD, rem);
-        Gb[e] = d_output[((size_t)table * B + rowidx[I[j].x]) * D + rem];
+        Gb[e] = d_output[((size_t)table * B + rowidx[I[j].x]) * D + rem] * (PC.psw ? PC.psw[I[j].x] : 1.f);
       }
     }
     // (visible to the tail after the barrier that follows the first GEMM)
@@ -1142,6 +1155,14 @@ int ttx_tt_forward(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const i
                    const int64_t* rowidx, const int64_t* tableidx, const float* const* tt_cores,
                    float* output, const void* plan, void* workspace, size_t workspace_bytes,
                    ttx_stream_t stream) {
+  return ttx_tt_forward_w(g, B, D, nnz, indices, rowidx, tableidx, nullptr, tt_cores, output, plan, workspace,
+                          workspace_bytes, stream);
+}
+
+int ttx_tt_forward_w(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const int64_t* indices,
+                     const int64_t* rowidx, const int64_t* tableidx, const float* psw,
+                     const float* const* tt_cores, float* output, const void* plan, void* workspace,
+                     size_t workspace_bytes, ttx_stream_t stream) {
   Dims d;
   int rc = make_dims(g, &d);
   if (rc) return rc;
@@ -1175,7 +1196,7 @@ int ttx_tt_forward(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const i
     ProfScope ps(TTX_PROF_POOL, st);
     const int groups = kThreads / 32;
     hipLaunchKernelGGL(pool_kernel, dim3(((int)nnz + groups - 1) / groups), dim3(kThreads), 0, st,
-                       (int)nnz, P.hdr, B, d.D, rowidx, tableidx, rows, output);
+                       (int)nnz, P.hdr, B, d.D, rowidx, tableidx, rows, psw, output);
     TTX_HIP(hipGetLastError());
   }
   return TTX_OK;
@@ -1224,6 +1245,15 @@ int ttx_tt_backward(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, floa
                     const int64_t* tableidx, const float* d_output, float* const* tt_cores,
                     float* const* optimizer_state, float* const* d_tt_cores, const void* plan,
                     void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
+  return ttx_tt_backward_w(g, optim, B, D, lr, eps, nnz, indices, rowidx, tableidx, nullptr, d_output, tt_cores,
+                           optimizer_state, d_tt_cores, plan, workspace, workspace_bytes, stream);
+}
+
+int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, float lr, float eps,
+                      int64_t nnz, const int64_t* indices, const int64_t* rowidx,
+                      const int64_t* tableidx, const float* psw, const float* d_output,
+                      float* const* tt_cores, float* const* optimizer_state, float* const* d_tt_cores,
+                      const void* plan, void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
   Dims d;
   int rc = make_dims(g, &d);
   if (rc) return rc;
@@ -1259,6 +1289,7 @@ int ttx_tt_backward(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, floa
   }
   Partials PC;
   for (int t = 0; t < TTX_MAX_CORES; ++t) PC.pc[t] = t < d.T ? (float*)(ws + offs[t]) : nullptr;
+  PC.psw = psw;
   CorePtrs C, S, DW;
   for (int t = 0; t < TTX_MAX_CORES; ++t) {
     C.c[t] = t < d.T ? tt_cores[t] : nullptr;

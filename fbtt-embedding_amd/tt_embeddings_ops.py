@@ -20,7 +20,15 @@ Deliberate differences (each is a superset or a fix):
     it on the CPU, :582-585); `reset_cache()` works (:795 has a typo);
     `get_params()` does not grow the ParameterList on every call (:882-886);
   * fused optimizers update every looked-up slice (the reference's apply-kernel
-    grid skips rows).
+    grid skips rows, SURVEY.md 0.5);
+  * nn.EmbeddingBag call forms: ctor keyword `include_last_offset` (default True =
+    the reference's form), int32 indices / offsets, forward keyword
+    `per_sample_weights`;
+  * when ttx_torch.so is built the lookup runs as a C++ autograd node (same C ABI
+    calls as TTLookupFunction below, which stays the reference-shaped route); with a
+    live cache that node keeps the partition's split point on the device instead of
+    reading it back every step, and in dense mode it always returns a (possibly zero)
+    gradient for cache_weight.
 """
 import itertools
 import logging
@@ -450,7 +458,13 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         which uses self.warmup, :822,:841.)  int32 indices / offsets are accepted; with
         include_last_offset=False the closing offset (nnz) is appended here."""
         if per_sample_weights is not None:
-            raise NotImplementedError("TT embedding bags pool with plain sums (mode='sum' without per_sample_weights)")
+            # nn.EmbeddingBag(mode="sum") semantics, forward and the cores' gradients; no gradient to the weights.
+            # Served by the C++ node while the cache is not live (cache rows are gathered unweighted).
+            if _native_node() is None or not self.warmup or not indices.is_cuda:
+                raise NotImplementedError("per_sample_weights needs ttx_torch.so and a cache that is not live")
+            if per_sample_weights.shape != indices.shape:
+                raise ValueError("per_sample_weights must have the shape of indices")
+            per_sample_weights = per_sample_weights.detach().float().contiguous()
         if indices.dim() != 1 or offsets.dim() != 1:
             raise ValueError("indices and offsets must be 1-D (the 2-D fixed-length form of nn.EmbeddingBag is not supported)")
         indices, offsets = indices.long(), offsets.long()
@@ -468,7 +482,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             return fast.lookup(indices.contiguous(), offsets.contiguous(), self.num_tables, self.tt_p_shapes,
                                self.tt_q_shapes, self.tt_ranks, optim, self.learning_rate, self.eps,
                                self.hashtbl if self.use_cache else None, self.cache_freq if self.use_cache else None,
-                               list(self.optimizer_state) if use_state else [], list(self.tt_cores))
+                               list(self.optimizer_state) if use_state else [], list(self.tt_cores), per_sample_weights)
         if (fast is not None and not self.warmup and self.use_cache and self.num_tables == 1 and indices.is_cuda
                 and indices.numel() > 0):
             # cache live: frequency update + hash lookup + stable partition (one host read-back), contraction of

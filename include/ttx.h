@@ -97,6 +97,15 @@ int ttx_tt_forward(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz,
                    float* output, const void* plan, void* workspace,
                    size_t workspace_bytes, ttx_stream_t stream);
 
+/* nn.EmbeddingBag's per_sample_weights (not in the reference): lookup n enters its
+ * bag scaled by per_sample_weights[n], and its share of the bag gradient is scaled the same way in
+ * ttx_tt_backward_w.  NULL = the plain entry point.  (No gradient with respect to the weights.) */
+int ttx_tt_forward_w(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz,
+                     const int64_t* indices, const int64_t* rowidx, const int64_t* tableidx,
+                     const float* per_sample_weights, const float* const* tt_cores,
+                     float* output, const void* plan, void* workspace, size_t workspace_bytes,
+                     ttx_stream_t stream);
+
 /* decompress rows: rows[n, :] = TT row of indices[n] in table tableidx[n]
  * (tableidx == NULL -> table 0).  This is the contraction alone, the part of
  * prefetch_cached_weights_cuda (tt_embeddings_cuda.cu:1156-1258) that fills
@@ -127,6 +136,14 @@ int ttx_tt_backward(const ttx_geom* g, int32_t optim, int32_t B, int32_t D,
                     float* const* tt_cores, float* const* optimizer_state,
                     float* const* d_tt_cores, const void* plan, void* workspace,
                     size_t workspace_bytes, ttx_stream_t stream);
+
+int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D,
+                      float learning_rate, float eps, int64_t nnz, const int64_t* indices,
+                      const int64_t* rowidx, const int64_t* tableidx,
+                      const float* per_sample_weights, const float* d_output,
+                      float* const* tt_cores, float* const* optimizer_state,
+                      float* const* d_tt_cores, const void* plan, void* workspace,
+                      size_t workspace_bytes, ttx_stream_t stream);
 
 /* ------------------------------------------------------ software cache -----
  * replaces update_cache_state_cuda (tt_embeddings.cpp:74,

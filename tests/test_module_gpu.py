@@ -174,3 +174,47 @@ def test_inference_no_grad_and_empty_batch():
     out = m(torch.empty(0, dtype=torch.int32, device=DEV), torch.zeros(9, dtype=torch.int32, device=DEV))
     out.sum().backward()
     assert all(float(c.grad.abs().max()) == 0.0 for c in m.tt_cores)
+
+
+@pytest.mark.parametrize("p,q,r", [([6, 5, 7], [4, 4, 4], [16, 16]), ([7, 9, 11], [3, 4, 5], [13, 12]), ([5, 8], [3, 4], [6])])
+def test_per_sample_weights_vs_nn_embedding_bag(node, p, q, r):
+    """nn.EmbeddingBag(mode='sum', per_sample_weights=...) semantics -- forward and the
+    cores' gradients against torch's own embedding_bag + autograd on the expanded table; fused SGD = one
+    step along that gradient.  (Specialised and generic kernels, T = 2 and 3.)"""
+    import tt_embeddings_ops as ops
+
+    E_, D, B = int(np.prod(p)), int(np.prod(q)), 37
+    rs = np.random.RandomState(3)
+    idx, off = G.make_bags(5, B, E_, 6, 3, 1)
+    psw = rs.rand(idx.size).astype(np.float32) * 2 - 0.5
+    cores = G.make_cores(8, 1, p, q, r, "signed")
+    d_out = G.make_grad(9, 1, B, D)[0]
+    kw = dict(use_cache=False, weight_dist="uniform", device=DEV)
+
+    def fresh(**extra):
+        m = ops.TTEmbeddingBag(E_, D, r, p, q, **kw, **extra)
+        with torch.no_grad():
+            for dst, src in zip(m.tt_cores, cores):
+                dst.copy_(t(src))
+        return m
+
+    m = fresh(sparse=False)
+    if node == "python":
+        with pytest.raises(NotImplementedError):
+            m(t(idx), t(off), per_sample_weights=t(psw))
+        return
+    out = m(t(idx), t(off), per_sample_weights=t(psw))
+    # torch reference on the expanded table (differentiable through tt_matrix_to_full)
+    ref_cores = [t(c).clone().requires_grad_(True) for c in cores]
+    full = ops.tt_matrix_to_full(p, q, [1] + r + [1], ref_cores, [1, 0, 2, 3])
+    ref = torch.nn.functional.embedding_bag(t(idx), full, t(off), mode="sum", per_sample_weights=t(psw),
+                                            include_last_offset=True)
+    assert_close(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), "weighted forward")
+    out.backward(t(d_out))
+    ref.backward(t(d_out))
+    for k in range(len(p)):
+        assert_close(m.tt_cores[k].grad.cpu().numpy(), ref_cores[k].grad.cpu().numpy(), f"weighted grad{k}")
+    ms = fresh(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=LR)
+    ms(t(idx), t(off), per_sample_weights=t(psw)).backward(t(d_out))
+    for k in range(len(p)):
+        assert_close(ms.tt_cores[k].detach().cpu().numpy(), cores[k] - LR * ref_cores[k].grad.cpu().numpy(), f"weighted sgd{k}")
