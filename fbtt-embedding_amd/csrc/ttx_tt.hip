@@ -930,11 +930,13 @@ __device__ __forceinline__ float apply_one(int optim, float g, float w, float lr
 // (V = lanes covering the slice, 4 floats per lane); group g sums partials g,
 // g+G, .. in index order, the G group sums are then added in group order
 // through LDS.  Long slices: 4 floats per thread, partials summed in order.
-__global__ __launch_bounds__(kThreads) void reduce_apply_kernel(Dims d, Plan P, Partials PC,
+constexpr int kReduceThreads = 1024;  // upper bound; launched with 512 when the largest slice is <= 4096 floats
+__global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Plan P, Partials PC,
                                                                int optim, float lr, float eps,
                                                                CorePtrs W, CorePtrs St,
                                                                CorePtrs DW) {
-  __shared__ float4 red[kThreads];
+  __shared__ float4 red[kReduceThreads];
+  const int nthreads = blockDim.x;
   int b = blockIdx.x;
   int t = 0;
   while (t < d.T - 1 && b >= d.S[t]) { b -= d.S[t]; ++t; }
@@ -951,16 +953,19 @@ __global__ __launch_bounds__(kThreads) void reduce_apply_kernel(Dims d, Plan P, 
   float* __restrict__ stt = St.c[t];
   if (beg == end) {
     if (optim == TTX_OPTIM_DENSE)
-      for (int e = tid; e < sl; e += kThreads) dw[base + e] = 0.f;
+      for (int e = tid; e < sl; e += nthreads) dw[base + e] = 0.f;
     return;
   }
   const float* __restrict__ pc = PC.pc[t];
   const int cnt = end - beg;
   if ((sl & 3) == 0) {
     const int V = sl / 4;  // float4 lanes per partial row
-    if (V <= kThreads / 2 && cnt >= 4) {
-      int G = kThreads / V;
-      if (G > cnt) G = cnt;
+    if (V <= nthreads / 2 && cnt >= 4) {
+      // G groups of V lanes share the slice's partial rows; at least 8 rows per group, so a short list
+      // stays with few groups (cheap final fold) and a hot slice (thousands of rows under a skewed
+      // stream) gets all 1024 threads
+      int G = nthreads / V;
+      if (G > cnt / 8) G = cnt / 8 > 0 ? cnt / 8 : 1;
       const int g = tid / V, v = tid - g * V;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       if (g < G) {
@@ -1007,9 +1012,21 @@ __global__ __launch_bounds__(kThreads) void reduce_apply_kernel(Dims d, Plan P, 
       }
       return;
     }
-    for (int v = tid; v < V; v += kThreads) {
+    for (int v = tid; v < V; v += nthreads) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i = beg; i < end; ++i) {
+      int i = beg;
+      for (; i + 3 < end; i += 4) {  // four partial rows in flight
+        size_t r0, r1, r2, r3;
+        if (list) { r0 = list[i]; r1 = list[i + 1]; r2 = list[i + 2]; r3 = list[i + 3]; }
+        else { r0 = i; r1 = i + 1; r2 = i + 2; r3 = i + 3; }
+        const float4 x0 = ((const float4*)(pc + r0 * sl))[v], x1 = ((const float4*)(pc + r1 * sl))[v];
+        const float4 x2 = ((const float4*)(pc + r2 * sl))[v], x3 = ((const float4*)(pc + r3 * sl))[v];
+        acc.x += x0.x; acc.y += x0.y; acc.z += x0.z; acc.w += x0.w;
+        acc.x += x1.x; acc.y += x1.y; acc.z += x1.z; acc.w += x1.w;
+        acc.x += x2.x; acc.y += x2.y; acc.z += x2.z; acc.w += x2.w;
+        acc.x += x3.x; acc.y += x3.y; acc.z += x3.z; acc.w += x3.w;
+      }
+      for (; i < end; ++i) {
         const size_t row = list ? (size_t)list[i] : (size_t)i;
         const float4 x = ((const float4*)(pc + row * sl))[v];
         acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
@@ -1031,7 +1048,7 @@ __global__ __launch_bounds__(kThreads) void reduce_apply_kernel(Dims d, Plan P, 
     }
     return;
   }
-  for (int e = tid; e < sl; e += kThreads) {
+  for (int e = tid; e < sl; e += nthreads) {
     float g = 0.f;
     for (int i = beg; i < end; ++i) g += pc[(list ? (size_t)list[i] : (size_t)i) * sl + e];
     if (optim == TTX_OPTIM_DENSE) {
@@ -1314,8 +1331,11 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
   {
     int blocks = 0;
     for (int t = 0; t < d.T; ++t) blocks += d.S[t];
+    int smax = 0;
+    for (int t = 0; t < d.T; ++t) smax = d.slice[t] > smax ? d.slice[t] : smax;
+    const int rthreads = smax <= 4096 ? 512 : kReduceThreads;  // (measured: 512 is 1.7 us faster at r = 32, 1024 at r = 64)
     ProfScope ps(TTX_PROF_APPLY, st);
-    hipLaunchKernelGGL(reduce_apply_kernel, dim3(blocks), dim3(kThreads), 0, st, d, P, PC, optim, lr,
+    hipLaunchKernelGGL(reduce_apply_kernel, dim3(blocks), dim3(rthreads), 0, st, d, P, PC, optim, lr,
                        eps, C, S, DW);
     TTX_HIP(hipGetLastError());
   }
