@@ -499,6 +499,13 @@ __global__ __launch_bounds__(kThreads) void pool_kernel(int Nmax, const int* __r
   for (int e = l; e < D; e += 32) {
     float acc = o[e];
     int j = 0;
+    for (; j + 8 <= sl; j += 8) {  // eight rows in flight, added in index order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(j + u) * D + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
     for (; j + 4 <= sl; j += 4) {
       const float v0 = src[(size_t)j * D + e], v1 = src[(size_t)(j + 1) * D + e];
       const float v2 = src[(size_t)(j + 2) * D + e], v3 = src[(size_t)(j + 3) * D + e];
