@@ -48,6 +48,8 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 MFMA/VALU dense peak (MI355X_MICROARCH.m
 WORKLOADS = {
     "cfg2": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "cfg3": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.2, populate=True),
+    # cfg3's index stream before the cache is populated: every hot row goes through the contraction
+    "cfg3warm": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.2, populate=False),
     "cfg4": dict(q=[4, 4, 8], ranks=[64, 64], tables=1, B=512, optimizer="adagrad", alpha=1.0, populate=False),
     # one rank's share of cfg5 at 8 GPUs: 4 of the 26 tables, the whole 4096-bag batch
     # all 26 tables of cfg5 on ONE GPU (2.13 M lookups per step): the table-batched path at scale

@@ -520,7 +520,19 @@ struct Partials {
   float* pc[TTX_MAX_CORES];  // pc[1] is per CHUNK, the others per lookup
   const float* psw;          // per_sample_weights by lookup (nn.EmbeddingBag), or NULL: the bag gradient of
                              // lookup n enters the backward scaled by psw[n]
+  // hot slices (reduce_apply_kernel): arrival counters, one per core slice (zeroed by the backward
+  // contraction kernel), and the segment partial sums, two slots per segment
+  int* hot_cnt;
+  int n_hot_cnt;
+  float* seg[TTX_MAX_CORES];
 };
+
+// zero the hot-slice arrival counters (called by work-group 0 of the backward contraction kernels,
+// which always run right before reduce_apply_kernel on the same stream)
+__device__ __forceinline__ void zero_hot_counters(const Partials& PC) {
+  if (blockIdx.x == 0 && PC.hot_cnt)
+    for (int i = threadIdx.x; i < PC.n_hot_cnt; i += blockDim.x) PC.hot_cnt[i] = 0;
+}
 
 // ---- backward tail stage, fused: for one (lookup, column kk) pair walk the rows once,
 //   d core partial[kk][0..NT) = sum_row x[row][kk] * G[row][0..NT)     -> HBM
@@ -860,6 +872,7 @@ __global__ __launch_bounds__(kThreads, 3) void bwd_kernel(Dims d, Plan P, CorePt
                                                          const float* __restrict__ d_output,
                                                          Partials PC, Lds L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  zero_hot_counters(PC);
   const int chunk = blockIdx.x;
 #define STAMP(i) do { if (L.stamps && threadIdx.x == 0) L.stamps[(size_t)chunk * 16 + (i)] = wall_clock64(); } while (0)
   STAMP(0);
@@ -938,13 +951,193 @@ __device__ __forceinline__ float apply_one(int optim, float g, float w, float lr
 // g+G, .. in index order, the G group sums are then added in group order
 // through LDS.  Long slices: 4 floats per thread, partials summed in order.
 constexpr int kReduceThreads = 1024;  // upper bound; launched with 512 when the largest slice is <= 4096 floats
+constexpr int kSegThin = 512;         // partial rows per segment of a thin core's sorted order
+constexpr int kSegPivot = 32;         // chunk partials per segment of the pivot core
+// A slice is HOT when it holds more than two segments' worth of partials (a skewed index stream puts
+// a third of a batch on one slice): one work-group per SEGMENT then sums its share, and the last one
+// to arrive folds the segment sums in segment order and applies the optimizer -- all other slices keep
+// their single owner.  Deterministic either way (fixed partition, fixed order).
+__device__ __forceinline__ int seg_len(int t) { return t == 1 ? kSegPivot : kSegThin; }
+
+struct ApplyEmit {
+  int optim;
+  float lr, eps;
+  float *wt, *stt, *dw;  // already offset to the slice
+  __device__ __forceinline__ void operator()(int v, float4 acc) const {
+    const size_t o = (size_t)v * 4;
+    if (optim == TTX_OPTIM_DENSE) {
+      *(float4*)(dw + o) = acc;
+    } else {
+      float4 wv = *(const float4*)(wt + o);
+      float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (optim == TTX_OPTIM_ADAGRAD) sv = *(const float4*)(stt + o);
+      wv.x = apply_one(optim, acc.x, wv.x, lr, eps, &sv.x);
+      wv.y = apply_one(optim, acc.y, wv.y, lr, eps, &sv.y);
+      wv.z = apply_one(optim, acc.z, wv.z, lr, eps, &sv.z);
+      wv.w = apply_one(optim, acc.w, wv.w, lr, eps, &sv.w);
+      *(float4*)(wt + o) = wv;
+      if (optim == TTX_OPTIM_ADAGRAD) *(float4*)(stt + o) = sv;
+    }
+  }
+};
+struct StoreEmit {
+  float* dst;
+  __device__ __forceinline__ void operator()(int v, float4 acc) const { ((float4*)dst)[v] = acc; }
+};
+
+// sum rows row(beg) .. row(end-1) of `pc` (sl floats each, sl % 4 == 0) in a fixed order and hand every
+// float4 lane of the result to emit(v, sum).  Whole work-group; contains block barriers.
+template <class RowFn, class Emit>
+__device__ __forceinline__ void sum_rows4(const float* __restrict__ pc, int sl, int beg, int end, float4* red,
+                                          RowFn row, Emit emit) {
+  const int nthreads = blockDim.x, tid = threadIdx.x;
+  const int V = sl / 4, cnt = end - beg;
+  if (V <= nthreads / 2 && cnt >= 4) {
+    // G groups of V lanes share the rows; at least 8 rows per group, so a short list stays with few
+    // groups (cheap final fold) and a long one gets every thread
+    int G = nthreads / V;
+    if (G > cnt / 8) G = cnt / 8 > 0 ? cnt / 8 : 1;
+    const int g = tid / V, v = tid - g * V;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g < G) {
+      int i = beg + g;
+      for (; i + 3 * G < end; i += 4 * G) {  // four rows in flight per lane
+        const size_t r0 = row(i), r1 = row(i + G), r2 = row(i + 2 * G), r3 = row(i + 3 * G);
+        const float4 x0 = ((const float4*)(pc + r0 * sl))[v], x1 = ((const float4*)(pc + r1 * sl))[v];
+        const float4 x2 = ((const float4*)(pc + r2 * sl))[v], x3 = ((const float4*)(pc + r3 * sl))[v];
+        acc.x += x0.x; acc.y += x0.y; acc.z += x0.z; acc.w += x0.w;
+        acc.x += x1.x; acc.y += x1.y; acc.z += x1.z; acc.w += x1.w;
+        acc.x += x2.x; acc.y += x2.y; acc.z += x2.z; acc.w += x2.w;
+        acc.x += x3.x; acc.y += x3.y; acc.z += x3.z; acc.w += x3.w;
+      }
+      for (; i < end; i += G) {
+        const float4 x = ((const float4*)(pc + row(i) * sl))[v];
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+      }
+      red[tid] = acc;
+    }
+    __syncthreads();
+    if (g == 0) {
+      for (int k = 1; k < G; ++k) {
+        const float4 x = red[k * V + v];
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+      }
+      emit(v, acc);
+    }
+    return;
+  }
+  for (int v = tid; v < V; v += nthreads) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = beg;
+    for (; i + 3 < end; i += 4) {  // four rows in flight
+      const size_t r0 = row(i), r1 = row(i + 1), r2 = row(i + 2), r3 = row(i + 3);
+      const float4 x0 = ((const float4*)(pc + r0 * sl))[v], x1 = ((const float4*)(pc + r1 * sl))[v];
+      const float4 x2 = ((const float4*)(pc + r2 * sl))[v], x3 = ((const float4*)(pc + r3 * sl))[v];
+      acc.x += x0.x; acc.y += x0.y; acc.z += x0.z; acc.w += x0.w;
+      acc.x += x1.x; acc.y += x1.y; acc.z += x1.z; acc.w += x1.w;
+      acc.x += x2.x; acc.y += x2.y; acc.z += x2.z; acc.w += x2.w;
+      acc.x += x3.x; acc.y += x3.y; acc.z += x3.z; acc.w += x3.w;
+    }
+    for (; i < end; ++i) {
+      const float4 x = ((const float4*)(pc + row(i) * sl))[v];
+      acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
+    emit(v, acc);
+  }
+}
+
+struct ListRow {  // thin cores: partial row = lookup id from the sorted order
+  const int* list;
+  __device__ __forceinline__ size_t operator()(int i) const { return (size_t)list[i]; }
+};
+struct IotaRow {  // pivot core: partial row = chunk slot
+  __device__ __forceinline__ size_t operator()(int i) const { return (size_t)i; }
+};
+struct SegRow {  // final fold of a hot slice: segment j's slot (1 = the slice starts inside the segment)
+  int j_first, first_slot;
+  __device__ __forceinline__ size_t operator()(int i) const { return (size_t)(2 * (j_first + i) + (i == 0 ? first_slot : 0)); }
+};
+
 __global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Plan P, Partials PC,
                                                                int optim, float lr, float eps,
                                                                CorePtrs W, CorePtrs St,
-                                                               CorePtrs DW) {
+                                                               CorePtrs DW, int nslices, int rows_max) {
   __shared__ float4 red[kReduceThreads];
-  const int nthreads = blockDim.x;
+  __shared__ int s_last;
+  const int nthreads = blockDim.x, tid = threadIdx.x;
   int b = blockIdx.x;
+  if (b >= nslices) {
+    // ---------------- segment work-group (t, j): its share of the hot slice(s) it intersects ----------------
+    b -= nslices;
+    int t = 0;
+    for (;; ++t) {
+      const int total_max = (t == 1) ? P.max_chunks : rows_max;
+      const int nseg = (total_max + seg_len(t) - 1) / seg_len(t);
+      if (b < nseg || t == d.T - 1) break;
+      b -= nseg;
+    }
+    const int SEG = seg_len(t), sl = d.slice[t];
+    if ((sl & 3) != 0) return;  // (odd slice sizes stay with their single owner)
+    const int total = (t == 1) ? P.hdr[0] : P.hdr[2];
+    const int p0 = b * SEG, p1 = min(p0 + SEG, total);
+    if (p0 >= total) return;
+    const int* off = (t == 1) ? P.chunk_off : P.off[t];
+    // the offset table goes to LDS in one coalesced round when it fits (a segment work-group of a
+    // uniform stream has nothing to do and should find that out in one memory round trip, not ten)
+    int* soff = (int*)red;
+    const bool in_lds = d.S[t] + 1 <= (int)(kReduceThreads * sizeof(float4) / sizeof(int));
+    if (in_lds) {
+      for (int e = tid; e <= d.S[t]; e += nthreads) soff[e] = off[e];
+      __syncthreads();
+      off = soff;
+    }
+    int lo = 0, hi = d.S[t];  // slice containing position p0: the last s with off[s] <= p0
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (off[mid] <= p0) lo = mid; else hi = mid;
+    }
+    bool any_hot = false;  // (wave-uniform: every thread scans the same few slices)
+    for (int s = lo; s < d.S[t] && off[s] < p1; ++s) any_hot |= (off[s + 1] - off[s] > 2 * SEG);
+    if (!any_hot) return;
+    if (in_lds) {  // `red` is about to be used by the reductions: back to the global table
+      __syncthreads();
+      off = (t == 1) ? P.chunk_off : P.off[t];
+    }
+    const float* __restrict__ pc = PC.pc[t];
+    for (int s = lo; s < d.S[t]; ++s) {  // at most two hot slices can touch one segment
+      const int sbeg = off[s], send = off[s + 1];
+      if (sbeg >= p1) break;
+      if (send - sbeg <= 2 * SEG) continue;  // not hot: its owner does everything
+      const int beg = max(sbeg, p0), end = min(send, p1);
+      const int slot = (sbeg > p0) ? 1 : 0;
+      float* dst = PC.seg[t] + (size_t)(2 * b + slot) * sl;
+      if (t == 1) sum_rows4(pc, sl, beg, end, red, IotaRow{}, StoreEmit{dst});
+      else sum_rows4(pc, sl, beg, end, red, ListRow{P.perm[t]}, StoreEmit{dst});
+      // arrival (the "last block" pattern): every thread publishes its stores device-wide, one thread
+      // counts the work-group in, and the work-group that completes the count folds the segment sums
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) {
+        int idx = s;
+        for (int tt = 0; tt < t; ++tt) idx += d.S[tt];
+        const int j_first = sbeg / SEG, j_last = (send - 1) / SEG;
+        const int old = atomicAdd(&PC.hot_cnt[idx], 1);
+        s_last = (old == j_last - j_first);
+      }
+      __syncthreads();
+      if (s_last) {
+        __threadfence();  // acquire: the other work-groups' segment sums
+        const int j_first = sbeg / SEG, j_last = (send - 1) / SEG;
+        const size_t base = (size_t)s * sl;
+        const ApplyEmit ap{optim, lr, eps, W.c[t] + base, St.c[t] ? St.c[t] + base : nullptr,
+                           DW.c[t] ? DW.c[t] + base : nullptr};
+        sum_rows4(PC.seg[t], sl, 0, j_last - j_first + 1, red, SegRow{j_first, sbeg > j_first * SEG ? 1 : 0}, ap);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // ---------------- slice owner ----------------
   int t = 0;
   while (t < d.T - 1 && b >= d.S[t]) { b -= d.S[t]; ++t; }
   const int s = b;
@@ -954,7 +1147,6 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Pl
   if (t == 1) { beg = P.chunk_off[s]; end = P.chunk_off[s + 1]; list = nullptr; }
   else { beg = P.off[t][s]; end = P.off[t][s + 1]; list = P.perm[t]; }
   const size_t base = (size_t)s * sl;
-  const int tid = threadIdx.x;
   float* __restrict__ dw = DW.c[t];
   float* __restrict__ wt = W.c[t];
   float* __restrict__ stt = St.c[t];
@@ -964,95 +1156,11 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Pl
     return;
   }
   const float* __restrict__ pc = PC.pc[t];
-  const int cnt = end - beg;
   if ((sl & 3) == 0) {
-    const int V = sl / 4;  // float4 lanes per partial row
-    if (V <= nthreads / 2 && cnt >= 4) {
-      // G groups of V lanes share the slice's partial rows; at least 8 rows per group, so a short list
-      // stays with few groups (cheap final fold) and a hot slice (thousands of rows under a skewed
-      // stream) gets all 1024 threads
-      int G = nthreads / V;
-      if (G > cnt / 8) G = cnt / 8 > 0 ? cnt / 8 : 1;
-      const int g = tid / V, v = tid - g * V;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g < G) {
-        // 4 partial rows in flight per lane (a hot slice under a skewed index stream holds
-        // thousands of partials: one dependent load at a time made that the step's tail)
-        int i = beg + g;
-        for (; i + 3 * G < end; i += 4 * G) {
-          size_t r0, r1, r2, r3;
-          if (list) { r0 = list[i]; r1 = list[i + G]; r2 = list[i + 2 * G]; r3 = list[i + 3 * G]; }
-          else { r0 = i; r1 = i + G; r2 = i + 2 * G; r3 = i + 3 * G; }
-          const float4 x0 = ((const float4*)(pc + r0 * sl))[v], x1 = ((const float4*)(pc + r1 * sl))[v];
-          const float4 x2 = ((const float4*)(pc + r2 * sl))[v], x3 = ((const float4*)(pc + r3 * sl))[v];
-          acc.x += x0.x; acc.y += x0.y; acc.z += x0.z; acc.w += x0.w;
-          acc.x += x1.x; acc.y += x1.y; acc.z += x1.z; acc.w += x1.w;
-          acc.x += x2.x; acc.y += x2.y; acc.z += x2.z; acc.w += x2.w;
-          acc.x += x3.x; acc.y += x3.y; acc.z += x3.z; acc.w += x3.w;
-        }
-        for (; i < end; i += G) {
-          const size_t row = list ? (size_t)list[i] : (size_t)i;
-          const float4 x = ((const float4*)(pc + row * sl))[v];
-          acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-        }
-        red[tid] = acc;
-      }
-      __syncthreads();
-      if (g != 0) return;
-      for (int k = 1; k < G; ++k) {
-        const float4 x = red[k * V + v];
-        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-      }
-      const size_t o = base + (size_t)v * 4;
-      if (optim == TTX_OPTIM_DENSE) {
-        *(float4*)(dw + o) = acc;
-      } else {
-        float4 wv = *(const float4*)(wt + o);
-        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (optim == TTX_OPTIM_ADAGRAD) sv = *(const float4*)(stt + o);
-        wv.x = apply_one(optim, acc.x, wv.x, lr, eps, &sv.x);
-        wv.y = apply_one(optim, acc.y, wv.y, lr, eps, &sv.y);
-        wv.z = apply_one(optim, acc.z, wv.z, lr, eps, &sv.z);
-        wv.w = apply_one(optim, acc.w, wv.w, lr, eps, &sv.w);
-        *(float4*)(wt + o) = wv;
-        if (optim == TTX_OPTIM_ADAGRAD) *(float4*)(stt + o) = sv;
-      }
-      return;
-    }
-    for (int v = tid; v < V; v += nthreads) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      int i = beg;
-      for (; i + 3 < end; i += 4) {  // four partial rows in flight
-        size_t r0, r1, r2, r3;
-        if (list) { r0 = list[i]; r1 = list[i + 1]; r2 = list[i + 2]; r3 = list[i + 3]; }
-        else { r0 = i; r1 = i + 1; r2 = i + 2; r3 = i + 3; }
-        const float4 x0 = ((const float4*)(pc + r0 * sl))[v], x1 = ((const float4*)(pc + r1 * sl))[v];
-        const float4 x2 = ((const float4*)(pc + r2 * sl))[v], x3 = ((const float4*)(pc + r3 * sl))[v];
-        acc.x += x0.x; acc.y += x0.y; acc.z += x0.z; acc.w += x0.w;
-        acc.x += x1.x; acc.y += x1.y; acc.z += x1.z; acc.w += x1.w;
-        acc.x += x2.x; acc.y += x2.y; acc.z += x2.z; acc.w += x2.w;
-        acc.x += x3.x; acc.y += x3.y; acc.z += x3.z; acc.w += x3.w;
-      }
-      for (; i < end; ++i) {
-        const size_t row = list ? (size_t)list[i] : (size_t)i;
-        const float4 x = ((const float4*)(pc + row * sl))[v];
-        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-      }
-      const size_t o = base + (size_t)v * 4;
-      if (optim == TTX_OPTIM_DENSE) {
-        *(float4*)(dw + o) = acc;
-      } else {
-        float4 wv = *(const float4*)(wt + o);
-        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (optim == TTX_OPTIM_ADAGRAD) sv = *(const float4*)(stt + o);
-        wv.x = apply_one(optim, acc.x, wv.x, lr, eps, &sv.x);
-        wv.y = apply_one(optim, acc.y, wv.y, lr, eps, &sv.y);
-        wv.z = apply_one(optim, acc.z, wv.z, lr, eps, &sv.z);
-        wv.w = apply_one(optim, acc.w, wv.w, lr, eps, &sv.w);
-        *(float4*)(wt + o) = wv;
-        if (optim == TTX_OPTIM_ADAGRAD) *(float4*)(stt + o) = sv;
-      }
-    }
+    if (end - beg > 2 * seg_len(t) && PC.hot_cnt) return;  // hot: the segment work-groups own it
+    const ApplyEmit ap{optim, lr, eps, wt + base, stt ? stt + base : nullptr, dw ? dw + base : nullptr};
+    if (list) sum_rows4(pc, sl, beg, end, red, ListRow{list}, ap);
+    else sum_rows4(pc, sl, beg, end, red, IotaRow{}, ap);
     return;
   }
   for (int e = tid; e < sl; e += nthreads) {
@@ -1244,6 +1352,15 @@ int ttx_tt_rows(const ttx_geom* g, int32_t D, int64_t nnz, const int64_t* indice
   return run_rows(d, nnz, P, tt_cores, rows, nullptr, 0, (hipStream_t)stream);
 }
 
+static int num_segments(const Dims& d, long long nnz, int MC, int t) {
+  const long long total = (t == 1) ? (long long)max_chunks(d, nnz, MC) : nnz;
+  const int SEG = (t == 1) ? kSegPivot : kSegThin;
+  return (int)((total + SEG - 1) / SEG);
+}
+
+// backward scratch: partial gradients per core, then the hot-slice segment sums (2 slots per segment) and
+// the arrival counters (one int per core slice).  offs[t] = partials of core t, offs[T + t] = segment sums
+// of core t, offs[2T] = counters.
 static size_t partial_bytes(const Dims& d, long long nnz, int MC, size_t* offs) {
   size_t o = 0;
   for (int t = 0; t < d.T; ++t) {
@@ -1251,6 +1368,14 @@ static size_t partial_bytes(const Dims& d, long long nnz, int MC, size_t* offs) 
     const size_t cnt = (t == 1) ? (size_t)max_chunks(d, nnz, MC) : (size_t)nnz;
     o += align_up(cnt * d.slice[t] * sizeof(float));
   }
+  for (int t = 0; t < d.T; ++t) {
+    offs[d.T + t] = o;
+    o += align_up((size_t)2 * num_segments(d, nnz, MC, t) * d.slice[t] * sizeof(float));
+  }
+  offs[2 * d.T] = o;
+  size_t ns = 0;
+  for (int t = 0; t < d.T; ++t) ns += d.S[t];
+  o += align_up(ns * sizeof(int));
   return o;
 }
 
@@ -1260,7 +1385,7 @@ size_t ttx_tt_backward_workspace_bytes(const ttx_geom* g, int32_t B, int32_t D, 
   if (make_dims(g, &d) != TTX_OK || nnz < 0) return 0;
   const int MC = choose_chunk(d);
   if (MC <= 0) return 0;
-  size_t offs[TTX_MAX_CORES];
+  size_t offs[2 * TTX_MAX_CORES + 1];
   return plan_bytes(d, nnz) + partial_bytes(d, nnz, MC, offs) + 256;
 }
 
@@ -1296,7 +1421,7 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
   if (rc) return rc;
   if (!indices || !rowidx || !tableidx || !d_output || !tt_cores) TTX_FAIL(TTX_EINVAL, "NULL input");
   const int MC = choose_chunk(d);
-  size_t offs[TTX_MAX_CORES];
+  size_t offs[2 * TTX_MAX_CORES + 1];
   const size_t pcb = partial_bytes(d, nnz, MC, offs);
   const size_t pb = plan ? 0 : plan_bytes(d, nnz);
   if (!workspace || workspace_bytes < pb + pcb)
@@ -1314,6 +1439,15 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
   Partials PC;
   for (int t = 0; t < TTX_MAX_CORES; ++t) PC.pc[t] = t < d.T ? (float*)(ws + offs[t]) : nullptr;
   PC.psw = psw;
+  int nslices = 0, nsegs = 0;
+  for (int t = 0; t < d.T; ++t) {
+    PC.seg[t] = (float*)(ws + offs[d.T + t]);
+    nslices += d.S[t];
+    nsegs += num_segments(d, nnz, MC, t);
+  }
+  for (int t = d.T; t < TTX_MAX_CORES; ++t) PC.seg[t] = nullptr;
+  PC.hot_cnt = (int*)(ws + offs[2 * d.T]);
+  PC.n_hot_cnt = nslices;
   CorePtrs C, S, DW;
   for (int t = 0; t < TTX_MAX_CORES; ++t) {
     C.c[t] = t < d.T ? tt_cores[t] : nullptr;
@@ -1336,14 +1470,13 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
     TTX_HIP(hipGetLastError());
   }
   {
-    int blocks = 0;
-    for (int t = 0; t < d.T; ++t) blocks += d.S[t];
+    const int blocks = nslices + nsegs;  // slice owners, then the segment work-groups of hot slices
     int smax = 0;
     for (int t = 0; t < d.T; ++t) smax = d.slice[t] > smax ? d.slice[t] : smax;
     const int rthreads = smax <= 4096 ? 512 : kReduceThreads;  // (measured: 512 is 1.7 us faster at r = 32, 1024 at r = 64)
     ProfScope ps(TTX_PROF_APPLY, st);
     hipLaunchKernelGGL(reduce_apply_kernel, dim3(blocks), dim3(rthreads), 0, st, d, P, PC, optim, lr,
-                       eps, C, S, DW);
+                       eps, C, S, DW, nslices, (int)nnz);
     TTX_HIP(hipGetLastError());
   }
   return TTX_OK;

@@ -199,6 +199,32 @@ def test_plan_paths_vs_oracle(tables, p, B, pf):
                 assert_close(got["cores"][k], orc["cores"][k], f"plan {p} sgd core{k}")
 
 
+@pytest.mark.parametrize("p,q,r", [([3, 2, 4], [4, 4, 4], [1, 16, 16, 1]), ([2, 3, 3], [2, 3, 2], [1, 4, 5, 1]),
+                                   ([3, 2], [4, 4], [1, 8, 1])])
+def test_hot_slices_are_reduced_by_several_work_groups(p, q, r):
+    """a skewed stream in miniature: few slices, thousands of lookups each -> reduce_apply's segment
+    work-groups and last-arriver fold (thin cores: > 1024 lookups per slice, pivot: > 64 chunks per slice);
+    dense gradients, fused SGD and Adagrad against the oracle, and bit-identical from run to run"""
+    E_, D, B = int(np.prod(p)), int(np.prod(q)), 300
+    idx, off = G.make_bags(41, B, E_, 25, 3, 1)
+    assert idx.size > 6000
+    c = dict(tables=1, T=len(p), p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+             cores=G.make_cores(42, 1, p, q, r, "signed"), d_out=G.make_grad(43, 1, B, D))
+    for mode in ("dense", "sgd", "adagrad"):
+        got, again, orc = run_case(c, mode, plan_shared=True), run_case(c, mode, plan_shared=True), oracle_case(c, mode)
+        gref = oracle_case(c, "dense")["grads"] if mode == "adagrad" else None
+        for k in range(len(p)):
+            if mode == "dense":
+                assert_close(got["grads"][k], orc["grads"][k], f"hot {p} grad{k}")
+                assert np.array_equal(got["grads"][k], again["grads"][k]), "not deterministic"
+            elif mode == "sgd":
+                assert_close(got["cores"][k], orc["cores"][k], f"hot {p} sgd core{k}")
+                assert np.array_equal(got["cores"][k], again["cores"][k]), "not deterministic"
+            else:
+                assert_close(got["state"][k], orc["state"][k], f"hot {p} state{k}")
+                assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"hot {p} adagrad core{k}")
+
+
 @pytest.mark.parametrize("ranks,q", [([32, 32], [4, 4, 4]), ([16, 16], [4, 4, 4]), ([32, 32], [4, 4, 8]), ([16, 16], [4, 4, 8]),
                                       ([64, 64], [4, 4, 8]), ([64, 64], [4, 4, 4])])
 def test_specialised_shapes_vs_oracle_and_generic(ranks, q):
