@@ -75,7 +75,7 @@ struct Plan {
   int MC;
 };
 
-int choose_chunk(const Dims& d);  // lookups per chunk (LDS-budget heuristic)
+int choose_chunk(const Dims& d, long long nnz);  // lookups per chunk (kernel variant / LDS-budget heuristic)
 int max_chunks(const Dims& d, long long nnz, int MC);
 size_t plan_bytes(const Dims& d, long long nnz);
 // carve `base` into the plan arrays (same function for builder and consumers)

@@ -54,13 +54,13 @@ static size_t plan_ints(const Dims& d, long long nnz, int MC) {
 }
 
 size_t plan_bytes(const Dims& d, long long nnz) {
-  return align_up(plan_ints(d, nnz, choose_chunk(d)) * sizeof(int));
+  return align_up(plan_ints(d, nnz, choose_chunk(d, nnz)) * sizeof(int));
 }
 
 Plan carve_plan(const Dims& d, long long nnz, void* base) {
   Plan P;
   memset(&P, 0, sizeof(P));
-  P.MC = choose_chunk(d);
+  P.MC = choose_chunk(d, nnz);
   P.max_chunks = max_chunks(d, nnz, P.MC);
   int* cur = (int*)base;
   auto take = [&](size_t k) { int* r = cur; cur += r64(k); return r; };

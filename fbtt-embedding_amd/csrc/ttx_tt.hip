@@ -90,7 +90,7 @@ static int g_chunk_override = 0;
 static int g_debug_skip = 0;
 static int g_disable_spec = 0;
 static bool spec_shape(const Dims& d);  // ttx_tt_spec.inc covers this geometry
-static int spec_mc(const Dims& d);      // ... with this many lookups per chunk
+static int spec_mc(const Dims& d, long long nnz);  // ... with this many lookups per chunk
 static long long* g_stamps = nullptr;
 
 long long* debug_stamps() { return g_stamps; }
@@ -148,8 +148,8 @@ static Lds make_lds(const Dims& d, int MC, bool bwd) {
   return L;
 }
 
-int choose_chunk(const Dims& d) {
-  if (spec_shape(d)) return spec_mc(d);  // wave-independent kernels: Shape3::MC (32; 16 for r = 64)
+int choose_chunk(const Dims& d, long long nnz) {
+  if (spec_shape(d)) return spec_mc(d, nnz);  // wave-independent kernels: Shape3::MC of the variant picked for nnz
   if (g_chunk_override > 0) return g_chunk_override;
   // three, then two work-groups per CU (160 KiB of LDS), else whatever fits
   for (int mc = 16; mc >= 8; mc >>= 1)
@@ -1179,9 +1179,17 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Pl
 #include "ttx_tt_spec.inc"
 
 static bool spec_shape(const Dims& d) { return spec_match(d) != SPEC_NONE; }
-static int spec_mc(const Dims& d) {
+// lookups per chunk of the specialised kernels.  The benchmark shape has two variants: small batches are
+// latency-bound and run best as 16-lookup chunks walked in two column passes (one M-tile per wave, half of
+// core_1 staged while the other half is in flight); large batches are bandwidth-bound in the pivot
+// partials and keep 32-lookup chunks (half as many 16 KB partial blocks).
+constexpr long long kSmallBatch = 32768;
+static int spec_mc(const Dims& d, long long nnz) {
   const SpecId id = spec_match(d);
-  return (id == SPEC_64_4_64_8 || id == SPEC_64_4_64_4) ? S_64_4_64_8::MC : S_32_4_32_4::MC;
+  if (id == SPEC_32_4_32_4) return nnz <= kSmallBatch ? S_32_4_32_4_P::MC : S_32_4_32_4::MC;
+  if (id == SPEC_32_4_32_8) return S_32_4_32_8::MC;
+  if (id == SPEC_16_4_16_8) return S_16_4_16_8::MC;
+  return (id == SPEC_64_4_64_8 || id == SPEC_64_4_64_4) ? S_64_4_64_8::MC : S_16_4_16_4::MC;
 }
 
 // ---------------------------------------------------------- host side ------
@@ -1278,7 +1286,7 @@ static int common_checks(const Dims& d, int32_t D, int64_t nnz) {
   if (D <= 0) TTX_FAIL(TTX_EINVAL, "D=%d must be > 0", D);
   if (D != d.D) TTX_FAIL(TTX_EINVAL, "D=%d does not match prod(q)=%d", D, d.D);
   if (nnz < 0 || nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz=%lld out of range", (long long)nnz);
-  if (choose_chunk(d) <= 0)
+  if (choose_chunk(d, nnz) <= 0)
     TTX_FAIL(TTX_EUNSUPPORTED, "core-1 slice (%d x %d floats) does not fit the LDS tiling", d.k[0], d.n[0]);
   return TTX_OK;
 }
@@ -1383,7 +1391,7 @@ size_t ttx_tt_backward_workspace_bytes(const ttx_geom* g, int32_t B, int32_t D, 
   (void)B; (void)D;
   Dims d;
   if (make_dims(g, &d) != TTX_OK || nnz < 0) return 0;
-  const int MC = choose_chunk(d);
+  const int MC = choose_chunk(d, nnz);
   if (MC <= 0) return 0;
   size_t offs[2 * TTX_MAX_CORES + 1];
   return plan_bytes(d, nnz) + partial_bytes(d, nnz, MC, offs) + 256;
@@ -1420,7 +1428,7 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
   rc = common_checks(d, D, nnz);
   if (rc) return rc;
   if (!indices || !rowidx || !tableidx || !d_output || !tt_cores) TTX_FAIL(TTX_EINVAL, "NULL input");
-  const int MC = choose_chunk(d);
+  const int MC = choose_chunk(d, nnz);
   size_t offs[2 * TTX_MAX_CORES + 1];
   const size_t pcb = partial_bytes(d, nnz, MC, offs);
   const size_t pb = plan ? 0 : plan_bytes(d, nnz);

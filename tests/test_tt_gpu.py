@@ -225,6 +225,25 @@ def test_hot_slices_are_reduced_by_several_work_groups(p, q, r):
                 assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"hot {p} adagrad core{k}")
 
 
+def test_benchmark_shape_large_batch_variant():
+    """the benchmark shape has two kernel variants (ttx_tt.hip spec_mc): batches above 32768 lookups take
+    32-lookup chunks in one column pass -- forward, dense gradients and fused SGD against the oracle"""
+    p, q, r = [9, 8, 7], [4, 4, 4], [1, 32, 32, 1]
+    E_, D, B = int(np.prod(p)), 64, 1700
+    idx, off = G.make_bags(51, B, E_, 20, 2, 1)
+    assert idx.size > 32768
+    c = dict(tables=1, T=3, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+             cores=G.make_cores(52, 1, p, q, r, "signed"), d_out=G.make_grad(53, 1, B, D))
+    for mode in ("dense", "sgd"):
+        got, orc = run_case(c, mode, plan_shared=True), oracle_case(c, mode)
+        assert_close(got["out"], orc["out"], "large-batch variant out")
+        for k in range(3):
+            if mode == "dense":
+                assert_close(got["grads"][k], orc["grads"][k], f"large-batch variant grad{k}")
+            else:
+                assert_close(got["cores"][k], orc["cores"][k], f"large-batch variant sgd core{k}")
+
+
 @pytest.mark.parametrize("ranks,q", [([32, 32], [4, 4, 4]), ([16, 16], [4, 4, 4]), ([32, 32], [4, 4, 8]), ([16, 16], [4, 4, 8]),
                                       ([64, 64], [4, 4, 8]), ([64, 64], [4, 4, 4])])
 def test_specialised_shapes_vs_oracle_and_generic(ranks, q):
