@@ -535,6 +535,9 @@ struct Prologue {
   int64_t* hashtbl;
   int64_t* cache_freq;
 };
+#ifndef TTX_PLAN_KU
+#define TTX_PLAN_KU 4
+#endif
 constexpr int kOneThreads = 1024;                 // 16 waves: the histogram of all N keys is 4x shorter per thread
 constexpr int kOneWaves = kOneThreads / kWave;
 template <bool PRO>
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
   for (int e = tid; e < kOneWaves * 256; e += kOneThreads) (&hrun[0][0])[e] = 0;
   __syncthreads();
   const int bbeg = blockIdx.x * (kOneWaves * kOneUnit), bend = min(N, bbeg + kOneWaves * kOneUnit);
-  constexpr int kU = 4;  // loads in flight per thread (every work-group reads all N indices: latency, not bandwidth)
+  constexpr int kU = TTX_PLAN_KU;  // loads in flight per thread (every work-group reads all N indices: latency, not bandwidth)
   for (int i0 = tid; i0 < N; i0 += kOneThreads * kU) {
     long long ix[kU];
     int tb[kU];
