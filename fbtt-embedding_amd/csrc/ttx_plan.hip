@@ -560,6 +560,32 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
   for (int e = tid; e < kOneWaves * 256; e += kOneThreads) (&hrun[0][0])[e] = 0;
   __syncthreads();
   const int bbeg = blockIdx.x * (kOneWaves * kOneUnit), bend = min(N, bbeg + kOneWaves * kOneUnit);
+  // Frequency update of this wave's 64 keys (work-groups of the last core, which have no bag rows to find),
+  // split in two so that its CAS round trip (random 8-byte slots in HBM) overlaps the histogram below:
+  // here equal keys of the wave are combined (hashtbl_count_wave's grouping) and the group leaders issue
+  // the CAS; its result is looked at after the histogram.
+  bool h_lead = false;
+  long long h_key = 0;
+  unsigned long long h_times = 0, h_old = 0;
+  int h_idx = 0;
+  const bool h_on = PRO && pg.H && t == (d.T >= 3 ? 2 : 0);
+  if (h_on) {
+    const int i = bbeg + w * kOneUnit + lane;
+    const bool valid = i < bend;
+    h_key = valid ? indices[i] : 0;
+    const unsigned h = valid ? hash64(h_key, pg.H) : 0u;
+    const unsigned long long peers = wave_match8(h & 255u, valid);
+    const int leader = valid ? __ffsll((long long)peers) - 1 : 0;
+    const int klo = __shfl((int)(unsigned)h_key, leader, kWave), khi = __shfl((int)(h_key >> 32), leader, kWave);
+    const bool eq = valid && klo == (int)(unsigned)h_key && khi == (int)(h_key >> 32);
+    const unsigned long long eqm = __ballot(eq);
+    if (valid && (!eq || lane == leader)) {
+      h_lead = true;
+      h_times = eq ? (unsigned long long)__popcll(peers & eqm) : 1ull;
+      h_idx = (int)h;
+      h_old = atomicCAS((unsigned long long*)&pg.hashtbl[h_idx], (unsigned long long)(-1ll), (unsigned long long)h_key);
+    }
+  }
   constexpr int kU = TTX_PLAN_KU;  // loads in flight per thread (every work-group reads all N indices: latency, not bandwidth)
   for (int i0 = tid; i0 < N; i0 += kOneThreads * kU) {
     long long ix[kU];
@@ -625,9 +651,17 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
       }
     }
   }
-  // the frequency update (a CAS round trip + an add) rides on the work-groups of the last core,
-  // which have no bag rows to find; equal keys of a wave are combined first
-  if (PRO && pg.H && t == (d.T >= 3 ? 2 : 0)) hashtbl_count_wave(idx, valid, pg.H, pg.hashtbl, pg.cache_freq);
+  if (h_lead) {  // second half of the frequency update: count, or keep probing (hashtbl_cuda_utils.cuh:102-133)
+    for (int pr = 0;; ++pr) {
+      if ((long long)h_old == -1 || (long long)h_old == h_key) {
+        atomicAdd((unsigned long long*)&pg.cache_freq[h_idx], h_times);
+        break;
+      }
+      if (pr == kMaxProbes - 1) break;  // dropped
+      h_idx = (h_idx + 1) % pg.H;
+      h_old = atomicCAS((unsigned long long*)&pg.hashtbl[h_idx], (unsigned long long)(-1ll), (unsigned long long)h_key);
+    }
+  }
   const unsigned long long peers = wave_match8((unsigned)kv, valid);
   if (valid) {
     const int pos = hrun[w][kv] + __popcll(peers & lanemask_lt());
