@@ -141,6 +141,11 @@ int ttx_profile_enable(int mask) {
   return TTX_OK;
 }
 
+int ttx_profile_mask(int mask) {  // as ttx_profile_enable, without reading back the pending event pairs
+  ttx::g_prof.mask = (unsigned)mask;
+  return TTX_OK;
+}
+
 int ttx_profile_reset(void) {
   ttx::prof_drain();
   for (int w = 0; w < TTX_PROF_NUM; ++w) {

@@ -519,6 +519,11 @@ def profile_enable(mask: int) -> None:
     _check(lib().ttx_profile_enable(int(mask)))
 
 
+def profile_mask(mask: int) -> None:
+    """profile_enable without draining: use around a hipGraph capture, read after the replays."""
+    _check(lib().ttx_profile_mask(int(mask)))
+
+
 def profile_reset() -> None:
     _check(lib().ttx_profile_reset())
 

@@ -312,6 +312,9 @@ int ttx_cache_backward_rowwise_adagrad_approx(
 #define TTX_PROF_CACHE_FWD 5
 #define TTX_PROF_NUM 6
 int ttx_profile_enable(int mask);
+/* the same without reading back pending event pairs: for launches recorded inside a hipGraph capture, whose
+ * events only carry times once the graph has been replayed (read them with ttx_profile_read afterwards) */
+int ttx_profile_mask(int mask);
 int ttx_profile_reset(void);
 int ttx_profile_read(int which, int64_t* launches, double* total_ms);
 
