@@ -485,8 +485,8 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                                list(self.optimizer_state) if use_state else [], list(self.tt_cores), per_sample_weights)
         if (fast is not None and not self.warmup and self.use_cache and self.num_tables == 1 and indices.is_cuda
                 and indices.numel() > 0):
-            # cache live: frequency update + hash lookup + stable partition (one host read-back), contraction of
-            # the misses, gather of the hits, and the matching backward -- the C++ node again
+            # cache live: frequency update + hash lookup + stable partition (split point kept on the device),
+            # contraction of the misses, gather of the hits, and the matching backward -- the C++ node again
             use_state = self.sparse and self.optimizer not in _SGD_LIKE
             optim = 2 if not self.sparse else (1 if use_state else 0)
             return fast.lookup_cached(indices.contiguous(), offsets.contiguous(), self.tt_p_shapes, self.tt_q_shapes,
