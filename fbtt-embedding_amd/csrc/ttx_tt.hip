@@ -1179,17 +1179,18 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Pl
 #include "ttx_tt_spec.inc"
 
 static bool spec_shape(const Dims& d) { return spec_match(d) != SPEC_NONE; }
-// lookups per chunk of the specialised kernels.  The benchmark shape has two variants: small batches are
-// latency-bound and run best as 16-lookup chunks walked in two column passes (one M-tile per wave, half of
-// core_1 staged while the other half is in flight); large batches are bandwidth-bound in the pivot
-// partials and keep 32-lookup chunks (half as many 16 KB partial blocks).
-constexpr long long kSmallBatch = 32768;
+// lookups per chunk of the specialised kernels (Shape3::MC of the variant that runs)
 static int spec_mc(const Dims& d, long long nnz) {
-  const SpecId id = spec_match(d);
-  if (id == SPEC_32_4_32_4) return nnz <= kSmallBatch ? S_32_4_32_4_P::MC : S_32_4_32_4::MC;
-  if (id == SPEC_32_4_32_8) return S_32_4_32_8::MC;
-  if (id == SPEC_16_4_16_8) return S_16_4_16_8::MC;
-  return (id == SPEC_64_4_64_8 || id == SPEC_64_4_64_4) ? S_64_4_64_8::MC : S_16_4_16_4::MC;
+  (void)nnz;
+  switch (spec_match(d)) {
+    case SPEC_32_4_32_4: return S_32_4_32_4::MC;
+    case SPEC_16_4_16_4: return S_16_4_16_4::MC;
+    case SPEC_32_4_32_8: return S_32_4_32_8::MC;
+    case SPEC_16_4_16_8: return S_16_4_16_8::MC;
+    case SPEC_64_4_64_8: return S_64_4_64_8::MC;
+    case SPEC_64_4_64_4: return S_64_4_64_4::MC;
+    default: return 0;
+  }
 }
 
 // ---------------------------------------------------------- host side ------

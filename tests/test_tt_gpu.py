@@ -226,8 +226,8 @@ def test_hot_slices_are_reduced_by_several_work_groups(p, q, r):
 
 
 def test_benchmark_shape_large_batch_variant():
-    """the benchmark shape has two kernel variants (ttx_tt.hip spec_mc): batches above 32768 lookups take
-    32-lookup chunks in one column pass -- forward, dense gradients and fused SGD against the oracle"""
+    """the benchmark shape at a batch that no longer fits the single-launch plan (> 16384 lookups): forward,
+    dense gradients and fused SGD against the oracle"""
     p, q, r = [9, 8, 7], [4, 4, 4], [1, 32, 32, 1]
     E_, D, B = int(np.prod(p)), 64, 1700
     idx, off = G.make_bags(51, B, E_, 20, 2, 1)
