@@ -218,3 +218,40 @@ def test_per_sample_weights_vs_nn_embedding_bag(node, p, q, r):
     ms(t(idx), t(off), per_sample_weights=t(psw)).backward(t(d_out))
     for k in range(len(p)):
         assert_close(ms.tt_cores[k].detach().cpu().numpy(), cores[k] - LR * ref_cores[k].grad.cpu().numpy(), f"weighted sgd{k}")
+
+
+@pytest.mark.parametrize("optim", ["sgd", "adagrad"])
+def test_several_training_steps_track_the_oracle(node, optim):
+    """six fused-optimizer steps on changing batches (cache counting, not live): the cores -- and the
+    Adagrad state -- after every step against the oracle run on the same stream of batches"""
+    import tt_embeddings_ops as ops
+
+    p, q, r = [6, 5, 7], [4, 4, 4], [16, 16]
+    E_, D, B = int(np.prod(p)), 64, 64
+    cores = G.make_cores(21, 1, p, q, r, "signed")
+    opt = ops.OptimType.SGD if optim == "sgd" else ops.OptimType.EXACT_ADAGRAD
+    m = ops.TTEmbeddingBag(E_, D, r, p, q, sparse=True, optimizer=opt, learning_rate=0.05, eps=1e-3, use_cache=True,
+                           cache_size=32, hashtbl_size=4096, weight_dist="uniform", device=DEV)
+    with torch.no_grad():
+        for dst, src in zip(m.tt_cores, cores):
+            dst.copy_(t(src))
+    g = O.make_geom(1, p, q, r)
+    ref = [c.copy() for c in cores]
+    state = [np.zeros_like(c) for c in cores]
+    for step in range(6):
+        idx, off = G.make_bags(100 + step, B, E_, 7, 3, 1)
+        d_out = G.make_grad(200 + step, 1, B, D)
+        out = m(t(idx), t(off))
+        rowidx, tableidx = O.rowidx_from_offsets(off, 1)
+        assert_close(out.detach().cpu().numpy(), O.tt_forward(g, B, D, idx, rowidx, tableidx, ref)[0], f"step {step} forward")
+        out.backward(t(d_out[0]))
+        if optim == "sgd":
+            O.tt_backward(g, O.OPTIM_SGD, B, D, 0.05, 0.0, idx, rowidx, tableidx, d_out, ref)
+        else:
+            O.tt_backward(g, O.OPTIM_ADAGRAD, B, D, 0.05, 1e-3, idx, rowidx, tableidx, d_out, ref, state)
+        for k in range(3):
+            # (error compounds over the steps: 4x the single-step tolerance)
+            a, b = m.tt_cores[k].detach().cpu().numpy().astype(np.float64), ref[k].astype(np.float64)
+            tol = 4 * (2e-6 * np.abs(b).max() + 1e-5 * np.abs(b)) * (8 if optim == "adagrad" else 1)
+            assert (np.abs(a - b) <= tol).all(), f"step {step} core {k}: max err {np.abs(a - b).max():.3e}"
+    assert int(m.cache_freq.sum()) > 0  # the frequency table counted along
