@@ -52,6 +52,9 @@ WORKLOADS = {
     "cfg3warm": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.2, populate=False),
     "cfg4": dict(q=[4, 4, 8], ranks=[64, 64], tables=1, B=512, optimizer="adagrad", alpha=1.0, populate=False),
     # one rank's share of cfg5 at 8 GPUs: 4 of the 26 tables, the whole 4096-bag batch
+    # shapes outside the specialised family (reference-default q for D = 32 has q0 = 2): generic kernels
+    "d32": dict(q=[2, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    "d32q4": dict(q=[4, 2, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d128r32": dict(q=[4, 4, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     # all 26 tables of cfg5 on ONE GPU (2.13 M lookups per step): the table-batched path at scale
     "cfg5full": dict(q=[4, 4, 4], ranks=[32, 32], tables=26, B=4096, optimizer="sgd", alpha=1.0, populate=False),
