@@ -122,6 +122,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL brings up 128 channels per communicator by default on this GPU; in the sandboxed boxes of this
+        # pool that alone took minutes (measured: > 120 s at world size 1, 3.6 s with 4 channels).  The two
+        # exchanges of a step are < 1 MB per peer: a handful of channels carries them.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         dist.init_process_group("nccl", device_id=dev)
 
     import gen_inputs as G
