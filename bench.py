@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="time the eager Python path only (no hipGraph replay)")
     ap.add_argument("--optimizer", default=None, choices=["sgd", "adagrad"])
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="(test) take the N > 1 code path -- process group, sharded module, all-to-all -- with one rank")
     args = ap.parse_args()
     global Q_SHAPES, RANKS, B_GLOBAL
     wl = WORKLOADS[args.workload]
@@ -112,6 +114,12 @@ def main():
         raise SystemExit("--gpus N > 1 runs the cfg2-per-rank sharded workload only")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    sharded = world > 1 or args.force_sharded
+    if args.force_sharded:
+        os.environ["TTX_FORCE_EXCHANGE"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29561")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -120,7 +128,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL brings up 128 channels per communicator by default on this GPU; in the sandboxed boxes of this
         # pool that alone took minutes (measured: > 120 s at world size 1, 3.6 s with 4 channels).  The two
@@ -140,7 +148,7 @@ def main():
     B_local = B_GLOBAL // world
     assert B_local * world == B_GLOBAL
     torch.manual_seed(1234 + rank)
-    if world == 1:
+    if not sharded:
         use_cache = (not args.no_cache) and ntab == 1
         kw = dict(sparse=True, optimizer=opt, learning_rate=0.1, use_cache=use_cache, weight_dist="uniform", device=dev)
         if wl["populate"]:  # cfg3: 256Ki-row cache behind a 1Mi-slot table
@@ -179,7 +187,7 @@ def main():
         nnz_step_total = world * B_GLOBAL * POOL  # every table sees the whole 512-bag batch
 
     def sync():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +205,7 @@ def main():
     t1 = time.perf_counter()
     E.profile_enable(0)
     eager_elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharded:
         dist.all_reduce(eager_elapsed, op=dist.ReduceOp.MAX)
     eager_elapsed = float(eager_elapsed.item())
     n_bwd, ms_bwd = E.profile_read(E.PROF_BWD)
@@ -210,7 +218,7 @@ def main():
     mode, elapsed = "eager", eager_elapsed
     # (cache live: capturable only through the C++ node, which keeps the partition's split point on the device;
     # the reference-shaped Python route reads it back to the host every step)
-    if not args.no_graph and world == 1 and (not wl["populate"] or ops._native_node() is not None):
+    if not args.no_graph and not sharded and (not wl["populate"] or ops._native_node() is not None):
         try:
             cap = torch.cuda.Stream()
             cap.wait_stream(torch.cuda.current_stream())
@@ -267,7 +275,7 @@ def main():
 
     # N > 1: the two exchanges of a step in isolation (xGMI all-to-all bandwidth vs the link roofline)
     a2a = None
-    if world > 1:
+    if sharded:
         try:
             a2a = {}
             for name, numel, dtype in (("indices_in", B_local * POOL * world, torch.int64),
@@ -284,7 +292,7 @@ def main():
                 dt = (time.perf_counter() - t0) / 50
                 sent = src.element_size() * numel * (world - 1) // world  # bytes this rank puts on the links
                 a2a[name] = {"bytes_per_rank": sent, "us": round(dt * 1e6, 1), "GB/s_per_rank": round(sent / dt / 1e9, 2),
-                             "frac_of_xgmi": round(sent / dt / 1e9 / (153.0 * min(world - 1, 7)), 4)}
+                             "frac_of_xgmi": round(sent / dt / 1e9 / (153.0 * max(1, min(world - 1, 7))), 4)}
             a2a["note"] = ("eager all_to_all_single over RCCL, barrier-synchronised loop of 50; link roofline = 153 GB/s x "
                            "peers (MI355X_MICROARCH.md); messages this small are latency-bound")
         except Exception as ex:  # noqa: BLE001
@@ -329,11 +337,11 @@ def main():
             "config": {"workload": (f"{args.workload}: {'TTEmbeddingBag' if ntab == 1 else f'TableBatchedTTEmbeddingBag x{ntab} tables'} "
                                     f"E=11000000 D={D} p=[200,220,250] q={Q_SHAPES} ranks={RANKS} B={B_GLOBAL} L=20 "
                                     f"nnz={per_rank_nnz} sparse {args.optimizer.upper()}, use_cache="
-                                    + ("False" if (args.no_cache or world > 1 or ntab > 1) else
+                                    + ("False" if (args.no_cache or sharded or ntab > 1) else
                                        (f"True(populated from 50 other batches, 256Ki rows, Zipf a={wl['alpha']}, hit rate {hit_rate:.3f})" if wl["populate"] else "True(unpopulated)"))
-                                    + ("" if world == 1 else f"; {world} such tables, one per rank, table-sharded, RCCL all-to-all; B_local={B_local}")),
+                                    + ("" if not sharded else f"; {world} such tables, one per rank, table-sharded, RCCL all-to-all; B_local={B_local}")),
                        "nnz_per_step_total": nnz_step_total, "flop_per_nnz_fwd_bwd": 3.0 * fl_fwd,
-                       "path": "Python module -> ctypes -> C ABI -> HIP" + ("; timed as hipGraph replay of the captured module fwd+bwd steps (one graph per round of the 10 request batches)" if mode == "hipgraph" else "; eager")},
+                       "path": "Python module -> C++ autograd node (or ctypes) -> C ABI -> HIP" + ("; timed as hipGraph replay of the captured module fwd+bwd steps (one graph per round of the 10 request batches)" if mode == "hipgraph" else "; eager")},
             "timed_mode": mode,
             "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
             "eager_value": round(3.0 * flop_per_nnz_fwd(Q_SHAPES, RANKS) * nnz_step_total / (eager_elapsed / args.steps) / 1e9, 2),
@@ -348,10 +356,10 @@ def main():
         }
         if a2a is not None:
             line["all_to_all"] = a2a
-        if world == 1 and not args.no_cpu_baseline and ntab == 1:
+        if not sharded and not args.no_cpu_baseline and ntab == 1:
             line["cpu_baseline"] = cpu_baseline(reqs_np, cores_np, d_out_np)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

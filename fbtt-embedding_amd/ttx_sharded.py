@@ -17,6 +17,7 @@ forward(indices, offsets) takes the local batch for ALL tables (table-major,
 include_last_offset form: offsets has num_tables*B_local + 1 entries) and
 returns [num_tables, B_local, D], like TableBatchedTTEmbeddingBag on one GPU.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -24,6 +25,9 @@ import torch.distributed as dist
 from torch import nn
 
 import tt_embeddings_ops as _ops
+
+# test hook: run the exchange code path even with a single rank (bench.py --force-sharded on a 1-GPU box)
+_FORCE_EXCHANGE = bool(os.environ.get("TTX_FORCE_EXCHANGE"))
 
 
 class _PooledAllToAll(torch.autograd.Function):
@@ -80,7 +84,7 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         W, NT, D = self.world, self.num_tables, self.embedding_dim
         indices, offsets = indices.long(), offsets.long()
         B = (offsets.numel() - 1) // NT
-        if W == 1:
+        if W == 1 and not _FORCE_EXCHANGE:
             return self.local(indices, offsets)
         dev = indices.device
         n_own = [len(o) for o in self.owned]
