@@ -2,6 +2,8 @@
 on the HIP path: the reference's six property tests restated with fixed seeds,
 the benchmark configs at full size against the golden vectors, the cache
 life-cycle, determinism."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -255,3 +257,49 @@ def test_several_training_steps_track_the_oracle(node, optim):
             tol = 4 * (2e-6 * np.abs(b).max() + 1e-5 * np.abs(b)) * (8 if optim == "adagrad" else 1)
             assert (np.abs(a - b) <= tol).all(), f"step {step} core {k}: max err {np.abs(a - b).max():.3e}"
     assert int(m.cache_freq.sum()) > 0  # the frequency table counted along
+
+
+def test_drop_in_for_nn_embedding_bag_in_a_dlrm_shaped_model(node):
+    """examples/mini_dlrm.py: the TT bags in DLRM's call form (offsets = bag starts only) give the same logits as
+    nn.EmbeddingBag tables holding the expanded TT weights, and a few training steps (dense side: torch SGD,
+    TT cores: fused SGD in backward) bring the loss down"""
+    import importlib.util
+    import tt_embeddings_ops as ops
+
+    spec = importlib.util.spec_from_file_location("mini_dlrm", os.path.join(os.path.dirname(__file__), "..", "examples", "mini_dlrm.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    torch.manual_seed(0)
+    p, q, r = [20, 22, 25], [4, 4, 4], [16, 16]
+    E_ = 20 * 22 * 25
+    tts = [ops.TTEmbeddingBag(E_, 64, r, p, q, sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05,
+                              use_cache=False, weight_dist="approx-normal", include_last_offset=False, device=DEV)
+           for _ in range(3)]
+    model = M.MiniDLRM(tts).to(DEV)
+    ref = M.MiniDLRM([torch.nn.EmbeddingBag.from_pretrained(e.full_weight().detach().clone(), mode="sum") for e in tts]).to(DEV)
+    ref.bot.load_state_dict(model.bot.state_dict())
+    ref.top.load_state_dict(model.top.state_dict())
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        dense = torch.rand(64, 13, generator=g).to(DEV)
+        sparse = []
+        for _ in range(3):
+            lengths = torch.randint(1, 6, (64,), generator=g)
+            offsets = torch.cat([torch.zeros(1, dtype=torch.int64), lengths.cumsum(0)[:-1]])
+            sparse.append((torch.randint(0, E_, (int(lengths.sum()),), generator=g).to(DEV), offsets.to(DEV)))
+        return dense, sparse, (dense.sum(1) > 6.5).float()
+
+    dense, sparse, label = batch(0)
+    with torch.no_grad():
+        assert_close(model(dense, sparse).cpu().numpy(), ref(dense, sparse).cpu().numpy(), "logits vs nn.EmbeddingBag model")
+    opt = torch.optim.SGD([p_ for n, p_ in model.named_parameters() if not n.startswith("emb.")], lr=0.1)
+    losses = []
+    for step in range(30):
+        dense, sparse, label = batch(step % 3)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(model(dense, sparse), label)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert np.isfinite(losses).all() and np.mean(losses[-3:]) < np.mean(losses[:3]), losses
