@@ -586,6 +586,29 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
       h_old = atomicCAS((unsigned long long*)&pg.hashtbl[h_idx], (unsigned long long)(-1ll), (unsigned long long)h_key);
     }
   }
+  // this wave's own 64 positions: index, key and bag row are fetched / searched HERE, before the histogram,
+  // so that their latency (and the rowidx / tableidx stores) overlaps it; ranking needs the scan below
+  const int i = bbeg + w * kOneUnit + lane;
+  const bool valid = i < bend;
+  int kv = 0, tbv = 0, row = 0;
+  long long idx = 0;
+  if (valid) {
+    idx = indices[i];
+    tbv = tableidx ? (int)tableidx[i] : 0;
+    kv = min(tbv * ct.p + decode_core(ct, idx), 255);
+    if (PRO && t <= 1) {  // bag of position i: the last b with offsets[b] <= i (empty bags skipped)
+      int lo = 0, hi = pg.nb;  // answer in [lo, hi)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offs[mid] <= i) lo = mid; else hi = mid;
+      }
+      row = lo;
+      if (t == 0) {
+        pg.rowidx[i] = row;
+        pg.tableidx[i] = 0;
+      }
+    }
+  }
   constexpr int kU = TTX_PLAN_KU;  // loads in flight per thread (every work-group reads all N indices: latency, not bandwidth)
   for (int i0 = tid; i0 < N; i0 += kOneThreads * kU) {
     long long ix[kU];
@@ -629,28 +652,7 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
   }
   __syncthreads();
   if (blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, N, PRO || rowidx != nullptr, P, wt5);
-  // rank + scatter this wave's 64 positions
-  const int i = bbeg + w * kOneUnit + lane;
-  const bool valid = i < bend;
-  int kv = 0, tbv = 0, row = 0;
-  long long idx = 0;
-  if (valid) {
-    idx = indices[i];
-    tbv = tableidx ? (int)tableidx[i] : 0;
-    kv = min(tbv * ct.p + decode_core(ct, idx), 255);
-    if (PRO && t <= 1) {  // bag of position i: the last b with offsets[b] <= i (empty bags skipped)
-      int lo = 0, hi = pg.nb;  // answer in [lo, hi)
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (offs[mid] <= i) lo = mid; else hi = mid;
-      }
-      row = lo;
-      if (t == 0) {
-        pg.rowidx[i] = row;
-        pg.tableidx[i] = 0;
-      }
-    }
-  }
+  // rank + scatter this wave's 64 positions (key, bag row: computed before the histogram, see above)
   if (h_lead) {  // second half of the frequency update: count, or keep probing (hashtbl_cuda_utils.cuh:102-133)
     for (int pr = 0;; ++pr) {
       if ((long long)h_old == -1 || (long long)h_old == h_key) {
