@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Cut-point timing of the backward contraction kernel at cfg2: run under rocprofv3 --kernel-trace --stats with one
+ablation mask per process (ttx_debug_skip: 16 = after the chunk record, 64 = after all loads, 12 = + LDS puts,
+6 = + GEMM1 and tail, 4 = all but the d core_1 stage, 1 = no thin-core stores, 0 = full kernel).
+usage: rocprofv3 --kernel-trace --stats -d out -- python scripts/bwd_cut_points.py <mask>"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "fbtt-embedding_amd"), os.path.join(ROOT, "tests")):
