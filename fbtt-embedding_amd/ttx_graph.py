@@ -1,0 +1,42 @@
+"""hipGraph capture of training steps (not in the reference).
+
+At the benchmark batch a fwd+bwd step is five kernels of ~10 us each; launching them one by one costs the host
+more than they take to run, and even one hipGraphLaunch per step costs about as much as the step's kernels.
+`GraphedRound` captures `step(*batch)` for a list of batches whose tensors stay resident (static input
+buffers: copy new data into them between replays) into ONE graph; `replay()` runs the whole round.
+Works with the C++ lookup node (tt_embeddings_ops falls back to the ctypes route, which also captures as long
+as the cache is not live).  bench.py times exactly this."""
+from typing import Callable, Sequence
+
+import torch
+
+
+class GraphedRound:
+    def __init__(self, step: Callable, batches: Sequence[tuple], warmup: int = 3) -> None:
+        assert len(batches) > 0
+        self.batches = list(batches)  # keep the captured tensors alive
+        self._stream = torch.cuda.Stream()
+        self._stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._stream):  # allocator / lazy-init warm-up outside the capture
+            for k in range(warmup):
+                step(*self.batches[k % len(self.batches)])
+        torch.cuda.current_stream().wait_stream(self._stream)
+        torch.cuda.synchronize()
+        try:
+            import tt_embeddings as _E
+
+            _E._ws_cache.clear()  # ctypes route: the graph must own its workspaces
+        except ImportError:
+            _E = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self._stream):
+            for b in self.batches:
+                step(*b)
+        if _E is not None:
+            _E._ws_cache.clear()
+
+    def replay(self) -> None:
+        self.graph.replay()
+
+    def __len__(self) -> int:
+        return len(self.batches)

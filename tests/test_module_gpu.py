@@ -303,3 +303,47 @@ def test_drop_in_for_nn_embedding_bag_in_a_dlrm_shaped_model(node):
         opt.step()
         losses.append(loss.item())
     assert np.isfinite(losses).all() and np.mean(losses[-3:]) < np.mean(losses[:3]), losses
+
+
+def test_graphed_round_equals_eager_steps(node):
+    """ttx_graph.GraphedRound: replaying a captured round of fused-SGD steps leaves the cores exactly where the
+    same steps run eagerly leave them (the kernels are deterministic, so bit-identical)"""
+    import tt_embeddings_ops as ops
+    import ttx_graph
+
+    p, q, r = [20, 22, 25], [4, 4, 4], [16, 16]
+    E_, D, B = 20 * 22 * 25, 64, 96
+
+    def fresh():
+        m = ops.TTEmbeddingBag(E_, D, r, p, q, sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, use_cache=True,
+                               cache_size=16, hashtbl_size=1 << 17, weight_dist="uniform", device=DEV)
+        with torch.no_grad():
+            for dst, src in zip(m.tt_cores, G.make_cores(31, 1, p, q, r, "signed")):
+                dst.copy_(t(src))
+        return m
+
+    batches = [tuple(t(a) for a in G.make_bags(300 + k, B, E_, 6, 2, 1)) for k in range(4)]
+    grad = t(G.make_grad(301, 1, B, D)[0])
+    me, mg = fresh(), fresh()
+    step_e = lambda i, o: me(i, o).backward(grad)  # noqa: E731
+    step_g = lambda i, o: mg(i, o).backward(grad)  # noqa: E731
+    before = [c.detach().clone() for c in mg.tt_cores]
+    rnd = ttx_graph.GraphedRound(step_g, batches, warmup=2)
+    with torch.no_grad():  # undo warm-up and capture-time side effects: same starting point as the eager model
+        for c, b in zip(mg.tt_cores, before):
+            c.copy_(b)
+        mg.hashtbl.fill_(-1)
+        mg.cache_freq.zero_()
+    for _ in range(3):
+        rnd.replay()
+        for b in batches:
+            step_e(*b)
+    torch.cuda.synchronize()
+    for a, b in zip(me.tt_cores, mg.tt_cores):
+        assert torch.equal(a, b)
+    # the frequency table counted the same keys the same number of times (slot assignment of keys that collide
+    # depends on arrival order, as in the reference)
+    def table(m):
+        k, f = m.hashtbl.cpu().numpy(), m.cache_freq.cpu().numpy()
+        return sorted(zip(k[k >= 0].tolist(), f[k >= 0].tolist()))
+    assert table(me) == table(mg)
