@@ -273,46 +273,7 @@ def main():
             print(f"[bench] graph capture unavailable ({type(ex).__name__}: {ex}); reporting the eager path", file=sys.stderr)
             torch.cuda.synchronize()
 
-    # N > 1: the two exchanges of a step in isolation (xGMI all-to-all bandwidth vs the link roofline)
-    a2a = None
-    if sharded:
-        try:
-            a2a = {}
-            for name, numel, dtype in (("indices_in", B_local * POOL * world, torch.int64),
-                                       ("pooled_out", B_local * D * world, torch.float32)):
-                src = torch.zeros(numel, dtype=dtype, device=dev)
-                dst = torch.empty_like(src)
-                for _ in range(5):
-                    dist.all_to_all_single(dst, src)
-                sync()
-                t0 = time.perf_counter()
-                for _ in range(50):
-                    dist.all_to_all_single(dst, src)
-                sync()
-                dt = (time.perf_counter() - t0) / 50
-                sent = src.element_size() * numel * (world - 1) // world  # bytes this rank puts on the links
-                a2a[name] = {"bytes_per_rank": sent, "us": round(dt * 1e6, 1), "GB/s_per_rank": round(sent / dt / 1e9, 2),
-                             "frac_of_xgmi": round(sent / dt / 1e9 / (153.0 * max(1, min(world - 1, 7))), 4)}
-            a2a["note"] = ("eager all_to_all_single over RCCL, barrier-synchronised loop of 50; link roofline = 153 GB/s x "
-                           "peers (MI355X_MICROARCH.md); messages this small are latency-bound")
-        except Exception as ex:  # noqa: BLE001
-            a2a = {"error": f"{type(ex).__name__}: {ex}"}
-
-    # second, untimed pass: per-kernel breakdown (all kernel slots bracketed)
-    E.profile_reset()
-    E.profile_enable(0x3F)
-    for k in range(min(args.steps, 50)):
-        step(*reqs[k % iters])
-    sync()
-    E.profile_enable(0)
-    names = ["fwd_contract", "bwd_contract", "reduce_apply", "plan", "bag_pool", "cache_gather"]
-    breakdown = {}
-    for w, nm in enumerate(names):
-        n, ms = E.profile_read(w)
-        if n:
-            breakdown[nm + "_us"] = round(ms / n * 1e3, 2)
-
-    if rank == 0:
+    def build_line(mode, elapsed, breakdown, a2a, note=None):
         fl_fwd = flop_per_nnz_fwd(Q_SHAPES, RANKS)
         ms_per_step = elapsed / args.steps * 1e3
         gflops = 3.0 * fl_fwd * nnz_step_total / (elapsed / args.steps) / 1e9
@@ -341,7 +302,8 @@ def main():
                                        (f"True(populated from 50 other batches, 256Ki rows, Zipf a={wl['alpha']}, hit rate {hit_rate:.3f})" if wl["populate"] else "True(unpopulated)"))
                                     + ("" if not sharded else f"; {world} such tables, one per rank, table-sharded, RCCL all-to-all; B_local={B_local}")),
                        "nnz_per_step_total": nnz_step_total, "flop_per_nnz_fwd_bwd": 3.0 * fl_fwd,
-                       "path": "Python module -> C++ autograd node (or ctypes) -> C ABI -> HIP" + ("; timed as hipGraph replay of the captured module fwd+bwd steps (one graph per round of the 10 request batches)" if mode == "hipgraph" else "; eager")},
+                       "path": "Python module -> C++ autograd node (or ctypes) -> C ABI -> HIP" + (("; timed as hipGraph replay of the captured module fwd+bwd steps (one graph per round of the 10 request batches)"
+                                + ("; all-to-all exchanges issued on RCCL directly, inside the graph" if "rccl" in mode else "")) if mode.startswith("hipgraph") else "; eager")},
             "timed_mode": mode,
             "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
             "eager_value": round(3.0 * flop_per_nnz_fwd(Q_SHAPES, RANKS) * nnz_step_total / (eager_elapsed / args.steps) / 1e9, 2),
@@ -356,12 +318,121 @@ def main():
         }
         if a2a is not None:
             line["all_to_all"] = a2a
+        if note:
+            line["note"] = note
+        return line
+
+
+    # ---- region 2 for N > 1: the sharded step with its exchanges issued on RCCL directly (ttx_sharded.DirectExchange:
+    # current stream, no side-stream hops) and captured, a round of request batches per graph.  torch.distributed's
+    # own collectives cannot be captured on this stack.  Never validated on more than one rank when written, so a
+    # watchdog thread prints the eager result and ends the process if this region does not finish in time.
+    if not args.no_graph and sharded and ops._native_node() is not None and not os.environ.get("TTX_NO_DIRECT_RCCL"):
+        import threading
+
+        def bail():
+            if rank == 0:
+                print(json.dumps(build_line("eager", eager_elapsed, {}, None,
+                                            note="direct-RCCL graph region did not finish; eager torch.distributed result")),
+                      flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(float(os.environ.get("TTX_DIRECT_TIMEOUT", "150")), bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            import ttx_graph
+
+            mod.enable_direct_exchange()
+            for k in range(5):
+                step(*reqs[k % iters])
+            sync()
+            rnd = ttx_graph.GraphedRound(step, reqs, warmup=2)
+            for _ in range(max(1, args.warmup // iters)):
+                rnd.replay()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps // iters):
+                rnd.replay()
+            for k in range(args.steps % iters):
+                step(*reqs[k])
+            sync()
+            t1 = time.perf_counter()
+            g_elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(g_elapsed, op=dist.ReduceOp.MAX)
+            mode, elapsed = "hipgraph+direct-rccl", float(g_elapsed.item())
+        except Exception as ex:  # noqa: BLE001
+            print(f"[bench] direct-RCCL graph path unavailable ({type(ex).__name__}: {ex}); reporting the eager path", file=sys.stderr)
+            mod.direct = None
+            torch.cuda.synchronize()
+        finally:
+            dog.cancel()
+
+    # N > 1: the two exchanges of a step in isolation (xGMI all-to-all bandwidth vs the link roofline)
+    a2a = None
+    if sharded:
+        try:
+            a2a = {}
+            for name, numel, dtype in (("indices_in", B_local * POOL * world, torch.int64),
+                                       ("pooled_out", B_local * D * world, torch.float32)):
+                src = torch.zeros(numel, dtype=dtype, device=dev)
+                dst = torch.empty_like(src)
+                for _ in range(5):
+                    dist.all_to_all_single(dst, src)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    dist.all_to_all_single(dst, src)
+                sync()
+                dt = (time.perf_counter() - t0) / 50
+                sent = src.element_size() * numel * (world - 1) // world  # bytes this rank puts on the links
+                a2a[name] = {"bytes_per_rank": sent, "us": round(dt * 1e6, 1), "GB/s_per_rank": round(sent / dt / 1e9, 2),
+                             "frac_of_xgmi": round(sent / dt / 1e9 / (153.0 * max(1, min(world - 1, 7))), 4)}
+            if getattr(mod, "direct", None) is not None:  # the same two messages through the direct RCCL route
+                for name, numel, dtype in (("indices_in_direct", B_local * POOL * world, torch.int64),
+                                           ("pooled_out_direct", B_local * D * world, torch.float32)):
+                    src = torch.zeros(numel, dtype=dtype, device=dev)
+                    dst = torch.empty_like(src)
+                    for _ in range(5):
+                        mod.direct.all_to_all(dst, src)
+                    sync()
+                    t0 = time.perf_counter()
+                    for _ in range(50):
+                        mod.direct.all_to_all(dst, src)
+                    sync()
+                    dt = (time.perf_counter() - t0) / 50
+                    sent = src.element_size() * numel * (world - 1) // world
+                    a2a[name] = {"bytes_per_rank": sent, "us": round(dt * 1e6, 1), "GB/s_per_rank": round(sent / dt / 1e9, 2),
+                                 "frac_of_xgmi": round(sent / dt / 1e9 / (153.0 * max(1, min(world - 1, 7))), 4)}
+            a2a["note"] = ("eager all_to_all_single over RCCL, barrier-synchronised loop of 50; link roofline = 153 GB/s x "
+                           "peers (MI355X_MICROARCH.md); messages this small are latency-bound")
+        except Exception as ex:  # noqa: BLE001
+            a2a = {"error": f"{type(ex).__name__}: {ex}"}
+
+    # second, untimed pass: per-kernel breakdown (all kernel slots bracketed)
+    E.profile_reset()
+    E.profile_enable(0x3F)
+    for k in range(min(args.steps, 50)):
+        step(*reqs[k % iters])
+    sync()
+    E.profile_enable(0)
+    names = ["fwd_contract", "bwd_contract", "reduce_apply", "plan", "bag_pool", "cache_gather"]
+    breakdown = {}
+    for w, nm in enumerate(names):
+        n, ms = E.profile_read(w)
+        if n:
+            breakdown[nm + "_us"] = round(ms / n * 1e3, 2)
+
+    if rank == 0:
+        line = build_line(mode, elapsed, breakdown, a2a)
         if not sharded and not args.no_cpu_baseline and ntab == 1:
             line["cpu_baseline"] = cpu_baseline(reqs_np, cores_np, d_out_np)
         print(json.dumps(line), flush=True)
     if sharded:
         dist.barrier()
-        dist.destroy_process_group()
+        # (no destroy_process_group / communicator teardown: both were seen to hang on this stack; exit ends them)
+        sys.stdout.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

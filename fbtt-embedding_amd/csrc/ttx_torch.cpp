@@ -16,6 +16,8 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
 
+#include <cstring>
+#include <string>
 #include <vector>
 
 #include "ttx.h"
@@ -345,6 +347,65 @@ Tensor lookup_cached(const Tensor& indices, const Tensor& offsets, std::vector<i
                                  at::TensorList(cores));
 }
 
+// ---- direct RCCL exchange (table-sharded multi-GPU lookup, ttx_sharded.py) -----------------------------
+// torch.distributed runs its collectives on a side stream of its own: every all_to_all costs two event hops
+// and ~30 us of wrapper time, and its watchdog aborts when a collective is captured into a hipGraph
+// (DESIGN.md section 7).  These four calls talk to the RCCL library torch already loaded, on the CURRENT
+// stream: equal-split all-to-all only (one table block per peer), capturable.  Prototypes are declared
+// here rather than taken from rccl.h so that the ROCm header and torch's bundled library need not match.
+extern "C" {
+typedef struct { char internal[128]; } ttx_ncclUniqueId;
+typedef void* ttx_ncclComm_t;
+int ncclGetUniqueId(ttx_ncclUniqueId* id);
+int ncclCommInitRank(ttx_ncclComm_t* comm, int nranks, ttx_ncclUniqueId id, int rank);
+int ncclCommDestroy(ttx_ncclComm_t comm);
+int ncclAllToAll(const void* sendbuff, void* recvbuff, size_t count, int datatype, ttx_ncclComm_t comm, void* stream);
+const char* ncclGetErrorString(int result);
+}
+
+void rccl_check(int rc, const char* what) { TORCH_CHECK(rc == 0, "RCCL ", what, ": ", ncclGetErrorString(rc)); }
+
+pybind11::bytes rccl_unique_id() {
+  ttx_ncclUniqueId id;
+  rccl_check(ncclGetUniqueId(&id), "ncclGetUniqueId");
+  return pybind11::bytes(id.internal, sizeof(id.internal));
+}
+
+int64_t rccl_comm_init(const std::string& id_bytes, int64_t rank, int64_t world, int64_t device_index) {
+  TORCH_CHECK(id_bytes.size() == sizeof(ttx_ncclUniqueId), "bad RCCL unique id");
+  ttx_ncclUniqueId id;
+  memcpy(id.internal, id_bytes.data(), sizeof(id.internal));
+  ttx_ncclComm_t comm = nullptr;
+  {
+    pybind11::gil_scoped_release nogil;  // collective call: blocks until every rank has arrived
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(c10::Device(c10::kCUDA, (c10::DeviceIndex)device_index));
+    rccl_check(ncclCommInitRank(&comm, (int)world, id, (int)rank), "ncclCommInitRank");
+  }
+  return (int64_t)(intptr_t)comm;
+}
+
+void rccl_comm_destroy(int64_t comm) {
+  if (comm) (void)ncclCommDestroy((ttx_ncclComm_t)(intptr_t)comm);
+}
+
+// out[p] <- block p of rank p's `in`, blocks of in.numel() / world elements; on the current stream
+void rccl_all_to_all(int64_t comm, const Tensor& out, const Tensor& in, int64_t world) {
+  TORCH_CHECK(out.is_cuda() && in.is_cuda() && out.is_contiguous() && in.is_contiguous() &&
+                  out.scalar_type() == in.scalar_type() && out.numel() == in.numel() && in.numel() % world == 0,
+              "rccl_all_to_all: contiguous GPU tensors of one dtype and size, divisible by the world size");
+  int dt;
+  switch (in.scalar_type()) {
+    case at::kFloat: dt = 7; break;  // ncclFloat32
+    case at::kLong: dt = 4; break;   // ncclInt64
+    case at::kInt: dt = 2; break;    // ncclInt32
+    default: TORCH_CHECK(false, "rccl_all_to_all: float32 / int64 / int32 only");
+  }
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(in.device());
+  auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  rccl_check(ncclAllToAll(in.data_ptr(), out.data_ptr(), (size_t)(in.numel() / world), dt,
+                          (ttx_ncclComm_t)(intptr_t)comm, (void*)stream), "ncclAllToAll");
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -355,5 +416,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         pybind11::arg("hashtbl"), pybind11::arg("cache_freq"), pybind11::arg("state"), pybind11::arg("cores"),
         pybind11::arg("per_sample_weights") = pybind11::none());
   m.def("lookup_cached", &lookup_cached, "cache-live lookup of one table: partition, contraction of the misses, gather of the hits");
+  m.def("rccl_unique_id", &rccl_unique_id, "ncclGetUniqueId (rank 0; broadcast the bytes to the others)");
+  m.def("rccl_comm_init", &rccl_comm_init, "ncclCommInitRank on the given device (collective; releases the GIL)");
+  m.def("rccl_comm_destroy", &rccl_comm_destroy);
+  m.def("rccl_all_to_all", &rccl_all_to_all, "equal-split all-to-all on the current stream (capturable)");
   m.def("abi_version", []() { return ttx_version(); });
 }

@@ -30,6 +30,61 @@ import tt_embeddings_ops as _ops
 _FORCE_EXCHANGE = bool(os.environ.get("TTX_FORCE_EXCHANGE"))
 
 
+def _a2a(group, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits) -> None:
+    """all_to_all_single straight on the process group's backend object: the python wrapper of
+    torch.distributed spends ~30 us per call on argument checking, more than the exchange itself takes at
+    the benchmark's message sizes.  Equal splits go without split lists (the backend's fast path)."""
+    pg = group if group is not None else dist.distributed_c10d._get_default_group()
+    if out_splits is not None and len(set(out_splits)) <= 1 and in_splits is not None and len(set(in_splits)) <= 1:
+        out_splits, in_splits = [], []
+    try:
+        pg.alltoall_base(out, inp, out_splits or [], in_splits or []).wait()
+    except (AttributeError, TypeError):  # an older / different backend object: the public entry point
+        dist.all_to_all_single(out, inp, out_splits or None, in_splits or None, group=group)
+
+
+class DirectExchange:
+    """Equal-split all-to-all straight on RCCL (csrc/ttx_torch.cpp), on the CURRENT stream: no side stream, no
+    event hops, ~5 us per exchange instead of ~17 + wrapper time, and capturable in a hipGraph (torch.distributed's
+    collectives are not: its watchdog aborts on an event recorded in a capturing stream).  One communicator per
+    process group, bootstrapped through torch.distributed.  (The communicator is never destroyed explicitly:
+    ncclCommDestroy was seen to hang on this stack; it dies with the process.)"""
+
+    def __init__(self, group, device: torch.device) -> None:
+        import ttx_torch
+
+        self._lib = ttx_torch
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        box = [ttx_torch.rccl_unique_id() if self.rank == 0 else None]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        self.comm = ttx_torch.rccl_comm_init(box[0], self.rank, self.world, index)
+
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        self._lib.rccl_all_to_all(self.comm, out, inp, self.world)
+
+
+class _DirectPooledAllToAll(torch.autograd.Function):
+    """differentiable equal-split all-to-all of [W * rows, D] blocks through a DirectExchange"""
+
+    @staticmethod
+    def forward(ctx, ex: "DirectExchange", x: torch.Tensor) -> torch.Tensor:
+        ctx.ex = ex
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        ex.all_to_all(out, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: torch.Tensor):
+        g = g.contiguous()
+        gin = torch.empty_like(g)
+        ctx.ex.all_to_all(gin, g)
+        return None, gin
+
+
 class _PooledAllToAll(torch.autograd.Function):
     """differentiable all_to_all_single with explicit split sizes (rows of D floats)"""
 
@@ -37,13 +92,13 @@ class _PooledAllToAll(torch.autograd.Function):
     def forward(ctx, group, x: torch.Tensor, in_splits: List[int], out_splits: List[int]) -> torch.Tensor:
         ctx.group, ctx.in_splits, ctx.out_splits = group, in_splits, out_splits
         out = x.new_empty((sum(out_splits),) + tuple(x.shape[1:]))
-        dist.all_to_all_single(out, x.contiguous(), out_splits, in_splits, group=group)
+        _a2a(group, out, x.contiguous(), out_splits, in_splits)
         return out
 
     @staticmethod
     def backward(ctx, g: torch.Tensor):
         gin = g.new_empty((sum(ctx.in_splits),) + tuple(g.shape[1:]))
-        dist.all_to_all_single(gin, g.contiguous(), ctx.in_splits, ctx.out_splits, group=ctx.group)
+        _a2a(ctx.group, gin, g.contiguous(), ctx.in_splits, ctx.out_splits)
         return None, gin, None, None
 
 
@@ -71,14 +126,24 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
             inv[t] = pos
         self._order, self._inv = order, inv
         self._identity = order == list(range(num_tables))  # e.g. one table per rank: no reordering on the wire
+        self.direct: Optional[DirectExchange] = None  # enable_direct_exchange()
         self._dev_cache = {}  # device tensors that only depend on the batch shape (built once, not per step)
         assert not kw.get("use_cache", False), "cache is single-table only (reference :458)"
         self.local = None
         if self.my_tables:
             self.local = _ops.TableBatchedTTEmbeddingBag(len(self.my_tables), num_embeddings, embedding_dim, tt_ranks, **kw)
 
+    def enable_direct_exchange(self) -> None:
+        """Route the fixed-pooling exchanges through RCCL directly (see DirectExchange).  Needs the same number
+        of tables on every rank (equal splits) and the C++ extension; collective call -- every rank must make it."""
+        if self.num_tables % self.world != 0:
+            raise ValueError("direct exchange needs num_tables to be a multiple of the world size")
+        if self.direct is None:
+            dev = next(self.local.parameters()).device
+            self.direct = DirectExchange(self.group, dev)
+
     def _a2a(self, out, inp, out_splits=None, in_splits=None):
-        dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+        _a2a(self.group, out, inp, out_splits, in_splits)
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, fixed_pooling: Optional[int] = None) -> torch.Tensor:
         W, NT, D = self.world, self.num_tables, self.embedding_dim
@@ -97,7 +162,10 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
             in_splits = [k * B * Lp for k in n_own]
             out_splits = [n_me * B * Lp] * W
             recv_idx = indices.new_empty(sum(out_splits))
-            self._a2a(recv_idx, send_idx, out_splits, in_splits)
+            if self.direct is not None:
+                self.direct.all_to_all(recv_idx, send_idx.contiguous())
+            else:
+                self._a2a(recv_idx, send_idx, out_splits, in_splits)
             # wire order [src][k][b][l] -> table-major [k][src][b][l]
             loc_idx = recv_idx.view(W, n_me, B * Lp).permute(1, 0, 2).contiguous().view(-1)
             loc_off = self._cached(("off", dev, n_me * W * B, Lp), lambda: torch.arange(
@@ -135,7 +203,10 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         else:
             send = torch.zeros((0, D), device=dev, dtype=torch.float32)
         # ---- 3. pooled out ---------------------------------------------------
-        got = _PooledAllToAll.apply(self.group, send, [n_me * B] * W, [k * B for k in n_own])
+        if self.direct is not None and fixed_pooling is not None:
+            got = _DirectPooledAllToAll.apply(self.direct, send)
+        else:
+            got = _PooledAllToAll.apply(self.group, send, [n_me * B] * W, [k * B for k in n_own])
         out = got.view(NT, B, D)
         if self._identity:
             return out
