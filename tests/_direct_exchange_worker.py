@@ -1,0 +1,62 @@
+"""worker of test_module_gpu.test_direct_rccl_exchange_one_rank: runs in its own process (and leaves through
+os._exit: tearing the process group / communicator down hangs on this stack)."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+for p in (HERE, os.path.join(os.path.dirname(HERE), "fbtt-embedding_amd")):
+    sys.path.insert(0, p)
+os.environ["TTX_FORCE_EXCHANGE"] = "1"
+os.environ.setdefault("NCCL_MAX_NCHANNELS", "4")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29581")
+os.environ.setdefault("RANK", "0")
+os.environ.setdefault("WORLD_SIZE", "1")
+import numpy as np
+import torch
+import torch.distributed as dist
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)
+import gen_inputs as G
+import tt_embeddings_ops as ops
+import ttx_graph
+import ttx_sharded
+
+p, q, r = [20, 22, 25], [4, 4, 4], [16, 16]
+E_, D, B, Lp = 20 * 22 * 25, 64, 48, 5
+cores = G.make_cores(61, 1, p, q, r, "signed")
+
+
+def module():
+    m = ttx_sharded.ShardedTableBatchedTTEmbeddingBag(1, E_, D, r, tt_p_shapes=p, tt_q_shapes=q, sparse=True,
+                                                      optimizer=ops.OptimType.SGD, learning_rate=0.05, use_cache=False,
+                                                      weight_dist="uniform", device=dev)
+    with torch.no_grad():
+        for dst, src in zip(m.local.tt_cores, cores):
+            dst.copy_(torch.from_numpy(src).to(dev))
+    return m
+
+
+reqs = [(torch.from_numpy(i).to(dev), torch.from_numpy(o).to(dev)) for i, o in G.make_requests(62, 3, B, 1, Lp, E_)]
+grad = torch.from_numpy(G.make_grad(63, 1, B, D)).to(dev)
+a, b = module(), module()
+b.enable_direct_exchange()
+for i, o in reqs:  # torch.distributed route vs direct route, eager
+    oa, ob = a(i, o, fixed_pooling=Lp), b(i, o, fixed_pooling=Lp)
+    assert torch.equal(oa, ob), "forward differs"
+    oa.backward(grad)
+    ob.backward(grad)
+for x, y in zip(a.local.tt_cores, b.local.tt_cores):
+    assert torch.equal(x, y), "cores differ after the eager steps"
+rnd = ttx_graph.GraphedRound(lambda i, o: b(i, o, fixed_pooling=Lp).backward(grad), reqs, warmup=0)
+before = [c.detach().clone() for c in b.local.tt_cores]  # (capture does not run the kernels)
+rnd.replay()
+for i, o in reqs:
+    a(i, o, fixed_pooling=Lp).backward(grad)
+torch.cuda.synchronize()
+for x, y in zip(a.local.tt_cores, b.local.tt_cores):
+    assert torch.equal(x, y), "cores differ after the captured round"
+print("DIRECT-EXCHANGE-OK", flush=True)
+os._exit(0)

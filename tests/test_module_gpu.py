@@ -347,3 +347,15 @@ def test_graphed_round_equals_eager_steps(node):
         k, f = m.hashtbl.cpu().numpy(), m.cache_freq.cpu().numpy()
         return sorted(zip(k[k >= 0].tolist(), f[k >= 0].tolist()))
     assert table(me) == table(mg)
+
+
+def test_direct_rccl_exchange_one_rank():
+    """ttx_sharded.DirectExchange (ncclAllToAll on the current stream, csrc/ttx_torch.cpp) against the
+    torch.distributed route, eagerly and captured in a hipGraph -- with the one rank this box has; own process,
+    because the process group cannot be torn down cleanly on this stack"""
+    import subprocess
+    import sys
+
+    worker = os.path.join(os.path.dirname(__file__), "_direct_exchange_worker.py")
+    res = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=240)
+    assert "DIRECT-EXCHANGE-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
