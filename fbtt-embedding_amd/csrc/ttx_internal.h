@@ -108,16 +108,18 @@ __device__ __forceinline__ unsigned udiv(unsigned n, const UDiv dv) {
 // peers of this lane: valid lanes of the wave holding the same 8-bit digit.
 // Built from 9 wave ballots (the gfx950 replacement for a CUB rank pass).
 // Must be called by all lanes of the wave (wave-uniform control flow).
-__device__ __forceinline__ unsigned long long wave_match8(unsigned dgt, bool valid) {
+template <int BITS>
+__device__ __forceinline__ unsigned long long wave_match(unsigned dgt, bool valid) {
   unsigned long long mask = __ballot(valid);
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
+  for (int b = 0; b < BITS; ++b) {
     const bool bit = (dgt >> b) & 1u;
     const unsigned long long bm = __ballot(bit && valid);
     mask &= bit ? bm : ~bm;
   }
   return mask;
 }
+__device__ __forceinline__ unsigned long long wave_match8(unsigned dgt, bool valid) { return wave_match<8>(dgt, valid); }
 
 __device__ __forceinline__ unsigned long long lanemask_lt() {
   return (1ull << lane_id()) - 1ull;

@@ -42,6 +42,10 @@ int max_chunks(const Dims& d, long long nnz, int MC) {
 
 static size_t r64(size_t k) { return (k + 63) / 64 * 64; }
 
+// digit counts of the multi-work-group plans: a 256-entry row per wave unit of 256 positions, or
+// (wide-digit plan) a 2048-entry row per work-group of 4096 positions
+static size_t cnt_ints(const Dims& d, long long nnz) { return (size_t)d.T * (256 * ((nnz + 255) / 256 + 1) + 2048); }
+
 static size_t plan_ints(const Dims& d, long long nnz, int MC) {
   size_t n = r64(64);                                               // hdr
   for (int t = 0; t < d.T; ++t) n += r64(nnz) * 5 + r64((size_t)d.S[t] + 1);  // sid, perm, 3 scratch, off
@@ -49,7 +53,7 @@ static size_t plan_ints(const Dims& d, long long nnz, int MC) {
   n += r64((size_t)max_chunks(d, nnz, MC) * 4);                     // chunk_rec
   n += r64((size_t)nnz * 4);                                        // lrec
   n += r64((size_t)nnz);                                            // lrow
-  n += r64((size_t)d.T * 256 * ((nnz + 255) / 256 + 1));            // multi-block digit counts
+  n += r64(cnt_ints(d, nnz));                                       // multi-block digit counts
   return n;
 }
 
@@ -68,7 +72,7 @@ Plan carve_plan(const Dims& d, long long nnz, void* base) {
   P.chunk_rec = (int4*)take((size_t)P.max_chunks * 4);
   P.lrec = (int4*)take((size_t)nnz * 4);
   P.lrow = take(nnz);
-  P.cnt = take((size_t)d.T * 256 * ((nnz + 255) / 256 + 1));
+  P.cnt = take(cnt_ints(d, nnz));
   for (int t = 0; t < d.T; ++t) {
     P.sid[t] = take(nnz);
     P.perm[t] = take(nnz);
@@ -783,6 +787,214 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
   }
 }
 
+// ---- wide-digit plan: 256 < max S[t] <= 2048 (a few tables batched), up to kWideMaxG work-groups ----
+// The slice id fits ONE digit of 10 / 11 bits, so the sort is a single pass and digit == slice as
+// in mb_single_kernel: mbw_count leaves one digit histogram per work-group of 4096 positions,
+// mbw_scatter sums the rows before its own (thread = digit), ranks its 16 x 256 positions
+// against per-wave histograms it rebuilds in LDS, and its first work-group writes the slice
+// offsets / chunk list.  Two launches and one pass over the indices instead of five and two.
+constexpr int kWideThreads = 1024;
+constexpr int kWideWaves = kWideThreads / kWave;
+constexpr int kWideSpan = kWideThreads * kSB;   // positions per work-group (kSB x 64 per wave)
+constexpr int kWideMaxG = 96;                   // every scatter work-group reads all count rows
+
+template <int BITS>
+__global__ __launch_bounds__(kWideThreads) void mbw_count_kernel(
+    Dims d, int Nmax, const int* __restrict__ n_dev, const int64_t* __restrict__ indices,
+    const int64_t* __restrict__ tableidx, int* __restrict__ cnt) {
+  constexpr int BINS = 1 << BITS;
+  __shared__ int hist[BINS];
+  const int t = blockIdx.y, tid = threadIdx.x;
+  for (int e = tid; e < BINS; e += kWideThreads) hist[e] = 0;
+  __syncthreads();
+  const int N = live_n(Nmax, n_dev);
+  const CoreDec ct = core_dec(d, t);
+  long long ix[kSB];
+  int tb[kSB];
+#pragma unroll
+  for (int k = 0; k < kSB; ++k) {
+    const int i = blockIdx.x * kWideSpan + k * kWideThreads + tid;
+    ix[k] = i < N ? indices[i] : 0;
+    tb[k] = (i < N && tableidx) ? (int)tableidx[i] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < kSB; ++k) {
+    const int i = blockIdx.x * kWideSpan + k * kWideThreads + tid;
+    if (i < N) atomicAdd(&hist[min(tb[k] * ct.p + decode_core(ct, ix[k]), BINS - 1)], 1);  // tableidx is not validated
+  }
+  __syncthreads();
+  int* row = cnt + ((size_t)t * gridDim.x + blockIdx.x) * BINS;
+  for (int e = tid; e < BINS; e += kWideThreads) row[e] = hist[e];
+}
+
+// offsets / chunk list from the digit totals (finish_single_pass for K digits per thread, 1024
+// threads): thread owns digits tid * K + j.  wt: LDS int[kWideWaves].  Block 0 only, all threads.
+template <int K>
+__device__ __forceinline__ void finish_wide(const Dims& d, int t, const int (&tot)[K], const int (&dbase)[K], int N,
+                                            bool has_row, const Plan& P, int* wt) {
+  const int tid = threadIdx.x, lane = lane_id(), w = tid / kWave;
+  const int S = d.S[t];
+  if (t != 1) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int dg = tid * K + j;
+      if (dg < S) P.off[t][dg] = dbase[j];
+    }
+    if (tid == 0) P.off[t][S] = N;
+    return;
+  }
+  const int MC = P.MC;
+  int nf[K], pr[K], packed[K], psum = 0;  // full chunks, lookups of the partial chunk, (full << 12) | partial
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const int dg = tid * K + j;
+    nf[j] = dg < S ? tot[j] / MC : 0;
+    pr[j] = dg < S ? tot[j] - nf[j] * MC : 0;
+    packed[j] = (nf[j] << 12) | (pr[j] ? 1 : 0);  // <= 2048 slices: the partial counts stay below 4096
+    psum += packed[j];
+  }
+  const int cinc = wave_incl_scan(psum);
+  __syncthreads();
+  if (lane == kWave - 1) wt[w] = cinc;
+  __syncthreads();
+  int cb = 0, call = 0;
+  for (int k = 0; k < kWideWaves; ++k) { const int v = wt[k]; if (k < w) cb += v; call += v; }
+  int exq = cb + cinc - psum;
+  const int ftot = call >> 12, ptot = call & 4095;
+  const int ctot = ftot + ptot;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const int dg = tid * K + j;
+    const int fbase = exq >> 12, pbase = exq & 4095;  // full / partial chunks of earlier slices
+    const int ex = fbase + pbase;                     // first slot of this slice
+    if (dg < S) {
+      P.chunk_off[dg] = ex;
+      for (int jj = 0; jj < nf[j]; ++jj) P.chunk_rec[fbase + jj] = make_int4(dg, dbase[j] + jj * MC, MC, ex + jj);
+      if (pr[j]) P.chunk_rec[ftot + pbase] = make_int4(dg, dbase[j] + nf[j] * MC, pr[j], ex + nf[j]);
+    }
+    exq += packed[j];
+  }
+  for (int cc = ctot + tid; cc < P.max_chunks; cc += kWideThreads) P.chunk_rec[cc] = make_int4(0, 0, 0, 0);
+  if (tid == 0) {
+    P.chunk_off[S] = ctot;
+    P.hdr[0] = ctot;
+    P.hdr[1] = MC;
+    P.hdr[2] = N;
+    P.hdr[3] = has_row ? 1 : 0;
+  }
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
+    Dims d, int Nmax, const int* __restrict__ n_dev, const int64_t* __restrict__ indices,
+    const int64_t* __restrict__ tableidx, const int64_t* __restrict__ rowidx, const int* __restrict__ cnt, Plan P) {
+  constexpr int BINS = 1 << BITS, K = BINS / kWideThreads;
+  extern __shared__ int wide_lds[];
+  int (*hrun)[BINS] = (int (*)[BINS])wide_lds;  // [kWideWaves][BINS]
+  int* wt = wide_lds + kWideWaves * BINS;       // [kWideWaves]
+  const int t = blockIdx.y, tid = threadIdx.x, lane = lane_id(), w = tid / kWave;
+  const int N = live_n(Nmax, n_dev);
+  const CoreDec ct = core_dec(d, t);
+  for (int e = lane; e < BINS; e += kWave) hrun[w][e] = 0;  // (wave-private row)
+  // this wave's kSB x 64 positions: key, peers of equal key in the batch, per-wave digit counts
+  long long ix[kSB];
+  int tb[kSB], kv[kSB];
+  unsigned long long peers[kSB];
+  const int wbeg = blockIdx.x * kWideSpan + w * (kSB * kWave);
+#pragma unroll
+  for (int k = 0; k < kSB; ++k) {
+    const int i = wbeg + k * kWave + lane;
+    ix[k] = i < N ? indices[i] : 0;
+    tb[k] = (i < N && tableidx) ? (int)tableidx[i] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < kSB; ++k) {
+    const int i = wbeg + k * kWave + lane;
+    const bool valid = i < N;
+    kv[k] = valid ? min(tb[k] * ct.p + decode_core(ct, ix[k]), BINS - 1) : 0;
+    peers[k] = wave_match<BITS>((unsigned)kv[k], valid);
+    if (valid && (peers[k] & lanemask_lt()) == 0) hrun[w][kv[k]] += __popcll(peers[k]);
+  }
+  __syncthreads();
+  // thread owns digits tid * K .. + K - 1: totals over all work-groups, over the earlier ones
+  int tot[K], bef[K], dbase[K], sum = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) { tot[j] = 0; bef[j] = 0; }
+  {
+    const int G = gridDim.x;
+    const int* c = cnt + (size_t)t * G * BINS + tid * K;
+    for (int g0 = 0; g0 < G; g0 += 8) {
+      int v[8][K];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int j = 0; j < K; ++j) v[r][j] = (g0 + r < G) ? c[(size_t)(g0 + r) * BINS + j] : 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          tot[j] += v[r][j];
+          if (g0 + r < (int)blockIdx.x) bef[j] += v[r][j];
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) sum += tot[j];
+  const int inc = wave_incl_scan(sum);
+  if (lane == kWave - 1) wt[w] = inc;
+  __syncthreads();
+  int wbase = 0;
+  for (int k = 0; k < w; ++k) wbase += wt[k];
+  dbase[0] = wbase + inc - sum;  // first position of the thread's first digit
+#pragma unroll
+  for (int j = 1; j < K; ++j) dbase[j] = dbase[j - 1] + tot[j - 1];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const int dg = tid * K + j;
+    int b = dbase[j] + bef[j];
+#pragma unroll
+    for (int k = 0; k < kWideWaves; ++k) { const int m = hrun[k][dg]; hrun[k][dg] = b; b += m; }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) finish_wide<K>(d, t, tot, dbase, N, rowidx != nullptr, P, wt);
+#pragma unroll
+  for (int k = 0; k < kSB; ++k) {
+    const int i = wbeg + k * kWave + lane;
+    const bool valid = i < N;
+    if (valid) {
+      const int before = hrun[w][kv[k]];
+      const int pos = before + __popcll(peers[k] & lanemask_lt());
+      if ((peers[k] & lanemask_lt()) == 0) hrun[w][kv[k]] = before + __popcll(peers[k]);
+      if (t != 1) {
+        P.perm[t][pos] = i;
+      } else {
+        const int s0 = tb[k] * d.p[0] + decode_core(d, 0, ix[k]);
+        const int s2 = d.T > 2 ? tb[k] * d.p[2] + decode_core(d, 2, ix[k]) : 0;
+        const int s3 = d.T > 3 ? tb[k] * d.p[3] + decode_core(d, 3, ix[k]) : 0;
+        P.lrec[pos] = make_int4(i, s0, s2, s3);
+        if (rowidx) P.lrow[pos] = (int)rowidx[i];
+      }
+    }
+  }
+}
+
+template <int BITS>
+static int plan_build_wide(const Dims& d, int N, const int* n_dev, const int64_t* indices, const int64_t* tableidx,
+                           const int64_t* rowidx, const Plan& P, hipStream_t stream) {
+  constexpr size_t lds = (size_t)(kWideWaves * (1 << BITS) + kWideWaves) * sizeof(int);
+  static bool attr_done = false;
+  if (!attr_done) {
+    TTX_HIP(hipFuncSetAttribute((const void*)mbw_scatter_kernel<BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const dim3 grid((N + kWideSpan - 1) / kWideSpan, d.T);
+  hipLaunchKernelGGL(mbw_count_kernel<BITS>, grid, dim3(kWideThreads), 0, stream, d, N, n_dev, indices, tableidx, P.cnt);
+  hipLaunchKernelGGL(mbw_scatter_kernel<BITS>, grid, dim3(kWideThreads), lds, stream, d, N, n_dev, indices, tableidx,
+                     rowidx, (const int*)P.cnt, P);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
 // first position of the sorted keys with key >= s
 __device__ __forceinline__ int lower_bound_key(const int* sk, int N, int s) {
   int lo = 0, hi = N;
@@ -853,6 +1065,12 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
                        dim3(kOneThreads), 0, stream, d, N, n_dev, indices, tableidx, rowidx, P, Prologue{});
     TTX_HIP(hipGetLastError());
     return TTX_OK;
+  }
+  if (maxp > 1 && (N + kWideSpan - 1) / kWideSpan <= kWideMaxG) {  // one wide digit instead of two passes?
+    int smax = 1;
+    for (int t = 0; t < d.T; ++t) if (d.S[t] > smax) smax = d.S[t];
+    if (smax <= 1024) return plan_build_wide<10>(d, N, n_dev, indices, tableidx, rowidx, P, stream);
+    if (smax <= 2048) return plan_build_wide<11>(d, N, n_dev, indices, tableidx, rowidx, P, stream);
   }
   // unit size: 256 positions per wave while that keeps the unit count small enough for the
   // scatter pass to scan the counts itself; longer walks (<= 4096) before falling back to the

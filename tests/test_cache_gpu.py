@@ -262,8 +262,9 @@ def test_lookup_prologue_equals_separate_calls(tables, p, B, pf, std, H):
     assert_close(o1.cpu().numpy(), ref, "prologue plan forward vs oracle")
 
 
+@pytest.mark.parametrize("p", [[20, 22, 25], [300, 29, 31]])  # 8-bit slice ids / the wide-digit plan
 @pytest.mark.parametrize("n_live", [0, 1, 777, 3000])
-def test_device_side_counts_equal_exact_sizes(n_live):
+def test_device_side_counts_equal_exact_sizes(n_live, p):
     """include/ttx.h 'device-side counts': a plan built by ttx_plan_build_n for nnz_dev = n_live out of an
     upper bound nnz, and the cache kernels driven by skip_dev, give what the exact-size calls give."""
     import ctypes as C
@@ -275,14 +276,14 @@ def test_device_side_counts_equal_exact_sizes(n_live):
     L.ttx_plan_build_n.argtypes = [C.POINTER(E._Geom), i64, vp, vp, vp, vp, vp, sz, vp]
     L.ttx_cache_forward_n.argtypes = [i32, i64, vp, vp, vp, i32, vp, vp, vp]
     L.ttx_cache_backward_sgd_n.argtypes = [i64, vp, i32, vp, vp, vp, C.c_float, vp, vp]
-    p, q, r = [20, 22, 25], [4, 4, 4], [1, 16, 16, 1]
-    E_, D, B, nnz = 20 * 22 * 25, 64, 150, 3000
+    q, r = [4, 4, 4], [1, 16, 16, 1]
+    E_, D, B, nnz = p[0] * p[1] * p[2], 64, 150, 3000
     rs = np.random.RandomState(n_live)
     idx = t(rs.randint(0, E_, size=nnz).astype(np.int64))
     rowidx = t(np.sort(rs.randint(0, B, size=nnz)).astype(np.int64))
     tableidx = torch.zeros(nnz, dtype=torch.int64, device=DEV)
     cores = [t(c) for c in G.make_cores(4, 1, p, q, r[1:-1], "signed")]
-    Lt = torch.tensor([22 * 25, 25, 1], dtype=torch.int64, device=DEV)
+    Lt = torch.tensor([p[1] * p[2], p[2], 1], dtype=torch.int64, device=DEV)
     g = E._geom(1, p, q, r)
     st = torch.cuda.current_stream().cuda_stream
     n_dev = torch.tensor([n_live], dtype=torch.int32, device=DEV)

@@ -179,11 +179,14 @@ def test_large_batch_uses_the_global_memory_plan():
     (3, [100, 120, 90], 400, 6),      # slice id = table * p + i_t exceeds one digit because of the table
     (2, [20, 600, 15], 350, 7),       # only the pivot core needs a second pass
     (1, [256, 255, 257], 500, 30),    # digit-boundary slice counts, single/multi pass mixed, N < 16384
+    (1, [2500, 30, 20], 600, 12),     # more than 2048 slices in a core: two 8-bit passes (no wide digit)
+    (7, [250, 260, 240], 300, 8),     # 7 tables: 1820 slice ids -> the 11-bit wide digit
+    (4, [250, 220, 200], 1100, 20),   # the table-batched benchmark geometry: 10-bit wide digit, ~10 work-groups
 ])
 def test_plan_paths_vs_oracle(tables, p, B, pf):
     """every route through the lookup plan (ttx_plan.hip): single launch (all sorts one 8-bit pass,
-    N <= 16384) is what the other tests take; here multi-pass sorts, the separate scan launch and
-    the finish launch.  Forward, dense grads and fused SGD against the oracle."""
+    N <= 16384) is what the other tests take; here the wide-digit single pass (256 < slices <= 2048,
+    up to 96 work-groups), multi-pass sorts, the separate scan launch and the finish launch.  Forward, dense grads and fused SGD against the oracle."""
     q, r = [2, 3, 2], [1, 4, 5, 1]
     E_, D = int(np.prod(np.array(p, dtype=np.int64))), int(np.prod(q))
     idx, off = G.make_bags(5 + B, B, E_, pf, 1, tables)
