@@ -356,15 +356,15 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
 #undef PSTAMP
 }
 
-// ---- multi-work-group plan (any nnz): the same stable LSD radix sort spread over the chip ----
-// A "unit" is one wavefront walking kUnit consecutive positions of the current order in batches
-// of 64 (ranking by wave_match8, running digit counters in LDS).  Per 8-bit pass:
-//   mb_count   : per-unit digit counts            -> cnt[t][digit][unit]   (pass 0 also decodes
-//                                                    idx -> sid[t][n] and stores it)
-//   mb_scan    : exclusive scan over (digit major, unit minor), one work-group per core
-//   mb_scatter : position = base[digit][unit] + rank; writes the next order; on a core's last
-//                pass also perm[t], the sorted keys and (pivot) the flat lookup records
-// then mb_finish: slice offsets by binary search on the sorted keys + the pivot chunk list.
+// ---- single 8-bit pass on wave units (every S[t] <= 256, 16384 < nnz <= ~1 M) ----
+// A "unit" is one wavefront walking A.unit consecutive positions in batches of 64 (ranking by
+// wave_match8, running digit counters in LDS):
+//   mb_count   : per-unit digit counts -> cnt[t][unit][digit]
+//   mb_scatter : every work-group scans the unit counts itself (<= kMbFuseU units), position =
+//                base[digit][unit] + rank; writes perm[t] / the pivot's flat lookup records; its
+//                first work-group per core writes offsets and chunk list (finish_single_pass).
+// (Both kernels still carry the pass index of the multi-pass plan they came from; that plan is
+// mbp_* below now.)
 constexpr int kMbThreads = 256;            // 4 wave units per work-group
 constexpr int kMbUnits = kMbThreads / kWave;
 constexpr int kSB = 4;                     // batches of 64 whose loads are in flight together
@@ -375,8 +375,6 @@ struct MbArgs {
   const int* n_dev;    // device-side lookup count (<= N), or NULL: N is exact
   int unit;            // positions per wave unit (multiple of 64)
   int pass;            // current pass
-  int fused_scan;      // scatter derives its bases itself (few units): no scan launch
-  int fused_finish;    // ... and, single-pass sorts, the offset tables / chunk list: no finish launch
   int passes[TTX_MAX_CORES];
   int* cnt;            // [T][U][256]  (unit-major: a unit's 256 digit counts are one 1 KiB row)
 };
@@ -443,32 +441,6 @@ __global__ __launch_bounds__(kMbThreads) void mb_count_kernel(
   }
   if (u < A.U)
     for (int e = lane; e < 256; e += kWave) A.cnt[((size_t)t * A.U + u) * 256 + e] = hist[w][e];
-}
-
-// many units (> kMbFuseU): counts -> first positions, in place.  One work-group per core,
-// thread = digit, walking the unit rows (coalesced 1 KiB each).
-__global__ __launch_bounds__(256) void mb_scan_kernel(MbArgs A) {
-  __shared__ int wt[kMbUnits];
-  const int t = blockIdx.x, dg = threadIdx.x;
-  if (A.pass >= A.passes[t]) return;
-  int* c = A.cnt + (size_t)t * A.U * 256 + dg;
-  int tot = 0;
-  for (int u0 = 0; u0 < A.U; u0 += 8) {
-    int v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (u0 + j < A.U) ? c[(size_t)(u0 + j) * 256] : 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (u0 + j < A.U) c[(size_t)(u0 + j) * 256] = tot;
-      tot += v[j];
-    }
-  }
-  const int inc = wave_incl_scan(tot);
-  if (lane_id() == kWave - 1) wt[dg / kWave] = inc;
-  __syncthreads();
-  int dbase = inc - tot;
-  for (int k = 0; k < dg / kWave; ++k) dbase += wt[k];
-  for (int u = 0; u < A.U; ++u) c[(size_t)u * 256] += dbase;
 }
 
 // Single 8-bit pass (every S[t] <= 256): digit == slice id, so the digit prefix IS the slice
@@ -693,8 +665,8 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
   if (A.pass >= A.passes[t]) return;
   const int lane = lane_id(), w = threadIdx.x / kWave;
   const int u = blockIdx.x * kMbUnits + w;
-  if (A.fused_scan) {
-    // few units: every work-group derives its own bases from the raw counts (no scan launch).
+  {
+    // every work-group derives its own bases from the raw counts (<= kMbFuseU units, no scan launch).
     // thread = digit: total of the digit, exclusive prefix over digits, prefix over earlier units
     const int dg = threadIdx.x;
     const int* c = A.cnt + (size_t)t * A.U * 256 + dg;
@@ -725,9 +697,7 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
 #pragma unroll
     for (int k = 0; k < kMbUnits; ++k) { run[k][dg] = b; b += mine[k]; }
     __syncthreads();
-    if (A.fused_finish && blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, live_n(A.N, A.n_dev), rowidx != nullptr, P, wt5);
-  } else if (u < A.U) {
-    for (int e = lane; e < 256; e += kWave) run[w][e] = A.cnt[((size_t)t * A.U + u) * 256 + e];
+    if (blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, live_n(A.N, A.n_dev), rowidx != nullptr, P, wt5);
   }
   const int N = live_n(A.N, A.n_dev);
   const int beg = min(N, u * A.unit), end = min(N, beg + A.unit);
@@ -978,6 +948,164 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
   }
 }
 
+// ---- multi-pass plan on full work-groups: more than 2048 slice ids, or more than kWideMaxG work-groups ----
+// 8-bit passes like mb_count / mb_scatter, but spread as the wide-digit plan is: 1024-thread
+// work-groups over 4096 positions of the current order (16 waves x kSB batches, all loads of a
+// wave in flight together), one 256-bin count row per work-group, a column scan launch in
+// between (mbp_scan: every scatter work-group reading all rows would be G^2 KiB of L2 traffic).
+// The wave units of mb_count walk up to 4096 positions each on a quarter of the chip's wave slots.
+struct MbpArgs {
+  int N;               // lookups (upper bound when n_dev is set)
+  const int* n_dev;
+  int pass;
+  int passes[TTX_MAX_CORES];
+  int* cnt;            // [T][G][256]
+};
+
+__global__ __launch_bounds__(kWideThreads) void mbp_count_kernel(
+    Dims d, MbpArgs A, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx, Plan P) {
+  __shared__ int hist[256];
+  const int t = blockIdx.y, tid = threadIdx.x;
+  if (A.pass >= A.passes[t]) return;
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  const int N = live_n(A.N, A.n_dev);
+  int* key = P.sid[t];
+  const int* src = (A.pass == 0) ? nullptr : ((A.pass & 1) ? P.scratch[t][1] : P.scratch[t][2]);
+  const int shift = A.pass * 8;
+  const CoreDec ct = core_dec(d, t);
+  MbItem it[kSB];
+#pragma unroll
+  for (int k = 0; k < kSB; ++k) {
+    const int i = blockIdx.x * kWideSpan + k * kWideThreads + tid;
+    it[k] = mb_load(i, i < N, A.pass, ct, indices, tableidx, src, key);
+  }
+#pragma unroll
+  for (int k = 0; k < kSB; ++k) {
+    const int i = blockIdx.x * kWideSpan + k * kWideThreads + tid;
+    if (i < N) {
+      if (A.pass == 0 && A.passes[t] > 1) key[i] = it[k].kv;  // later passes chase order -> key
+      atomicAdd(&hist[((unsigned)it[k].kv >> shift) & 255u], 1);
+    }
+  }
+  __syncthreads();
+  if (tid < 256) A.cnt[((size_t)t * gridDim.x + blockIdx.x) * 256 + tid] = hist[tid];
+}
+
+// counts -> first positions, in place, (digit major, work-group minor).  One work-group per core:
+// thread = (digit, quarter of the rows); two walks over the rows with 8 loads in flight.
+__global__ __launch_bounds__(kWideThreads) void mbp_scan_kernel(MbpArgs A, int G) {
+  __shared__ int psum[4][256], dbase[256], wt[4];
+  const int t = blockIdx.x, tid = threadIdx.x, dg = tid & 255, part = tid >> 8;
+  if (A.pass >= A.passes[t]) return;
+  const int per = (G + 3) / 4, r0 = min(G, part * per), r1 = min(G, r0 + per);
+  int* c = A.cnt + (size_t)t * G * 256 + dg;
+  int s = 0;
+  for (int r = r0; r < r1; r += 8) {
+    int v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (r + j < r1) ? c[(size_t)(r + j) * 256] : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  psum[part][dg] = s;
+  __syncthreads();
+  if (tid < 256) {
+    const int tot = psum[0][dg] + psum[1][dg] + psum[2][dg] + psum[3][dg];
+    const int inc = wave_incl_scan(tot);
+    if (lane_id() == kWave - 1) wt[tid / kWave] = inc;
+    dbase[dg] = inc - tot;  // (+ the totals of the earlier waves, below)
+  }
+  __syncthreads();
+  int run = dbase[dg];
+  for (int k = 0; k < dg / kWave; ++k) run += wt[k];
+  for (int k = 0; k < part; ++k) run += psum[k][dg];
+  for (int r = r0; r < r1; r += 8) {
+    int v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (r + j < r1) ? c[(size_t)(r + j) * 256] : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (r + j < r1) c[(size_t)(r + j) * 256] = run;
+      run += v[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kWideThreads) void mbp_scatter_kernel(
+    Dims d, MbpArgs A, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx,
+    const int64_t* __restrict__ rowidx, Plan P) {
+  __shared__ int hrun[kWideWaves][256];
+  const int t = blockIdx.y, tid = threadIdx.x, lane = lane_id(), w = tid / kWave;
+  if (A.pass >= A.passes[t]) return;
+  const int N = live_n(A.N, A.n_dev);
+  int* key = P.sid[t];
+  const int* src = (A.pass == 0) ? nullptr : ((A.pass & 1) ? P.scratch[t][1] : P.scratch[t][2]);
+  const bool last = (A.pass == A.passes[t] - 1);
+  int* dst = last ? P.perm[t] : ((A.pass & 1) ? P.scratch[t][2] : P.scratch[t][1]);
+  int* sk = P.scratch[t][0];  // sorted keys (last pass): what mb_finish searches
+  const int shift = A.pass * 8;
+  const bool pivot = (t == 1);
+  const CoreDec ct = core_dec(d, t);
+  for (int e = lane; e < 256; e += kWave) hrun[w][e] = 0;  // (wave-private row)
+  const int wbeg = blockIdx.x * kWideSpan + w * (kSB * kWave);
+  MbItem it[kSB];
+  unsigned long long peers[kSB];
+#pragma unroll
+  for (int k = 0; k < kSB; ++k) {
+    const int i = wbeg + k * kWave + lane;
+    it[k] = mb_load(i, i < N, A.pass, ct, indices, tableidx, src, key);
+  }
+  long long ix[kSB];
+  int tb[kSB], brow[kSB];
+  if (last && pivot) {  // the record gathers of the wave's positions, in flight together
+#pragma unroll
+    for (int k = 0; k < kSB; ++k) {
+      const int i = wbeg + k * kWave + lane;
+      const int v = it[k].val;
+      ix[k] = i < N ? indices[v] : 0;
+      tb[k] = (i < N && tableidx) ? (int)tableidx[v] : 0;
+      brow[k] = (i < N && rowidx) ? (int)rowidx[v] : 0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kSB; ++k) {
+    const int i = wbeg + k * kWave + lane;
+    const bool valid = i < N;
+    const unsigned dg = ((unsigned)it[k].kv >> shift) & 255u;
+    peers[k] = wave_match8(dg, valid);
+    if (valid && (peers[k] & lanemask_lt()) == 0) hrun[w][dg] += __popcll(peers[k]);
+  }
+  __syncthreads();
+  if (tid < 256) {  // thread = digit: first position of (digit, this work-group), then of each wave
+    int b = A.cnt[((size_t)t * gridDim.x + blockIdx.x) * 256 + tid];
+#pragma unroll
+    for (int k = 0; k < kWideWaves; ++k) { const int m = hrun[k][tid]; hrun[k][tid] = b; b += m; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kSB; ++k) {
+    const int i = wbeg + k * kWave + lane;
+    if (i < N) {
+      const unsigned dg = ((unsigned)it[k].kv >> shift) & 255u;
+      const int before = hrun[w][dg];
+      const int pos = before + __popcll(peers[k] & lanemask_lt());
+      if ((peers[k] & lanemask_lt()) == 0) hrun[w][dg] = before + __popcll(peers[k]);
+      if (!(last && pivot)) dst[pos] = it[k].val;  // the pivot's final order lives in lrec.x
+      if (last) {
+        sk[pos] = it[k].kv;
+        if (pivot) {
+          const int s0 = tb[k] * d.p[0] + decode_core(d, 0, ix[k]);
+          const int s2 = d.T > 2 ? tb[k] * d.p[2] + decode_core(d, 2, ix[k]) : 0;
+          const int s3 = d.T > 3 ? tb[k] * d.p[3] + decode_core(d, 3, ix[k]) : 0;
+          P.lrec[pos] = make_int4(it[k].val, s0, s2, s3);
+          if (rowidx) P.lrow[pos] = brow[k];
+        }
+      }
+    }
+  }
+}
+
 template <int BITS>
 static int plan_build_wide(const Dims& d, int N, const int* n_dev, const int64_t* indices, const int64_t* tableidx,
                            const int64_t* rowidx, const Plan& P, hipStream_t stream) {
@@ -1005,26 +1133,29 @@ __device__ __forceinline__ int lower_bound_key(const int* sk, int N, int s) {
   return lo;
 }
 
-// blockIdx.y = core: slice offsets of the thin cores; the pivot's work-group(s) build the chunk list
-__global__ __launch_bounds__(1024) void mb_finish_kernel(Dims d, int Nmax, const int* __restrict__ n_dev, int has_row, Plan P) {
+// blockIdx.y = core: slice offsets of every core by binary search on its sorted keys
+__global__ __launch_bounds__(1024) void mb_finish_kernel(Dims d, int Nmax, const int* __restrict__ n_dev, Plan P) {
   const int N = live_n(Nmax, n_dev);
-  __shared__ int wtot[kPlanWaves + 1];
   const int t = blockIdx.y, tid = threadIdx.x;
   const int* sk = P.scratch[t][0];
-  if (t != 1) {
-    const int S = d.S[t];
-    for (int s = blockIdx.x * 1024 + tid; s <= S; s += gridDim.x * 1024) P.off[t][s] = (s == S) ? N : lower_bound_key(sk, N, s);
-    return;
-  }
-  if (blockIdx.x != 0) return;
+  const int S = d.S[t];
+  for (int s = blockIdx.x * 1024 + tid; s <= S; s += gridDim.x * 1024) P.off[t][s] = (s == S) ? N : lower_bound_key(sk, N, s);
+}
+
+// ... then the pivot's chunk list from its offsets (one work-group; chunk slots are slice-major)
+__global__ __launch_bounds__(1024) void mb_chunks_kernel(Dims d, int Nmax, const int* __restrict__ n_dev, int has_row, Plan P) {
+  const int N = live_n(Nmax, n_dev);
+  __shared__ int wtot[kPlanWaves + 1];
+  const int tid = threadIdx.x;
   const int S1 = d.S[1], MC = P.MC;
+  const int* off = P.off[1];
   int carry = 0;
   for (int s0 = 0; s0 < S1; s0 += 1024) {
     const int s = s0 + tid;
     int nch = 0, beg = 0, cnt = 0;
     if (s < S1) {
-      beg = lower_bound_key(sk, N, s);
-      cnt = lower_bound_key(sk, N, s + 1) - beg;
+      beg = off[s];
+      cnt = off[s + 1] - beg;
       nch = (cnt + MC - 1) / MC;
     }
     int total;
@@ -1043,6 +1174,13 @@ __global__ __launch_bounds__(1024) void mb_finish_kernel(Dims d, int Nmax, const
     P.hdr[2] = N;
     P.hdr[3] = has_row;
   }
+}
+
+static void launch_finish(const Dims& d, int N, const int* n_dev, bool has_row, const Plan& P, hipStream_t stream) {
+  int smax = 1;
+  for (int t = 0; t < d.T; ++t) if (d.S[t] + 1 > smax) smax = d.S[t] + 1;
+  hipLaunchKernelGGL(mb_finish_kernel, dim3((smax + 1023) / 1024, d.T), dim3(1024), 0, stream, d, N, n_dev, P);
+  hipLaunchKernelGGL(mb_chunks_kernel, dim3(1), dim3(1024), 0, stream, d, N, n_dev, has_row ? 1 : 0, P);
 }
 
 static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* indices, const int64_t* tableidx,
@@ -1072,30 +1210,34 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
     if (smax <= 1024) return plan_build_wide<10>(d, N, n_dev, indices, tableidx, rowidx, P, stream);
     if (smax <= 2048) return plan_build_wide<11>(d, N, n_dev, indices, tableidx, rowidx, P, stream);
   }
-  // unit size: 256 positions per wave while that keeps the unit count small enough for the
-  // scatter pass to scan the counts itself; longer walks (<= 4096) before falling back to the
-  // scan launch.  cnt was sized for units of 256 (carve_plan), any larger unit fits.
-  A.unit = 256;
-  if ((N + 255) / 256 > kMbFuseU) {
-    A.unit = ((N + kMbFuseU - 1) / kMbFuseU + 63) / 64 * 64;
-    if (A.unit > 4096) A.unit = 4096;
+  if (maxp > 1 || N > kMbFuseU * 4096) {  // 8-bit passes on full work-groups, then mb_finish
+    MbpArgs B;
+    B.N = N;
+    B.n_dev = n_dev;
+    B.cnt = P.cnt;
+    for (int t = 0; t < TTX_MAX_CORES; ++t) B.passes[t] = A.passes[t];
+    const int G = (N + kWideSpan - 1) / kWideSpan;
+    const dim3 grid(G, d.T);
+    for (int ps = 0; ps < maxp; ++ps) {
+      B.pass = ps;
+      hipLaunchKernelGGL(mbp_count_kernel, grid, dim3(kWideThreads), 0, stream, d, B, indices, tableidx, P);
+      hipLaunchKernelGGL(mbp_scan_kernel, dim3(d.T), dim3(kWideThreads), 0, stream, B, G);
+      hipLaunchKernelGGL(mbp_scatter_kernel, grid, dim3(kWideThreads), 0, stream, d, B, indices, tableidx, rowidx, P);
+    }
+    launch_finish(d, N, n_dev, rowidx != nullptr, P, stream);
+    TTX_HIP(hipGetLastError());
+    return TTX_OK;
   }
+  // one 8-bit pass, up to ~1 M lookups: wave units of 256..4096 positions (<= kMbFuseU of them), the
+  // scatter launch scans the unit counts itself and its first work-group writes offsets / chunk list
+  A.unit = 256;
+  if ((N + 255) / 256 > kMbFuseU) A.unit = ((N + kMbFuseU - 1) / kMbFuseU + 63) / 64 * 64;
   A.U = (N + A.unit - 1) / A.unit;
   A.cnt = P.cnt;
-  A.fused_scan = A.U <= kMbFuseU ? 1 : 0;
-  A.fused_finish = (A.fused_scan && maxp == 1) ? 1 : 0;
+  A.pass = 0;
   const dim3 gu((A.U + kMbUnits - 1) / kMbUnits, d.T);
-  for (int ps = 0; ps < maxp; ++ps) {
-    A.pass = ps;
-    hipLaunchKernelGGL(mb_count_kernel, gu, dim3(kMbThreads), 0, stream, d, A, indices, tableidx, P);
-    if (!A.fused_scan) hipLaunchKernelGGL(mb_scan_kernel, dim3(d.T), dim3(256), 0, stream, A);
-    hipLaunchKernelGGL(mb_scatter_kernel, gu, dim3(kMbThreads), 0, stream, d, A, indices, tableidx, rowidx, P);
-  }
-  if (A.fused_finish) { TTX_HIP(hipGetLastError()); return TTX_OK; }
-  int smax = 1;
-  for (int t = 0; t < d.T; ++t) if (t != 1 && d.S[t] + 1 > smax) smax = d.S[t] + 1;
-  hipLaunchKernelGGL(mb_finish_kernel, dim3((smax + 1023) / 1024, d.T), dim3(1024), 0, stream, d, N, n_dev,
-                     rowidx ? 1 : 0, P);
+  hipLaunchKernelGGL(mb_count_kernel, gu, dim3(kMbThreads), 0, stream, d, A, indices, tableidx, P);
+  hipLaunchKernelGGL(mb_scatter_kernel, gu, dim3(kMbThreads), 0, stream, d, A, indices, tableidx, rowidx, P);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }

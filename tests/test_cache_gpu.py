@@ -262,7 +262,7 @@ def test_lookup_prologue_equals_separate_calls(tables, p, B, pf, std, H):
     assert_close(o1.cpu().numpy(), ref, "prologue plan forward vs oracle")
 
 
-@pytest.mark.parametrize("p", [[20, 22, 25], [300, 29, 31]])  # 8-bit slice ids / the wide-digit plan
+@pytest.mark.parametrize("p", [[20, 22, 25], [300, 29, 31], [2100, 3, 2]])  # 8-bit slice ids / wide digit / two passes
 @pytest.mark.parametrize("n_live", [0, 1, 777, 3000])
 def test_device_side_counts_equal_exact_sizes(n_live, p):
     """include/ttx.h 'device-side counts': a plan built by ttx_plan_build_n for nnz_dev = n_live out of an
