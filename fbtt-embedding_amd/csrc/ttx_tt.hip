@@ -516,6 +516,81 @@ __global__ __launch_bounds__(kThreads) void pool_kernel(int Nmax, const int* __r
   }
 }
 
+// the same for D % 4 == 0, at memory speed: a wave owns 64 consecutive lookups, finds the run heads
+// among them with one ballot, and its four 16-lane groups take those heads round-robin (16-byte
+// loads: a 64-float row is one load per lane; a run is summed in index order by ONE group, eight
+// rows in flight).  pool_kernel keeps one half-wave in twenty busy at 20 lookups per bag.
+__global__ __launch_bounds__(kThreads) void pool4_kernel(int Nmax, const int* __restrict__ hdr, int B, int D4,
+                                                        const int64_t* __restrict__ rowidx,
+                                                        const int64_t* __restrict__ tableidx,
+                                                        const float4* __restrict__ rows,
+                                                        const float* __restrict__ psw, float4* __restrict__ out) {
+  __shared__ unsigned char hpos[kThreads / kWave][kWave];
+  const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  const int N = min(Nmax, hdr[2]);  // the plan knows how many lookups are live (device-side counts)
+  const int n0 = (blockIdx.x * (kThreads / kWave) + w) * kWave;
+  if (n0 >= N) return;  // (wave-uniform)
+  const int n = n0 + lane;
+  bool head = false;
+  if (n < N) head = n == 0 || rowidx[n - 1] != rowidx[n] || tableidx[n - 1] != tableidx[n];
+  const unsigned long long heads = __ballot(head);
+  if (head) hpos[w][__popcll(heads & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+  const int nheads = __popcll(heads);
+  const int g = lane >> 4, l = lane & 15, sh = lane & 48;
+  for (int k = g; k < nheads; k += 4) {
+    const int pos = hpos[w][k];
+    const int hn = n0 + pos;
+    const int64_t r = rowidx[hn], tb = tableidx[hn];
+    int sl;
+    if (k + 1 < nheads) {
+      sl = hpos[w][k + 1] - pos;
+    } else {  // the span's last run may go on behind it: 16 candidates per ballot (one group gets here)
+      sl = min(N, n0 + kWave) - hn;
+      if (hn + sl < N)
+        for (;;) {
+          const int c = hn + sl + l;
+          const bool same = c < N && rowidx[c] == r && tableidx[c] == tb;
+          const unsigned m = (unsigned)(__ballot(!same) >> sh) & 0xffffu;
+          if (m) { sl += __builtin_ctz(m); break; }
+          sl += 16;
+        }
+    }
+    float4* o = out + ((size_t)tb * B + r) * D4;
+    const float4* src = rows + (size_t)hn * D4;
+    for (int e = l; e < D4; e += 16) {
+      float4 acc = o[e];
+      if (psw) {  // weighted sum (per_sample_weights), same order
+        for (int j = 0; j < sl; ++j) {
+          const float wj = psw[hn + j];
+          const float4 v = src[(size_t)j * D4 + e];
+          acc.x = fmaf(wj, v.x, acc.x); acc.y = fmaf(wj, v.y, acc.y); acc.z = fmaf(wj, v.z, acc.z); acc.w = fmaf(wj, v.w, acc.w);
+        }
+      } else {
+        int j = 0;
+        for (; j + 8 <= sl; j += 8) {
+          float4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(j + u) * D4 + e];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; j + 4 <= sl; j += 4) {
+          float4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(j + u) * D4 + e];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; j < sl; ++j) {
+          const float4 v = src[(size_t)j * D4 + e];
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
+      o[e] = acc;
+    }
+  }
+}
+
 struct Partials {
   float* pc[TTX_MAX_CORES];  // pc[1] is per CHUNK, the others per lookup
   const float* psw;          // per_sample_weights by lookup (nn.EmbeddingBag), or NULL: the bag gradient of
@@ -1357,9 +1432,14 @@ int ttx_tt_forward_w(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const
   if (rc) return rc;
   {
     ProfScope ps(TTX_PROF_POOL, st);
-    const int groups = kThreads / 32;
-    hipLaunchKernelGGL(pool_kernel, dim3(((int)nnz + groups - 1) / groups), dim3(kThreads), 0, st,
-                       (int)nnz, P.hdr, B, d.D, rowidx, tableidx, rows, psw, output);
+    if (d.D % 4 == 0 && (((uintptr_t)rows | (uintptr_t)output) & 15) == 0) {
+      hipLaunchKernelGGL(pool4_kernel, dim3(((int)nnz + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
+                         (int)nnz, P.hdr, B, d.D / 4, rowidx, tableidx, (const float4*)rows, psw, (float4*)output);
+    } else {
+      const int groups = kThreads / 32;
+      hipLaunchKernelGGL(pool_kernel, dim3(((int)nnz + groups - 1) / groups), dim3(kThreads), 0, st,
+                         (int)nnz, P.hdr, B, d.D, rowidx, tableidx, rows, psw, output);
+    }
     TTX_HIP(hipGetLastError());
   }
   return TTX_OK;
