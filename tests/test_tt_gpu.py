@@ -202,6 +202,37 @@ def test_plan_paths_vs_oracle(tables, p, B, pf):
                 assert_close(got["cores"][k], orc["cores"][k], f"plan {p} sgd core{k}")
 
 
+@pytest.mark.parametrize("p,tables", [([100, 120, 90], 3), ([2500, 30, 20], 1)])  # wide digit / two passes
+@pytest.mark.parametrize("nnz", [4096, 4097, 8191, 12288])
+@pytest.mark.parametrize("skew", [False, True])
+def test_plan_work_group_boundaries(p, tables, nnz, skew):
+    """the 4096-position work-groups of the wide-digit and the multi-pass plan: lookup counts on and
+    next to the work-group boundary, uniform and with nearly every lookup in one slice per core
+    (one histogram bin takes the whole work-group; a slice's chunk count exceeds its neighbours')."""
+    q, r = [2, 3, 2], [1, 4, 5, 1]
+    E_, D, B = int(np.prod(np.array(p, dtype=np.int64))), int(np.prod(q)), 64
+    rs = np.random.RandomState(nnz + tables)
+    sizes = rs.multinomial(nnz, np.ones(tables * B) / (tables * B))  # ragged bags, some empty
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    idx = rs.randint(0, E_, size=nnz).astype(np.int64)
+    if skew:
+        hot = rs.randint(0, E_)
+        idx = np.where(rs.rand(nnz) < 0.9, hot, idx).astype(np.int64)
+    c = dict(tables=tables, T=3, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+             cores=G.make_cores(11, tables, p, q, r, "signed"), d_out=G.make_grad(12, tables, B, D))
+    # a hot slice's gradient is an fp32 sum of up to 11k signed terms (partial sums ~100) whose order differs
+    # from the oracle's sequential one: the rounding random walk is ~sqrt(n) * 6e-8 * 100
+    tol = dict(rtol=5e-5, atol_scale=1e-5) if skew else {}
+    for mode in ("dense", "sgd"):
+        got, orc = run_case(c, mode, plan_shared=True), oracle_case(c, mode)
+        assert_close(got["out"], orc["out"], f"boundary {nnz} out")
+        for k in range(3):
+            if mode == "dense":
+                assert_close(got["grads"][k], orc["grads"][k], f"boundary {nnz} grad{k}", **tol)
+            else:
+                assert_close(got["cores"][k], orc["cores"][k], f"boundary {nnz} sgd core{k}", **tol)
+
+
 @pytest.mark.parametrize("p,q,r", [([3, 2, 4], [4, 4, 4], [1, 16, 16, 1]), ([2, 3, 3], [2, 3, 2], [1, 4, 5, 1]),
                                    ([3, 2], [4, 4], [1, 8, 1])])
 def test_hot_slices_are_reduced_by_several_work_groups(p, q, r):
