@@ -35,14 +35,21 @@ __global__ __launch_bounds__(kCT) void update_cache_state_kernel(
   hashtbl_count_wave(n < N ? colidx[n] : 0, n < N, H, hashtbl, cache_freq);
 }
 
-// rowidx/tableidx of every bag AND the frequency update of every index in one launch
-// (tiny kernels cost ~4 us each on this chip whatever they do): threads [0, 8*nb) walk the
-// bags 8 lanes per bag, threads [0, N) each insert one index.
+// rowidx/tableidx of every bag AND, per index, the frequency update and / or the cache lookup, in one
+// launch (tiny kernels cost ~4 us each on this chip whatever they do): threads [0, 8*nb) walk the
+// bags 8 lanes per bag, threads [0, N) each handle one index.
+//   upd_hashtbl != NULL : update_cache_state (cu:1077-1113) on (upd_hashtbl, cache_freq)
+//   loc != NULL         : cache_lookup_kernel (cu:1356-1375): loc[i] = cache row or -1 (TT entry), and
+//                         unit_cnt[blockIdx.x] = TT entries among the work-group's kCT positions
 __global__ __launch_bounds__(kCT) void rowidx_update_kernel(int64_t nb, int32_t B,
                                                            const int64_t* __restrict__ offsets,
                                                            int64_t* rowidx, int64_t* tableidx, int64_t N,
                                                            const int64_t* __restrict__ colidx, int32_t H,
-                                                           int64_t* hashtbl, int64_t* cache_freq) {
+                                                           int64_t* upd_hashtbl, int64_t* cache_freq,
+                                                           const int64_t* __restrict__ hashtbl,
+                                                           const int32_t* __restrict__ cache_state, int32_t* loc,
+                                                           int* unit_cnt) {
+  __shared__ int wc[kCT / kWave];
   const int64_t gt = (int64_t)blockIdx.x * kCT + threadIdx.x;
   const int64_t b = gt >> 3;
   if (b < nb) {
@@ -52,7 +59,27 @@ __global__ __launch_bounds__(kCT) void rowidx_update_kernel(int64_t nb, int32_t 
       tableidx[l] = b / B;
     }
   }
-  hashtbl_count_wave(gt < N ? colidx[gt] : 0, gt < N, H, hashtbl, cache_freq);
+  const bool valid = gt < N;
+  const int64_t key = valid ? colidx[gt] : 0;
+  if (upd_hashtbl) hashtbl_count_wave(key, valid, H, upd_hashtbl, cache_freq);
+  if (loc) {
+    bool tt = false;
+    if (valid) {
+      const int32_t slot = hashtbl_find(key, H, hashtbl);
+      int32_t cl = -1;
+      if (slot != -1) cl = cache_state[slot];
+      tt = (cl == -1);
+      loc[gt] = cl;
+    }
+    const int n = __popcll(__ballot(tt));
+    if (lane_id() == 0) wc[threadIdx.x / kWave] = n;
+    __syncthreads();
+    if (threadIdx.x == 0 && (int64_t)blockIdx.x * kCT < N) {
+      int s = 0;
+      for (int k = 0; k < kCT / kWave; ++k) s += wc[k];
+      unit_cnt[blockIdx.x] = s;
+    }
+  }
 }
 
 __global__ void set_int_kernel(int32_t* p, int32_t v) { *p = v; }
@@ -71,33 +98,9 @@ __global__ __launch_bounds__(kCT) void compute_rowidx_kernel(int64_t nb, int32_t
 }
 
 // ---- stable partition (cache_lookup_kernel cu:1356-1375 + Flagged) ---------
-// pass 1: look every index up, record flag / location, count TT entries per
-// wave unit.  unit u covers [u*WT, (u+1)*WT).
-__global__ __launch_bounds__(kCT) void lookup_count_kernel(
-    int N, int WT, const int64_t* __restrict__ colidx, int32_t H, const int64_t* __restrict__ hashtbl,
-    const int32_t* __restrict__ cache_state, int32_t* loc, int* unit_cnt) {
-  const int u = blockIdx.x * (kCT / kWave) + threadIdx.x / kWave;
-  const int beg = u * WT;
-  if (beg >= N) return;
-  const int end = min(N, beg + WT);
-  const int lane = lane_id();
-  int cnt = 0;
-  for (int base = beg; base < end; base += kWave) {
-    const int i = base + lane;
-    bool tt = false;
-    if (i < end) {
-      const int32_t slot = hashtbl_find(colidx[i], H, hashtbl);
-      int32_t cl = -1;
-      if (slot != -1) cl = cache_state[slot];
-      tt = (cl == -1);
-      loc[i] = cl;  // -1 <=> TT entry
-    }
-    cnt += __popcll(__ballot(tt));
-  }
-  if (lane == 0) unit_cnt[u] = cnt;
-}
-
-// single work-group exclusive scan of U ints (U <= a few thousand)
+// rowidx_update_kernel looked every index up (loc, -1 <=> TT entry) and counted the TT entries of
+// every unit = work-group of kCT positions.  Few units: the scatter launch sums the counts before
+// its own itself; many: scan_units_kernel turns them into exclusive prefixes first.
 __global__ __launch_bounds__(1024) void scan_units_kernel(int U, int* unit_cnt, int* total_out) {
   __shared__ int wt[17];
   int carry = 0;
@@ -122,30 +125,41 @@ __global__ __launch_bounds__(1024) void scan_units_kernel(int U, int* unit_cnt, 
 }
 
 __global__ __launch_bounds__(kCT) void partition_scatter_kernel(
-    int N, int WT, const int64_t* __restrict__ colidx, const int64_t* __restrict__ rowidx,
-    const int32_t* __restrict__ loc, const int* __restrict__ unit_base, int64_t* pcol, int64_t* prow,
-    int32_t* ploc) {
-  const int u = blockIdx.x * (kCT / kWave) + threadIdx.x / kWave;
-  const int beg = u * WT;
-  if (beg >= N) return;
-  const int end = min(N, beg + WT);
-  const int lane = lane_id();
-  int run = unit_base[u];  // TT entries before this unit
-  for (int base = beg; base < end; base += kWave) {
-    const int i = base + lane;
-    const bool valid = i < end;
-    const int32_t cl = valid ? loc[i] : 0;
-    const bool tt = valid && cl == -1;
-    const unsigned long long m = __ballot(tt);
-    if (valid) {
-      const int tt_before = run + __popcll(m & lanemask_lt());
-      // selected keep their order at the front; rejected go to the rear, reversed
-      const int dst = tt ? tt_before : (N - 1 - (i - tt_before));
-      pcol[dst] = colidx[i];
-      prow[dst] = rowidx[i];
-      ploc[dst] = cl;
-    }
-    run += __popcll(m);
+    int N, int U, int scanned, const int64_t* __restrict__ colidx, const int64_t* __restrict__ rowidx,
+    const int32_t* __restrict__ loc, const int* __restrict__ unit_cnt, int64_t* pcol, int64_t* prow,
+    int32_t* ploc, int* total_out, int32_t* num_tt_dev) {
+  __shared__ int wsum[kCT / kWave], wbase[kCT / kWave];
+  const int g = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid / kWave;
+  int part = 0;  // TT entries before this unit
+  if (scanned) {
+    part = (tid == 0) ? unit_cnt[g] : 0;
+  } else {
+    for (int u = tid; u < g; u += kCT) part += unit_cnt[u];
+  }
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
+  const int i = g * kCT + tid;
+  const bool valid = i < N;
+  const int32_t cl = valid ? loc[i] : 0;
+  const bool tt = valid && cl == -1;
+  const unsigned long long m = __ballot(tt);
+  if (lane == 0) { wsum[w] = __popcll(m); wbase[w] = part; }
+  __syncthreads();
+  int run = 0, own = 0;
+  for (int k = 0; k < kCT / kWave; ++k) { run += wbase[k]; if (k < w) run += wsum[k]; own += wsum[k]; }
+  if (g == U - 1 && tid == 0) {  // the split point, for the host copy and for the device-side consumers
+    int base = 0;
+    for (int k = 0; k < kCT / kWave; ++k) base += wbase[k];
+    *total_out = base + own;
+    if (num_tt_dev) *num_tt_dev = base + own;
+  }
+  if (valid) {
+    const int tt_before = run + __popcll(m & lanemask_lt());
+    // selected keep their order at the front; rejected go to the rear, reversed
+    const int dst = tt ? tt_before : (N - 1 - (i - tt_before));
+    pcol[dst] = colidx[i];
+    prow[dst] = rowidx[i];
+    ploc[dst] = cl;
   }
 }
 
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(kCT) void mark_popular_kernel(int32_t H, int64_t ca
   }
 }
 
-static void unit_shape(long long n, int* WT, int* U) {
+static void unit_shape(long long n, int* WT, int* U) {  // wave units of the populate-time sorts
   long long wt = (n + 2047) / 2048;
   wt = (wt + kWave - 1) / kWave * kWave;
   if (wt < 256) wt = 256;
@@ -410,6 +424,9 @@ static void unit_shape(long long n, int* WT, int* U) {
   *U = (int)((n + wt - 1) / wt);
   if (*U < 1) *U = 1;
 }
+
+constexpr int kScanUnits = 1024;  // beyond this many units the counts are scanned by their own launch
+static int num_units(long long n) { return n > 0 ? (int)((n + kCT - 1) / kCT) : 1; }
 
 }  // namespace ttx
 
@@ -429,9 +446,7 @@ int ttx_update_cache_state(int64_t nnz, const int64_t* indices, int64_t H, int64
 }
 
 size_t ttx_preprocess_workspace_bytes(int64_t nnz) {
-  int WT, U;
-  unit_shape(nnz, &WT, &U);
-  return align_up((size_t)nnz * 4) + align_up((size_t)(U + 64) * 4) + 256;
+  return align_up((size_t)nnz * 4) + align_up((size_t)(num_units(nnz) + 64) * 4) + 256;
 }
 
 int ttx_preprocess_indices_sync(int64_t nnz, const int64_t* colidx, int64_t nb,
@@ -474,45 +489,46 @@ int ttx_preprocess_indices_async(int64_t nnz, const int64_t* colidx, int64_t nb,
     TTX_FAIL(TTX_EINVAL, "offsets has %lld bags, not a multiple of num_tables=%d", (long long)nb, num_tables);
   if (!colidx || !offsets || !rowidx || !tableidx) TTX_FAIL(TTX_EINVAL, "NULL input");
   const int32_t B = (int32_t)(nb / num_tables);
-  if (upd_hashtbl && upd_cache_freq) {  // fused update_cache_state (cu:1077-1113) + compute_rowidx
-    if (H <= 0 || H >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
+  const bool upd = upd_hashtbl && upd_cache_freq;
+  const bool lookup = !(warmup || num_tables != 1);  // cu:1410-1412
+  if ((upd || lookup) && (H <= 0 || H >= (1ll << 31)))
+    TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
+  int32_t* loc = nullptr;
+  int *unit_cnt = nullptr, *total = nullptr;
+  const int N = (int)nnz, U = num_units(nnz);
+  if (lookup) {
+    if (!hashtbl || !cache_state || !pcol || !prow || !ploc) TTX_FAIL(TTX_EINVAL, "NULL cache input");
+    if (!workspace || workspace_bytes < ttx_preprocess_workspace_bytes(nnz))
+      TTX_FAIL(TTX_EWORKSPACE, "preprocess workspace too small");
+    loc = (int32_t*)workspace;
+    unit_cnt = (int*)((char*)workspace + align_up((size_t)nnz * 4));
+    total = unit_cnt + U;
+  }
+  if (upd || lookup) {  // compute_rowidx + update_cache_state (cu:1077-1113) + cache_lookup in one launch
     const int64_t threads = nb * 8 > nnz ? nb * 8 : nnz;
     hipLaunchKernelGGL(rowidx_update_kernel, dim3((unsigned)((threads + kCT - 1) / kCT)), dim3(kCT), 0, st, nb, B,
-                       offsets, rowidx, tableidx, nnz, colidx, (int32_t)H, upd_hashtbl, upd_cache_freq);
+                       offsets, rowidx, tableidx, nnz, colidx, (int32_t)H, upd ? upd_hashtbl : nullptr,
+                       upd ? upd_cache_freq : nullptr, hashtbl, cache_state, loc, unit_cnt);
   } else {
     hipLaunchKernelGGL(compute_rowidx_kernel, dim3((unsigned)((nb + kCT / 8 - 1) / (kCT / 8))), dim3(kCT), 0,
                        st, nb, B, offsets, rowidx, tableidx);
   }
   TTX_HIP(hipGetLastError());
-  if (warmup || num_tables != 1) {  // cu:1410-1412
+  if (!lookup) {
     if (num_tt_dev) {  // every lookup is a TT lookup
       hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, st, num_tt_dev, (int32_t)nnz);
       TTX_HIP(hipGetLastError());
     }
     return TTX_OK;
   }
-  if (H <= 0 || H >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
-  if (!hashtbl || !cache_state || !pcol || !prow || !ploc) TTX_FAIL(TTX_EINVAL, "NULL cache input");
-  if (!workspace || workspace_bytes < ttx_preprocess_workspace_bytes(nnz))
-    TTX_FAIL(TTX_EWORKSPACE, "preprocess workspace too small");
-  int WT, U;
-  unit_shape(nnz, &WT, &U);
-  int32_t* loc = (int32_t*)workspace;
-  int* unit_cnt = (int*)((char*)workspace + align_up((size_t)nnz * 4));
-  int* total = unit_cnt + U;
-  const int N = (int)nnz;
-  const unsigned blocks = (unsigned)((U + kCT / kWave - 1) / (kCT / kWave));
-  hipLaunchKernelGGL(lookup_count_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, colidx, (int32_t)H,
-                     hashtbl, cache_state, loc, unit_cnt);
-  hipLaunchKernelGGL(scan_units_kernel, dim3(1), dim3(1024), 0, st, U, unit_cnt, total);
-  hipLaunchKernelGGL(partition_scatter_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, colidx, rowidx,
-                     loc, unit_cnt, pcol, prow, ploc);
+  const int scanned = U > kScanUnits ? 1 : 0;
+  if (scanned) hipLaunchKernelGGL(scan_units_kernel, dim3(1), dim3(1024), 0, st, U, unit_cnt, total);
+  hipLaunchKernelGGL(partition_scatter_kernel, dim3(U), dim3(kCT), 0, st, N, U, scanned, colidx, rowidx, loc,
+                     unit_cnt, pcol, prow, ploc, total, num_tt_dev);
   TTX_HIP(hipGetLastError());
   *partitioned_host = 1;
-  if (num_tt_dev) {  // the split point stays on the device: no host synchronisation at all
-    TTX_HIP(hipMemcpyAsync(num_tt_dev, total, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    return TTX_OK;  // (*num_tt_host keeps the upper bound nnz)
-  }
+  if (num_tt_dev) return TTX_OK;  // the split point stays on the device: no host synchronisation at all
+                                  // (*num_tt_host keeps the upper bound nnz)
   // the one host synchronisation of the hot path (cu:1481-1488)
   TTX_HIP(hipMemcpyAsync(num_tt_host, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   TTX_HIP(hipStreamSynchronize(st));

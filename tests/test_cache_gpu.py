@@ -149,7 +149,8 @@ def test_preprocess_partition_bit_exact():
     state = np.full(H, -1, dtype=np.int32)
     w = np.zeros((cs, 64), dtype=np.float32)
     O.cache_populate(O.make_geom(1, p, q, r), cores, keys, freq, state, w)
-    for n, B in ((1, 1), (63, 7), (64, 8), (4097, 100), (20000, 512)):
+    # (256, 257: the 256-position units of the partition; 300000: more than 1024 units -> the scan launch)
+    for n, B in ((1, 1), (63, 7), (64, 8), (256, 9), (257, 9), (4097, 100), (20000, 512), (300000, 2000)):
         idx = zipf_indices(rs, n, E_, 1.3)
         lens = rs.multinomial(n, np.ones(B) / B)
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
