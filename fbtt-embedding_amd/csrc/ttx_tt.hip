@@ -1086,7 +1086,10 @@ __device__ __forceinline__ float apply_one(int optim, float g, float w, float lr
 // g+G, .. in index order, the G group sums are then added in group order
 // through LDS.  Long slices: 4 floats per thread, partials summed in order.
 constexpr int kReduceThreads = 1024;  // upper bound; launched with 512 when the largest slice is <= 4096 floats
-constexpr int kSegThin = 512;         // partial rows per segment of a thin core's sorted order
+#ifndef TTX_SEG_THIN
+#define TTX_SEG_THIN 512
+#endif
+constexpr int kSegThin = TTX_SEG_THIN;         // partial rows per segment of a thin core's sorted order
 constexpr int kSegPivot = 32;         // chunk partials per segment of the pivot core
 // A slice is HOT when it holds more than two segments' worth of partials (a skewed index stream puts
 // a third of a batch on one slice): one work-group per SEGMENT then sums its share, and the last one
