@@ -210,6 +210,44 @@ def test_cache_gather_forward_backward():
         assert_close(dst2.cpu().numpy(), st2, f"rowwise adagrad state total D={D}", rtol=2e-5, atol_scale=4e-6)
 
 
+@pytest.mark.parametrize("n,D", [(5000, 64), (20000, 128), (300000, 64), (5000, 6)])
+def test_cache_backward_hot_rows(n, D):
+    """a Zipf stream over the cache rows (row 0 takes a sixth of the lookups): the rows [0, K) summed by their
+    own work-groups (K = 64, 55 at 300k lookups, 0 for D % 4 != 0) and the per-lookup path for the rest give
+    the oracle's SGD / dense result; also behind a device-side split point (skip_dev)."""
+    import ctypes as C
+
+    import tt_embeddings as E
+
+    rs = np.random.RandomState(n + D)
+    cs, B = 1000, 512
+    loc = ((rs.zipf(1.2, size=n) - 1) % cs).astype(np.int32)
+    rowidx = np.sort(rs.randint(0, B, size=n)).astype(np.int64)
+    w = rs.randn(cs, D).astype(np.float32)
+    grad = (rs.rand(B, D) * 0.1).astype(np.float32)
+    w_sgd = w.copy()
+    O.cache_backward_sgd(grad, loc, rowidx, 0.1, w_sgd)
+    dw = t(w)
+    E.cache_backward_sgd(n, t(grad), t(loc), t(rowidx), 0.1, dw)
+    # (the hottest row's update is a sum of n/6 terms, in an order of its own)
+    assert_close(dw.cpu().numpy(), w_sgd, "cache_backward_sgd, hot rows", rtol=1e-4, atol_scale=2e-5)
+    gd = E.cache_backward_dense(n, t(grad), t(loc), t(rowidx), 0.1, t(w))
+    assert_close(gd.cpu().numpy(), O.cache_backward_dense(grad, loc, rowidx, cs, D), "cache_backward_dense, hot rows",
+                 rtol=1e-4, atol_scale=2e-5)
+    # the same entries behind a split point that lives in device memory
+    k = 777
+    L = E.lib()
+    L.ttx_cache_backward_sgd_n.argtypes = [C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_float, C.c_void_p, C.c_void_p]
+    loc2 = t(np.concatenate([np.full(k, -1, dtype=np.int32), loc]))
+    row2 = t(np.concatenate([np.zeros(k, dtype=np.int64), rowidx]))
+    skip = torch.tensor([k], dtype=torch.int32, device=DEV)
+    dw2, g = t(w), t(grad)
+    assert L.ttx_cache_backward_sgd_n(n + k, skip.data_ptr(), D, g.data_ptr(), loc2.data_ptr(), row2.data_ptr(), 0.1,
+                                      dw2.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0, L.ttx_last_error()
+    assert_close(dw2.cpu().numpy(), w_sgd, "cache_backward_sgd_n, hot rows", rtol=1e-4, atol_scale=2e-5)
+
+
 @pytest.mark.parametrize("tables,p,B,pf,std,H", [
     (1, [20, 22, 25], 300, 10, 3, 1 << 19),     # one launch: rows by binary search over the offsets, fused update
     (1, [20, 22, 25], 400, 8, 4, 0),            # one launch, no frequency table
