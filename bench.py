@@ -67,6 +67,32 @@ def flop_per_nnz_fwd(q, r):
     return 2.0 * (q[0] * r[0] * q[1] * r[1] + q[0] * q[1] * r[1] * q[2])
 
 
+def dense_baseline(E_, D, reqs, grad, steps, warmup):
+    """the table the TT cores replace: nn.EmbeddingBag(E, D, mode="sum", sparse=True) + SGD(lr=0.1) on the same
+    requests, eager, as tt_embeddings_benchmark.py:195-211 does behind --run-baseline"""
+    import torch
+
+    dev = grad.device
+    emb = torch.nn.EmbeddingBag(E_, D, mode="sum", sparse=True, include_last_offset=True, device=dev)
+    opt = torch.optim.SGD(emb.parameters(), lr=0.1)
+    g2 = grad.reshape(-1, D)
+
+    def one(idx, off):
+        opt.zero_grad(set_to_none=True)
+        emb(idx, off).backward(g2)
+        opt.step()
+
+    for k in range(warmup):
+        one(*reqs[k % len(reqs)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one(*reqs[k % len(reqs)])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": round(ms, 4), "table_bytes": E_ * D * 4, "what": "nn.EmbeddingBag(sparse=True) fwd+bwd + SGD step, eager"}
+
+
 def cpu_baseline(requests, cores, d_out, budget_s=12.0):
     """the oracle (scalar C port, 1 thread) on the same requests: fwd + fused-SGD bwd"""
     import oracle_lib as O
@@ -102,6 +128,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="time the eager Python path only (no hipGraph replay)")
     ap.add_argument("--optimizer", default=None, choices=["sgd", "adagrad"])
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--run-baseline", action="store_true",
+                    help="also time the uncompressed nn.EmbeddingBag(E, D, sparse) + SGD on the same requests "
+                         "(tt_embeddings_benchmark.py --run-baseline; needs E*D*4 bytes per table)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="(test) take the N > 1 code path -- process group, sharded module, all-to-all -- with one rank")
     args = ap.parse_args()
@@ -428,6 +457,8 @@ def main():
         line = build_line(mode, elapsed, breakdown, a2a)
         if not sharded and not args.no_cpu_baseline and ntab == 1:
             line["cpu_baseline"] = cpu_baseline(reqs_np, cores_np, d_out_np)
+        if args.run_baseline and not sharded and ntab == 1:
+            line["dense_embedding_bag"] = dense_baseline(E_, D, reqs, grad, args.steps, args.warmup)
         print(json.dumps(line), flush=True)
     if sharded:
         dist.barrier()
