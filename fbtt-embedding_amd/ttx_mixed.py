@@ -1,0 +1,104 @@
+"""Tables of DIFFERENT cardinality behind one module.
+
+The reference batches only tables of identical shape (`TableBatchedTTEmbeddingBag`
+asserts one `num_embeddings` / one set of TT shapes, tt_embeddings_ops.py:424,
+README.md:136-141), so a real DLRM -- 26 sparse features with 26 different
+cardinalities -- needs 26 separate modules and 26 x the launches.  Here the tables
+are grouped by their TT shape: every group is ONE `TableBatchedTTEmbeddingBag`
+(one plan, one forward, one backward for all its tables), and the call form is
+DLRM's: one (indices, offsets) pair per table in, one [B, D] per table out.
+Measured (scripts/bench_mixed.py, 8 tables of 4 shapes, B=512 x 20 lookups, eager
+fwd+bwd+SGD): one module per table 0.634 ms/step, grouped 0.467 ms/step.
+`streams=True` puts every group on a HIP stream of its own; the eager step is
+host-bound at these sizes and the stream switches cost more than the overlap
+gives (0.818 ms/step) -- it is there for large batches and captured graphs.
+
+    emb = MixedTTEmbeddingBag([1460, 583, 10131227, ...], 64, tt_ranks=[32, 32])
+    outs = emb(lS_i, lS_o)        # lists of per-table tensors -> list of [B, D]
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from tt_embeddings_ops import OptimType, TableBatchedTTEmbeddingBag, suggested_tt_shapes
+
+
+def merge_bags(indices: Sequence[torch.Tensor], offsets: Sequence[torch.Tensor],
+               include_last_offset: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """per-table (indices, offsets) -> the table-major batched form of `TableBatchedTTEmbeddingBag`
+    (offsets with num_tables * B + 1 entries).  Lengths come from tensor shapes: no device read-back."""
+    assert len(indices) == len(offsets) and len(indices) > 0
+    parts, base = [], 0
+    for idx, off in zip(indices, offsets):
+        starts = off[:-1] if include_last_offset else off
+        parts.append(starts + base if base else starts)
+        base += int(idx.numel())
+    parts.append(torch.full((1,), base, dtype=parts[0].dtype, device=parts[0].device))
+    return torch.cat([i.reshape(-1) for i in indices]), torch.cat(parts)
+
+
+class MixedTTEmbeddingBag(nn.Module):
+    """TT embedding bags for tables of different cardinality, same embedding dimension and TT ranks.
+
+    tables with equal TT row shape (`tt_p_shapes`) share one `TableBatchedTTEmbeddingBag`;
+    `self.groups[k]` is the module of group k, `self.group_tables[k]` its table ids.
+    forward(indices, offsets[, per_sample_weights]) takes one tensor per table (nn.EmbeddingBag call form,
+    `include_last_offset` as given to the constructor) and returns one [B, D] tensor per table."""
+
+    def __init__(self, num_embeddings: Sequence[int], embedding_dim: int, tt_ranks: List[int],
+                 tt_p_shapes: Optional[Sequence[Optional[List[int]]]] = None, tt_q_shapes: Optional[List[int]] = None,
+                 optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
+                 sparse: bool = True, weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
+                 device: Optional[torch.device] = None, include_last_offset: bool = False,
+                 streams: bool = False) -> None:
+        super().__init__()
+        nd = len(tt_ranks) + 1
+        self.num_embeddings = [int(e) for e in num_embeddings]
+        self.embedding_dim = int(embedding_dim)
+        self.include_last_offset = bool(include_last_offset)
+        shapes: List[Tuple[int, ...]] = []
+        for k, e in enumerate(self.num_embeddings):
+            given = tt_p_shapes[k] if tt_p_shapes is not None else None
+            shapes.append(tuple(int(x) for x in given) if given is not None else tuple(suggested_tt_shapes(e, nd)))
+        by_shape: Dict[Tuple[int, ...], List[int]] = {}
+        for k, s in enumerate(shapes):
+            by_shape.setdefault(s, []).append(k)
+        self.group_tables: List[List[int]] = list(by_shape.values())
+        self.groups = nn.ModuleList()
+        for s, tables in by_shape.items():
+            self.groups.append(TableBatchedTTEmbeddingBag(
+                len(tables), max(self.num_embeddings[k] for k in tables), self.embedding_dim, list(tt_ranks), list(s),
+                tt_q_shapes, optimizer, learning_rate, eps, sparse, False, 0, 0, weight_dist, enforce_embedding_dim,
+                device, True))
+        self._streams = [torch.cuda.Stream(device=self.groups[0].tt_cores[0].device) for _ in self.groups] \
+            if streams and len(self.groups) > 1 else None
+
+    def forward(self, indices: Sequence[torch.Tensor], offsets: Sequence[torch.Tensor],
+                per_sample_weights: Optional[Sequence[Optional[torch.Tensor]]] = None) -> List[torch.Tensor]:
+        n = len(self.num_embeddings)
+        assert len(indices) == n and len(offsets) == n, f"one (indices, offsets) pair per table: {n} tables"
+        outs: List[Optional[torch.Tensor]] = [None] * n
+        cur = torch.cuda.current_stream() if self._streams else None
+        for g, (mod, tables) in enumerate(zip(self.groups, self.group_tables)):
+            idx, off = merge_bags([indices[k] for k in tables], [offsets[k] for k in tables], self.include_last_offset)
+            psw = None
+            if per_sample_weights is not None and any(per_sample_weights[k] is not None for k in tables):
+                psw = torch.cat([per_sample_weights[k].reshape(-1) if per_sample_weights[k] is not None
+                                 else torch.ones(indices[k].numel(), device=idx.device) for k in tables])
+            if self._streams:
+                s = self._streams[g]
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    res = mod(idx, off, True, psw)  # [tables, B, D]
+                for t in (idx, off) + ((psw,) if psw is not None else ()):
+                    t.record_stream(s)   # allocated on the caller's stream, read on the group's
+                res.record_stream(cur)   # ... and the other way round
+            else:
+                res = mod(idx, off, True, psw)
+            for j, k in enumerate(tables):
+                outs[k] = res[j]
+        if self._streams:
+            for s in self._streams:
+                cur.wait_stream(s)
+        return outs  # type: ignore[return-value]

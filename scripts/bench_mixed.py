@@ -1,0 +1,38 @@
+"""eager fwd+bwd(SGD) step over 8 tables of 4 different cardinalities (B=512, 20 lookups per bag): one
+TTEmbeddingBag per table vs MixedTTEmbeddingBag (grouped by TT shape), without / with a HIP stream per group"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fbtt-embedding_amd"))
+import tt_embeddings_ops as ops, ttx_mixed
+
+dev = torch.device("cuda:0")
+D, q, r, B, L = 64, [4, 4, 4], [32, 32], 512, 20
+shapes = {10_000_000: [200, 220, 250], 5_000_000: [160, 180, 200], 1_000_000: [100, 100, 100], 300_000: [64, 70, 72]}
+Es = [10_000_000, 5_000_000, 1_000_000, 300_000] * 2
+ps = [shapes[e] for e in Es]
+kw = dict(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, weight_dist="uniform", device=dev)
+rs = np.random.RandomState(0)
+reqs = []
+for it in range(10):
+    idx = [torch.from_numpy(rs.randint(0, e, size=B * L).astype(np.int64)).to(dev) for e in Es]
+    off = [torch.arange(0, B * L, L, dtype=torch.int64, device=dev) for _ in Es]
+    reqs.append((idx, off))
+grads = [torch.rand(B, D, device=dev) * 0.1 for _ in Es]
+
+def timeit(step, n=100):
+    for k in range(10): step(*reqs[k % 10])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for k in range(n): step(*reqs[k % 10])
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+
+singles = [ops.TTEmbeddingBag(Es[k], D, r, ps[k], q, use_cache=False, include_last_offset=False, **kw) for k in range(len(Es))]
+def step_single(idx, off):
+    outs = [m(i, o) for m, i, o in zip(singles, idx, off)]
+    torch.autograd.backward(outs, grads)
+print(f"one module per table      : {timeit(step_single):.3f} ms/step")
+for streams in (False, True):
+    mm = ttx_mixed.MixedTTEmbeddingBag(Es, D, r, ps, q, include_last_offset=False, streams=streams, **kw)
+    def step_mixed(idx, off):
+        torch.autograd.backward(mm(idx, off), grads)
+    print(f"mixed, streams={streams!s:5} ({len(mm.groups)} groups): {timeit(step_mixed):.3f} ms/step")

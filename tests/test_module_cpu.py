@@ -227,3 +227,42 @@ def test_cache_life_cycle(ops):
     assert not torch.equal(m.cache_weight.detach(), w0) and not torch.equal(m.tt_cores[1].detach(), c0[1])
     m.reset_cache()
     assert m.warmup and int((m.hashtbl >= 0).sum()) == 0
+
+
+def test_mixed_cardinality_tables(ops):
+    """tables of different cardinality behind one module (ttx_mixed): grouped by TT
+    row shape, one table-batched lookup per group, DLRM call form (a tensor pair per table in, [B, D] per
+    table out) -- against one TTEmbeddingBag per table holding the same cores; forward and core gradients"""
+    import ttx_mixed
+
+    D, q, r, B = 12, [2, 3, 2], [4, 5], 9
+    Es = [100, 700, 90, 5000, 650]
+    ps = [[4, 5, 5], [8, 9, 10], [4, 5, 5], [20, 16, 16], [8, 9, 10]]
+    mm = ttx_mixed.MixedTTEmbeddingBag(Es, D, r, ps, q, sparse=False, weight_dist="uniform", device="cpu")
+    assert mm.group_tables == [[0, 2], [1, 4], [3]]
+    rs = np.random.RandomState(3)
+    idx, off, psw = [], [], []
+    for e in Es:
+        lens = rs.randint(0, 5, size=B)
+        off.append(torch.from_numpy(np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)))
+        idx.append(torch.from_numpy(rs.randint(0, e, size=int(lens.sum())).astype(np.int64)))
+    outs = mm(idx, off)
+    gsum = sum((o * (k + 1)).sum() for k, o in enumerate(outs))
+    gsum.backward()
+    for g, tables in enumerate(mm.group_tables):
+        for j, k in enumerate(tables):
+            one = ops.TTEmbeddingBag(Es[k], D, r, ps[k], q, sparse=False, use_cache=False, weight_dist="uniform",
+                                     device="cpu", include_last_offset=False)
+            with torch.no_grad():
+                for dst, src in zip(one.tt_cores, mm.groups[g].tt_cores):
+                    dst.copy_(src[j:j + 1])
+            ref = one(idx[k], off[k])
+            assert outs[k].shape == (B, D)
+            assert_close(outs[k].detach().numpy(), ref.detach().numpy(), f"table {k} forward")
+            (ref * (k + 1)).sum().backward()
+            for t in range(3):
+                assert_close(mm.groups[g].tt_cores[t].grad[j].numpy(), one.tt_cores[t].grad[0].numpy(), f"table {k} grad{t}")
+    # the merged bags of one group: table-major, closing offset appended
+    i2, o2 = ttx_mixed.merge_bags([idx[0], idx[2]], [off[0], off[2]], False)
+    assert i2.numel() == idx[0].numel() + idx[2].numel() and o2.numel() == 2 * B + 1
+    assert int(o2[B]) == idx[0].numel() and int(o2[-1]) == i2.numel()

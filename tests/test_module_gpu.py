@@ -305,6 +305,50 @@ def test_drop_in_for_nn_embedding_bag_in_a_dlrm_shaped_model(node):
     assert np.isfinite(losses).all() and np.mean(losses[-3:]) < np.mean(losses[:3]), losses
 
 
+@pytest.mark.parametrize("streams", [False, True])
+def test_mixed_cardinality_tables(node, streams):
+    """ttx_mixed.MixedTTEmbeddingBag: five tables of three different TT row shapes ->
+    three table-batched groups, optionally on a HIP stream each; two fused-SGD steps leave every table's cores
+    where a TTEmbeddingBag of its own leaves them, and the outputs agree."""
+    import tt_embeddings_ops as ops
+    import ttx_mixed
+
+    D, q, r, B = 64, [4, 4, 4], [16, 16], 128
+    Es = [9000, 60000, 8000, 900000, 50000]
+    ps = [[20, 22, 25], [40, 40, 40], [20, 22, 25], [100, 100, 100], [40, 40, 40]]
+    kw = dict(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, weight_dist="uniform", device=DEV)
+    mm = ttx_mixed.MixedTTEmbeddingBag(Es, D, r, ps, q, include_last_offset=False, streams=streams, **kw)
+    assert mm.group_tables == [[0, 2], [1, 4], [3]]
+    ones = []
+    for k in range(len(Es)):
+        g = next(i for i, tb in enumerate(mm.group_tables) if k in tb)
+        j = mm.group_tables[g].index(k)
+        one = ops.TTEmbeddingBag(Es[k], D, r, ps[k], q, use_cache=False, include_last_offset=False, **kw)
+        with torch.no_grad():
+            for dst, src in zip(one.tt_cores, mm.groups[g].tt_cores):
+                dst.copy_(src[j:j + 1])
+        ones.append((one, g, j))
+    rs = np.random.RandomState(11)
+    grads = [t((rs.rand(B, D) * 0.1).astype(np.float32)) for _ in Es]
+    for step in range(2):
+        idx, off = [], []
+        for e in Es:
+            lens = rs.randint(0, 12, size=B)
+            off.append(t(np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)))
+            idx.append(t(rs.randint(0, e, size=int(lens.sum())).astype(np.int64)))
+        outs = mm(idx, off)
+        torch.autograd.backward(outs, grads)
+        for k, (one, g, j) in enumerate(ones):
+            ref = one(idx[k], off[k])
+            assert_close(outs[k].detach().cpu().numpy(), ref.detach().cpu().numpy(), f"step {step} table {k} forward")
+            ref.backward(grads[k])
+    torch.cuda.synchronize()
+    for k, (one, g, j) in enumerate(ones):
+        for c in range(3):
+            assert_close(mm.groups[g].tt_cores[c][j].detach().cpu().numpy(), one.tt_cores[c][0].detach().cpu().numpy(),
+                         f"table {k} core{c} after two SGD steps")
+
+
 def test_graphed_round_equals_eager_steps(node):
     """ttx_graph.GraphedRound: replaying a captured round of fused-SGD steps leaves the cores exactly where the
     same steps run eagerly leave them (the kernels are deterministic, so bit-identical)"""
