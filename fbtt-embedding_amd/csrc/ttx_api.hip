@@ -1,6 +1,8 @@
 // ttx_api.hip -- error reporting, geometry validation, live kernel timing.
 #include <stdarg.h>
 
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "ttx_internal.h"
@@ -28,6 +30,36 @@ static UDiv make_udiv(unsigned long long dd) {
   return v;
 }
 
+// device copy of a mixed geometry's per-table factors, created at first sight of the geometry
+static const TabGeom* tab_geom_for(const ttx_geom* g) {
+  static std::mutex mu;
+  static std::map<std::vector<int>, const TabGeom*> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::vector<int> key = {dev, g->T, g->num_tables};
+  key.insert(key.end(), g->p_tables, g->p_tables + (size_t)g->num_tables * g->T);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  std::vector<TabGeom> h(1);
+  memset(h.data(), 0, sizeof(TabGeom));
+  int base[TTX_MAX_CORES] = {0, 0, 0, 0};
+  for (int k = 0; k < g->num_tables; ++k) {
+    long long Lv = 1;
+    for (int t = g->T - 1; t >= 0; --t) {
+      h[0].p[k][t] = g->p_tables[(size_t)k * g->T + t];
+      h[0].L[k][t] = Lv;
+      Lv *= h[0].p[k][t];
+    }
+    for (int t = 0; t < g->T; ++t) { h[0].base[k][t] = base[t]; base[t] += h[0].p[k][t]; }
+  }
+  TabGeom* dptr = nullptr;
+  if (hipMalloc((void**)&dptr, sizeof(TabGeom)) != hipSuccess) return nullptr;
+  if (hipMemcpy(dptr, h.data(), sizeof(TabGeom), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  cache[key] = dptr;
+  return dptr;
+}
+
 int make_dims(const ttx_geom* g, Dims* d) {
   if (!g) TTX_FAIL(TTX_EINVAL, "geometry is NULL");
   if (g->T < 2 || g->T > TTX_MAX_CORES)
@@ -40,26 +72,56 @@ int make_dims(const ttx_geom* g, Dims* d) {
     TTX_FAIL(TTX_EINVAL, "padded ranks must start and end with 1 (got %d, %d)", g->r[0], g->r[g->T]);
   long long Lv = 1;
   long long Dv = 1;
+  const bool mixed = g->p_tables && g->num_tables > 1;
   for (int t = g->T - 1; t >= 0; --t) {
-    if (g->p[t] <= 0 || g->q[t] <= 0 || g->r[t] <= 0)
+    const int pt = mixed ? 1 : g->p[t];  // (mixed: p, S, L are set from p_tables below)
+    if (pt <= 0 || g->q[t] <= 0 || g->r[t] <= 0)
       TTX_FAIL(TTX_EINVAL, "core %d: p, q, r must be > 0", t);
-    d->p[t] = g->p[t];
+    d->p[t] = pt;
     d->q[t] = g->q[t];
     d->L[t] = Lv;
-    Lv *= g->p[t];
+    Lv *= pt;
     Dv *= g->q[t];
     long long sl = (long long)g->r[t] * g->q[t] * g->r[t + 1];
-    long long S = (long long)g->num_tables * g->p[t];
+    long long S = (long long)g->num_tables * pt;
     if (sl > (1ll << 30) || S > (1ll << 30) || Lv > (1ll << 62))
       TTX_FAIL(TTX_EINVAL, "core %d too large (slice %lld, slices %lld)", t, sl, S);
     d->slice[t] = (int)sl;
     d->S[t] = (int)S;
   }
   for (int t = 0; t <= g->T; ++t) d->r[t] = g->r[t];
+  if (mixed) {  // tables of different row factors: S = the sums, p = the largest
+    if (g->num_tables > TTX_MAX_TABLES_MIXED)
+      TTX_FAIL(TTX_EINVAL, "num_tables=%d: at most %d tables with per-table row factors", g->num_tables,
+               TTX_MAX_TABLES_MIXED);
+    for (int t = 0; t < g->T; ++t) {
+      long long S = 0;
+      int pmax = 0;
+      for (int k = 0; k < g->num_tables; ++k) {
+        const int pk = g->p_tables[(size_t)k * g->T + t];
+        if (pk <= 0) TTX_FAIL(TTX_EINVAL, "table %d core %d: p must be > 0", k, t);
+        S += pk;
+        pmax = pk > pmax ? pk : pmax;
+      }
+      if (S > (1ll << 30)) TTX_FAIL(TTX_EINVAL, "core %d: too many slices (%lld)", t, S);
+      d->S[t] = (int)S;
+      d->p[t] = pmax;
+    }
+    for (int k = 0; k < g->num_tables; ++k) {
+      long long Lk = 1;
+      for (int t = 0; t < g->T; ++t) {
+        Lk *= g->p_tables[(size_t)k * g->T + t];
+        if (Lk > (1ll << 62)) TTX_FAIL(TTX_EINVAL, "table %d: prod(p) too large", k);
+      }
+    }
+    d->tab = tab_geom_for(g);
+    if (!d->tab) TTX_FAIL(TTX_EHIP, "could not place the per-table geometry on the device");
+    Lv = 1ll << 40;  // (no 32-bit decode)
+  }
   d->idx32 = Lv <= (1ll << 32);
   for (int t = 0; t < g->T; ++t) {
     d->dvL[t] = make_udiv(d->idx32 ? (unsigned long long)d->L[t] : 1ull);
-    d->dvP[t] = make_udiv((unsigned long long)g->p[t]);
+    d->dvP[t] = make_udiv((unsigned long long)d->p[t]);
   }
   if (Dv > (1ll << 24)) TTX_FAIL(TTX_EINVAL, "embedding_dim %lld too large", Dv);
   d->D = (int)Dv;

@@ -705,6 +705,7 @@ int ttx_cache_populate(const ttx_geom* g, const float* const* tt_cores, int64_t 
   Dims d;
   int rc = make_dims(g, &d);
   if (rc) return rc;
+  if (d.tab || d.num_tables != 1) TTX_FAIL(TTX_EINVAL, "cache_populate serves one table (tt_embeddings_ops.py:456)");
   // cu:1271-1274
   if (H <= 0 || H >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
   if (cache_size < 0 || cache_size > H) TTX_FAIL(TTX_EINVAL, "cache_size=%lld must be <= hashtbl_size", (long long)cache_size);

@@ -36,8 +36,17 @@ struct UDiv {
   unsigned m, sh1, sh2, d;
 };
 
+// tables of different row factors in one batch (ttx_geom::p_tables): device-resident, one per distinct
+// geometry (cached by make_dims, never freed: a few KiB each)
+struct TabGeom {
+  int p[TTX_MAX_TABLES_MIXED][TTX_MAX_CORES];
+  int base[TTX_MAX_TABLES_MIXED][TTX_MAX_CORES];  // first slice of the table in core t
+  long long L[TTX_MAX_TABLES_MIXED][TTX_MAX_CORES];
+};
+
 struct Dims {
   int T, num_tables;
+  const TabGeom* tab;        // NULL unless the tables differ in p (then p[] = the largest, S[] = the sums)
   int p[TTX_MAX_CORES], q[TTX_MAX_CORES], r[TTX_MAX_CORES + 1];
   long long L[TTX_MAX_CORES];
   int slice[TTX_MAX_CORES];  // r_t q_t r_{t+1}

@@ -136,6 +136,22 @@ __device__ __forceinline__ int decode_core(const CoreDec& c, long long idx) {
 __device__ __forceinline__ int decode_core(const Dims& d, int t, long long idx) {
   return decode_core(core_dec(d, t), idx);
 }
+// slice id of (table tb, index idx) in core t: tb * p_t + i_t -- or, tables of different row
+// factors (Dims::tab), base_t[tb] + i_t with the table's own factors (plain divisions: only the
+// wide-digit and the multi-pass plan take such a geometry)
+__device__ __forceinline__ int slice_id(const Dims& d, const CoreDec& ct, int t, int tb, long long idx) {
+  if (!d.tab) return tb * ct.p + decode_core(ct, idx);
+  tb = min(max(tb, 0), d.num_tables - 1);
+  const int p = d.tab->p[tb][t];
+  const long long L = d.tab->L[tb][t];
+  if (idx < 0) idx = 0;
+  long long a;
+  if ((((unsigned long long)idx | (unsigned long long)L) >> 32) == 0) a = (unsigned)idx / (unsigned)L;
+  else a = idx / L;
+  if (t > 0) a %= p;
+  if (a >= p) a = p - 1;
+  return d.tab->base[tb][t] + (int)a;
+}
 // branch-free 32-bit decode (prod(p) <= 2^32; idx already clamped to [0, 2^32))
 __device__ __forceinline__ int decode32(const CoreDec& c, unsigned idx) {
   const unsigned q = udiv(idx, c.dl);
@@ -390,7 +406,7 @@ __device__ __forceinline__ int live_n(int n_host, const int* n_dev) {
 struct MbItem { int val, kv; };
 
 // pass 0 reads (and decodes) the indices; later passes chase order -> key
-__device__ __forceinline__ MbItem mb_load(int i, bool valid, int pass, const CoreDec& ct,
+__device__ __forceinline__ MbItem mb_load(int i, bool valid, int pass, const Dims& d, int t, const CoreDec& ct,
                                           const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx,
                                           const int* __restrict__ src, const int* __restrict__ key) {
   MbItem it{0, 0};
@@ -398,7 +414,7 @@ __device__ __forceinline__ MbItem mb_load(int i, bool valid, int pass, const Cor
   if (pass == 0) {
     const int tb = tableidx ? (int)tableidx[i] : 0;
     it.val = i;
-    it.kv = tb * ct.p + decode_core(ct, indices[i]);
+    it.kv = slice_id(d, ct, t, tb, indices[i]);
   } else {
     it.val = src[i];
     it.kv = key[it.val];
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(kMbThreads) void mb_count_kernel(
 #pragma unroll
     for (int k = 0; k < kSB; ++k) {
       const int i = base + k * kWave + lane;
-      it[k] = mb_load(i, i < end, A.pass, ct, indices, tableidx, src, key);
+      it[k] = mb_load(i, i < end, A.pass, d, t, ct, indices, tableidx, src, key);
     }
 #pragma unroll
     for (int k = 0; k < kSB; ++k) {
@@ -717,7 +733,7 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
 #pragma unroll
     for (int k = 0; k < kSB; ++k) {
       const int i = base + k * kWave + lane;
-      it[k] = mb_load(i, i < end, A.pass, ct, indices, tableidx, src, key);
+      it[k] = mb_load(i, i < end, A.pass, d, t, ct, indices, tableidx, src, key);
     }
     if (last && pivot) {  // the record gathers of the whole super-batch, in flight together
 #pragma unroll
@@ -790,7 +806,7 @@ __global__ __launch_bounds__(kWideThreads) void mbw_count_kernel(
 #pragma unroll
   for (int k = 0; k < kSB; ++k) {
     const int i = blockIdx.x * kWideSpan + k * kWideThreads + tid;
-    if (i < N) atomicAdd(&hist[min(tb[k] * ct.p + decode_core(ct, ix[k]), BINS - 1)], 1);  // tableidx is not validated
+    if (i < N) atomicAdd(&hist[min(slice_id(d, ct, t, tb[k], ix[k]), BINS - 1)], 1);  // tableidx is not validated
   }
   __syncthreads();
   int* row = cnt + ((size_t)t * gridDim.x + blockIdx.x) * BINS;
@@ -881,7 +897,7 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
   for (int k = 0; k < kSB; ++k) {
     const int i = wbeg + k * kWave + lane;
     const bool valid = i < N;
-    kv[k] = valid ? min(tb[k] * ct.p + decode_core(ct, ix[k]), BINS - 1) : 0;
+    kv[k] = valid ? min(slice_id(d, ct, t, tb[k], ix[k]), BINS - 1) : 0;
     peers[k] = wave_match<BITS>((unsigned)kv[k], valid);
     if (valid && (peers[k] & lanemask_lt()) == 0) hrun[w][kv[k]] += __popcll(peers[k]);
   }
@@ -938,9 +954,9 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
       if (t != 1) {
         P.perm[t][pos] = i;
       } else {
-        const int s0 = tb[k] * d.p[0] + decode_core(d, 0, ix[k]);
-        const int s2 = d.T > 2 ? tb[k] * d.p[2] + decode_core(d, 2, ix[k]) : 0;
-        const int s3 = d.T > 3 ? tb[k] * d.p[3] + decode_core(d, 3, ix[k]) : 0;
+        const int s0 = slice_id(d, core_dec(d, 0), 0, tb[k], ix[k]);
+        const int s2 = d.T > 2 ? slice_id(d, core_dec(d, 2), 2, tb[k], ix[k]) : 0;
+        const int s3 = d.T > 3 ? slice_id(d, core_dec(d, 3), 3, tb[k], ix[k]) : 0;
         P.lrec[pos] = make_int4(i, s0, s2, s3);
         if (rowidx) P.lrow[pos] = (int)rowidx[i];
       }
@@ -978,7 +994,7 @@ __global__ __launch_bounds__(kWideThreads) void mbp_count_kernel(
 #pragma unroll
   for (int k = 0; k < kSB; ++k) {
     const int i = blockIdx.x * kWideSpan + k * kWideThreads + tid;
-    it[k] = mb_load(i, i < N, A.pass, ct, indices, tableidx, src, key);
+    it[k] = mb_load(i, i < N, A.pass, d, t, ct, indices, tableidx, src, key);
   }
 #pragma unroll
   for (int k = 0; k < kSB; ++k) {
@@ -1054,7 +1070,7 @@ __global__ __launch_bounds__(kWideThreads) void mbp_scatter_kernel(
 #pragma unroll
   for (int k = 0; k < kSB; ++k) {
     const int i = wbeg + k * kWave + lane;
-    it[k] = mb_load(i, i < N, A.pass, ct, indices, tableidx, src, key);
+    it[k] = mb_load(i, i < N, A.pass, d, t, ct, indices, tableidx, src, key);
   }
   long long ix[kSB];
   int tb[kSB], brow[kSB];
@@ -1095,9 +1111,9 @@ __global__ __launch_bounds__(kWideThreads) void mbp_scatter_kernel(
       if (last) {
         sk[pos] = it[k].kv;
         if (pivot) {
-          const int s0 = tb[k] * d.p[0] + decode_core(d, 0, ix[k]);
-          const int s2 = d.T > 2 ? tb[k] * d.p[2] + decode_core(d, 2, ix[k]) : 0;
-          const int s3 = d.T > 3 ? tb[k] * d.p[3] + decode_core(d, 3, ix[k]) : 0;
+          const int s0 = slice_id(d, core_dec(d, 0), 0, tb[k], ix[k]);
+          const int s2 = d.T > 2 ? slice_id(d, core_dec(d, 2), 2, tb[k], ix[k]) : 0;
+          const int s3 = d.T > 3 ? slice_id(d, core_dec(d, 3), 3, tb[k], ix[k]) : 0;
           P.lrec[pos] = make_int4(it[k].val, s0, s2, s3);
           if (rowidx) P.lrow[pos] = brow[k];
         }
@@ -1198,19 +1214,20 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
       if (A.passes[t] > maxp) maxp = A.passes[t];
     }
   }
-  if (maxp == 1 && N <= kOneMaxN) {
+  if (maxp == 1 && N <= kOneMaxN && !d.tab) {
     hipLaunchKernelGGL(mb_single_kernel<false>, dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit), d.T),
                        dim3(kOneThreads), 0, stream, d, N, n_dev, indices, tableidx, rowidx, P, Prologue{});
     TTX_HIP(hipGetLastError());
     return TTX_OK;
   }
-  if (maxp > 1 && (N + kWideSpan - 1) / kWideSpan <= kWideMaxG) {  // one wide digit instead of two passes?
+  // (tables of different row factors, d.tab: only the wide-digit and the multi-pass plan decode them)
+  if ((maxp > 1 || d.tab) && (N + kWideSpan - 1) / kWideSpan <= kWideMaxG) {  // one wide digit instead of two passes?
     int smax = 1;
     for (int t = 0; t < d.T; ++t) if (d.S[t] > smax) smax = d.S[t];
     if (smax <= 1024) return plan_build_wide<10>(d, N, n_dev, indices, tableidx, rowidx, P, stream);
     if (smax <= 2048) return plan_build_wide<11>(d, N, n_dev, indices, tableidx, rowidx, P, stream);
   }
-  if (maxp > 1 || N > kMbFuseU * 4096) {  // 8-bit passes on full work-groups, then mb_finish
+  if (maxp > 1 || N > kMbFuseU * 4096 || d.tab) {  // 8-bit passes on full work-groups, then mb_finish
     MbpArgs B;
     B.N = N;
     B.n_dev = n_dev;

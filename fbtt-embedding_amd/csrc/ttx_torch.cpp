@@ -30,28 +30,45 @@ using torch::autograd::variable_list;
 
 void check(int rc) { TORCH_CHECK(rc == TTX_OK, "tt_embeddings (libttx): ", ttx_last_error()); }
 
-ttx_geom make_geom(int64_t num_tables, const std::vector<int64_t>& p, const std::vector<int64_t>& q,
-                   const std::vector<int64_t>& r) {
-  const size_t T = p.size();
-  TORCH_CHECK(T >= 2 && T <= TTX_MAX_CORES && q.size() == T && r.size() == T + 1,
-              "tt_embeddings: need 2..4 cores with len(q) == len(p) and len(ranks) == len(p)+1");
+// `p` holds T row factors -- or num_tables * T of them, table after table: tables of different row factors
+// (include/ttx.h ttx_geom::p_tables).  The geometry then points into `ptab`, which must outlive its use.
+struct Geom {
   ttx_geom g{};
+  std::vector<int32_t> ptab;
+};
+
+void make_geom(Geom& G, int64_t num_tables, const std::vector<int64_t>& p, const std::vector<int64_t>& q,
+               const std::vector<int64_t>& r) {
+  const size_t T = q.size();
+  const bool mixed = num_tables > 1 && p.size() == (size_t)num_tables * T && p.size() != T;
+  TORCH_CHECK(T >= 2 && T <= TTX_MAX_CORES && (p.size() == T || mixed) && r.size() == T + 1,
+              "tt_embeddings: need 2..4 cores with len(q) == len(p) and len(ranks) == len(p)+1");
+  ttx_geom& g = G.g;
+  g = ttx_geom{};
   g.T = (int32_t)T;
   g.num_tables = (int32_t)num_tables;
-  for (size_t t = 0; t < T; ++t) { g.p[t] = (int32_t)p[t]; g.q[t] = (int32_t)q[t]; }
+  for (size_t t = 0; t < T; ++t) { g.p[t] = mixed ? 0 : (int32_t)p[t]; g.q[t] = (int32_t)q[t]; }
   for (size_t t = 0; t <= T; ++t) g.r[t] = (int32_t)r[t];
-  return g;
+  if (mixed) {
+    G.ptab.assign(p.begin(), p.end());
+    g.p_tables = G.ptab.data();
+  }
 }
 
 void check_cores(const ttx_geom& g, at::TensorList cores, const char* what) {
   TORCH_CHECK((int64_t)cores.size() == g.T, "tt_embeddings: expected ", g.T, " ", what);
   for (int t = 0; t < g.T; ++t) {
     const Tensor& c = cores[t];
+    int64_t n0 = g.num_tables, n1 = g.p[t];
+    if (g.p_tables) {  // one array of all the tables' slices
+      n0 = 1;
+      n1 = 0;
+      for (int k = 0; k < g.num_tables; ++k) n1 += g.p_tables[(size_t)k * g.T + t];
+    }
     TORCH_CHECK(c.is_cuda() && c.scalar_type() == at::kFloat && c.is_contiguous() && c.dim() == 3 &&
-                    c.size(0) == g.num_tables && c.size(1) == g.p[t] &&
-                    c.size(2) == (int64_t)g.r[t] * g.q[t] * g.r[t + 1],
-                "tt_embeddings: ", what, "[", t, "] must be a contiguous float32 GPU tensor of shape [",
-                g.num_tables, ", ", g.p[t], ", ", (int64_t)g.r[t] * g.q[t] * g.r[t + 1], "]");
+                    c.size(0) == n0 && c.size(1) == n1 && c.size(2) == (int64_t)g.r[t] * g.q[t] * g.r[t + 1],
+                "tt_embeddings: ", what, "[", t, "] must be a contiguous float32 GPU tensor of shape [", n0, ", ", n1,
+                ", ", (int64_t)g.r[t] * g.q[t] * g.r[t + 1], "]");
   }
 }
 
@@ -67,7 +84,9 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
                         double lr, double eps, const c10::optional<Tensor>& hashtbl,
                         const c10::optional<Tensor>& cache_freq, const c10::optional<Tensor>& psw,
                         at::TensorList state, at::TensorList cores) {
-    const ttx_geom g = make_geom(num_tables, p, q, r);
+    Geom G;
+    make_geom(G, num_tables, p, q, r);
+    const ttx_geom& g = G.g;
     check_cores(g, cores, "tt_cores");
     const bool weighted = psw.has_value() && psw->defined();
     if (weighted)
@@ -139,7 +158,9 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
     auto keep = ctx->saved_data["keep"].toTensorVector();
     auto cores = ctx->saved_data["cores"].toTensorVector();
     auto state = ctx->saved_data["state"].toTensorVector();
-    const ttx_geom g = make_geom(num_tables, p, q, r);
+    Geom G;
+    make_geom(G, num_tables, p, q, r);
+    const ttx_geom& g = G.g;
     const Tensor &indices = keep[0], &rowidx = keep[1], &tableidx = keep[2];
     const int64_t nnz = indices.numel();
 
@@ -202,7 +223,9 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
                         const Tensor& hashtbl, const Tensor& cache_freq, const Tensor& cache_state,
                         const c10::optional<Tensor>& cache_opt_state, const Tensor& cache_weight,
                         at::TensorList state, at::TensorList cores) {
-    const ttx_geom g = make_geom(1, p, q, r);
+    Geom G;
+    make_geom(G, 1, p, q, r);
+    const ttx_geom& g = G.g;
     check_cores(g, cores, "tt_cores");
     if (optim == TTX_OPTIM_ADAGRAD) check_cores(g, state, "optimizer_state");
     TORCH_CHECK(indices.is_cuda() && indices.scalar_type() == at::kLong && indices.is_contiguous() &&
@@ -279,7 +302,9 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     auto keep = ctx->saved_data["keep"].toTensorVector();
     auto cores = ctx->saved_data["cores"].toTensorVector();
     auto state = ctx->saved_data["state"].toTensorVector();
-    const ttx_geom g = make_geom(1, p, q, r);
+    Geom G;
+    make_geom(G, 1, p, q, r);
+    const ttx_geom& g = G.g;
     const Tensor &pcol = keep[0], &prow = keep[1], &tableidx = keep[2], &ploc = keep[3], &cache_weight = keep[4];
     const int32_t* n_tt = keep[5].data_ptr<int32_t>();  // device-side split point
     const Tensor cache_opt_state = ctx->saved_data.count("copt") ? ctx->saved_data["copt"].toTensor() : Tensor();

@@ -655,6 +655,8 @@ struct Partials {
   float* pc[TTX_MAX_CORES];  // pc[1] is per CHUNK, the others per lookup
   const float* psw;          // per_sample_weights by lookup (nn.EmbeddingBag), or NULL: the bag gradient of
                              // lookup n enters the backward scaled by psw[n]
+  const int64_t* tableidx;   // tables of different row factors (Dims::tab): the table of a pivot slice is read
+                             // from one of its lookups; NULL otherwise (table = slice / p_1)
   // hot slices (reduce_apply_kernel): arrival counters, one per core slice (zeroed by the backward
   // contraction kernel), and the segment partial sums, two slots per segment
   int* hot_cnt;
@@ -1021,7 +1023,7 @@ __global__ __launch_bounds__(kThreads, 3) void bwd_kernel(Dims d, Plan P, CorePt
   STAMP(2);
   if (L.dbg & 16) return;
   const int4* I = (const int4*)(smem + L.oI);
-  const int table = s / d.p[1];
+  const int table = PC.tableidx ? (int)PC.tableidx[I[0].x] : s / d.p[1];
   if (d.T >= 3) {
     // bag gradients of the chunk's lookups
     float* Gb = smem + L.oG;
@@ -1617,6 +1619,7 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
   Partials PC;
   for (int t = 0; t < TTX_MAX_CORES; ++t) PC.pc[t] = t < d.T ? (float*)(ws + offs[t]) : nullptr;
   PC.psw = psw;
+  PC.tableidx = d.tab ? tableidx : nullptr;
   int nslices = 0, nsegs = 0;
   for (int t = 0; t < d.T; ++t) {
     PC.seg[t] = (float*)(ws + offs[d.T + t]);

@@ -37,6 +37,7 @@ class _Geom(C.Structure):
         ("p", C.c_int32 * MAX_CORES),
         ("q", C.c_int32 * MAX_CORES),
         ("r", C.c_int32 * (MAX_CORES + 1)),
+        ("p_tables", C.POINTER(C.c_int32)),  # NULL, or [num_tables][T]: tables of different row factors
     ]
 
 
@@ -101,7 +102,11 @@ def _check(rc: int) -> None:
 _geom_cache = {}
 
 
-def _geom(num_tables: int, p: Sequence[int], q: Sequence[int], ranks: Sequence[int]) -> _Geom:
+def _geom(num_tables: int, p: Sequence, q: Sequence[int], ranks: Sequence[int]) -> _Geom:
+    """`p` = tt_p_shapes, or (beyond the reference: include/ttx.h ttx_geom::p_tables) one list per table for
+    tables of different row factors -- the cores are then [1, sum of the tables' p_t, slice]."""
+    if len(p) > 0 and isinstance(p[0], (list, tuple)):
+        return _geom_mixed(p, q, ranks)
     key = (int(num_tables), tuple(int(x) for x in p), tuple(int(x) for x in q), tuple(int(x) for x in ranks))
     g = _geom_cache.get(key)
     if g is None:
@@ -114,6 +119,27 @@ def _geom(num_tables: int, p: Sequence[int], q: Sequence[int], ranks: Sequence[i
         g.T, g.num_tables = T, key[0]
         for t in range(T):
             g.p[t], g.q[t] = key[1][t], key[2][t]
+        for t in range(T + 1):
+            g.r[t] = key[3][t]
+        _geom_cache[key] = g
+    return g
+
+
+def _geom_mixed(p, q, ranks) -> _Geom:
+    key = ("mixed", tuple(tuple(int(x) for x in row) for row in p), tuple(int(x) for x in q), tuple(int(x) for x in ranks))
+    g = _geom_cache.get(key)
+    if g is None:
+        T = len(key[2])
+        if not (2 <= T <= MAX_CORES) or len(key[3]) != T + 1 or any(len(row) != T for row in key[1]):
+            raise RuntimeError(f"tt_embeddings: per-table tt_p_shapes need {T} factors each and len(ranks) == {T + 1}")
+        g = _Geom()
+        g.T, g.num_tables = T, len(key[1])
+        flat = [v for row in key[1] for v in row]
+        g._ptab = (C.c_int32 * len(flat))(*flat)  # kept alive by the cached struct
+        g.p_tables = C.cast(g._ptab, C.POINTER(C.c_int32))
+        g._psum = [sum(row[t] for row in key[1]) for t in range(T)]
+        for t in range(T):
+            g.p[t], g.q[t] = max(row[t] for row in key[1]), key[2][t]
         for t in range(T + 1):
             g.r[t] = key[3][t]
         _geom_cache[key] = g
@@ -196,6 +222,8 @@ def _cores(tt_cores: Sequence[torch.Tensor], g: _Geom, name="tt_cores"):
     for t, c in enumerate(tt_cores):
         c = c.detach() if c.requires_grad else c
         want = (g.num_tables, g.p[t], g.r[t] * g.q[t] * g.r[t + 1])
+        if bool(g.p_tables):  # tables of different row factors: one array of all their slices
+            want = (1, g._psum[t], want[2])
         if tuple(c.shape) != want or c.dtype != torch.float32 or not c.is_contiguous() or not c.is_cuda:
             raise RuntimeError(f"tt_embeddings: {name}[{t}] must be a contiguous float32 GPU tensor of shape {want}, "
                                f"got {tuple(c.shape)} {c.dtype} on {c.device}")
@@ -295,8 +323,8 @@ def tt_forward(batch_count: int, num_tables: int, B: int, D: int, tt_p_shapes: L
 
 
 def _backward(optim, D, lr, eps, p, q, ranks, nnz, indices, rowidx, tableidx, d_output, tt_cores, state, plan):
-    num_tables = tt_cores[0].size(0)
-    g = _geom(num_tables, p, q, ranks)
+    g = _geom(tt_cores[0].size(0), p, q, ranks)
+    num_tables = g.num_tables  # (tables of different row factors: len(p), the cores are [1, sum p, slice])
     dev = _dev(d_output)
     cores = _cores(tt_cores, g)
     d_output = _f32(d_output, "d_output")

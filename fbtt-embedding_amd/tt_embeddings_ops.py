@@ -168,6 +168,8 @@ class TTLookupFunction(torch.autograd.Function):
         ctx.has_cache = cache_weight is not None
         ctx.save_for_backward(L, indices, rowidx, tableidx, cache_locations, cache_optimizer_state, cache_weight)
         num_tables = tt_cores[0].size(0)
+        if len(tt_p_shapes) > 0 and isinstance(tt_p_shapes[0], (list, tuple)):
+            num_tables = len(tt_p_shapes)  # tables of different row factors: cores are [1, sum p, slice]
         # one lookup plan serves forward and backward of this batch
         mk = getattr(_engine, "make_plan", None)
         ctx.plan = getattr(rowidx, "_ttx_plan", None)  # built by the module's lookup prologue
@@ -479,7 +481,8 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             # is the C++ autograd node of csrc/ttx_torch.cpp -- same C ABI calls, no interpreter in between
             use_state = self.sparse and self.optimizer not in _SGD_LIKE
             optim = 2 if not self.sparse else (1 if use_state else 0)
-            return fast.lookup(indices.contiguous(), offsets.contiguous(), self.num_tables, self.tt_p_shapes,
+            return fast.lookup(indices.contiguous(), offsets.contiguous(), self.num_tables,
+                               getattr(self, "_p_flat", self.tt_p_shapes),  # (per-table factors: flattened)
                                self.tt_q_shapes, self.tt_ranks, optim, self.learning_rate, self.eps,
                                self.hashtbl if self.use_cache else None, self.cache_freq if self.use_cache else None,
                                list(self.optimizer_state) if use_state else [], list(self.tt_cores), per_sample_weights)

@@ -7,17 +7,20 @@ cardinalities -- needs 26 separate modules and 26 x the launches.  Here the tabl
 are grouped by their TT shape: every group is ONE `TableBatchedTTEmbeddingBag`
 (one plan, one forward, one backward for all its tables), and the call form is
 DLRM's: one (indices, offsets) pair per table in, one [B, D] per table out.
+`fused=True` goes one step further: ONE batched lookup for all tables whatever
+their row factors (`VarTableTTEmbeddingBag`, include/ttx.h `ttx_geom::p_tables`).
 Measured (scripts/bench_mixed.py, 8 tables of 4 shapes, B=512 x 20 lookups, eager
-fwd+bwd+SGD): one module per table 0.634 ms/step, grouped 0.467 ms/step.
+fwd+bwd+SGD): one module per table 0.600 ms/step, grouped 0.506, fused 0.293.
 `streams=True` puts every group on a HIP stream of its own; the eager step is
-host-bound at these sizes and the stream switches cost more than the overlap
-gives (0.818 ms/step) -- it is there for large batches and captured graphs.
+host-bound at these sizes and the stream switches cost what the overlap gives
+(0.600 ms/step) -- it is there for large batches and captured graphs.
 
     emb = MixedTTEmbeddingBag([1460, 583, 10131227, ...], 64, tt_ranks=[32, 32])
     outs = emb(lS_i, lS_o)        # lists of per-table tensors -> list of [B, D]
 """
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -38,11 +41,86 @@ def merge_bags(indices: Sequence[torch.Tensor], offsets: Sequence[torch.Tensor],
     return torch.cat([i.reshape(-1) for i in indices]), torch.cat(parts)
 
 
+class VarTableTTEmbeddingBag(TableBatchedTTEmbeddingBag):
+    """`TableBatchedTTEmbeddingBag` for tables of DIFFERENT row factors (same q and ranks): one plan, one
+    forward, one backward launch set for all of them (include/ttx.h `ttx_geom::p_tables`).  Core t is one
+    Parameter [1, sum_k p_k_t, r_t q_t r_{t+1}] holding the tables' slices one table after the other
+    (`table_rows(t)[k]` = table k's rows of it); forward takes the table-major batched form, like the parent,
+    and returns [num_tables, B, D].  No cache (the parent allows one for a single table only)."""
+
+    def __init__(self, num_embeddings: Sequence[int], embedding_dim: int, tt_ranks: List[int],
+                 tt_p_shapes: Optional[Sequence[Optional[List[int]]]] = None, tt_q_shapes: Optional[List[int]] = None,
+                 optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
+                 sparse: bool = True, weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
+                 device: Optional[torch.device] = None, include_last_offset: bool = True) -> None:
+        nn.Module.__init__(self)
+        self.include_last_offset = bool(include_last_offset)
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("VarTableTTEmbeddingBag needs a GPU")
+            device = torch.device("cuda", torch.cuda.current_device())
+        device = torch.device(device)
+        nd = len(tt_ranks) + 1
+        Es = [int(e) for e in num_embeddings]
+        assert len(Es) >= 1 and all(e > 0 for e in Es)
+        ps = []
+        for k, e in enumerate(Es):
+            given = tt_p_shapes[k] if tt_p_shapes is not None else None
+            ps.append([int(x) for x in given] if given is not None else suggested_tt_shapes(e, nd))
+            assert len(ps[-1]) == nd and int(np.prod(np.asarray(ps[-1], dtype=np.int64))) >= e
+        self.tt_q_shapes = [int(x) for x in tt_q_shapes] if tt_q_shapes is not None \
+            else suggested_tt_shapes(int(embedding_dim), nd, allow_round_up=not enforce_embedding_dim)
+        assert int(np.prod(self.tt_q_shapes)) == int(embedding_dim)
+        self.num_tables, self.tt_ndim = len(Es), nd
+        self.table_num_embeddings, self.embedding_dim = Es, int(embedding_dim)
+        self.num_embeddings = max(Es)
+        self.tt_ranks = [1] + [int(x) for x in tt_ranks] + [1]
+        self.tt_p_shapes = ps                                  # one list per table (the ctypes route)
+        self._p_flat = [v for row in ps for v in row]          # ... flattened for the C++ node
+        self.sparse, self.optimizer, self.learning_rate, self.eps = sparse, optimizer, learning_rate, eps
+        self.register_buffer("L", torch.zeros(nd, dtype=torch.int64, device=device))  # (strides are per table)
+        from tt_embeddings_ops import _SGD_LIKE, BufferList
+        self.tt_cores = nn.ParameterList()
+        self.optimizer_state = BufferList("optimizer_state")
+        stateful = optimizer not in _SGD_LIKE
+        for t in range(nd):
+            shape = (1, sum(p[t] for p in ps), self.tt_ranks[t] * self.tt_q_shapes[t] * self.tt_ranks[t + 1])
+            self.tt_cores.append(nn.Parameter(torch.empty(shape, device=device, dtype=torch.float32)))
+            self.optimizer_state.append(torch.zeros(shape if stateful else 0, device=device, dtype=torch.float32))
+        # every table is initialised as a table of its own cardinality would be
+        for k, e in enumerate(Es):
+            one = TableBatchedTTEmbeddingBag.__new__(TableBatchedTTEmbeddingBag)
+            nn.Module.__init__(one)
+            one.num_tables, one.tt_ndim, one.num_embeddings, one.embedding_dim = 1, nd, e, self.embedding_dim
+            one.tt_ranks, one.tt_p_shapes, one.tt_q_shapes = self.tt_ranks, ps[k], self.tt_q_shapes
+            one.tt_cores = [torch.empty((1, ps[k][t], self.tt_cores[t].shape[2]), device=device) for t in range(nd)]
+            TableBatchedTTEmbeddingBag.reset_parameters(one, weight_dist)
+            with torch.no_grad():
+                for t in range(nd):
+                    self.table_rows(t)[k].copy_(one.tt_cores[t][0])
+        self.use_cache = False
+        self.register_buffer("hashtbl", torch.empty(0, device=device, dtype=torch.int64))
+        self.register_buffer("cache_freq", torch.empty(0, device=device, dtype=torch.int64))
+        self.register_buffer("cache_state", torch.empty(0, device=device, dtype=torch.int32))
+        self.cache_optimizer_state = None
+        self.cache_weight = None
+        self.warmup = True
+
+    def table_rows(self, t: int) -> List[torch.Tensor]:
+        """views [p_k_t, slice] of core t, one per table"""
+        sizes = [p[t] for p in self.tt_p_shapes]
+        return list(torch.split(self.tt_cores[t].detach()[0], sizes, dim=0))
+
+    def full_weight(self) -> torch.Tensor:
+        raise NotImplementedError("full_weight() is per table: build a TTEmbeddingBag from table_rows()")
+
+
 class MixedTTEmbeddingBag(nn.Module):
     """TT embedding bags for tables of different cardinality, same embedding dimension and TT ranks.
 
     tables with equal TT row shape (`tt_p_shapes`) share one `TableBatchedTTEmbeddingBag`;
     `self.groups[k]` is the module of group k, `self.group_tables[k]` its table ids.
+    `fused=True`: a single group, a `VarTableTTEmbeddingBag` over all tables.
     forward(indices, offsets[, per_sample_weights]) takes one tensor per table (nn.EmbeddingBag call form,
     `include_last_offset` as given to the constructor) and returns one [B, D] tensor per table."""
 
@@ -51,12 +129,19 @@ class MixedTTEmbeddingBag(nn.Module):
                  optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
                  sparse: bool = True, weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
                  device: Optional[torch.device] = None, include_last_offset: bool = False,
-                 streams: bool = False) -> None:
+                 streams: bool = False, fused: bool = False) -> None:
         super().__init__()
         nd = len(tt_ranks) + 1
         self.num_embeddings = [int(e) for e in num_embeddings]
         self.embedding_dim = int(embedding_dim)
         self.include_last_offset = bool(include_last_offset)
+        self._streams = None
+        if fused:  # ONE batched lookup for all tables, whatever their row factors (VarTableTTEmbeddingBag)
+            self.group_tables = [list(range(len(self.num_embeddings)))]
+            self.groups = nn.ModuleList([VarTableTTEmbeddingBag(
+                self.num_embeddings, self.embedding_dim, list(tt_ranks), tt_p_shapes, tt_q_shapes, optimizer,
+                learning_rate, eps, sparse, weight_dist, enforce_embedding_dim, device, True)])
+            return
         shapes: List[Tuple[int, ...]] = []
         for k, e in enumerate(self.num_embeddings):
             given = tt_p_shapes[k] if tt_p_shapes is not None else None

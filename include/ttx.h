@@ -56,14 +56,28 @@ extern "C" {
 
 typedef void* ttx_stream_t; /* hipStream_t */
 
+#define TTX_MAX_TABLES_MIXED 64
+
 /* TT geometry shared by all tables of one TableBatchedTTEmbeddingBag
- * (reference tt_embeddings_ops.py:459-488). */
+ * (reference tt_embeddings_ops.py:459-488).
+ *
+ * p_tables (beyond the reference, which batches tables of ONE shape only,
+ * tt_embeddings_ops.py:424): NULL, or a host array [num_tables][T] of per-table
+ * row factors -- tables of different cardinality in one batched lookup
+ * (num_tables <= TTX_MAX_TABLES_MIXED).  q and the ranks stay common, so every core
+ * slice has one size and core t is ONE array of sum_k p_tables[k][t] slices, table
+ * after table: tt_cores[t] points at [sum_k p_k_t][r_t q_t r_{t+1}] floats and the
+ * slice of (table k, i_t) is base_t[k] + i_t with base_t[k] = sum_{j<k} p_tables[j][t].
+ * p[] is ignored then.  Only the calls that take tableidx accept such a geometry (plan,
+ * forward, backward; not the one-table cache entry points).  The array is read during
+ * the call only. */
 typedef struct ttx_geom {
   int32_t T;                    /* number of TT cores, 2..4 */
   int32_t num_tables;           /* tt_cores[t].size(0) */
   int32_t p[TTX_MAX_CORES];     /* tt_p_shapes */
   int32_t q[TTX_MAX_CORES];     /* tt_q_shapes */
   int32_t r[TTX_MAX_CORES + 1]; /* padded ranks [1, r1, .., 1] */
+  const int32_t* p_tables;      /* NULL: every table has the row factors p[] */
 } ttx_geom;
 
 const char* ttx_last_error(void);

@@ -1,10 +1,11 @@
 """eager fwd+bwd(SGD) step over 8 tables of 4 different cardinalities (B=512, 20 lookups per bag): one
-TTEmbeddingBag per table vs MixedTTEmbeddingBag (grouped by TT shape), without / with a HIP stream per group"""
+TTEmbeddingBag per table vs MixedTTEmbeddingBag grouped by TT shape (without / with a HIP stream per group)
+vs fused (ONE batched lookup over all tables, ttx_geom::p_tables); the fused one also as a hipGraph round"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fbtt-embedding_amd"))
-import tt_embeddings_ops as ops, ttx_mixed
+import tt_embeddings_ops as ops, ttx_mixed, ttx_graph
 
 dev = torch.device("cuda:0")
 D, q, r, B, L = 64, [4, 4, 4], [32, 32], 512, 20
@@ -30,9 +31,15 @@ singles = [ops.TTEmbeddingBag(Es[k], D, r, ps[k], q, use_cache=False, include_la
 def step_single(idx, off):
     outs = [m(i, o) for m, i, o in zip(singles, idx, off)]
     torch.autograd.backward(outs, grads)
-print(f"one module per table      : {timeit(step_single):.3f} ms/step")
-for streams in (False, True):
-    mm = ttx_mixed.MixedTTEmbeddingBag(Es, D, r, ps, q, include_last_offset=False, streams=streams, **kw)
+print(f"one module per table         : {timeit(step_single):.3f} ms/step")
+for streams, fused in ((False, False), (True, False), (False, True)):
+    mm = ttx_mixed.MixedTTEmbeddingBag(Es, D, r, ps, q, include_last_offset=False, streams=streams, fused=fused, **kw)
     def step_mixed(idx, off):
         torch.autograd.backward(mm(idx, off), grads)
-    print(f"mixed, streams={streams!s:5} ({len(mm.groups)} groups): {timeit(step_mixed):.3f} ms/step")
+    print(f"mixed, streams={streams!s:5} fused={fused!s:5} ({len(mm.groups)} groups): {timeit(step_mixed):.3f} ms/step")
+rnd = ttx_graph.GraphedRound(step_mixed, reqs, warmup=2)
+for _ in range(3): rnd.replay()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20): rnd.replay()
+torch.cuda.synchronize()
+print(f"fused, hipGraph round        : {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step")

@@ -305,6 +305,70 @@ def test_drop_in_for_nn_embedding_bag_in_a_dlrm_shaped_model(node):
     assert np.isfinite(losses).all() and np.mean(losses[-3:]) < np.mean(losses[:3]), losses
 
 
+@pytest.mark.parametrize("optimizer", ["sgd", "adagrad", "dense"])
+@pytest.mark.parametrize("shape", ["generic", "spec", "many-slices"])
+def test_var_table_batched_lookup(node, optimizer, shape):
+    """include/ttx.h ttx_geom::p_tables through ttx_mixed.VarTableTTEmbeddingBag: five tables of three different
+    row-factor sets in ONE batched lookup (one plan, one forward, one backward) against a TTEmbeddingBag per
+    table with the same cores -- outputs, and cores / state / gradients after a step.  `spec`: the
+    specialised r=16 q=[4,4,4] kernels; `generic`: the any-shape ones (wide-digit plan); `many-slices`: the
+    multi-pass plan."""
+    import tt_embeddings_ops as ops
+    import ttx_mixed
+
+    if shape == "spec":
+        D, q, r, B = 64, [4, 4, 4], [16, 16], 96
+        Es, ps = [9000, 60000, 8000, 900000, 50000], [[20, 22, 25], [40, 40, 40], [20, 22, 25], [100, 100, 100], [40, 40, 40]]
+    elif shape == "many-slices":  # 2700 slice ids in core 0: the multi-pass plan (no wide digit)
+        D, q, r, B = 12, [2, 3, 2], [4, 5], 300
+        Es, ps = [800000, 700000, 90], [[1500, 30, 20], [1200, 25, 30], [4, 5, 5]]
+    else:
+        D, q, r, B = 12, [2, 3, 2], [4, 5], 50
+        Es, ps = [100, 700, 90, 5000, 650], [[4, 5, 5], [8, 9, 10], [4, 5, 5], [20, 16, 16], [8, 9, 10]]
+    opt = {"sgd": ops.OptimType.SGD, "adagrad": ops.OptimType.EXACT_ADAGRAD, "dense": ops.OptimType.SGD}[optimizer]
+    kw = dict(sparse=optimizer != "dense", optimizer=opt, learning_rate=0.05, eps=1e-4, weight_dist="uniform", device=DEV)
+    vm = ttx_mixed.VarTableTTEmbeddingBag(Es, D, r, ps, q, **kw)
+    ones = []
+    for k in range(len(Es)):
+        one = ops.TTEmbeddingBag(Es[k], D, r, ps[k], q, use_cache=False, **kw)
+        with torch.no_grad():
+            for c in range(3):
+                one.tt_cores[c][0].copy_(vm.table_rows(c)[k])
+        ones.append(one)
+    rs = np.random.RandomState(5)
+    grads = t((rs.rand(len(Es), B, D) * 0.1).astype(np.float32))
+    for step in range(2):
+        idx, off = [], []
+        for e in Es:
+            lens = rs.randint(0, 9, size=B)
+            off.append(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64))
+            idx.append(rs.randint(0, e, size=int(lens.sum())).astype(np.int64))
+        mi, mo = ttx_mixed.merge_bags([t(i) for i in idx], [t(o) for o in off], True)
+        out = vm(mi, mo)
+        assert out.shape == (len(Es), B, D)
+        out.backward(grads)
+        for k, one in enumerate(ones):
+            ref = one(t(idx[k]), t(off[k]))
+            assert_close(out[k].detach().cpu().numpy(), ref.detach().cpu().numpy(), f"step {step} table {k} forward")
+            ref.backward(grads[k])
+        if optimizer == "dense":
+            for c in range(3):
+                gv = torch.split(vm.tt_cores[c].grad[0], [p[c] for p in ps], dim=0)
+                for k, one in enumerate(ones):
+                    assert_close(gv[k].cpu().numpy(), one.tt_cores[c].grad[0].cpu().numpy(), f"table {k} grad{c}")
+            vm.zero_grad()
+            for one in ones:
+                one.zero_grad()
+    torch.cuda.synchronize()
+    for k, one in enumerate(ones):
+        for c in range(3):
+            assert_close(vm.table_rows(c)[k].cpu().numpy(), one.tt_cores[c][0].detach().cpu().numpy(),
+                         f"table {k} core{c} after two steps", rtol=2e-5)
+            if optimizer == "adagrad":
+                sv = torch.split(vm.optimizer_state[c][0], [p[c] for p in ps], dim=0)
+                assert_close(sv[k].cpu().numpy(), one.optimizer_state[c][0].cpu().numpy(), f"table {k} state{c}")
+
+
 @pytest.mark.parametrize("streams", [False, True])
 def test_mixed_cardinality_tables(node, streams):
     """ttx_mixed.MixedTTEmbeddingBag: five tables of three different TT row shapes ->
