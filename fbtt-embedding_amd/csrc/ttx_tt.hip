@@ -1154,7 +1154,7 @@ __device__ __forceinline__ void sum_rows4(const float* __restrict__ pc, int sl, 
     if (g == 0) pre = emit.prefetch(v);
     if (g < G) {
       int i = beg + g;
-      for (; i + 3 * G < end; i += 4 * G) {  // four rows in flight per lane
+      for (; i + 3 * G < end; i += 4 * G) {  // four rows in flight per lane (eight: slower, 13.7 vs 12.3 us at cfg2)
         const size_t r0 = row(i), r1 = row(i + G), r2 = row(i + 2 * G), r3 = row(i + 3 * G);
         const float4 x0 = ((const float4*)(pc + r0 * sl))[v], x1 = ((const float4*)(pc + r1 * sl))[v];
         const float4 x2 = ((const float4*)(pc + r2 * sl))[v], x3 = ((const float4*)(pc + r3 * sl))[v];
