@@ -266,3 +266,26 @@ def test_mixed_cardinality_tables(ops):
     i2, o2 = ttx_mixed.merge_bags([idx[0], idx[2]], [off[0], off[2]], False)
     assert i2.numel() == idx[0].numel() + idx[2].numel() and o2.numel() == 2 * B + 1
     assert int(o2[B]) == idx[0].numel() and int(o2[-1]) == i2.numel()
+
+
+def test_geometry_struct_layout_matches_the_header(tmp_path):
+    """the ctypes mirror of ttx_geom (tt_embeddings._Geom) has the size and field offsets the C compiler gives
+    include/ttx.h's struct -- incl. the trailing p_tables pointer of the per-table-row-factor geometry"""
+    import subprocess
+
+    import tt_embeddings as E
+
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "ttx.h"\nint main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ttx_geom), offsetof(ttx_geom, T), '
+                   'offsetof(ttx_geom, num_tables), offsetof(ttx_geom, p), offsetof(ttx_geom, q), offsetof(ttx_geom, r), '
+                   'offsetof(ttx_geom, p_tables));\n  return 0;\n}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    G_ = E._Geom
+    want = [ctypes.sizeof(G_)] + [getattr(G_, f).offset for f in ("T", "num_tables", "p", "q", "r", "p_tables")]
+    assert got == want, (got, want)
+    g = E._geom(3, [[4, 5, 5], [8, 9, 10], [4, 5, 5]], [2, 3, 2], [1, 4, 5, 1])
+    assert g.num_tables == 3 and g.T == 3 and [g.p_tables[i] for i in range(9)] == [4, 5, 5, 8, 9, 10, 4, 5, 5]
+    assert not bool(E._geom(3, [4, 5, 5], [2, 3, 2], [1, 4, 5, 1]).p_tables)
