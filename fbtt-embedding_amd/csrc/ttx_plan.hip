@@ -884,7 +884,7 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
   for (int e = lane; e < BINS; e += kWave) hrun[w][e] = 0;  // (wave-private row)
   // this wave's kSB x 64 positions: key, peers of equal key in the batch, per-wave digit counts
   long long ix[kSB];
-  int tb[kSB], kv[kSB];
+  int tb[kSB], kv[kSB], brow[kSB];
   unsigned long long peers[kSB];
   const int wbeg = blockIdx.x * kWideSpan + w * (kSB * kWave);
 #pragma unroll
@@ -892,17 +892,10 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
     const int i = wbeg + k * kWave + lane;
     ix[k] = i < N ? indices[i] : 0;
     tb[k] = (i < N && tableidx) ? (int)tableidx[i] : 0;
+    brow[k] = (t == 1 && rowidx && i < N) ? (int)rowidx[i] : 0;  // (the pivot's bag rows: fetched with the indices)
   }
-#pragma unroll
-  for (int k = 0; k < kSB; ++k) {
-    const int i = wbeg + k * kWave + lane;
-    const bool valid = i < N;
-    kv[k] = valid ? min(slice_id(d, ct, t, tb[k], ix[k]), BINS - 1) : 0;
-    peers[k] = wave_match<BITS>((unsigned)kv[k], valid);
-    if (valid && (peers[k] & lanemask_lt()) == 0) hrun[w][kv[k]] += __popcll(peers[k]);
-  }
-  __syncthreads();
-  // thread owns digits tid * K .. + K - 1: totals over all work-groups, over the earlier ones
+  // thread owns digits tid * K .. + K - 1: totals over all work-groups, over the earlier ones (the count
+  // rows of the previous launch: fetched here, behind the index loads, not after the barrier below)
   int tot[K], bef[K], dbase[K], sum = 0;
 #pragma unroll
   for (int j = 0; j < K; ++j) { tot[j] = 0; bef[j] = 0; }
@@ -924,6 +917,15 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
         }
     }
   }
+#pragma unroll
+  for (int k = 0; k < kSB; ++k) {
+    const int i = wbeg + k * kWave + lane;
+    const bool valid = i < N;
+    kv[k] = valid ? min(slice_id(d, ct, t, tb[k], ix[k]), BINS - 1) : 0;
+    peers[k] = wave_match<BITS>((unsigned)kv[k], valid);
+    if (valid && (peers[k] & lanemask_lt()) == 0) hrun[w][kv[k]] += __popcll(peers[k]);
+  }
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < K; ++j) sum += tot[j];
   const int inc = wave_incl_scan(sum);
@@ -958,7 +960,7 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
         const int s2 = d.T > 2 ? slice_id(d, core_dec(d, 2), 2, tb[k], ix[k]) : 0;
         const int s3 = d.T > 3 ? slice_id(d, core_dec(d, 3), 3, tb[k], ix[k]) : 0;
         P.lrec[pos] = make_int4(i, s0, s2, s3);
-        if (rowidx) P.lrow[pos] = (int)rowidx[i];
+        if (rowidx) P.lrow[pos] = brow[k];
       }
     }
   }
