@@ -58,6 +58,8 @@ WORKLOADS = {
     "d128r32": dict(q=[4, 4, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     # all 26 tables of cfg5 on ONE GPU (2.13 M lookups per step): the table-batched path at scale
     "cfg5full": dict(q=[4, 4, 4], ranks=[32, 32], tables=26, B=4096, optimizer="sgd", alpha=1.0, populate=False),
+    "tb16": dict(q=[4, 4, 4], ranks=[32, 32], tables=16, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    "tb8": dict(q=[4, 4, 4], ranks=[32, 32], tables=8, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "tb4": dict(q=[4, 4, 4], ranks=[32, 32], tables=4, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "cfg5shard": dict(q=[4, 4, 4], ranks=[32, 32], tables=4, B=4096, optimizer="sgd", alpha=1.0, populate=False),
 }

@@ -1335,9 +1335,10 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Pl
 static bool spec_shape(const Dims& d) { return spec_match(d) != SPEC_NONE; }
 // lookups per chunk of the specialised kernels (Shape3::MC of the variant that runs)
 // Large batches of the r <= 32 shapes: four sub-chunks per plan chunk -- one pivot partial per 64 lookups
-// (measured at 327k lookups: 1 / 2 / 4 / 8 sub-chunks -> 0.794 / 0.771 / 0.758 / 0.770 ms per step).
+// (measured at 327k lookups: 1 / 2 / 4 / 8 sub-chunks -> 0.794 / 0.771 / 0.758 / 0.770 ms per step; at 82k
+// lookups one sub-chunk wins, 0.227 vs 0.240, at 164k four, 0.460 vs 0.464: the switch sits at 128k).
 #ifndef TTX_SUBCHUNK_NNZ
-#define TTX_SUBCHUNK_NNZ 65536
+#define TTX_SUBCHUNK_NNZ 131072
 #endif
 #ifndef TTX_SUBCHUNKS
 #define TTX_SUBCHUNKS 4

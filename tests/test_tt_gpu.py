@@ -263,9 +263,9 @@ def test_benchmark_shape_large_batch_variant():
     """the benchmark shape at a batch that no longer fits the single-launch plan (> 16384 lookups): forward,
     dense gradients and fused SGD against the oracle"""
     p, q, r = [9, 8, 7], [4, 4, 4], [1, 32, 32, 1]
-    E_, D, B = int(np.prod(p)), 64, 3400
+    E_, D, B = int(np.prod(p)), 64, 6800
     idx, off = G.make_bags(51, B, E_, 20, 2, 1)
-    assert idx.size > 65536  # ... and the plan's chunks hold eight 16-lookup sub-chunks (kernel variant MULTI: several 16-lookup sub-chunks per chunk of the plan)
+    assert idx.size > 131072  # ... and the plan's chunks hold four 16-lookup sub-chunks (kernel variant MULTI)
     c = dict(tables=1, T=3, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
              cores=G.make_cores(52, 1, p, q, r, "signed"), d_out=G.make_grad(53, 1, B, D))
     for mode in ("dense", "sgd"):
