@@ -91,7 +91,9 @@ size_t plan_bytes(const Dims& d, long long nnz);
 Plan carve_plan(const Dims& d, long long nnz, void* base);
 int plan_build(const Dims& d, long long nnz, const int64_t* indices,
                const int64_t* tableidx, const int64_t* rowidx, const Plan& P, hipStream_t stream,
-               const int* n_dev = nullptr);  // n_dev: device-side lookup count <= nnz (nnz is then an upper bound)
+               const int* n_dev = nullptr, const int64_t* offsets = nullptr, int bags_per_table = 0);
+// (offsets != NULL: the caller vouches that the lookups are table-major with table k at positions
+//  [offsets[k * bags_per_table], offsets[(k + 1) * bags_per_table)) -- the module's bag offsets)  // n_dev: device-side lookup count <= nnz (nnz is then an upper bound)
 
 long long* debug_stamps();  // debug stamp buffer (ttx_debug_stamps), or nullptr
 

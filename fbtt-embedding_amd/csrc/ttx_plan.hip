@@ -42,9 +42,12 @@ int max_chunks(const Dims& d, long long nnz, int MC) {
 
 static size_t r64(size_t k) { return (k + 63) / 64 * 64; }
 
+constexpr int kMaxGroupsHost = 32;  // == kMaxGroups (table groups of the wide plan, below)
 // digit counts of the multi-work-group plans: a 256-entry row per wave unit of 256 positions, or
 // (wide-digit plan) a 2048-entry row per work-group of 4096 positions
-static size_t cnt_ints(const Dims& d, long long nnz) { return (size_t)d.T * (256 * ((nnz + 255) / 256 + 1) + 2048); }
+static size_t cnt_ints(const Dims& d, long long nnz) {  // (+ a row per table group of the grouped wide plan)
+  return (size_t)d.T * (256 * ((nnz + 255) / 256 + 1) + 2048 * (kMaxGroupsHost + 2));
+}
 
 static size_t plan_ints(const Dims& d, long long nnz, int MC) {
   size_t n = r64(64);                                               // hdr
@@ -784,29 +787,91 @@ constexpr int kWideWaves = kWideThreads / kWave;
 constexpr int kWideSpan = kWideThreads * kSB;   // positions per work-group (kSB x 64 per wave)
 constexpr int kWideMaxG = 96;                   // every scatter work-group reads all count rows
 
-template <int BITS>
+// Table groups (more than 2048 slice ids in a core, bags table-major as the module's offsets make them):
+// the tables are cut into groups of `gsz` consecutive tables whose slice ids fit one wide digit, every
+// group is sorted by itself inside its own range of positions [offsets[k gsz B], offsets[(k+1) gsz B))
+// (already contiguous: the table IS the high digit and the input is sorted by it), work-groups are
+// dealt to the groups in order (each group at least one), and the pivot's chunk list is built
+// afterwards from the offsets (mb_chunks_kernel).  Three launches and one pass over the indices
+// for what the multi-pass plan does in seven launches and two passes.
+constexpr int kMaxGroups = kMaxGroupsHost;
+struct GrpArgs {
+  const int64_t* offsets;  // [num_tables * B + 1], or NULL: one group, all positions
+  int B, gsz, ngroups;
+};
+struct GrpMap {  // what a work-group learns about its group
+  int k, tb0, pos0, beg, end, wg0, wg1;  // group, first table, first position, own span, the group's work-groups
+};
+// whole work-group; gpos / gwg: LDS int[kMaxGroups + 1].  Returns false for a work-group without a group.
+__device__ __forceinline__ bool grp_map(const Dims& d, const GrpArgs& ga, int N, int* gpos, int* gwg, GrpMap* m) {
+  const int tid = threadIdx.x;
+  if (tid <= ga.ngroups) {
+    const int tb = min(tid * ga.gsz, d.num_tables);
+    gpos[tid] = (int)min(ga.offsets[(size_t)tb * ga.B], (int64_t)N);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0;
+    for (int k = 0; k < ga.ngroups; ++k) {
+      gwg[k] = a;
+      const int len = gpos[k + 1] - gpos[k];
+      a += len > 0 ? (len + kWideSpan - 1) / kWideSpan : 1;  // (an empty group still writes its slice offsets)
+    }
+    gwg[ga.ngroups] = a;
+  }
+  __syncthreads();
+  const int g = blockIdx.x;
+  if (g >= gwg[ga.ngroups]) return false;
+  int k = 0;
+  while (k + 1 < ga.ngroups && gwg[k + 1] <= g) ++k;
+  m->k = k;
+  m->tb0 = k * ga.gsz;
+  m->pos0 = gpos[k];
+  m->beg = min(gpos[k + 1], gpos[k] + (g - gwg[k]) * kWideSpan);
+  m->end = min(gpos[k + 1], m->beg + kWideSpan);
+  m->wg0 = gwg[k];
+  m->wg1 = gwg[k + 1];
+  return true;
+}
+// first slice id of table tb in core t
+__device__ __forceinline__ int slice_base(const Dims& d, const CoreDec& ct, int t, int tb) {
+  if (tb >= d.num_tables) return d.S[t];
+  return d.tab ? d.tab->base[tb][t] : tb * ct.p;
+}
+
+template <int BITS, bool GRP>
 __global__ __launch_bounds__(kWideThreads) void mbw_count_kernel(
     Dims d, int Nmax, const int* __restrict__ n_dev, const int64_t* __restrict__ indices,
-    const int64_t* __restrict__ tableidx, int* __restrict__ cnt) {
+    const int64_t* __restrict__ tableidx, int* __restrict__ cnt, GrpArgs ga) {
   constexpr int BINS = 1 << BITS;
   __shared__ int hist[BINS];
+  __shared__ int gpos[GRP ? kMaxGroups + 1 : 1], gwg[GRP ? kMaxGroups + 1 : 1];
   const int t = blockIdx.y, tid = threadIdx.x;
   for (int e = tid; e < BINS; e += kWideThreads) hist[e] = 0;
-  __syncthreads();
   const int N = live_n(Nmax, n_dev);
   const CoreDec ct = core_dec(d, t);
+  int beg = blockIdx.x * kWideSpan, end = min(N, beg + kWideSpan), sb = 0;
+  if (GRP) {
+    GrpMap m;
+    if (!grp_map(d, ga, N, gpos, gwg, &m)) return;
+    beg = m.beg;
+    end = m.end;
+    sb = slice_base(d, ct, t, m.tb0);
+  } else {
+    __syncthreads();
+  }
   long long ix[kSB];
   int tb[kSB];
 #pragma unroll
   for (int k = 0; k < kSB; ++k) {
-    const int i = blockIdx.x * kWideSpan + k * kWideThreads + tid;
-    ix[k] = i < N ? indices[i] : 0;
-    tb[k] = (i < N && tableidx) ? (int)tableidx[i] : 0;
+    const int i = beg + k * kWideThreads + tid;
+    ix[k] = i < end ? indices[i] : 0;
+    tb[k] = (i < end && tableidx) ? (int)tableidx[i] : 0;
   }
 #pragma unroll
   for (int k = 0; k < kSB; ++k) {
-    const int i = blockIdx.x * kWideSpan + k * kWideThreads + tid;
-    if (i < N) atomicAdd(&hist[min(slice_id(d, ct, t, tb[k], ix[k]), BINS - 1)], 1);  // tableidx is not validated
+    const int i = beg + k * kWideThreads + tid;
+    if (i < end) atomicAdd(&hist[min(max(slice_id(d, ct, t, tb[k], ix[k]) - sb, 0), BINS - 1)], 1);  // tableidx is not validated
   }
   __syncthreads();
   int* row = cnt + ((size_t)t * gridDim.x + blockIdx.x) * BINS;
@@ -870,44 +935,54 @@ __device__ __forceinline__ void finish_wide(const Dims& d, int t, const int (&to
   }
 }
 
-template <int BITS>
+template <int BITS, bool GRP>
 __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
     Dims d, int Nmax, const int* __restrict__ n_dev, const int64_t* __restrict__ indices,
-    const int64_t* __restrict__ tableidx, const int64_t* __restrict__ rowidx, const int* __restrict__ cnt, Plan P) {
+    const int64_t* __restrict__ tableidx, const int64_t* __restrict__ rowidx, const int* __restrict__ cnt, Plan P,
+    GrpArgs ga) {
   constexpr int BINS = 1 << BITS, K = BINS / kWideThreads;
   extern __shared__ int wide_lds[];
   int (*hrun)[BINS] = (int (*)[BINS])wide_lds;  // [kWideWaves][BINS]
   int* wt = wide_lds + kWideWaves * BINS;       // [kWideWaves]
+  __shared__ int gpos[GRP ? kMaxGroups + 1 : 1], gwg[GRP ? kMaxGroups + 1 : 1];
   const int t = blockIdx.y, tid = threadIdx.x, lane = lane_id(), w = tid / kWave;
   const int N = live_n(Nmax, n_dev);
   const CoreDec ct = core_dec(d, t);
+  int beg = blockIdx.x * kWideSpan, end = min(N, beg + kWideSpan), sb = 0, pos0 = 0, wg0 = 0, wg1 = gridDim.x;
+  int grp = 0, sg = d.S[t];  // group, its number of slices in this core
+  if (GRP) {
+    GrpMap m;
+    if (!grp_map(d, ga, N, gpos, gwg, &m)) return;
+    beg = m.beg; end = m.end; pos0 = m.pos0; wg0 = m.wg0; wg1 = m.wg1; grp = m.k;
+    sb = slice_base(d, ct, t, m.tb0);
+    sg = slice_base(d, ct, t, m.tb0 + ga.gsz) - sb;
+  }
   for (int e = lane; e < BINS; e += kWave) hrun[w][e] = 0;  // (wave-private row)
   // this wave's kSB x 64 positions: key, peers of equal key in the batch, per-wave digit counts
   long long ix[kSB];
   int tb[kSB], kv[kSB], brow[kSB];
   unsigned long long peers[kSB];
-  const int wbeg = blockIdx.x * kWideSpan + w * (kSB * kWave);
+  const int wbeg = beg + w * (kSB * kWave);
 #pragma unroll
   for (int k = 0; k < kSB; ++k) {
     const int i = wbeg + k * kWave + lane;
-    ix[k] = i < N ? indices[i] : 0;
-    tb[k] = (i < N && tableidx) ? (int)tableidx[i] : 0;
-    brow[k] = (t == 1 && rowidx && i < N) ? (int)rowidx[i] : 0;  // (the pivot's bag rows: fetched with the indices)
+    ix[k] = i < end ? indices[i] : 0;
+    tb[k] = (i < end && tableidx) ? (int)tableidx[i] : 0;
+    brow[k] = (t == 1 && rowidx && i < end) ? (int)rowidx[i] : 0;  // (the pivot's bag rows: fetched with the indices)
   }
-  // thread owns digits tid * K .. + K - 1: totals over all work-groups, over the earlier ones (the count
-  // rows of the previous launch: fetched here, behind the index loads, not after the barrier below)
+  // thread owns digits tid * K .. + K - 1: totals over the (group's) work-groups, over the earlier ones (the
+  // count rows of the previous launch: fetched here, behind the index loads, not after the barrier below)
   int tot[K], bef[K], dbase[K], sum = 0;
 #pragma unroll
   for (int j = 0; j < K; ++j) { tot[j] = 0; bef[j] = 0; }
   {
-    const int G = gridDim.x;
-    const int* c = cnt + (size_t)t * G * BINS + tid * K;
-    for (int g0 = 0; g0 < G; g0 += 8) {
+    const int* c = cnt + (size_t)t * gridDim.x * BINS + tid * K;
+    for (int g0 = wg0; g0 < wg1; g0 += 8) {
       int v[8][K];
 #pragma unroll
       for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int j = 0; j < K; ++j) v[r][j] = (g0 + r < G) ? c[(size_t)(g0 + r) * BINS + j] : 0;
+        for (int j = 0; j < K; ++j) v[r][j] = (g0 + r < wg1) ? c[(size_t)(g0 + r) * BINS + j] : 0;
 #pragma unroll
       for (int r = 0; r < 8; ++r)
 #pragma unroll
@@ -920,8 +995,8 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
 #pragma unroll
   for (int k = 0; k < kSB; ++k) {
     const int i = wbeg + k * kWave + lane;
-    const bool valid = i < N;
-    kv[k] = valid ? min(slice_id(d, ct, t, tb[k], ix[k]), BINS - 1) : 0;
+    const bool valid = i < end;
+    kv[k] = valid ? min(max(slice_id(d, ct, t, tb[k], ix[k]) - sb, 0), BINS - 1) : 0;
     peers[k] = wave_match<BITS>((unsigned)kv[k], valid);
     if (valid && (peers[k] & lanemask_lt()) == 0) hrun[w][kv[k]] += __popcll(peers[k]);
   }
@@ -933,7 +1008,7 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
   __syncthreads();
   int wbase = 0;
   for (int k = 0; k < w; ++k) wbase += wt[k];
-  dbase[0] = wbase + inc - sum;  // first position of the thread's first digit
+  dbase[0] = pos0 + wbase + inc - sum;  // first position of the thread's first digit
 #pragma unroll
   for (int j = 1; j < K; ++j) dbase[j] = dbase[j - 1] + tot[j - 1];
 #pragma unroll
@@ -944,11 +1019,20 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
     for (int k = 0; k < kWideWaves; ++k) { const int m = hrun[k][dg]; hrun[k][dg] = b; b += m; }
   }
   __syncthreads();
-  if (blockIdx.x == 0) finish_wide<K>(d, t, tot, dbase, N, rowidx != nullptr, P, wt);
+  if (!GRP) {
+    if (blockIdx.x == 0) finish_wide<K>(d, t, tot, dbase, N, rowidx != nullptr, P, wt);
+  } else if ((int)blockIdx.x == wg0) {  // the group's slice offsets, every core (the chunk list: mb_chunks_kernel)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int dg = tid * K + j;
+      if (dg < sg) P.off[t][sb + dg] = dbase[j];
+    }
+    if (grp == ga.ngroups - 1 && tid == 0) P.off[t][d.S[t]] = N;
+  }
 #pragma unroll
   for (int k = 0; k < kSB; ++k) {
     const int i = wbeg + k * kWave + lane;
-    const bool valid = i < N;
+    const bool valid = i < end;
     if (valid) {
       const int before = hrun[w][kv[k]];
       const int pos = before + __popcll(peers[k] & lanemask_lt());
@@ -1124,19 +1208,19 @@ __global__ __launch_bounds__(kWideThreads) void mbp_scatter_kernel(
   }
 }
 
-template <int BITS>
+template <int BITS, bool GRP>
 static int plan_build_wide(const Dims& d, int N, const int* n_dev, const int64_t* indices, const int64_t* tableidx,
-                           const int64_t* rowidx, const Plan& P, hipStream_t stream) {
+                           const int64_t* rowidx, const Plan& P, hipStream_t stream, const GrpArgs& ga) {
   constexpr size_t lds = (size_t)(kWideWaves * (1 << BITS) + kWideWaves) * sizeof(int);
   static bool attr_done = false;
   if (!attr_done) {
-    TTX_HIP(hipFuncSetAttribute((const void*)mbw_scatter_kernel<BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TTX_HIP(hipFuncSetAttribute((const void*)mbw_scatter_kernel<BITS, GRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  const dim3 grid((N + kWideSpan - 1) / kWideSpan, d.T);
-  hipLaunchKernelGGL(mbw_count_kernel<BITS>, grid, dim3(kWideThreads), 0, stream, d, N, n_dev, indices, tableidx, P.cnt);
-  hipLaunchKernelGGL(mbw_scatter_kernel<BITS>, grid, dim3(kWideThreads), lds, stream, d, N, n_dev, indices, tableidx,
-                     rowidx, (const int*)P.cnt, P);
+  const dim3 grid((N + kWideSpan - 1) / kWideSpan + (GRP ? ga.ngroups : 0), d.T);
+  hipLaunchKernelGGL((mbw_count_kernel<BITS, GRP>), grid, dim3(kWideThreads), 0, stream, d, N, n_dev, indices, tableidx, P.cnt, ga);
+  hipLaunchKernelGGL((mbw_scatter_kernel<BITS, GRP>), grid, dim3(kWideThreads), lds, stream, d, N, n_dev, indices, tableidx,
+                     rowidx, (const int*)P.cnt, P, ga);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }
@@ -1202,7 +1286,8 @@ static void launch_finish(const Dims& d, int N, const int* n_dev, bool has_row, 
 }
 
 static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* indices, const int64_t* tableidx,
-                         const int64_t* rowidx, const Plan& P, hipStream_t stream) {
+                         const int64_t* rowidx, const Plan& P, hipStream_t stream, const int64_t* offsets,
+                         int bags_per_table) {
   MbArgs A;
   A.N = N;
   A.n_dev = n_dev;
@@ -1226,8 +1311,27 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
   if ((maxp > 1 || d.tab) && (N + kWideSpan - 1) / kWideSpan <= kWideMaxG) {  // one wide digit instead of two passes?
     int smax = 1;
     for (int t = 0; t < d.T; ++t) if (d.S[t] > smax) smax = d.S[t];
-    if (smax <= 1024) return plan_build_wide<10>(d, N, n_dev, indices, tableidx, rowidx, P, stream);
-    if (smax <= 2048) return plan_build_wide<11>(d, N, n_dev, indices, tableidx, rowidx, P, stream);
+    if (smax <= 1024) return plan_build_wide<10, false>(d, N, n_dev, indices, tableidx, rowidx, P, stream, GrpArgs{});
+    if (smax <= 2048) return plan_build_wide<11, false>(d, N, n_dev, indices, tableidx, rowidx, P, stream, GrpArgs{});
+  }
+  if (offsets && d.num_tables > 1 && maxp > 1) {
+    // more slice ids than one digit holds, bags known to be table-major (the module's offsets): table groups.
+    // As many groups as allowed -- every scatter work-group reads the count rows of its whole group
+    int pmax = 1;
+    for (int t = 0; t < d.T; ++t) if (d.p[t] > pmax) pmax = d.p[t];  // (the largest table's, if they differ)
+    int gsz = (d.num_tables + kMaxGroups - 1) / kMaxGroups;
+    const int ngroups = (d.num_tables + gsz - 1) / gsz;
+    const long long rows_per_group = (long long)N / kWideSpan / ngroups + 1;
+    if ((long long)gsz * pmax <= 2048 && rows_per_group <= kWideMaxG) {
+      GrpArgs ga{offsets, bags_per_table, gsz, ngroups};
+      const int rc = (long long)gsz * pmax <= 1024
+                         ? plan_build_wide<10, true>(d, N, n_dev, indices, tableidx, rowidx, P, stream, ga)
+                         : plan_build_wide<11, true>(d, N, n_dev, indices, tableidx, rowidx, P, stream, ga);
+      if (rc != TTX_OK) return rc;
+      hipLaunchKernelGGL(mb_chunks_kernel, dim3(1), dim3(1024), 0, stream, d, N, n_dev, rowidx ? 1 : 0, P);
+      TTX_HIP(hipGetLastError());
+      return TTX_OK;
+    }
   }
   if (maxp > 1 || N > kMbFuseU * 4096 || d.tab) {  // 8-bit passes on full work-groups, then mb_finish
     MbpArgs B;
@@ -1263,10 +1367,11 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
 
 int plan_build(const Dims& d, long long nnz, const int64_t* indices,
                const int64_t* tableidx, const int64_t* rowidx, const Plan& P, hipStream_t stream,
-               const int* n_dev) {
+               const int* n_dev, const int64_t* offsets, int bags_per_table) {
   if (nnz < 0 || nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz=%lld out of range", nnz);
   ProfScope ps(TTX_PROF_PLAN, stream);
-  if (nnz > 1024 || !d.idx32 || n_dev) return plan_build_mb(d, (int)nnz, n_dev, indices, tableidx, rowidx, P, stream);
+  if (nnz > 1024 || !d.idx32 || n_dev)
+    return plan_build_mb(d, (int)nnz, n_dev, indices, tableidx, rowidx, P, stream, offsets, bags_per_table);
   {  // tiny batch: one launch, one work-group per core, everything on chip
     const size_t lds = (256 * kPlanWaves + 32 + 2 * ((nnz + 63) / 64 * 64)) * sizeof(int);
     const int per = (((int)nnz + kPlanWaves - 1) / kPlanWaves + kWave - 1) / kWave * kWave;
@@ -1336,7 +1441,9 @@ int ttx_lookup_prologue(const ttx_geom* g, int64_t nnz, const int64_t* colidx, i
                                          rowidx, tableidx, nullptr, nullptr, nullptr, &ntt, &part, upd_hashtbl,
                                          upd_cache_freq, nullptr, 0, stream);
   if (rc != TTX_OK) return rc;
-  return ttx::plan_build(d, nnz, colidx, tableidx, rowidx, P, (hipStream_t)stream);
+  // (the bags are table-major by construction here: the plan may sort table groups on their own)
+  return ttx::plan_build(d, nnz, colidx, tableidx, rowidx, P, (hipStream_t)stream, nullptr, offsets,
+                         (int)(nb / d.num_tables));
 }
 
 size_t ttx_plan_bytes(const ttx_geom* g, int64_t nnz) {

@@ -256,6 +256,9 @@ def test_cache_backward_hot_rows(n, D):
     (1, [20, 22, 25], 60, 5, 2, 1 << 16),       # nnz <= 1024: separate launches
     (1, [300, 22, 25], 300, 10, 2, 1 << 19),    # a two-pass sort: separate launches
     (1, [20, 22, 25], 5000, 2, 1, 1 << 20),     # more bags than the LDS copy of the offsets holds
+    (12, [300, 22, 25], 150, 8, 2, 0),          # 3600 slice ids in core 0: table groups (one table each), wide digit per group
+    (40, [60, 22, 25], 40, 6, 2, 0),            # more tables than groups: two tables per group
+    (9, [400, 300, 25], 700, 12, 3, 0),         # ~75k lookups, 3600 / 2700 slice ids, several work-groups per group
 ])
 def test_lookup_prologue_equals_separate_calls(tables, p, B, pf, std, H):
     """ttx_lookup_prologue == update_cache_state + preprocess_indices_sync(warmup) + make_plan:
@@ -267,6 +270,8 @@ def test_lookup_prologue_equals_separate_calls(tables, p, B, pf, std, H):
     E_ = int(np.prod(np.array(p, dtype=np.int64)))
     idx, off = G.make_bags(17 + B, B, E_, pf, std, tables)
     off[1:3] = off[1]  # an empty bag near the front (idx beyond stays valid: offsets only move boundaries)
+    if tables >= 9:
+        off[B + 1:2 * B + 1] = off[B]  # ... and a table without any lookup (its neighbour's first bag takes them)
     cores = [t(c) for c in G.make_cores(3, tables, p, q, r, "signed")]
     ix, of = t(idx), t(off)
     empty64, empty32 = torch.empty(0, dtype=torch.int64, device=DEV), torch.empty(0, dtype=torch.int32, device=DEV)
@@ -299,6 +304,14 @@ def test_lookup_prologue_equals_separate_calls(tables, p, B, pf, std, H):
     g = O.make_geom(tables, p, q, r)
     ref = O.tt_forward(g, Bq, D, idx, orow, otab, [c.cpu().numpy() for c in cores])
     assert_close(o1.cpu().numpy(), ref, "prologue plan forward vs oracle")
+    # ... and the backward through either plan (chunk list, slice offsets of every core)
+    d_out = t(G.make_grad(19, tables, Bq, D))
+    g1 = E.tt_dense_backward(1000, D, p, q, r, Lt, idx.size, ix, row1, tab1, d_out, cores, plan=plan1)
+    g2 = E.tt_dense_backward(1000, D, p, q, r, Lt, idx.size, ix, row2, tab2, d_out, cores, plan=plan2)
+    gref = O.tt_backward(g, O.OPTIM_DENSE, Bq, D, 0, 0, idx, orow, otab, d_out.cpu().numpy(), [c.cpu().numpy() for c in cores])
+    for k in range(3):
+        assert_close(g1[k].cpu().numpy(), g2[k].cpu().numpy(), f"prologue plan backward grad{k} vs make_plan's")
+        assert_close(g1[k].cpu().numpy(), gref[k], f"prologue plan backward grad{k} vs oracle")
 
 
 @pytest.mark.parametrize("p", [[20, 22, 25], [300, 29, 31], [2100, 3, 2]])  # 8-bit slice ids / wide digit / two passes
