@@ -16,7 +16,7 @@ rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t0, n, routes = time.time(), 0, {}
 while time.time() - t0 < budget:
     T = int(rs.choice([2, 3, 3, 3, 4]))
-    tables = int(rs.choice([1, 1, 2, 3, 5, 9]))
+    tables = int(rs.choice([1, 1, 2, 3, 5, 9, 20, 40]))
     spec = T == 3 and rs.rand() < 0.4
     if spec:
         q, r = [4, 4, int(rs.choice([4, 8]))], [1] + [int(rs.choice([16, 32]))] * 2 + [1]
@@ -56,9 +56,13 @@ while time.time() - t0 < budget:
         tcores = [G.make_cores(int(rs.randint(1 << 30)), 1, ps[k], q, r[1:-1], "signed") for k in range(tables)]
         gc = [t(np.concatenate([tcores[k][c_] for k in range(tables)], axis=1)) for c_ in range(T)]
         Lt = torch.zeros(T, dtype=torch.int64, device=dev)
-        ri, ti = E.preprocess_indices_sync(t(idx), t(off), tables, True, torch.empty(0, dtype=torch.int64, device=dev),
-                                           torch.empty(0, dtype=torch.int32, device=dev))[1:3]
-        plan = E.make_plan(tables, ps, q, r, nnz, t(idx), ti, ri)
+        if rs.rand() < 0.5:  # the module's route: offsets -> rows + plan (table groups when the slice ids need them)
+            ri, ti, plan = E.lookup_prologue(t(idx), t(off), tables, ps, q, r)
+            routes["prologue"] = routes.get("prologue", 0) + 1
+        else:
+            ri, ti = E.preprocess_indices_sync(t(idx), t(off), tables, True, torch.empty(0, dtype=torch.int64, device=dev),
+                                               torch.empty(0, dtype=torch.int32, device=dev))[1:3]
+            plan = E.make_plan(tables, ps, q, r, nnz, t(idx), ti, ri)
         out = E.tt_forward(1000, tables, B, D, ps, q, r, Lt, nnz, t(idx), ri, ti, gc, plan=plan)
         grads = E.tt_dense_backward(1000, D, ps, q, r, Lt, nnz, t(idx), ri, ti, t(d_out), gc, plan=plan)
         what = f"case {n} (mixed): T={T} p={ps} q={q} r={r} B={B} nnz={nnz}"
@@ -82,10 +86,14 @@ while time.time() - t0 < budget:
     ref_out = O.tt_forward(g, B, D, idx, rowidx, tableidx, cores)
     ref_g = O.tt_backward(g, O.OPTIM_DENSE, B, D, 0, 0, idx, rowidx, tableidx, d_out, [x.copy() for x in cores])
     Lt = t(np.array([int(np.prod(p[k + 1:])) for k in range(T)], dtype=np.int64))
-    ri, ti = E.preprocess_indices_sync(t(idx), t(off), tables, True, torch.empty(0, dtype=torch.int64, device=dev),
-                                       torch.empty(0, dtype=torch.int32, device=dev))[1:3]
     gc = [t(x) for x in cores]
-    plan = E.make_plan(tables, p, q, r, nnz, t(idx), ti, ri)
+    if tables > 1 and rs.rand() < 0.5:
+        ri, ti, plan = E.lookup_prologue(t(idx), t(off), tables, p, q, r)
+        routes["prologue"] = routes.get("prologue", 0) + 1
+    else:
+        ri, ti = E.preprocess_indices_sync(t(idx), t(off), tables, True, torch.empty(0, dtype=torch.int64, device=dev),
+                                           torch.empty(0, dtype=torch.int32, device=dev))[1:3]
+        plan = E.make_plan(tables, p, q, r, nnz, t(idx), ti, ri)
     out = E.tt_forward(1000, tables, B, D, p, q, r, Lt, nnz, t(idx), ri, ti, gc, plan=plan)
     grads = E.tt_dense_backward(1000, D, p, q, r, Lt, nnz, t(idx), ri, ti, t(d_out), gc, plan=plan)
     what = f"case {n}: T={T} tables={tables} p={p} q={q} r={r} B={B} nnz={nnz}"
