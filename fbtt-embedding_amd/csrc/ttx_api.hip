@@ -61,6 +61,9 @@ static const TabGeom* tab_geom_for(const ttx_geom* g) {
 }
 
 int make_dims(const ttx_geom* g, Dims* d) {
+  // every entry point starts here: whatever error an earlier, unrelated runtime call left behind on this thread
+  // is not this call's (the launches below check hipGetLastError() after themselves)
+  (void)hipGetLastError();
   if (!g) TTX_FAIL(TTX_EINVAL, "geometry is NULL");
   if (g->T < 2 || g->T > TTX_MAX_CORES)
     TTX_FAIL(TTX_EINVAL, "T=%d: number of TT cores must be 2..4", g->T);
@@ -188,6 +191,9 @@ static void prof_drain() {
     }
     g_prof.pending[w].clear();
   }
+  // a failed event query (pairs recorded inside a captured graph that was not replayed since, ..) is not an
+  // error of the next launch: do not leave it behind for that launch's hipGetLastError()
+  (void)hipGetLastError();
 }
 
 }  // namespace ttx
@@ -204,6 +210,16 @@ int ttx_profile_enable(int mask) {
 }
 
 int ttx_profile_mask(int mask) {  // as ttx_profile_enable, without reading back the pending event pairs
+  // Meant to be called right before a stream capture: the events the captured launches will record must exist
+  // by then (creating one while a capture is open left an invalid handle behind on this stack -- the next launch
+  // reported hipErrorInvalidResourceHandle), so the pool is stocked here.
+  if (mask) {
+    while (ttx::g_prof.pool.size() < 512) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) break;
+      ttx::g_prof.pool.push_back(e);
+    }
+  }
   ttx::g_prof.mask = (unsigned)mask;
   return TTX_OK;
 }
