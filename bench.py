@@ -263,7 +263,7 @@ def main():
             for i, o in reqs:
                 E._ws_cache.clear()  # every graph owns its workspace (allocated from its pool)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=cap):
+                with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
                     step(i, o)
                 graphs.append(g)
             # one more graph holding a whole round of the request batches (iters steps): a graph launch costs
@@ -273,7 +273,7 @@ def main():
             g_round = torch.cuda.CUDAGraph()
             E.profile_reset()
             E.profile_mask(1 << E.PROF_BWD)  # the event pairs around the backward kernel become graph nodes
-            with torch.cuda.graph(g_round, stream=cap):
+            with torch.cuda.graph(g_round, stream=cap, capture_error_mode="thread_local"):
                 for i, o in reqs:
                     step(i, o)
             E.profile_mask(0)

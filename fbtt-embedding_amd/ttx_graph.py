@@ -29,7 +29,10 @@ class GraphedRound:
         except ImportError:
             _E = None
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self._stream):
+        # "thread_local": only this thread's calls are held to the capture rules.  With a process group alive,
+        # torch.distributed's watchdog thread polls its events all the time; under the default ("global") mode
+        # such a poll during the capture fails and the watchdog aborts the process.
+        with torch.cuda.graph(self.graph, stream=self._stream, capture_error_mode="thread_local"):
             for b in self.batches:
                 step(*b)
         if _E is not None:
