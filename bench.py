@@ -392,7 +392,8 @@ def main():
             t1 = time.perf_counter()
             g_elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
             dist.all_reduce(g_elapsed, op=dist.ReduceOp.MAX)
-            mode, elapsed = "hipgraph+direct-rccl", float(g_elapsed.item())
+            # (fewer steps than one round: no replay took place, the steps ran eagerly over the direct exchange)
+            mode, elapsed = ("hipgraph+direct-rccl" if args.steps >= iters else "eager+direct-rccl"), float(g_elapsed.item())
         except Exception as ex:  # noqa: BLE001
             print(f"[bench] direct-RCCL graph path unavailable ({type(ex).__name__}: {ex}); reporting the eager path", file=sys.stderr)
             mod.direct = None
