@@ -382,8 +382,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
 //   mb_scatter : every work-group scans the unit counts itself (<= kMbFuseU units), position =
 //                base[digit][unit] + rank; writes perm[t] / the pivot's flat lookup records; its
 //                first work-group per core writes offsets and chunk list (finish_single_pass).
-// (Both kernels still carry the pass index of the multi-pass plan they came from; that plan is
-// mbp_* below now.)
+// (Several 8-bit passes: mbp_* below.)
 constexpr int kMbThreads = 256;            // 4 wave units per work-group
 constexpr int kMbUnits = kMbThreads / kWave;
 constexpr int kSB = 4;                     // batches of 64 whose loads are in flight together
@@ -393,8 +392,6 @@ struct MbArgs {
   int N, U;            // lookups (upper bound when n_dev is set), units per core
   const int* n_dev;    // device-side lookup count (<= N), or NULL: N is exact
   int unit;            // positions per wave unit (multiple of 64)
-  int pass;            // current pass
-  int passes[TTX_MAX_CORES];
   int* cnt;            // [T][U][256]  (unit-major: a unit's 256 digit counts are one 1 KiB row)
 };
 
@@ -426,18 +423,14 @@ __device__ __forceinline__ MbItem mb_load(int i, bool valid, int pass, const Dim
 }
 
 __global__ __launch_bounds__(kMbThreads) void mb_count_kernel(
-    Dims d, MbArgs A, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx, Plan P) {
+    Dims d, MbArgs A, const int64_t* __restrict__ indices, const int64_t* __restrict__ tableidx) {
   __shared__ int hist[kMbUnits][256];
   const int t = blockIdx.y;
-  if (A.pass >= A.passes[t]) return;
   const int lane = lane_id(), w = threadIdx.x / kWave;
   const int u = blockIdx.x * kMbUnits + w;
   for (int e = lane; e < 256; e += kWave) hist[w][e] = 0;
   const int N = live_n(A.N, A.n_dev);
   const int beg = min(N, u * A.unit), end = min(N, beg + A.unit);
-  int* key = P.sid[t];
-  const int* src = (A.pass == 0) ? nullptr : ((A.pass & 1) ? P.scratch[t][1] : P.scratch[t][2]);
-  const int shift = A.pass * 8;
   const CoreDec ct = core_dec(d, t);
   // super-batches of kSB x 64 positions: all their (dependent) loads are issued before any is used --
   // a wave walks thousands of positions and one round trip per 64 was the whole cost of the pass
@@ -446,14 +439,13 @@ __global__ __launch_bounds__(kMbThreads) void mb_count_kernel(
 #pragma unroll
     for (int k = 0; k < kSB; ++k) {
       const int i = base + k * kWave + lane;
-      it[k] = mb_load(i, i < end, A.pass, d, t, ct, indices, tableidx, src, key);
+      it[k] = mb_load(i, i < end, 0, d, t, ct, indices, tableidx, nullptr, nullptr);
     }
 #pragma unroll
     for (int k = 0; k < kSB; ++k) {
       const int i = base + k * kWave + lane;
       const bool valid = i < end;
-      if (valid && A.pass == 0) key[i] = it[k].kv;
-      const unsigned dg = ((unsigned)it[k].kv >> shift) & 255u;
+      const unsigned dg = (unsigned)it[k].kv & 255u;
       const unsigned long long peers = wave_match8(dg, valid);
       if (valid && (peers & lanemask_lt()) == 0) hist[w][dg] += __popcll(peers);
     }
@@ -681,7 +673,6 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
   __shared__ int run[kMbUnits][256];
   __shared__ int wt5[kMbUnits + 1];
   const int t = blockIdx.y;
-  if (A.pass >= A.passes[t]) return;
   const int lane = lane_id(), w = threadIdx.x / kWave;
   const int u = blockIdx.x * kMbUnits + w;
   {
@@ -720,55 +711,37 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
   }
   const int N = live_n(A.N, A.n_dev);
   const int beg = min(N, u * A.unit), end = min(N, beg + A.unit);
-  const int* key = P.sid[t];
-  const int* src = (A.pass == 0) ? nullptr : ((A.pass & 1) ? P.scratch[t][1] : P.scratch[t][2]);
-  const bool last = (A.pass == A.passes[t] - 1);
-  int* dst = last ? P.perm[t] : ((A.pass & 1) ? P.scratch[t][2] : P.scratch[t][1]);
-  int* sk = P.scratch[t][0];  // sorted keys (last pass)
-  const int shift = A.pass * 8;
   const bool pivot = (t == 1);
   const CoreDec ct = core_dec(d, t);
-  // pass 0 re-derives the key from the index (cheaper than chasing key[i] behind the count launch's store)
+  // the key is re-derived from the index (cheaper than a key array written by the count launch); the pivot
+  // decodes the other cores' slice ids of its records from the same index
   for (int base = beg; base < end; base += kSB * kWave) {
-    MbItem it[kSB];
-    int4 rec[kSB];
-    int brow[kSB];
+    long long ix[kSB];
+    int tb[kSB], brow[kSB];
 #pragma unroll
     for (int k = 0; k < kSB; ++k) {
       const int i = base + k * kWave + lane;
-      it[k] = mb_load(i, i < end, A.pass, d, t, ct, indices, tableidx, src, key);
-    }
-    if (last && pivot) {  // the record gathers of the whole super-batch, in flight together
-#pragma unroll
-      for (int k = 0; k < kSB; ++k) {
-        const int i = base + k * kWave + lane;
-        const int v = it[k].val;
-        rec[k] = make_int4(v, 0, 0, 0);
-        brow[k] = 0;
-        if (i < end) {
-          rec[k].y = P.sid[0][v];
-          rec[k].z = d.T > 2 ? P.sid[2][v] : 0;
-          rec[k].w = d.T > 3 ? P.sid[3][v] : 0;
-          if (rowidx) brow[k] = (int)rowidx[v];
-        }
-      }
+      ix[k] = i < end ? indices[i] : 0;
+      tb[k] = (i < end && tableidx) ? (int)tableidx[i] : 0;
+      brow[k] = (pivot && rowidx && i < end) ? (int)rowidx[i] : 0;
     }
 #pragma unroll
     for (int k = 0; k < kSB; ++k) {
       const int i = base + k * kWave + lane;
       const bool valid = i < end;
-      const unsigned dg = ((unsigned)it[k].kv >> shift) & 255u;
+      const unsigned dg = valid ? (unsigned)slice_id(d, ct, t, tb[k], ix[k]) & 255u : 0u;
       const unsigned long long peers = wave_match8(dg, valid);
       if (valid) {
         const int before = run[w][dg];
         const int pos = before + __popcll(peers & lanemask_lt());
-        if (!(last && pivot)) dst[pos] = it[k].val;  // the pivot's final order lives in lrec.x
-        if (last) {
-          sk[pos] = it[k].kv;
-          if (pivot) {
-            P.lrec[pos] = rec[k];
-            if (rowidx) P.lrow[pos] = brow[k];
-          }
+        if (!pivot) {
+          P.perm[t][pos] = i;
+        } else {  // the pivot's final order lives in lrec.x
+          const int s0 = slice_id(d, core_dec(d, 0), 0, tb[k], ix[k]);
+          const int s2 = d.T > 2 ? slice_id(d, core_dec(d, 2), 2, tb[k], ix[k]) : 0;
+          const int s3 = d.T > 3 ? slice_id(d, core_dec(d, 3), 3, tb[k], ix[k]) : 0;
+          P.lrec[pos] = make_int4(i, s0, s2, s3);
+          if (rowidx) P.lrow[pos] = brow[k];
         }
         if ((peers & lanemask_lt()) == 0) run[w][dg] = before + __popcll(peers);
       }
@@ -1291,14 +1264,14 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
   MbArgs A;
   A.N = N;
   A.n_dev = n_dev;
-  int maxp = 1;
+  int maxp = 1, passes[TTX_MAX_CORES];  // 8-bit passes the slice ids of each core need
   for (int t = 0; t < TTX_MAX_CORES; ++t) {
-    A.passes[t] = 0;
+    passes[t] = 0;
     if (t < d.T) {
       int bits = 0;
       while ((1ll << bits) < d.S[t]) ++bits;
-      A.passes[t] = (bits + 7) / 8 > 0 ? (bits + 7) / 8 : 1;
-      if (A.passes[t] > maxp) maxp = A.passes[t];
+      passes[t] = (bits + 7) / 8 > 0 ? (bits + 7) / 8 : 1;
+      if (passes[t] > maxp) maxp = passes[t];
     }
   }
   if (maxp == 1 && N <= kOneMaxN && !d.tab) {
@@ -1338,7 +1311,7 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
     B.N = N;
     B.n_dev = n_dev;
     B.cnt = P.cnt;
-    for (int t = 0; t < TTX_MAX_CORES; ++t) B.passes[t] = A.passes[t];
+    for (int t = 0; t < TTX_MAX_CORES; ++t) B.passes[t] = passes[t];
     const int G = (N + kWideSpan - 1) / kWideSpan;
     const dim3 grid(G, d.T);
     for (int ps = 0; ps < maxp; ++ps) {
@@ -1357,9 +1330,8 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
   if ((N + 255) / 256 > kMbFuseU) A.unit = ((N + kMbFuseU - 1) / kMbFuseU + 63) / 64 * 64;
   A.U = (N + A.unit - 1) / A.unit;
   A.cnt = P.cnt;
-  A.pass = 0;
   const dim3 gu((A.U + kMbUnits - 1) / kMbUnits, d.T);
-  hipLaunchKernelGGL(mb_count_kernel, gu, dim3(kMbThreads), 0, stream, d, A, indices, tableidx, P);
+  hipLaunchKernelGGL(mb_count_kernel, gu, dim3(kMbThreads), 0, stream, d, A, indices, tableidx);
   hipLaunchKernelGGL(mb_scatter_kernel, gu, dim3(kMbThreads), 0, stream, d, A, indices, tableidx, rowidx, P);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
