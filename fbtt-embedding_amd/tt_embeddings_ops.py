@@ -387,15 +387,21 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                 with torch.no_grad():
                     core.mul_(1.0 / self.tt_ranks[0])
         elif weight_dist == "approx-normal":
-            # N(0,1) truncated to |x| >= 2 by rejection, scaled by (3E)^(-1/6)
+            # N(0,1) truncated to |x| >= 2 by rejection, scaled by (3E)^(-1/6).  The reference redraws entry after
+            # entry (:650-654): the j-th rejected entry ends up with the j-th accepted value of the stream that
+            # follows the first draw.  Done here in blocks -- each block draws exactly as many values as are still
+            # missing, so the stream is consumed to the same point and every entry gets the same value.
             scale = (1.0 / math.sqrt(3 * E)) ** (1.0 / 3.0)
             for t, core in enumerate(self.tt_cores):
-                w = np.random.normal(0.0, 1.0, size=tuple(core.shape)).astype(np.float32)
-                small = np.abs(w) < 2
-                while small.any():
-                    w[small] = np.random.normal(0.0, 1.0, size=int(small.sum())).astype(np.float32)
-                    small = np.abs(w) < 2
-                self._assign(t, w * scale)
+                w = np.random.normal(0.0, 1.0, size=tuple(core.shape)).astype(np.float32).ravel()
+                small = np.flatnonzero(np.abs(w) < 2)
+                done = 0
+                while done < small.size:
+                    x = np.random.normal(0.0, 1.0, size=small.size - done).astype(np.float32)
+                    x = x[np.abs(x) >= 2]
+                    w[small[done:done + x.size]] = x
+                    done += x.size
+                self._assign(t, w * np.float64(scale))  # (float64 product, rounded once: `W *= scale` with a numpy scalar)
         elif weight_dist == "approx-uniform":
             self._init_approx_uniform()
         else:

@@ -90,3 +90,25 @@ def test_shape(T):
 CFG1 = dict(p=[1, 2, 5], q=[1, 1, 3], ranks=[2, 2])                  # README toy example
 CFG2 = dict(p=[200, 220, 250], q=[4, 4, 4], ranks=[32, 32], B=512, L=20)  # benchmark default
 CFG4 = dict(p=[200, 220, 250], q=[4, 4, 8], ranks=[64, 64], B=512, L=20)
+CFG5 = dict(p=[200, 220, 250], q=[4, 4, 4], ranks=[32, 32], tables=26, L=20)  # 26-table batched lookup, global B = 4096
+CFG5_SEED = 5150
+CFG5_GOLDEN_TABLES = (0, 13, 25)  # tables whose reference results are stored in tests/golden/cfg5.npz (B = 512)
+
+
+def cfg5_case(B, seed=CFG5_SEED):
+    """BASELINE configs[4] on one device: 26 tables of cfg2's shape, B bags per table, 20 lookups per bag"""
+    c = CFG5
+    p, q, r = c["p"], c["q"], pad_ranks(c["ranks"], 3)
+    E, D = int(np.prod(p)), int(np.prod(q))
+    idx, off = make_requests(seed + 1 + B, 1, B, c["tables"], c["L"], E)[0]
+    return dict(tables=c["tables"], T=3, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+                cores=make_cores(seed, c["tables"], p, q, r, "uniform"), d_out=make_grad(seed + 2, c["tables"], B, D))
+
+
+def table_of(c, k):
+    """the one-table case made of table k of a table-batched case"""
+    B = c["B"]
+    lo, hi = int(c["offsets"][k * B]), int(c["offsets"][(k + 1) * B])
+    return dict(tables=1, T=c["T"], p=c["p"], q=c["q"], r=c["r"], B=B, D=c["D"], indices=c["indices"][lo:hi],
+                offsets=c["offsets"][k * B:(k + 1) * B + 1] - lo, cores=[x[k:k + 1] for x in c["cores"]],
+                d_out=c["d_out"][k:k + 1])

@@ -127,9 +127,32 @@ def write_big(tag, cfg, seed):
     print(tag, "out", out.shape, [float(blob[f"grad{t}_sum"][0]) for t in range(3)])
 
 
+def write_cfg5():
+    """BASELINE configs[4] (26 tables of cfg2's shape) at B = 512: the reference's results for three of the 26
+    tables (tables are independent; each is a full 11M x 64 expansion)"""
+    c = G.cfg5_case(512)
+    blob = {"seed": np.array([G.CFG5_SEED]), "tables": np.array(G.CFG5_GOLDEN_TABLES)}
+    rs = np.random.RandomState(G.CFG5_SEED + 3)
+    for k in G.CFG5_GOLDEN_TABLES:
+        ck = G.table_of(c, k)
+        out, grads, sgd, ada, state = reference_case(1, ck["p"], ck["q"], ck["r"], [np.ascontiguousarray(x) for x in ck["cores"]],
+                                                     ck["indices"], ck["offsets"], ck["d_out"])
+        blob[f"t{k}_out"] = out[0]
+        for t in range(3):
+            g = grads[t].reshape(-1, grads[t].shape[-1])
+            rows = np.sort(rs.choice(g.shape[0], size=8, replace=False))
+            blob[f"t{k}_grad{t}_rows"] = rows
+            blob[f"t{k}_grad{t}_sub"] = g[rows]
+            blob[f"t{k}_sgd{t}_sub"] = sgd[t].reshape(g.shape)[rows]
+            blob[f"t{k}_grad{t}_rowsum"] = g.astype(np.float64).sum(axis=1)
+        print("cfg5 table", k, "out", out.shape)
+    np.savez_compressed(os.path.join(HERE, "cfg5.npz"), **blob)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     write_small()
     if "--small" not in sys.argv:
         write_big("cfg2", G.CFG2, 1234)
         write_big("cfg4", G.CFG4, 4321)
+        write_cfg5()

@@ -1,0 +1,21 @@
+"""Fixed-seed slices of the randomised parity sweeps (tests/fuzz_cases.py) as part of the GPU suite:
+250 geometry/batch cases of the TT path (every plan route must be hit) and 250 of the cache path."""
+import pytest
+
+import fuzz_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_plan_and_contraction_fuzz_slice(seed):
+    n, routes = fuzz_cases.run_plan_cases(seed=seed, max_cases=125)
+    assert n == 125
+    if seed == 0:
+        for route in ("tiny", "single", "units", "wide", "multi-pass", "mixed", "prologue"):
+            assert routes.get(route, 0) > 0, f"plan route {route!r} not exercised: {routes}"
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_cache_prologue_gather_scatter_fuzz_slice(seed):
+    assert fuzz_cases.run_cache_cases(seed=seed, max_cases=125) == 125

@@ -109,6 +109,35 @@ def test_initialisers(ops, dist):
         assert hist.min() > 0.02 * w.size
 
 
+def test_initialisers_match_reference_moments(ops):
+    """tests/golden/init_moments.json holds per-core statistics of the REFERENCE's five initialisers under fixed
+    seeds (made by tests/golden/make_init_moments.py, which imports the reference's Python).  This repository's own
+    reset_parameters consumes the three generators in the same order, so under the same seeds every statistic must
+    agree to float rounding -- not just in distribution."""
+    import json
+    import random
+
+    z = json.load(open(os.path.join(ROOT, "tests", "golden", "init_moments.json")))
+    for case in z["cases"]:
+        c, dist = case["cfg"], case["dist"]
+        torch.manual_seed(z["seed"])
+        np.random.seed(z["seed"])
+        random.seed(z["seed"])
+        m = ops.TTEmbeddingBag(c["E"], c["D"], c["ranks"], c["p"], c["q"], sparse=False, use_cache=False, weight_dist=dist,
+                               device="cpu")
+        what = f"E={c['E']} {dist}"
+        for k, (core, ref) in enumerate(zip(m.tt_cores, case["cores"])):
+            x = core.detach().double().numpy().ravel()
+            scale = max(abs(ref["max"]), abs(ref["min"]))
+            for name, got in (("mean", x.mean()), ("std", x.std()), ("min", x.min()), ("max", x.max()), ("abs_mean", np.abs(x).mean())):
+                assert abs(got - ref[name]) <= 1e-5 * scale, f"{what} core{k} {name}: {got!r} vs reference {ref[name]!r}"
+            assert np.allclose(x[:4], ref["first"], rtol=1e-5, atol=1e-6 * scale), f"{what} core{k}: first entries differ"
+        if case["full"] is not None:
+            w = m.full_weight().detach().double().numpy().ravel()
+            assert abs(w.std() - case["full"]["std"]) <= 1e-4 * case["full"]["std"], f"{what}: std of the full table"
+            assert abs(w.mean() - case["full"]["mean"]) <= 1e-4 * max(abs(case["full"]["mean"]), case["full"]["std"])
+
+
 def _module_for(ops, c, **kw):
     m = ops.TableBatchedTTEmbeddingBag(c["tables"], int(np.prod(c["p"])), c["D"], c["r"][1:-1], c["p"], c["q"],
                                        weight_dist="uniform", use_cache=False, device="cpu", **kw)

@@ -122,3 +122,38 @@ def test_hash_vs_reference_build():
             assert O.hash64(int(k), size) == ref.ref_hash64(int(k), size)
     for k in rs.randint(-2 ** 31, 2 ** 31, size=2000):
         assert O.hash32(int(k), 1000003) == ref.ref_hash32(int(k), 1000003)
+
+
+def check_cfg5_tables(c, out, grads=None, sgd_cores=None):
+    """a 26-table run at B = 512 (out [26, 512, 64], dense core gradients / SGD-updated cores [26, p_t, slice]) against
+    the reference's results for the tables stored in tests/golden/cfg5.npz"""
+    z = np.load(os.path.join(HERE, "golden", "cfg5.npz"))
+    assert int(z["seed"][0]) == G.CFG5_SEED and c["B"] == 512
+    for k in z["tables"].tolist():
+        assert_close(out[k], z[f"t{k}_out"], f"cfg5 table {k} out")
+        for t in range(3):
+            rows = z[f"t{k}_grad{t}_rows"]
+            if grads is not None:
+                assert_close(grads[t][k][rows], z[f"t{k}_grad{t}_sub"], f"cfg5 table {k} grad{t} rows")
+                assert_close(grads[t][k].astype(np.float64).sum(axis=1), z[f"t{k}_grad{t}_rowsum"], f"cfg5 table {k} grad{t} per-slice sums",
+                             rtol=2e-5)
+            if sgd_cores is not None:
+                assert_close(sgd_cores[t][k][rows], z[f"t{k}_sgd{t}_sub"], f"cfg5 table {k} sgd{t} rows")
+
+
+def test_cfg5_tables_vs_reference_golden():
+    """BASELINE configs[4] geometry: the oracle on the three golden tables of the 26 (one table at a time: the tables of a
+    batched lookup are independent)"""
+    c = G.cfg5_case(512)
+    out = np.zeros((c["tables"], 512, c["D"]), dtype=np.float32)
+    grads = [np.zeros_like(x) for x in c["cores"]]
+    sgd = [x.copy() for x in c["cores"]]
+    for k in G.CFG5_GOLDEN_TABLES:
+        ck = G.table_of(c, k)
+        ck["cores"] = [np.ascontiguousarray(x) for x in ck["cores"]]
+        r = _run(ck, "dense")
+        out[k] = r["out"][0]
+        for t in range(3):
+            grads[t][k] = r["grads"][t][0]
+            sgd[t][k] = _run(ck, "sgd")["cores"][t][0]
+    check_cfg5_tables(c, out, grads, sgd)
