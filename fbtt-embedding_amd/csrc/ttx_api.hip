@@ -148,6 +148,12 @@ struct ProfState {
   double ms[TTX_PROF_NUM] = {};
 };
 static ProfState g_prof;
+// forward runs on the caller's thread, backward on the autograd engine's, MixedTTEmbeddingBag(streams=True) on
+// several streams: the event lists are shared, so every access takes this lock.  (The `open` slot pairs ONE begin
+// with the next end of the same kernel slot: with several streams in flight the pairs are still well-formed per
+// thread because a launch's begin/end happen under one ProfScope on one thread; profile single-stream for timings
+// that mean something.)
+static std::mutex g_prof_mu;
 
 static hipEvent_t get_event() {
   if (!g_prof.pool.empty()) {
@@ -161,7 +167,8 @@ static hipEvent_t get_event() {
 }
 
 void prof_begin(int which, hipStream_t s) {
-  if (!(g_prof.mask >> which & 1u)) return;
+  if (!(g_prof.mask >> which & 1u)) return;  // (unlocked fast path: profiling off)
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   hipEvent_t e = get_event();
   if (!e) return;
   (void)hipEventRecord(e, s);
@@ -169,6 +176,8 @@ void prof_begin(int which, hipStream_t s) {
 }
 
 void prof_end(int which, hipStream_t s) {
+  if (!g_prof.mask && !g_prof.open[which]) return;  // (unlocked fast path: profiling off, nothing open)
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof.open[which]) return;
   hipEvent_t e = get_event();
   if (!e) return;
@@ -178,6 +187,7 @@ void prof_end(int which, hipStream_t s) {
 }
 
 static void prof_drain() {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int w = 0; w < TTX_PROF_NUM; ++w) {
     for (auto& pr : g_prof.pending[w]) {
       float ms = 0.f;
@@ -213,6 +223,7 @@ int ttx_profile_mask(int mask) {  // as ttx_profile_enable, without reading back
   // Meant to be called right before a stream capture: the events the captured launches will record must exist
   // by then (creating one while a capture is open left an invalid handle behind on this stack -- the next launch
   // reported hipErrorInvalidResourceHandle), so the pool is stocked here.
+  std::lock_guard<std::mutex> lk(ttx::g_prof_mu);
   if (mask) {
     while (ttx::g_prof.pool.size() < 512) {
       hipEvent_t e;
@@ -226,6 +237,7 @@ int ttx_profile_mask(int mask) {  // as ttx_profile_enable, without reading back
 
 int ttx_profile_reset(void) {
   ttx::prof_drain();
+  std::lock_guard<std::mutex> lk(ttx::g_prof_mu);
   for (int w = 0; w < TTX_PROF_NUM; ++w) {
     ttx::g_prof.launches[w] = 0;
     ttx::g_prof.ms[w] = 0.0;
@@ -236,6 +248,7 @@ int ttx_profile_reset(void) {
 int ttx_profile_read(int which, int64_t* launches, double* total_ms) {
   if (which < 0 || which >= TTX_PROF_NUM) TTX_FAIL(TTX_EINVAL, "profile slot %d out of range", which);
   ttx::prof_drain();
+  std::lock_guard<std::mutex> lk(ttx::g_prof_mu);
   if (launches) *launches = ttx::g_prof.launches[which];
   if (total_ms) *total_ms = ttx::g_prof.ms[which];
   return TTX_OK;

@@ -481,6 +481,10 @@ __global__ __launch_bounds__(kCT) void mark_popular_kernel(int32_t H, int64_t ca
     } else {
       hashtbl[slot] = -1;
       cache_freq[slot] = 0;
+      // Deliberate fix (the reference leaves cache_state[slot] as it was): after a SECOND populate an evicted slot
+      // would keep its old cache row number, and the next key inserted into that slot would be served -- and would
+      // update -- another index's cached row.  Identical to the reference on a first populate (state is all -1).
+      cache_state[slot] = -1;
     }
   } else if (n < cache_size) {
     sorted_keys[n] = 0;  // "a hack to use batch gemm"

@@ -32,6 +32,14 @@ def merge_bags(indices: Sequence[torch.Tensor], offsets: Sequence[torch.Tensor],
     """per-table (indices, offsets) -> the table-major batched form of `TableBatchedTTEmbeddingBag`
     (offsets with num_tables * B + 1 entries).  Lengths come from tensor shapes: no device read-back."""
     assert len(indices) == len(offsets) and len(indices) > 0
+    nb = {int(o.numel()) for o in offsets}
+    if len(nb) != 1:
+        raise ValueError(f"every table must describe the same number of bags, got offsets of {sorted(nb)} entries")
+    if include_last_offset and nb.pop() < 1:
+        raise ValueError("include_last_offset form: offsets needs at least the closing entry")
+    if __debug__ and include_last_offset and not indices[0].is_cuda:  # (host tensors only: no device read-back)
+        for idx, off in zip(indices, offsets):
+            assert int(off[-1]) == idx.numel(), "closing offset must equal the number of indices of the table"
     parts, base = [], 0
     for idx, off in zip(indices, offsets):
         starts = off[:-1] if include_last_offset else off

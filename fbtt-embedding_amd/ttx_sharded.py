@@ -139,7 +139,8 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         if self.num_tables % self.world != 0:
             raise ValueError("direct exchange needs num_tables to be a multiple of the world size")
         if self.direct is None:
-            dev = next(self.local.parameters()).device
+            dev = (next(self.local.parameters()).device if self.local is not None
+                   else torch.device("cuda", torch.cuda.current_device()))
             self.direct = DirectExchange(self.group, dev)
 
     def _a2a(self, out, inp, out_splits=None, in_splits=None):
@@ -201,7 +202,9 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
             pooled = self.local(loc_idx, loc_off)                          # [n_me, W*B, D]
             send = pooled.view(n_me, W, B, D).permute(1, 0, 2, 3).reshape(W * n_me * B, D)
         else:
-            send = torch.zeros((0, D), device=dev, dtype=torch.float32)
+            # (a rank that owns no table still takes part in BOTH exchanges: without requires_grad its autograd
+            #  node would be missing, it would skip the backward all-to-all and the owners would wait for ever)
+            send = torch.zeros((0, D), device=dev, dtype=torch.float32, requires_grad=True)
         # ---- 3. pooled out ---------------------------------------------------
         if self.direct is not None and fixed_pooling is not None:
             got = _DirectPooledAllToAll.apply(self.direct, send)

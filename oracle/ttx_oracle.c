@@ -433,7 +433,13 @@ int ttxo_cache_populate(const ttx_geom* g, const float* const* cores, int64_t H,
       int32_t slot = ttxo_hashtbl_find(sorted[n], (int32_t)H, MAX_PROBES, hashtbl);
       if (slot < 0) continue;
       if (n < cache_size) cache_state[slot] = (int32_t)n;
-      else { hashtbl[slot] = -1; cache_freq[slot] = 0; }
+      else {
+        hashtbl[slot] = -1; cache_freq[slot] = 0;
+        /* NOT in the reference (cu:1131-1133 leaves cache_state[slot] stale): deliberate fix shared with the
+         * product, see DESIGN.md section 5 "Deviations"; no effect on a first populate.  The -m gpu test
+         * test_second_populate_differs_from_reference_only_on_evicted_slots pins the difference. */
+        cache_state[slot] = -1;
+      }
     } else if (n < cache_size) {
       sorted[n] = 0; /* "a hack to use batch gemm", cu:1135-1138 */
     }

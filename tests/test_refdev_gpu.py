@@ -249,3 +249,59 @@ def test_populate_mark_and_evict_vs_reference_kernel(H, cache_size):
     sub = np.flatnonzero(top != -1)[:: max(1, n_rows // 512)]
     rows = O.tt_rows(O.make_geom(1, p, q, r), 64, top[sub], None, [c.cpu().numpy() for c in cores])
     assert_close(pw.cpu().numpy()[sub], rows, "decompressed cache rows (sub-sample)")
+
+
+def test_second_populate_differs_from_reference_only_on_evicted_slots():
+    """f3 / deliberate deviation: the reference's mark_popular_colidx_kernel leaves
+    cache_state[slot] untouched when it evicts a key, so after a SECOND populate an evicted slot still carries the
+    cache row it had before -- the next key inserted there is served (and updates) another index's row.  The
+    product (and the oracle) reset it to -1.  Everything else of the second populate must equal the reference
+    kernel's result: hashtbl, cache_freq, and cache_state on every slot that was not evicted."""
+    import gen_inputs as G
+    import tt_embeddings as E
+
+    rs = np.random.RandomState(17)
+    H, cs, E_ = 1 << 14, 1500, 11000
+    p, q, r = [20, 22, 25], [4, 4, 4], [1, 16, 16, 1]
+    cores = [t(c) for c in G.make_cores(3, 1, p, q, r)]
+    Lt = torch.zeros(3, dtype=torch.int64, device=DEV)
+    keys, freq = empty_table(H)
+    for _ in range(6):
+        O.update_cache_state((rs.zipf(1.3, size=4000).astype(np.int64)) % E_, keys, freq)
+    dk, df, ds, dw = t(keys), t(freq), t(np.full(H, -1, dtype=np.int32)), torch.zeros(cs, 64, device=DEV)
+    E.cache_populate(E_, p, q, r, cores, Lt, dk, df, ds, dw)           # first populate (== reference, tested above)
+    keys1, freq1, state1 = dk.cpu().numpy(), df.cpu().numpy(), ds.cpu().numpy()
+    assert int((state1 >= 0).sum()) == cs
+    # the stream moves on: a different popularity profile, inserted sequentially (one defined table state)
+    # Only lookups that cannot leave a key in TWO slots: keys sitting on their home slot, and new keys whose home
+    # slot is free.  (A key stored behind an evicted slot is re-inserted in front of its old copy -- in the reference
+    # too -- and mark_popular's outcome for such twins depends on which thread runs first, in either build.)
+    present = set(int(k) for k in keys1[keys1 != -1])
+    keep = []
+    for k in ((rs.zipf(1.15, size=32000).astype(np.int64) * 7 + 3) % E_).tolist():
+        h = O.hash64(k, H)
+        if keys1[h] == k:
+            keep.append(k)
+        elif keys1[h] == -1 and k not in present:
+            keep.append(k)
+            keys1[h] = k
+            present.add(k)
+    keys1[freq1 == 0] = -1  # (slots claimed by the filter above: the oracle insert below fills them again)
+    O.update_cache_state(np.array(keep, dtype=np.int64), keys1, freq1)
+    assert len(keep) > 8000
+    order = np.argsort(-freq1, kind="stable")
+    rk, rf, rstate = t(keys1), t(freq1), t(state1)
+    R.mark_popular(cs, t(keys1[order].copy()), rk, rf, rstate)          # the reference's kernel on the stale state
+    pk, pf_, pstate = t(keys1), t(freq1), t(state1)
+    E.cache_populate(E_, p, q, r, cores, Lt, pk, pf_, pstate, dw)
+    assert torch.equal(pk, rk) and torch.equal(pf_, rf), "table contents after the second populate"
+    got, ref = pstate.cpu().numpy(), rstate.cpu().numpy()
+    evicted = (keys1 != -1) & (rk.cpu().numpy() == -1)
+    assert evicted.sum() > 100, "the case must evict keys"
+    assert np.array_equal(got[~evicted], ref[~evicted]), "cache_state of the slots that were not evicted"
+    assert (got[evicted] == -1).all(), "evicted slots must not keep a cache row"
+    stale = int((ref[evicted] != -1).sum())
+    assert stale > 0, "the reference leaves stale rows on evicted slots here (otherwise the case shows nothing)"
+    ok, of, ost = keys1.copy(), freq1.copy(), state1.copy()
+    O.cache_populate(O.make_geom(1, p, q, r), [c.cpu().numpy() for c in cores], ok, of, ost, np.zeros((cs, 64), dtype=np.float32))
+    assert np.array_equal(ost, got) and np.array_equal(ok, pk.cpu().numpy())
