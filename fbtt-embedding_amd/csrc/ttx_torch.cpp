@@ -376,7 +376,7 @@ Tensor lookup_cached(const Tensor& indices, const Tensor& offsets, std::vector<i
 // torch.distributed runs its collectives on a side stream of its own: every all_to_all costs two event hops
 // and ~30 us of wrapper time, and its watchdog aborts when a collective is captured into a hipGraph
 // (DESIGN.md section 7).  These four calls talk to the RCCL library torch already loaded, on the CURRENT
-// stream: equal-split all-to-all only (one table block per peer), capturable.  Prototypes are declared
+// stream: equal-split all-to-all (ncclAllToAll) and per-peer counts (a ncclSend/ncclRecv group), both capturable.  Prototypes are declared
 // here rather than taken from rccl.h so that the ROCm header and torch's bundled library need not match.
 extern "C" {
 typedef struct { char internal[128]; } ttx_ncclUniqueId;
@@ -385,6 +385,10 @@ int ncclGetUniqueId(ttx_ncclUniqueId* id);
 int ncclCommInitRank(ttx_ncclComm_t* comm, int nranks, ttx_ncclUniqueId id, int rank);
 int ncclCommDestroy(ttx_ncclComm_t comm);
 int ncclAllToAll(const void* sendbuff, void* recvbuff, size_t count, int datatype, ttx_ncclComm_t comm, void* stream);
+int ncclSend(const void* sendbuff, size_t count, int datatype, int peer, ttx_ncclComm_t comm, void* stream);
+int ncclRecv(void* recvbuff, size_t count, int datatype, int peer, ttx_ncclComm_t comm, void* stream);
+int ncclGroupStart(void);
+int ncclGroupEnd(void);
 const char* ncclGetErrorString(int result);
 }
 
@@ -431,6 +435,47 @@ void rccl_all_to_all(int64_t comm, const Tensor& out, const Tensor& in, int64_t 
                           (ttx_ncclComm_t)(intptr_t)comm, (void*)stream), "ncclAllToAll");
 }
 
+// Uneven splits (26 tables on 8 ranks: 4,4,3,3,3,3,3,3 table blocks per owner): block p of `in` holds
+// send_counts[p] elements for rank p, block p of `out` receives recv_counts[p] elements from rank p.  One
+// ncclSend + ncclRecv per peer inside a group -- over xGMI every pair of GPUs has its own link, so the group is
+// W - 1 concurrent point-to-point transfers -- on the current stream, capturable like ncclAllToAll.
+void rccl_all_to_allv(int64_t comm, const Tensor& out, const Tensor& in, const std::vector<int64_t>& send_counts,
+                      const std::vector<int64_t>& recv_counts) {
+  TORCH_CHECK(out.is_cuda() && in.is_cuda() && out.is_contiguous() && in.is_contiguous() &&
+                  out.scalar_type() == in.scalar_type() && send_counts.size() == recv_counts.size(),
+              "rccl_all_to_allv: contiguous GPU tensors of one dtype, one count per rank and direction");
+  int dt;
+  switch (in.scalar_type()) {
+    case at::kFloat: dt = 7; break;  // ncclFloat32
+    case at::kLong: dt = 4; break;   // ncclInt64
+    case at::kInt: dt = 2; break;    // ncclInt32
+    default: TORCH_CHECK(false, "rccl_all_to_allv: float32 / int64 / int32 only");
+  }
+  int64_t ns = 0, nr = 0;
+  for (size_t p = 0; p < send_counts.size(); ++p) {
+    TORCH_CHECK(send_counts[p] >= 0 && recv_counts[p] >= 0, "rccl_all_to_allv: negative count");
+    ns += send_counts[p];
+    nr += recv_counts[p];
+  }
+  TORCH_CHECK(ns == in.numel() && nr == out.numel(), "rccl_all_to_allv: counts do not add up to the tensor sizes");
+  const size_t esz = (size_t)in.element_size();
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(in.device());
+  auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  ttx_ncclComm_t c = (ttx_ncclComm_t)(intptr_t)comm;
+  rccl_check(ncclGroupStart(), "ncclGroupStart");
+  size_t so = 0, ro = 0;
+  int rc = 0;
+  for (size_t p = 0; p < send_counts.size() && rc == 0; ++p) {
+    if (send_counts[p]) rc = ncclSend((const char*)in.data_ptr() + so * esz, (size_t)send_counts[p], dt, (int)p, c, (void*)stream);
+    if (rc == 0 && recv_counts[p]) rc = ncclRecv((char*)out.data_ptr() + ro * esz, (size_t)recv_counts[p], dt, (int)p, c, (void*)stream);
+    so += (size_t)send_counts[p];
+    ro += (size_t)recv_counts[p];
+  }
+  const int rc_end = ncclGroupEnd();  // (always close the group)
+  rccl_check(rc, "ncclSend/ncclRecv");
+  rccl_check(rc_end, "ncclGroupEnd");
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -445,5 +490,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rccl_comm_init", &rccl_comm_init, "ncclCommInitRank on the given device (collective; releases the GIL)");
   m.def("rccl_comm_destroy", &rccl_comm_destroy);
   m.def("rccl_all_to_all", &rccl_all_to_all, "equal-split all-to-all on the current stream (capturable)");
+  m.def("rccl_all_to_allv", &rccl_all_to_allv, "all-to-all with per-peer element counts (ncclSend/ncclRecv group) on the current stream (capturable)");
   m.def("abi_version", []() { return ttx_version(); });
 }

@@ -44,11 +44,13 @@ def _a2a(group, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits) -> 
 
 
 class DirectExchange:
-    """Equal-split all-to-all straight on RCCL (csrc/ttx_torch.cpp), on the CURRENT stream: no side stream, no
-    event hops, ~5 us per exchange instead of ~17 + wrapper time, and capturable in a hipGraph (torch.distributed's
-    collectives are not: its watchdog aborts on an event recorded in a capturing stream).  One communicator per
-    process group, bootstrapped through torch.distributed.  (The communicator is never destroyed explicitly:
-    ncclCommDestroy was seen to hang on this stack; it dies with the process.)"""
+    """All-to-all straight on RCCL (csrc/ttx_torch.cpp), on the CURRENT stream: no side stream, no event hops,
+    ~5 us per exchange instead of ~17 + wrapper time, and capturable in a hipGraph (torch.distributed's
+    collectives are not: its watchdog aborts on an event recorded in a capturing stream).  Equal splits go through
+    ncclAllToAll, per-peer counts (tables not a multiple of the world size: 26 on 8 ranks) through one
+    ncclSend/ncclRecv group.  One communicator per process group, bootstrapped through torch.distributed.
+    (The communicator is never destroyed explicitly: ncclCommDestroy was seen to hang on this stack; it dies with
+    the process.)"""
 
     def __init__(self, group, device: torch.device) -> None:
         import ttx_torch
@@ -62,27 +64,53 @@ class DirectExchange:
         index = device.index if device.index is not None else torch.cuda.current_device()
         self.comm = ttx_torch.rccl_comm_init(box[0], self.rank, self.world, index)
 
-    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor) -> None:
-        self._lib.rccl_all_to_all(self.comm, out, inp, self.world)
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None) -> None:
+        """block p of `inp` (in_splits[p] elements) -> rank p; block p of `out` (out_splits[p] elements) <- rank p.
+        Splits are element counts; None = equal blocks."""
+        if _equal_splits(out_splits, in_splits):
+            self._lib.rccl_all_to_all(self.comm, out, inp, self.world)
+        else:
+            self._lib.rccl_all_to_allv(self.comm, out, inp, [int(x) for x in in_splits], [int(x) for x in out_splits])
+
+
+class CollectiveExchange:
+    """The DirectExchange interface on top of torch.distributed.all_to_all_single (any backend).  What the tests
+    use to drive the direct route's split bookkeeping on CPU (gloo); never faster than the plain route."""
+
+    def __init__(self, group) -> None:
+        self.group = group
+        self.world = dist.get_world_size(group)
+
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None) -> None:
+        if _equal_splits(out_splits, in_splits):
+            out_splits = in_splits = None
+        dist.all_to_all_single(out.view(-1), inp.contiguous().view(-1), None if out_splits is None else [int(x) for x in out_splits],
+                               None if in_splits is None else [int(x) for x in in_splits], group=self.group)
+
+
+def _equal_splits(out_splits, in_splits) -> bool:
+    return (out_splits is None or len(set(out_splits)) <= 1) and (in_splits is None or len(set(in_splits)) <= 1)
 
 
 class _DirectPooledAllToAll(torch.autograd.Function):
-    """differentiable equal-split all-to-all of [W * rows, D] blocks through a DirectExchange"""
+    """differentiable all-to-all of row blocks ([rows, D], split by rows) through a DirectExchange"""
 
     @staticmethod
-    def forward(ctx, ex: "DirectExchange", x: torch.Tensor) -> torch.Tensor:
-        ctx.ex = ex
+    def forward(ctx, ex, x: torch.Tensor, in_rows: List[int], out_rows: List[int]) -> torch.Tensor:
+        ctx.ex, ctx.in_rows, ctx.out_rows = ex, in_rows, out_rows
         x = x.contiguous()
-        out = torch.empty_like(x)
-        ex.all_to_all(out, x)
+        D = x.shape[1]
+        out = x.new_empty((sum(out_rows), D))
+        ex.all_to_all(out, x, [r * D for r in out_rows], [r * D for r in in_rows])
         return out
 
     @staticmethod
     def backward(ctx, g: torch.Tensor):
         g = g.contiguous()
-        gin = torch.empty_like(g)
-        ctx.ex.all_to_all(gin, g)
-        return None, gin
+        D = g.shape[1]
+        gin = g.new_empty((sum(ctx.in_rows), D))
+        ctx.ex.all_to_all(gin, g, [r * D for r in ctx.in_rows], [r * D for r in ctx.out_rows])
+        return None, gin, None, None
 
 
 class _PooledAllToAll(torch.autograd.Function):
@@ -133,12 +161,13 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         if self.my_tables:
             self.local = _ops.TableBatchedTTEmbeddingBag(len(self.my_tables), num_embeddings, embedding_dim, tt_ranks, **kw)
 
-    def enable_direct_exchange(self) -> None:
-        """Route the fixed-pooling exchanges through RCCL directly (see DirectExchange).  Needs the same number
-        of tables on every rank (equal splits) and the C++ extension; collective call -- every rank must make it."""
-        if self.num_tables % self.world != 0:
-            raise ValueError("direct exchange needs num_tables to be a multiple of the world size")
-        if self.direct is None:
+    def enable_direct_exchange(self, exchange=None) -> None:
+        """Route the fixed-pooling exchanges through RCCL directly (see DirectExchange): any number of tables per
+        rank (uneven ownership goes through a ncclSend/ncclRecv group).  Needs the C++ extension; collective call --
+        every rank must make it.  `exchange`: an object with DirectExchange's all_to_all (tests: CollectiveExchange)."""
+        if exchange is not None:
+            self.direct = exchange
+        elif self.direct is None:
             dev = (next(self.local.parameters()).device if self.local is not None
                    else torch.device("cuda", torch.cuda.current_device()))
             self.direct = DirectExchange(self.group, dev)
@@ -164,7 +193,7 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
             out_splits = [n_me * B * Lp] * W
             recv_idx = indices.new_empty(sum(out_splits))
             if self.direct is not None:
-                self.direct.all_to_all(recv_idx, send_idx.contiguous())
+                self.direct.all_to_all(recv_idx, send_idx.contiguous(), out_splits, in_splits)
             else:
                 self._a2a(recv_idx, send_idx, out_splits, in_splits)
             # wire order [src][k][b][l] -> table-major [k][src][b][l]
@@ -207,7 +236,7 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
             send = torch.zeros((0, D), device=dev, dtype=torch.float32, requires_grad=True)
         # ---- 3. pooled out ---------------------------------------------------
         if self.direct is not None and fixed_pooling is not None:
-            got = _DirectPooledAllToAll.apply(self.direct, send)
+            got = _DirectPooledAllToAll.apply(self.direct, send, [n_me * B] * W, [k * B for k in n_own])
         else:
             got = _PooledAllToAll.apply(self.group, send, [n_me * B] * W, [k * B for k in n_own])
         out = got.view(NT, B, D)

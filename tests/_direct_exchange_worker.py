@@ -58,5 +58,14 @@ for i, o in reqs:
 torch.cuda.synchronize()
 for x, y in zip(a.local.tt_cores, b.local.tt_cores):
     assert torch.equal(x, y), "cores differ after the captured round"
+# the per-peer-count route (ncclSend/ncclRecv group; what uneven table ownership takes) with the one peer there is
+x = torch.arange(5000, device=dev, dtype=torch.float32)
+y = torch.zeros_like(x)
+b.direct._lib.rccl_all_to_allv(b.direct.comm, y, x, [5000], [5000])
+xi = torch.arange(777, device=dev, dtype=torch.int64)
+yi = torch.zeros_like(xi)
+b.direct._lib.rccl_all_to_allv(b.direct.comm, yi, xi, [777], [777])
+torch.cuda.synchronize()
+assert torch.equal(x, y) and torch.equal(xi, yi), "rccl_all_to_allv"
 print("DIRECT-EXCHANGE-OK", flush=True)
 os._exit(0)

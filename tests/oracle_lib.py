@@ -239,3 +239,42 @@ def cache_backward_rowwise_adagrad_approx(grad, loc, rowidx, lr, eps, state, cac
             C.c_int64(loc.size), C.c_int32(cache_weight.shape[1]), _p(grad), _p(loc), _p(rowidx), C.c_float(lr), C.c_float(eps), _p(state), _p(cache_weight)),
         "cache_backward_rowwise_adagrad_approx",
     )
+
+
+# ---- all-cores build (oracle/ttx_cpu_baseline.c): bench.py's cpu_baseline leg only -------------------------
+_BASE_SO = os.path.join(_ROOT, "oracle", "libttx_cpu_baseline.so")
+_blib = None
+
+
+def baseline_lib():
+    global _blib
+    if _blib is None:
+        if not os.path.exists(_BASE_SO):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "libttx_cpu_baseline.so"])
+        _blib = C.CDLL(_BASE_SO)
+        _blib.ttxo_omp_threads.restype = C.c_int
+    return _blib
+
+
+def omp_threads():
+    return int(baseline_lib().ttxo_omp_threads())
+
+
+class OmpStep:
+    """fwd + fused-optimizer bwd of one batch on all host cores (workspaces allocated once)"""
+
+    def __init__(self, geom, B, D, nnz_max, cores):
+        self.geom, self.B, self.D = geom, B, D
+        self.threads = omp_threads()
+        self.rows = np.empty((nnz_max, D), dtype=np.float32)
+        self.grad = np.empty((self.threads, sum(int(c.size) for c in cores)), dtype=np.float32)
+        self.out = np.empty((geom.num_tables, B, D), dtype=np.float32)
+
+    def __call__(self, optim, lr, eps, indices, offsets, rowidx, tableidx, d_output, cores, state=None):
+        indices, offsets, rowidx, tableidx = _i64(indices), _i64(offsets), _i64(rowidx), _i64(tableidx)
+        d_output = _f32(d_output)
+        _check(baseline_lib().ttxo_omp_step(
+            C.byref(self.geom), C.c_int32(optim), C.c_int32(self.B), C.c_int32(self.D), C.c_float(lr), C.c_float(eps),
+            C.c_int64(indices.size), _p(indices), _p(offsets), _p(rowidx), _p(tableidx), _p(d_output), _ptrs(cores),
+            _ptrs(state) if state is not None else None, _p(self.out), _p(self.rows), _p(self.grad)), "omp_step")
+        return self.out

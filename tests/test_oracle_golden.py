@@ -157,3 +157,27 @@ def test_cfg5_tables_vs_reference_golden():
             grads[t][k] = r["grads"][t][0]
             sgd[t][k] = _run(ck, "sgd")["cores"][t][0]
     check_cfg5_tables(c, out, grads, sgd)
+
+
+def test_all_cores_baseline_equals_the_sequential_oracle(small_cases):
+    """oracle/ttx_cpu_baseline.c (OpenMP; what bench.py times as cpu_baseline) against the sequential oracle:
+    forward bit-identical (same per-bag order), fused SGD / Adagrad to rounding (thread-partial gradient sums)"""
+    for name in ("t3_tb3_s1", "t2_tb1_s0", "t4_tb3_s0"):
+        c = small_cases[name]
+        g = O.make_geom(c["tables"], c["p"], c["q"], c["r"])
+        rowidx, tableidx = O.rowidx_from_offsets(c["offsets"], c["tables"])
+        for optim in (O.OPTIM_SGD, O.OPTIM_ADAGRAD):
+            ref_cores = [x.copy() for x in c["cores"]]
+            ref_state = [np.zeros_like(x) for x in ref_cores]
+            ref_out = O.tt_forward(g, c["B"], c["D"], c["indices"], rowidx, tableidx, ref_cores)
+            O.tt_backward(g, optim, c["B"], c["D"], LR, EPS, c["indices"], rowidx, tableidx, c["d_out"], ref_cores, ref_state)
+            cores = [x.copy() for x in c["cores"]]
+            state = [np.zeros_like(x) for x in cores]
+            step = O.OmpStep(g, c["B"], c["D"], c["indices"].size, cores)
+            out = step(optim, LR, EPS, c["indices"], c["offsets"], rowidx, tableidx, c["d_out"], cores, state)
+            assert np.array_equal(out, ref_out), f"{name}: forward of the all-cores build"
+            for k in range(c["T"]):
+                if optim == O.OPTIM_SGD:
+                    assert_close(cores[k], ref_cores[k], f"{name} omp sgd core{k}")
+                else:
+                    assert_close(state[k], ref_state[k], f"{name} omp adagrad state{k}")

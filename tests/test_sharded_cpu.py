@@ -41,7 +41,7 @@ def _make_inputs(rank, fixed, NT=NT):
     return idx, off, grad
 
 
-def _worker(rank, world, port, fixed, q, NT=NT):
+def _worker(rank, world, port, fixed, q, NT=NT, direct=False):
     try:
         for p in (HERE, os.path.join(ROOT, "fbtt-embedding_amd")):
             sys.path.insert(0, p)
@@ -59,13 +59,16 @@ def _worker(rank, world, port, fixed, q, NT=NT):
             NT, int(np.prod(P)), D, R, tt_p_shapes=P, tt_q_shapes=Q, sparse=True, optimizer=ops.OptimType.SGD,
             learning_rate=0.1, weight_dist="uniform", device="cpu")
         mine = m.my_tables
-        with torch.no_grad():
-            for t, core in enumerate(m.local.tt_cores):
-                core.copy_(torch.from_numpy(cores_all[t][mine]))
+        if direct:  # the direct route's bookkeeping (per-peer element counts), carried by gloo instead of RCCL
+            m.enable_direct_exchange(ttx_sharded.CollectiveExchange(None))
+        if m.local is not None:
+            with torch.no_grad():
+                for t, core in enumerate(m.local.tt_cores):
+                    core.copy_(torch.from_numpy(cores_all[t][mine]))
         idx, off, grad = _make_inputs(rank, fixed, NT)
         out = m(torch.from_numpy(idx), torch.from_numpy(off), fixed_pooling=fixed or None)
         out.backward(torch.from_numpy(grad))
-        q.put((rank, out.detach().numpy(), mine, [c.detach().numpy() for c in m.local.tt_cores]))
+        q.put((rank, out.detach().numpy(), mine, [c.detach().numpy() for c in m.local.tt_cores] if m.local is not None else []))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001
@@ -74,8 +77,11 @@ def _worker(rank, world, port, fixed, q, NT=NT):
         q.put((rank, "ERROR", traceback.format_exc(), None))
 
 
-@pytest.mark.parametrize("fixed,NT", [(0, 5), (3, 5), (3, 2)])  # NT == world: one table per rank (the bench shape)
-def test_two_rank_table_sharding_matches_single_process(fixed, NT):
+# NT == world: one table per rank (the bench shape); NT = 5: uneven ownership (3 + 2 tables); NT = 1: a rank that owns
+# no table still has to take part in both exchanges, forward and backward; direct: DirectExchange's split lists
+@pytest.mark.parametrize("fixed,NT,direct", [(0, 5, False), (3, 5, False), (3, 2, False), (3, 5, True), (3, 2, True),
+                                             (3, 1, False), (0, 1, False), (3, 1, True), (2, 7, True)])
+def test_two_rank_table_sharding_matches_single_process(fixed, NT, direct):
     sys.path.insert(0, HERE)
     import gen_inputs as G
     import oracle_lib as O
@@ -84,7 +90,7 @@ def test_two_rank_table_sharding_matches_single_process(fixed, NT):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, fixed, q, NT)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fixed, q, NT, direct)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -118,5 +124,5 @@ def test_two_rank_table_sharding_matches_single_process(fixed, NT):
         _, out, mine, cr = res[r]
         np.testing.assert_allclose(out, out_g[:, r * B_LOCAL:(r + 1) * B_LOCAL], rtol=1e-5, atol=1e-7)
         assert mine == [t for t in range(NT) if t % world == r]
-        for t in range(3):
+        for t in range(3 if mine else 0):
             np.testing.assert_allclose(cr[t], new_cores[t][mine], rtol=1e-5, atol=1e-7)
