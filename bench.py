@@ -59,6 +59,9 @@ WORKLOADS = {
     "cfg3": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.2, populate=True),
     # cfg3's index stream before the cache is populated: every hot row goes through the contraction
     "cfg3warm": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.2, populate=False),
+    # ... with duplicate lookups sharing their contraction (TTEmbeddingBag(dedup=True))
+    "cfg3warm-dedup": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.2, populate=False, dedup=True),
+    "cfg2-dedup": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False, dedup=True),
     "cfg4": dict(q=[4, 4, 8], ranks=[64, 64], tables=1, B=512, optimizer="adagrad", alpha=1.0, populate=False),
     # BASELINE.json configs[4]: 26 tables, global batch 4096; shards over the ranks it is launched with
     "cfg5": dict(q=[4, 4, 4], ranks=[32, 32], tables=26, B=4096, optimizer="sgd", alpha=1.0, populate=False),
@@ -210,7 +213,8 @@ def main():
     reqs_np = cores_np = d_out_np = None
     if not sharded:
         use_cache = (not args.no_cache) and ntab == 1
-        kw = dict(sparse=True, optimizer=opt, learning_rate=0.1, use_cache=use_cache, weight_dist="uniform", device=dev)
+        kw = dict(sparse=True, optimizer=opt, learning_rate=0.1, use_cache=use_cache, weight_dist="uniform", device=dev,
+                  dedup=bool(wl.get("dedup", False)))
         if wl["populate"]:  # cfg3: 256Ki-row cache behind a 1Mi-slot table
             kw.update(cache_size=1 << 18, hashtbl_size=1 << 20)
         if ntab == 1:

@@ -97,6 +97,31 @@ int plan_build(const Dims& d, long long nnz, const int64_t* indices,
 
 long long* debug_stamps();  // debug stamp buffer (ttx_debug_stamps), or nullptr
 
+// --------------------------------------------------- duplicate lookups ----
+// Device-resident map of a batch onto its DISTINCT (table, index) pairs (include/ttx.h, ttx_dedup_build): the
+// contraction kernels then run once per distinct pair, bag pooling gathers a lookup's row through uid[], and the
+// backward first sums the bag gradients of a pair's occurrences (in index order) into one row.
+//   nu         = number of distinct pairs                                   (device int)
+//   uidx/utab  = the distinct pairs, ascending (table, index)               [nnz], first nu valid
+//   iota       = 0..nnz-1: "bag row" u of distinct pair u                   [nnz]
+//   uid[n]     = distinct pair of lookup n                                  [nnz]
+//   occ        = lookups sorted by (uid, n); occ_off[u] = first position of pair u, occ_off[nu] = nnz
+struct DedupMap {
+  int* nu;
+  int64_t* uidx;
+  int64_t* utab;
+  int64_t* iota;
+  int* uid;
+  int* occ;
+  int* occ_off;
+};
+constexpr int kDedupMaxN = 16384;  // one work-group sorts the batch in LDS
+bool dedup_supported(const Dims& d, long long nnz);
+size_t dedup_bytes(long long nnz);
+DedupMap carve_dedup(long long nnz, void* base);
+int dedup_build(const Dims& d, long long nnz, const int64_t* indices, const int64_t* tableidx, const DedupMap& M,
+                hipStream_t stream);
+
 // ------------------------------------------------------------ profiling ----
 void prof_begin(int which, hipStream_t s);
 void prof_end(int which, hipStream_t s);

@@ -1370,6 +1370,186 @@ int plan_build(const Dims& d, long long nnz, const int64_t* indices,
   return TTX_OK;
 }
 
+// ---- duplicate lookups (DedupMap, ttx_internal.h) ----------------------------------------------------------
+// One work-group sorts the batch's (table, index) keys -- 32 bits, stable LSD radix sort in LDS, the same wave
+// ranking as plan_small_kernel -- so that equal pairs end up adjacent with their occurrences in index order;
+// run heads are the distinct pairs.  Deterministic (no ordering-dependent atomics), one launch, <= 16384 lookups
+// (144 KB of LDS); larger batches and key spaces beyond 2^32 are not deduplicated (same results either way:
+// sharing the contraction of duplicates never changes a value, only how often it is computed).
+size_t dedup_bytes(long long nnz) {
+  const size_t n = r64((size_t)nnz + 1);
+  return align_up(64 * sizeof(int)) + 3 * align_up(n * sizeof(int64_t)) + 3 * align_up(n * sizeof(int));
+}
+
+DedupMap carve_dedup(long long nnz, void* base) {
+  const size_t n = r64((size_t)nnz + 1);
+  char* cur = (char*)base;
+  auto take = [&](size_t bytes) { char* r = cur; cur += align_up(bytes); return r; };
+  DedupMap M;
+  M.nu = (int*)take(64 * sizeof(int));
+  M.uidx = (int64_t*)take(n * sizeof(int64_t));
+  M.utab = (int64_t*)take(n * sizeof(int64_t));
+  M.iota = (int64_t*)take(n * sizeof(int64_t));
+  M.uid = (int*)take(n * sizeof(int));
+  M.occ = (int*)take(n * sizeof(int));
+  M.occ_off = (int*)take(n * sizeof(int));
+  return M;
+}
+
+static unsigned long long dedup_key_space(const Dims& d) {  // tables * prod(p), or 0 if beyond 2^32
+  if (d.tab || !d.idx32) return 0;
+  unsigned long long e = 1;
+  for (int t = 0; t < d.T; ++t) e *= (unsigned long long)d.p[t];
+  const unsigned long long all = e * (unsigned long long)d.num_tables;
+  return (e <= (1ull << 32) && all <= (1ull << 32)) ? all : 0;
+}
+
+bool dedup_supported(const Dims& d, long long nnz) {
+  return nnz > 0 && nnz <= kDedupMaxN && dedup_key_space(d) != 0;
+}
+
+template <int kBPW>
+__global__ __launch_bounds__(kPlanThreads) void dedup_small_kernel(int N, unsigned long long E, int num_tables, int passes,
+                                                                   const int64_t* __restrict__ indices,
+                                                                   const int64_t* __restrict__ tableidx, DedupMap M) {
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+  int* hist = lds;                        // [256][kPlanWaves]
+  int* wtot = hist + 256 * kPlanWaves;    // [kPlanWaves + 1] (+pad)
+  int* keyL = wtot + 32;                  // [N]
+  int* valL = keyL + ((N + 63) / 64 * 64);  // [N]
+  const int tid = threadIdx.x, lane = lane_id(), w = tid / kWave;
+  const int per = ((N + kPlanWaves - 1) / kPlanWaves + kWave - 1) / kWave * kWave;
+  const int nb = per / kWave;  // <= kBPW
+  const int wbeg = w * per, wend = min(N, wbeg + per);
+  unsigned k[kBPW];
+  int v[kBPW], r[kBPW];
+  {
+    const int last_i = N - 1;
+    long long ix[kBPW];
+    int tbv[kBPW];
+#pragma unroll
+    for (int b = 0; b < kBPW; ++b) {
+      const int i = min(wbeg + b * kWave + lane, last_i);
+      ix[b] = indices[i];
+      tbv[b] = (tableidx && num_tables > 1) ? (int)tableidx[i] : 0;
+    }
+#pragma unroll
+    for (int b = 0; b < kBPW; ++b) {
+      // out-of-range inputs are clamped into the table's key range (the plan's decode clamps them likewise)
+      const unsigned long long e = (unsigned long long)max(ix[b], 0ll);
+      const unsigned long long tb = (unsigned long long)min(max(tbv[b], 0), num_tables - 1);
+      k[b] = (unsigned)(tb * E + (e < E ? e : E - 1));
+      v[b] = wbeg + b * kWave + lane;
+    }
+  }
+  for (int ps = 0; ps < passes; ++ps) {
+    const int shift = ps * 8;
+    for (int e = tid; e < 256 * kPlanWaves; e += kPlanThreads) hist[e] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < kBPW; ++b) {
+      if (b < nb) {  // wave-uniform
+        const bool valid = wbeg + b * kWave + lane < wend;
+        const unsigned dg = (k[b] >> shift) & 255u;
+        const unsigned long long peers = wave_match8(dg, valid);
+        if (valid) {
+          const int before = hist[dg * kPlanWaves + w];
+          r[b] = before + __popcll(peers & lanemask_lt());
+          if ((peers & lanemask_lt()) == 0) hist[dg * kPlanWaves + w] = before + __popcll(peers);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      int v0 = hist[tid * 4 + 0], v1 = hist[tid * 4 + 1], v2 = hist[tid * 4 + 2], v3 = hist[tid * 4 + 3];
+      int total;
+      int ex = block_excl_scan(v0 + v1 + v2 + v3, wtot, &total);
+      hist[tid * 4 + 0] = ex;
+      hist[tid * 4 + 1] = ex + v0;
+      hist[tid * 4 + 2] = ex + v0 + v1;
+      hist[tid * 4 + 3] = ex + v0 + v1 + v2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < kBPW; ++b) {
+      if (b < nb && wbeg + b * kWave + lane < wend) {
+        const unsigned dg = (k[b] >> shift) & 255u;
+        const int pos = hist[dg * kPlanWaves + w] + r[b];
+        keyL[pos] = (int)k[b];
+        valL[pos] = v[b];
+      }
+    }
+    __syncthreads();
+    if (ps + 1 < passes) {
+#pragma unroll
+      for (int b = 0; b < kBPW; ++b) {
+        const int i = wbeg + b * kWave + lane;
+        if (b < nb && i < wend) { k[b] = (unsigned)keyL[i]; v[b] = valL[i]; }
+      }
+      __syncthreads();
+    }
+  }
+  // run heads -> distinct pairs.  Thread tid owns positions [tid*cpt, (tid+1)*cpt) of the sorted order.
+  const int cpt = (N + kPlanThreads - 1) / kPlanThreads;
+  const int beg = min(N, tid * cpt), end = min(N, beg + cpt);
+  int cnt = 0;
+  for (int i = beg; i < end; ++i) cnt += (i == 0 || keyL[i] != keyL[i - 1]) ? 1 : 0;
+  int total;
+  int u = block_excl_scan(cnt, wtot, &total) - 1;  // pair of position beg - 1
+  for (int i = beg; i < end; ++i) {
+    const unsigned key = (unsigned)keyL[i];
+    if (i == 0 || keyL[i] != keyL[i - 1]) {
+      ++u;
+      const unsigned long long tb = (unsigned long long)key / E;
+      M.occ_off[u] = i;
+      M.uidx[u] = (int64_t)((unsigned long long)key - tb * E);
+      M.utab[u] = (int64_t)tb;
+    }
+    const int n = valL[i];
+    M.uid[n] = u;
+    M.occ[i] = n;
+    M.iota[i] = i;
+  }
+  if (tid == 0) {
+    M.nu[0] = total;
+    M.occ_off[total] = N;
+  }
+}
+
+int dedup_build(const Dims& d, long long nnz, const int64_t* indices, const int64_t* tableidx, const DedupMap& M,
+                hipStream_t stream) {
+  if (!dedup_supported(d, nnz)) TTX_FAIL(TTX_EUNSUPPORTED, "batch of %lld lookups / this key space is not deduplicated", nnz);
+  const unsigned long long all = dedup_key_space(d);
+  const unsigned long long E = all / (unsigned long long)d.num_tables;
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) < all) ++bits;
+  const int passes = (bits + 7) / 8;
+  const int N = (int)nnz;
+  const size_t lds = (256 * kPlanWaves + 32 + 2 * (((size_t)N + 63) / 64 * 64)) * sizeof(int);
+  const int per = ((N + kPlanWaves - 1) / kPlanWaves + kWave - 1) / kWave * kWave;
+  const int nb = per / kWave;
+  ProfScope ps(TTX_PROF_PLAN, stream);
+#define TTX_DEDUP_LAUNCH(BPW)                                                                                 \
+  do {                                                                                                        \
+    static bool attr_done = false;                                                                            \
+    if (!attr_done) {                                                                                         \
+      TTX_HIP(hipFuncSetAttribute((const void*)dedup_small_kernel<BPW>,                                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+      attr_done = true;                                                                                       \
+    }                                                                                                         \
+    hipLaunchKernelGGL(dedup_small_kernel<BPW>, dim3(1), dim3(kPlanThreads), lds, stream, N, E, d.num_tables, \
+                       passes, indices, tableidx, M);                                                         \
+  } while (0)
+  if (nb <= 2) TTX_DEDUP_LAUNCH(2);
+  else if (nb <= 4) TTX_DEDUP_LAUNCH(4);
+  else if (nb <= 8) TTX_DEDUP_LAUNCH(8);
+  else if (nb <= 12) TTX_DEDUP_LAUNCH(12);
+  else TTX_DEDUP_LAUNCH(16);
+#undef TTX_DEDUP_LAUNCH
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
 // one launch for "offsets -> bag rows (+ frequency update) + plan" when the batch qualifies
 bool prologue_fusable(const Dims& d, long long nnz, long long nb) {
   if (d.num_tables != 1 || !(nnz > 1024 && nnz <= kOneMaxN) || nb < 1 || nb > kProMaxBags) return false;

@@ -651,6 +651,139 @@ __global__ __launch_bounds__(kThreads) void pool4_small_kernel(int Nmax, const i
   }
 }
 
+// ---- duplicate lookups (DedupMap): pooling through uid[], and the bag gradients of a pair's occurrences ----
+// Bag sums when the contraction ran once per DISTINCT (table, index) pair: row of lookup n = rows[uid[n]].  Same
+// runs, same order of addition as pool4_small_kernel (index order), so the output is bit-identical to the plain
+// path's.  One 16-lane group per lookup, only the run heads work.  V = float4 (D % 4 == 0) or float.
+template <typename V>
+__device__ __forceinline__ void vfma(V& acc, float w, const V& v);
+template <>
+__device__ __forceinline__ void vfma<float4>(float4& acc, float w, const float4& v) {
+  acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+}
+template <>
+__device__ __forceinline__ void vfma<float>(float& acc, float w, const float& v) { acc = fmaf(w, v, acc); }
+__device__ __forceinline__ void vadd(float4& acc, const float4& v) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+__device__ __forceinline__ void vadd(float& acc, const float& v) { acc += v; }
+__device__ __forceinline__ void vzero(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void vzero(float& a) { a = 0.f; }
+
+template <typename V>
+__global__ __launch_bounds__(kThreads) void pool_gather_kernel(int N, int B, int DV, const int64_t* __restrict__ rowidx,
+                                                              const int64_t* __restrict__ tableidx,
+                                                              const int* __restrict__ uid, const V* __restrict__ rows,
+                                                              const float* __restrict__ psw, V* __restrict__ out) {
+  const int n = blockIdx.x * (kThreads / 16) + threadIdx.x / 16;
+  const int l = threadIdx.x & 15;
+  if (n >= N) return;
+  const int64_t r = rowidx[n], tb = tableidx[n];
+  if (n > 0 && rowidx[n - 1] == r && tableidx[n - 1] == tb) return;
+  const int sh = threadIdx.x & 48;  // this group's 16 bits of the wave ballot
+  int sl = 1;
+  for (;;) {
+    const int c = n + sl + l;
+    const bool same = c < N && rowidx[c] == r && tableidx[c] == tb;
+    const unsigned m = (unsigned)(__ballot(!same) >> sh) & 0xffffu;
+    if (m) { sl += __builtin_ctz(m); break; }
+    sl += 16;
+  }
+  V* o = out + ((size_t)tb * B + r) * DV;
+  for (int e = l; e < DV; e += 16) {
+    V acc = o[e];
+    int j = 0;
+    for (; j + 4 <= sl; j += 4) {  // four rows in flight, added in index order
+      int u[4];
+      V v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) u[q] = uid[n + j + q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = rows[(size_t)u[q] * DV + e];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (psw) vfma(acc, psw[n + j + q], v[q]);
+        else vadd(acc, v[q]);
+      }
+    }
+    for (; j < sl; ++j) {
+      const V v = rows[(size_t)uid[n + j] * DV + e];
+      if (psw) vfma(acc, psw[n + j], v);
+      else vadd(acc, v);
+    }
+    o[e] = acc;
+  }
+}
+
+// Gu[u, :] = sum over the occurrences n of distinct pair u, in index order, of (psw[n] *) d_output[table(n), row(n), :].
+// A work-group owns 16 pairs: pairs with fewer than kGsumCoop occurrences are summed by one 16-lane group each;
+// a pair hit more often (a hot row of a skewed stream takes a sixth of the batch) is then summed by all 16 groups,
+// group g taking the g-th sixteenth of its occurrence list, the 16 part sums folded in group order through LDS --
+// a fixed order either way: deterministic.
+constexpr int kGsumCoop = 64;
+template <typename V>
+__device__ __forceinline__ V gsum_range(int lo, int hi, int e, int B, int DV, const int* __restrict__ occ,
+                                        const int64_t* __restrict__ rowidx, const int64_t* __restrict__ tableidx,
+                                        const float* __restrict__ psw, const V* __restrict__ dout) {
+  V acc;
+  vzero(acc);
+  int k = lo;
+  for (; k + 4 <= hi; k += 4) {
+    int n[4];
+    V v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) n[q] = occ[k + q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = dout[((size_t)tableidx[n[q]] * B + rowidx[n[q]]) * DV + e];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (psw) vfma(acc, psw[n[q]], v[q]);
+      else vadd(acc, v[q]);
+    }
+  }
+  for (; k < hi; ++k) {
+    const int n = occ[k];
+    const V v = dout[((size_t)tableidx[n] * B + rowidx[n]) * DV + e];
+    if (psw) vfma(acc, psw[n], v);
+    else vadd(acc, v);
+  }
+  return acc;
+}
+
+template <typename V>
+__global__ __launch_bounds__(kThreads) void gsum_kernel(DedupMap M, int B, int DV, const int64_t* __restrict__ rowidx,
+                                                       const int64_t* __restrict__ tableidx,
+                                                       const float* __restrict__ psw, const V* __restrict__ dout,
+                                                       V* __restrict__ Gu) {
+  extern __shared__ __attribute__((aligned(16))) float gs_lds[];
+  V* part = (V*)gs_lds;  // [16][DV]
+  const int nu = M.nu[0];
+  const int u0 = blockIdx.x * 16;
+  if (u0 >= nu) return;
+  const int g = threadIdx.x / 16, l = threadIdx.x & 15;
+  {
+    const int u = u0 + g;
+    if (u < nu) {
+      const int lo = M.occ_off[u], hi = M.occ_off[u + 1];
+      if (hi - lo < kGsumCoop)
+        for (int e = l; e < DV; e += 16) Gu[(size_t)u * DV + e] = gsum_range<V>(lo, hi, e, B, DV, M.occ, rowidx, tableidx, psw, dout);
+    }
+  }
+  for (int uu = 0; uu < 16 && u0 + uu < nu; ++uu) {  // (work-group-uniform control flow)
+    const int u = u0 + uu;
+    const int lo = M.occ_off[u], hi = M.occ_off[u + 1];
+    if (hi - lo < kGsumCoop) continue;
+    const int per = (hi - lo + 15) / 16;
+    const int a = min(hi, lo + g * per), b = min(hi, a + per);
+    __syncthreads();
+    for (int e = l; e < DV; e += 16) part[g * DV + e] = gsum_range<V>(a, b, e, B, DV, M.occ, rowidx, tableidx, psw, dout);
+    __syncthreads();
+    for (int e = threadIdx.x; e < DV; e += kThreads) {
+      V acc = part[e];
+      for (int q = 1; q < 16; ++q) vadd(acc, part[q * DV + e]);
+      Gu[(size_t)u * DV + e] = acc;
+    }
+  }
+}
+
 struct Partials {
   float* pc[TTX_MAX_CORES];  // pc[1] is per CHUNK, the others per lookup
   const float* psw;          // per_sample_weights by lookup (nn.EmbeddingBag), or NULL: the bag gradient of
@@ -1664,4 +1797,113 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
   return TTX_OK;
 }
 
+// ---- duplicate lookups share their contraction (include/ttx.h) --------------------------------------------
+size_t ttx_dedup_bytes(const ttx_geom* g, int64_t nnz) {
+  Dims d;
+  if (make_dims(g, &d) != TTX_OK || !dedup_supported(d, nnz)) return 0;
+  return dedup_bytes(nnz);
+}
+
+int ttx_dedup_build(const ttx_geom* g, int64_t nnz, const int64_t* indices, const int64_t* tableidx, void* dedup,
+                    size_t dedup_bytes_, void* plan, size_t plan_bytes_, ttx_stream_t stream) {
+  Dims d;
+  int rc = make_dims(g, &d);
+  if (rc) return rc;
+  if (!dedup_supported(d, nnz))
+    TTX_FAIL(TTX_EUNSUPPORTED, "duplicate sharing needs 1..%d lookups and tables * prod(p) <= 2^32", kDedupMaxN);
+  if (!indices || (d.num_tables > 1 && !tableidx)) TTX_FAIL(TTX_EINVAL, "NULL input");
+  if (!dedup || dedup_bytes_ < dedup_bytes(nnz)) TTX_FAIL(TTX_EWORKSPACE, "dedup buffer too small: %zu < %zu", dedup_bytes_, dedup_bytes(nnz));
+  if (!plan || plan_bytes_ < plan_bytes(d, nnz)) TTX_FAIL(TTX_EWORKSPACE, "plan buffer too small: %zu < %zu", plan_bytes_, plan_bytes(d, nnz));
+  rc = common_checks(d, d.D, nnz);
+  if (rc) return rc;
+  const DedupMap M = carve_dedup(nnz, dedup);
+  rc = dedup_build(d, nnz, indices, tableidx, M, (hipStream_t)stream);
+  if (rc) return rc;
+  // the plan of the DISTINCT pairs: their count lives on the device, "bag row" of pair u is u
+  Plan P = carve_plan(d, nnz, plan);
+  return plan_build(d, nnz, M.uidx, M.utab, M.iota, P, (hipStream_t)stream, M.nu);
+}
+
+size_t ttx_tt_forward_dd_workspace_bytes(const ttx_geom* g, int32_t D, int64_t nnz) {
+  (void)D;
+  Dims d;
+  if (make_dims(g, &d) != TTX_OK || nnz < 0) return 0;
+  return rows_bytes(d, nnz) + 256;
+}
+
+int ttx_tt_forward_dd(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const int64_t* rowidx,
+                      const int64_t* tableidx, const float* psw, const void* dedup, const void* plan,
+                      const float* const* tt_cores, float* output, void* workspace, size_t workspace_bytes,
+                      ttx_stream_t stream) {
+  Dims d;
+  int rc = make_dims(g, &d);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (B < 0 || !output) TTX_FAIL(TTX_EINVAL, "bad B/output");
+  if (!dedup_supported(d, nnz)) TTX_FAIL(TTX_EUNSUPPORTED, "not a deduplicated batch");
+  rc = common_checks(d, D, nnz);
+  if (rc) return rc;
+  if (!rowidx || !tableidx || !tt_cores || !dedup || !plan) TTX_FAIL(TTX_EINVAL, "NULL input");
+  if (!workspace || workspace_bytes < rows_bytes(d, nnz))
+    TTX_FAIL(TTX_EWORKSPACE, "forward workspace too small: %zu < %zu", workspace_bytes, rows_bytes(d, nnz));
+  const DedupMap M = carve_dedup(nnz, (void*)dedup);
+  Plan P = carve_plan(d, nnz, (void*)plan);
+  float* rows = (float*)workspace;
+  const long long nout = (long long)d.num_tables * B * d.D;
+  rc = run_rows(d, nnz, P, tt_cores, rows, output, nout, st);  // rows of the distinct pairs; also zeroes `output`
+  if (rc) return rc;
+  ProfScope ps(TTX_PROF_POOL, st);
+  const int blocks = ((int)nnz + kThreads / 16 - 1) / (kThreads / 16);
+  if (d.D % 4 == 0 && (((uintptr_t)rows | (uintptr_t)output) & 15) == 0)
+    hipLaunchKernelGGL(pool_gather_kernel<float4>, dim3(blocks), dim3(kThreads), 0, st, (int)nnz, B, d.D / 4, rowidx, tableidx,
+                       M.uid, (const float4*)rows, psw, (float4*)output);
+  else
+    hipLaunchKernelGGL(pool_gather_kernel<float>, dim3(blocks), dim3(kThreads), 0, st, (int)nnz, B, d.D, rowidx, tableidx, M.uid,
+                       (const float*)rows, psw, output);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
+static size_t gu_bytes(const Dims& d, long long nnz) { return align_up((size_t)nnz * d.D * sizeof(float)); }
+
+size_t ttx_tt_backward_dd_workspace_bytes(const ttx_geom* g, int32_t D, int64_t nnz) {
+  Dims d;
+  if (make_dims(g, &d) != TTX_OK || nnz < 0) return 0;
+  const size_t inner = ttx_tt_backward_workspace_bytes(g, 0, D, nnz);
+  return inner ? gu_bytes(d, nnz) + inner : 0;
+}
+
+int ttx_tt_backward_dd(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, float lr, float eps, int64_t nnz,
+                       const int64_t* rowidx, const int64_t* tableidx, const float* psw, const float* d_output,
+                       const void* dedup, const void* plan, float* const* tt_cores, float* const* optimizer_state,
+                       float* const* d_tt_cores, void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
+  Dims d;
+  int rc = make_dims(g, &d);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (!dedup_supported(d, nnz)) TTX_FAIL(TTX_EUNSUPPORTED, "not a deduplicated batch");
+  rc = common_checks(d, D, nnz);
+  if (rc) return rc;
+  if (!rowidx || !tableidx || !d_output || !dedup || !plan) TTX_FAIL(TTX_EINVAL, "NULL input");
+  const size_t gb = gu_bytes(d, nnz);
+  if (!workspace || workspace_bytes < gb) TTX_FAIL(TTX_EWORKSPACE, "backward workspace too small");
+  const DedupMap M = carve_dedup(nnz, (void*)dedup);
+  float* Gu = (float*)workspace;
+  {
+    ProfScope ps(TTX_PROF_POOL, st);
+    const int blocks = ((int)nnz + 15) / 16;  // (upper bound: work-groups beyond the distinct pairs leave at once)
+    if (d.D % 4 == 0 && (((uintptr_t)d_output) & 15) == 0)
+      hipLaunchKernelGGL(gsum_kernel<float4>, dim3(blocks), dim3(kThreads), (size_t)16 * d.D * sizeof(float), st, M, B, d.D / 4,
+                         rowidx, tableidx, psw, (const float4*)d_output, (float4*)Gu);
+    else
+      hipLaunchKernelGGL(gsum_kernel<float>, dim3(blocks), dim3(kThreads), (size_t)16 * d.D * sizeof(float), st, M, B, d.D,
+                         rowidx, tableidx, psw, d_output, Gu);
+    TTX_HIP(hipGetLastError());
+  }
+  // the distinct pairs as a batch of their own: bag row of pair u is u, its bag gradient Gu[u] (B = 0: no table term)
+  return ttx_tt_backward_w(g, optim, 0, D, lr, eps, nnz, M.uidx, M.iota, M.utab, nullptr, Gu, tt_cores, optimizer_state,
+                           d_tt_cores, plan, (char*)workspace + gb, workspace_bytes - gb, stream);
+}
+
 }  // extern "C"
+

@@ -12,7 +12,8 @@ There is NO CPU or PyTorch fallback: if `libttx.so` is missing, or a tensor is
 not on a GPU, the call raises.
 
 Extras beyond the reference's eleven names (used by tt_embeddings_ops.py and
-bench.py): `make_plan` (share the lookup plan between forward and backward),
+bench.py): `make_plan` (share the lookup plan between forward and backward; `dedup=True`: duplicate lookups of
+the batch share one contraction),
 `profile_*` (live kernel timings), `lib()` (the loaded ctypes library).
 """
 import ctypes as C
@@ -90,6 +91,14 @@ def lib():
     L.ttx_profile_enable.argtypes = [C.c_int]
     L.ttx_profile_read.argtypes = [C.c_int, C.POINTER(i64), C.POINTER(C.c_double)]
     L.ttx_set_chunk.argtypes = [i32]
+    for name in ("ttx_dedup_bytes", "ttx_tt_forward_dd_workspace_bytes", "ttx_tt_backward_dd_workspace_bytes"):
+        getattr(L, name).restype = C.c_size_t
+    L.ttx_dedup_bytes.argtypes = [G, i64]
+    L.ttx_dedup_build.argtypes = [G, i64, vp, vp, vp, sz, vp, sz, vp]
+    L.ttx_tt_forward_dd_workspace_bytes.argtypes = [G, i32, i64]
+    L.ttx_tt_forward_dd.argtypes = [G, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.ttx_tt_backward_dd_workspace_bytes.argtypes = [G, i32, i64]
+    L.ttx_tt_backward_dd.argtypes = [G, i32, i32, i32, f32, f32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     _lib = L
     return L
 
@@ -240,13 +249,36 @@ class Plan:
         self.buf, self.nnz, self.key = buf, nnz, key
 
 
-def make_plan(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, tableidx, rowidx=None) -> Optional[Plan]:
+class DedupPlan(Plan):
+    """A plan of the batch's DISTINCT (table, index) pairs plus the map of the lookups onto them (include/ttx.h,
+    "duplicate lookups"): tt_forward / the backward entry points given such a plan contract every distinct pair
+    once.  Built by make_plan(..., dedup=True) when the batch qualifies."""
+
+    __slots__ = ("dd",)
+
+    def __init__(self, buf, dd, nnz, key):
+        super().__init__(buf, nnz, key)
+        self.dd = dd
+
+
+def make_plan(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, tableidx, rowidx=None,
+              dedup: bool = False) -> Optional[Plan]:
     if nnz == 0:
         return None
     g = _geom(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks)
     dev = _dev(indices)
     indices, tableidx = _i64(indices, "indices"), _i64(tableidx, "tableidx")
     L = lib()
+    if dedup:
+        db = L.ttx_dedup_bytes(C.byref(g), nnz)
+        if db:  # (0: more than 16384 lookups or a key space beyond 2^32 -- the plain plan gives the same results)
+            nb = L.ttx_plan_bytes(C.byref(g), nnz)
+            buf = torch.empty(nb, dtype=torch.uint8, device=dev)
+            dd = torch.empty(db, dtype=torch.uint8, device=dev)
+            with _guard(dev):
+                _check(L.ttx_dedup_build(C.byref(g), nnz, indices.data_ptr(), tableidx.data_ptr(), dd.data_ptr(), db,
+                                         buf.data_ptr(), nb, _stream(dev)))
+            return DedupPlan(buf, dd, nnz, (num_tables, tuple(tt_p_shapes), tuple(tt_q_shapes), tuple(tt_ranks)))
     nb = L.ttx_plan_bytes(C.byref(g), nnz)
     buf = torch.empty(nb, dtype=torch.uint8, device=dev)
     with _guard(dev):
@@ -314,6 +346,13 @@ def tt_forward(batch_count: int, num_tables: int, B: int, D: int, tt_p_shapes: L
         raise RuntimeError("tt_embeddings: nnz exceeds the index tensors")
     lb = lib()
     st = _stream(dev)
+    if isinstance(plan, DedupPlan) and nnz > 0:
+        nb = lb.ttx_tt_forward_dd_workspace_bytes(C.byref(g), D, nnz)
+        ws = _workspace(dev, st, nb)
+        with _guard(dev):
+            _check(lb.ttx_tt_forward_dd(C.byref(g), B, D, nnz, rowidx.data_ptr(), tableidx.data_ptr(), None, plan.dd.data_ptr(),
+                                        _plan_ptr(plan, nnz), _ptr_array(cores), out.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        return out
     nb = lb.ttx_tt_forward_workspace_bytes(C.byref(g), B, D, nnz)
     ws = _workspace(dev, st, nb)
     with _guard(dev):
@@ -341,6 +380,14 @@ def _backward(optim, D, lr, eps, p, q, ranks, nnz, indices, rowidx, tableidx, d_
         sptr = _ptr_array(_cores(state, g, "optimizer_state"))
     lb = lib()
     st = _stream(dev)
+    if isinstance(plan, DedupPlan) and nnz > 0:
+        nb = lb.ttx_tt_backward_dd_workspace_bytes(C.byref(g), D, nnz)
+        ws = _workspace(dev, st, nb)
+        with _guard(dev):
+            _check(lb.ttx_tt_backward_dd(C.byref(g), optim, B, D, lr, eps, nnz, rowidx.data_ptr(), tableidx.data_ptr(), None,
+                                         d_output.data_ptr(), plan.dd.data_ptr(), _plan_ptr(plan, nnz), _ptr_array(cores), sptr,
+                                         gptr, ws.data_ptr(), ws.numel(), st))
+        return grads
     nb = lb.ttx_tt_backward_workspace_bytes(C.byref(g), B, D, nnz)
     ws = _workspace(dev, st, nb)
     with _guard(dev):

@@ -296,8 +296,13 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                  optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
                  sparse: bool = True, use_cache: bool = False, cache_size: int = 0, hashtbl_size: int = 0,
                  weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
-                 device: Optional[torch.device] = None, include_last_offset: bool = True) -> None:
+                 device: Optional[torch.device] = None, include_last_offset: bool = True, dedup: bool = False) -> None:
         super().__init__()
+        # dedup (not in the reference): lookups of a batch that repeat a (table, row) pair share ONE contraction,
+        # forward and backward (include/ttx.h "duplicate lookups").  Same results; pays on skewed index streams
+        # while the row cache is not live, costs two extra launches on uniform ones.  Batches the map does not
+        # take (> 16384 lookups, key space > 2^32) run the plain path.
+        self.dedup = bool(dedup)
         # nn.EmbeddingBag call form: False = offsets hold only the bag starts (PyTorch's default,
         # what DLRM passes); True = the reference's form, num_tables*B + 1 entries (:851)
         self.include_last_offset = bool(include_last_offset)
@@ -482,6 +487,20 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             raise ValueError(f"offsets must describe num_tables * B bags, got {offsets.numel() - 1} bags for "
                              f"{self.num_tables} tables")
         fast = _native_node()
+        if self.dedup and self.warmup and indices.is_cuda and indices.numel() > 0 and per_sample_weights is None \
+                and getattr(_engine, "DedupPlan", None) is not None:
+            # duplicate lookups share their contraction: frequency update + bag rows as usual, then the map and the
+            # plan of the distinct pairs (one work-group sorts the batch's keys), through the reference-shaped route
+            indices, rowidx, tableidx, n_tt, cache_locations = _engine.preprocess_indices_sync(
+                indices, offsets, self.num_tables, True, self.hashtbl, self.cache_state,
+                *((self.cache_freq,) if self.use_cache else ()))
+            rowidx._ttx_plan = _engine.make_plan(self.num_tables, self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks,
+                                                 n_tt, indices, tableidx, rowidx, dedup=True)
+            return TTLookupFunction.apply(
+                (offsets.numel() - 1) // self.num_tables, self.embedding_dim, self.tt_p_shapes, self.tt_q_shapes,
+                self.tt_ranks, self.L, n_tt, 0, indices, rowidx, tableidx, self.optimizer, self.learning_rate,
+                self.eps, self.sparse, None, self.cache_optimizer_state, self.cache_weight,
+                list(self.optimizer_state), *self.tt_cores)
         if fast is not None and self.warmup and indices.is_cuda and indices.numel() > 0:
             # cache not live: the whole lookup (prologue, forward, and the backward / fused optimizer node)
             # is the C++ autograd node of csrc/ttx_torch.cpp -- same C ABI calls, no interpreter in between
@@ -545,10 +564,10 @@ class TTEmbeddingBag(TableBatchedTTEmbeddingBag):
                  optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
                  sparse: bool = True, use_cache: bool = True, cache_size: int = 0, hashtbl_size: int = 0,
                  weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
-                 device: Optional[torch.device] = None, include_last_offset: bool = True) -> None:
+                 device: Optional[torch.device] = None, include_last_offset: bool = True, dedup: bool = False) -> None:
         super().__init__(1, num_embeddings, embedding_dim, tt_ranks, tt_p_shapes, tt_q_shapes, optimizer,
                          learning_rate, eps, sparse, use_cache, cache_size, hashtbl_size, weight_dist,
-                         enforce_embedding_dim, device, include_last_offset)
+                         enforce_embedding_dim, device, include_last_offset, dedup)
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True,
                 per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -159,6 +159,35 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D,
                       float* const* d_tt_cores, const void* plan, void* workspace,
                       size_t workspace_bytes, ttx_stream_t stream);
 
+/* ----------------------------------------------- duplicate lookups -----
+ * Not in the reference (which contracts every lookup on its own): a batch's lookups are mapped onto their
+ * DISTINCT (table, index) pairs, the contraction runs once per pair, bag pooling gathers each lookup's row
+ * through the map (same sums in the same order: the output is bit-identical to ttx_tt_forward's), and the
+ * backward first adds up, in index order, the bag gradients of a pair's occurrences -- one contraction, one
+ * set of partial gradients per pair.  Pays when a batch repeats rows (a Zipf stream before its cache is
+ * populated: 28 % of the lookups distinct); on a uniform stream it only adds the launches of the map.
+ *
+ *   ttx_dedup_bytes     size of the map buffer; 0 = this batch is not deduplicated (more than 16384 lookups,
+ *                       per-table row factors, or num_tables * prod(p) > 2^32): use the plain entry points.
+ *   ttx_dedup_build     builds the map (one work-group sorts the batch's keys in LDS: deterministic) AND the
+ *                       lookup plan of the distinct pairs into `plan` (ttx_plan_bytes(g, nnz) bytes).
+ *   ttx_tt_forward_dd / ttx_tt_backward_dd   as ttx_tt_forward_w / ttx_tt_backward_w (psw may be NULL), driven
+ *                       by a map + plan built for the same (indices, tableidx). */
+size_t ttx_dedup_bytes(const ttx_geom* g, int64_t nnz);
+int ttx_dedup_build(const ttx_geom* g, int64_t nnz, const int64_t* indices, const int64_t* tableidx,
+                    void* dedup, size_t dedup_bytes, void* plan, size_t plan_bytes, ttx_stream_t stream);
+size_t ttx_tt_forward_dd_workspace_bytes(const ttx_geom* g, int32_t D, int64_t nnz);
+int ttx_tt_forward_dd(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const int64_t* rowidx,
+                      const int64_t* tableidx, const float* per_sample_weights, const void* dedup,
+                      const void* plan, const float* const* tt_cores, float* output, void* workspace,
+                      size_t workspace_bytes, ttx_stream_t stream);
+size_t ttx_tt_backward_dd_workspace_bytes(const ttx_geom* g, int32_t D, int64_t nnz);
+int ttx_tt_backward_dd(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, float learning_rate, float eps,
+                       int64_t nnz, const int64_t* rowidx, const int64_t* tableidx,
+                       const float* per_sample_weights, const float* d_output, const void* dedup,
+                       const void* plan, float* const* tt_cores, float* const* optimizer_state,
+                       float* const* d_tt_cores, void* workspace, size_t workspace_bytes, ttx_stream_t stream);
+
 /* ------------------------------------------------------ software cache -----
  * replaces update_cache_state_cuda (tt_embeddings.cpp:74,
  * tt_embeddings_cuda.cu:1077-1113): cache_freq[slot(idx)] += 1 with at most 3

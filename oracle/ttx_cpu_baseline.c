@@ -9,8 +9,11 @@
  *             [nnz, D] buffer), then `omp parallel for` over the bags, each summing its rows in index order
  *             (the same order as the sequential oracle -> bit-identical output);
  *   backward: `omp parallel for` over the lookups with one private gradient buffer per thread (the CPU
- *             counterpart of the reference's atomicAdd scatter, cu:362-377), a parallel tree-free sum of
- *             the thread buffers per element, and the fused SGD / Adagrad update over every element.
+ *             counterpart of the reference's atomicAdd scatter, cu:362-377).  A thread zeroes a core slice of
+ *             its buffer when it first touches it (with 128+ threads, zeroing and re-reading whole buffers
+ *             costs several times the arithmetic); then every core slice is owned by one thread, which sums
+ *             the buffers of the threads that touched it, in thread order, and applies the fused SGD /
+ *             Adagrad update (untouched slices have g = 0: unchanged).
  *
  * Built by `make -C oracle baseline` with -O3 -fopenmp -mavx2 -mfma (x86-64-v3: any EPYC host of an MI355X).
  */
@@ -21,7 +24,7 @@
 int ttxo_omp_threads(void) { return omp_get_max_threads(); }
 
 /* one fwd + fused-optimizer bwd step of a batch (what tt_embeddings_benchmark.py:183-187 times), all cores.
- * rows_ws: float[nnz * D]; grad_ws: float[threads * sum_t core elements] (zeroed here). */
+ * rows_ws: float[nnz * D]; grad_ws: float[threads * sum_t core elements] (need not be zeroed). */
 int ttxo_omp_step(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, float lr, float eps, int64_t nnz,
                   const int64_t* indices, const int64_t* offsets, const int64_t* rowidx, const int64_t* tableidx,
                   const float* d_output, float* const* cores, float* const* state, float* output, float* rows_ws,
@@ -40,6 +43,12 @@ int ttxo_omp_step(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, float 
   int64_t maxs = d.max_x;
   for (int t = 0; t < T; ++t) if (d.slice[t] > maxs) maxs = d.slice[t];
   const int64_t nbags = (int64_t)g->num_tables * B;
+  int64_t soff[TTX_MAX_CORES + 1]; /* slice numbering over all cores */
+  soff[0] = 0;
+  for (int t = 0; t < T; ++t) soff[t + 1] = soff[t] + (int64_t)g->num_tables * g->p[t];
+  const int64_t stot = soff[T];
+  unsigned char* touched = (unsigned char*)calloc((size_t)nthr * stot, 1);
+  if (!touched) return TTX_EINVAL;
 #pragma omp parallel
   {
     const int me = omp_get_thread_num();
@@ -65,7 +74,7 @@ int ttxo_omp_step(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, float 
     }
     /* ---- backward: private gradient buffers ---- */
     float* mine = grad_ws + (int64_t)me * gtot;
-    memset(mine, 0, sizeof(float) * gtot);
+    unsigned char* mt = touched + (int64_t)me * stot;
 #pragma omp for schedule(static)
     for (int64_t n = 0; n < nnz; ++n) {
       decode(&d, indices[n], ii);
@@ -76,30 +85,49 @@ int ttxo_omp_step(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, float 
         const float* in = (t == 0) ? core_slice(g, &d, (const float* const*)cores, 0, tb, ii[0]) : x[t - 1];
         const float* ct = core_slice(g, &d, (const float* const*)cores, t + 1, tb, ii[t + 1]);
         gemm_tn(d.m[t], d.n[t], d.k[t], in, G, tmp);
-        float* dst = mine + coff[t + 1] + (tb * g->p[t + 1] + ii[t + 1]) * d.slice[t + 1];
+        const int64_t sl = tb * g->p[t + 1] + ii[t + 1];
+        float* dst = mine + coff[t + 1] + sl * d.slice[t + 1];
+        if (!mt[soff[t + 1] + sl]) { mt[soff[t + 1] + sl] = 1; memset(dst, 0, sizeof(float) * d.slice[t + 1]); }
         for (int64_t e = 0; e < d.slice[t + 1]; ++e) dst[e] += tmp[e];
         gemm_nt(d.m[t], d.n[t], d.k[t], G, ct, G2);
         float* sw = G; G = G2; G2 = sw;
       }
-      float* dst0 = mine + coff[0] + (tb * g->p[0] + ii[0]) * d.slice[0];
+      const int64_t sl0 = tb * g->p[0] + ii[0];
+      float* dst0 = mine + coff[0] + sl0 * d.slice[0];
+      if (!mt[soff[0] + sl0]) { mt[soff[0] + sl0] = 1; memset(dst0, 0, sizeof(float) * d.slice[0]); }
       for (int64_t e = 0; e < d.slice[0]; ++e) dst0[e] += G[e];
     }
-    /* (implicit barrier) sum the thread buffers in thread order and apply the optimizer to every element */
+    /* (implicit barrier) every slice has one owner: sum the touching threads' buffers in thread order, apply */
     for (int t = 0; t < T; ++t) {
-#pragma omp for schedule(static)
-      for (int64_t e = 0; e < csz[t]; ++e) {
-        float gg = 0.0f;
-        for (int k = 0; k < nthr; ++k) gg += grad_ws[(int64_t)k * gtot + coff[t] + e];
+      const int64_t ns = (int64_t)g->num_tables * g->p[t], ssz = d.slice[t];
+#pragma omp for schedule(dynamic, 4)
+      for (int64_t sl = 0; sl < ns; ++sl) {
+        float* gsum = tmp; /* (slice <= maxs floats) */
+        int any = 0;
+        for (int k = 0; k < nthr; ++k) {
+          if (!touched[(int64_t)k * stot + soff[t] + sl]) continue;
+          const float* src = grad_ws + (int64_t)k * gtot + coff[t] + sl * ssz;
+          if (!any) { memcpy(gsum, src, sizeof(float) * ssz); any = 1; }
+          else for (int64_t e = 0; e < ssz; ++e) gsum[e] += src[e];
+        }
+        if (!any) continue;
+        float* w = cores[t] + sl * ssz;
         if (optim == TTX_OPTIM_SGD) {
-          cores[t][e] -= lr * gg;
-        } else if (optim == TTX_OPTIM_ADAGRAD && gg != 0.0f) {
-          state[t][e] += gg * gg;
-          cores[t][e] -= lr * gg / (sqrtf(state[t][e]) + eps);
+          for (int64_t e = 0; e < ssz; ++e) w[e] -= lr * gsum[e];
+        } else if (optim == TTX_OPTIM_ADAGRAD) {
+          float* st = state[t] + sl * ssz;
+          for (int64_t e = 0; e < ssz; ++e) {
+            const float gg = gsum[e];
+            if (gg == 0.0f) continue;
+            st[e] += gg * gg;
+            w[e] -= lr * gg / (sqrtf(st[e]) + eps);
+          }
         }
       }
     }
     for (int t = 0; t < T - 1; ++t) free(x[t]);
     free(G); free(G2); free(tmp);
   }
+  free(touched);
   return TTX_OK;
 }

@@ -1,0 +1,173 @@
+"""Duplicate lookups share their contraction (include/ttx.h "duplicate lookups"; north_star: "duplicate rows share
+contraction work"): the map of a batch onto its distinct (table, index) pairs, one contraction per pair, bag
+pooling through the map, bag gradients of a pair's occurrences summed in index order before the backward.
+
+Against the CPU oracle (which, like the reference, contracts every lookup on its own) and against the plain HIP
+path: forward bit-identical to the plain path, gradients / fused optimizers within the fp32 tolerance, the same
+from run to run."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import gen_inputs as G
+import oracle_lib as O
+from util import EPS, LR, assert_adagrad_close, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def make_case(seed, tables, p, q, r, B, pf, dup_frac, dist="signed"):
+    rs = np.random.RandomState(seed)
+    E_, D = int(np.prod(np.array(p, dtype=np.int64))), int(np.prod(q))
+    lens = rs.randint(0, 2 * pf + 1, size=tables * B)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nnz = int(off[-1])
+    idx = rs.randint(0, E_, size=nnz).astype(np.int64)
+    hot = rs.randint(0, E_, size=max(3, nnz // 200))  # a small set of rows takes dup_frac of the lookups
+    pick = rs.zipf(1.5, size=nnz) % hot.size
+    idx = np.where(rs.rand(nnz) < dup_frac, hot[pick], idx).astype(np.int64)
+    return dict(tables=tables, T=len(p), p=p, q=q, r=G.pad_ranks(r, len(p)), B=B, D=D, indices=idx, offsets=off,
+                cores=G.make_cores(seed + 1, tables, p, q, r, dist), d_out=G.make_grad(seed + 2, tables, B, D))
+
+
+def run(c, mode, dedup):
+    import tt_embeddings as E
+
+    tables, p, q, r, B, D = c["tables"], c["p"], c["q"], c["r"], c["B"], c["D"]
+    idx, off = t(c["indices"]), t(c["offsets"])
+    Lt = torch.zeros(len(p), dtype=torch.int64, device=DEV)
+    _, rowidx, tableidx, _, _ = E.preprocess_indices_sync(idx, off, tables, True, torch.empty(0, dtype=torch.int64, device=DEV),
+                                                          torch.empty(0, dtype=torch.int32, device=DEV))
+    nnz = idx.numel()
+    plan = E.make_plan(tables, p, q, r, nnz, idx, tableidx, rowidx, dedup=dedup)
+    assert isinstance(plan, E.DedupPlan) == dedup
+    cores = [t(x) for x in c["cores"]]
+    res = {"out": E.tt_forward(1000, tables, B, D, p, q, r, Lt, nnz, idx, rowidx, tableidx, cores, plan=plan).cpu().numpy()}
+    d_out = t(c["d_out"])
+    if mode == "dense":
+        res["grads"] = [g.cpu().numpy() for g in E.tt_dense_backward(1000, D, p, q, r, Lt, nnz, idx, rowidx, tableidx, d_out, cores, plan=plan)]
+    elif mode == "sgd":
+        E.tt_sgd_backward(1000, D, LR, p, q, r, Lt, nnz, idx, rowidx, tableidx, d_out, cores, plan=plan)
+    elif mode == "adagrad":
+        state = [torch.zeros_like(x) for x in cores]
+        E.tt_adagrad_backward(1000, D, LR, EPS, p, q, r, Lt, nnz, idx, rowidx, tableidx, d_out, state, cores, plan=plan)
+        res["state"] = [s.cpu().numpy() for s in state]
+    res["cores"] = [x.cpu().numpy() for x in cores]
+    if dedup:  # the map itself: distinct pairs, occurrences in index order
+        L = E.lib()
+        dd = plan.dd.cpu().numpy()
+        nu = int(np.frombuffer(dd[:4].tobytes(), dtype=np.int32)[0])
+        res["nu"] = nu
+    return res
+
+
+def oracle(c, mode):
+    g = O.make_geom(c["tables"], c["p"], c["q"], c["r"])
+    rowidx, tableidx = O.rowidx_from_offsets(c["offsets"], c["tables"])
+    res = {"out": O.tt_forward(g, c["B"], c["D"], c["indices"], rowidx, tableidx, c["cores"])}
+    cores = [x.copy() for x in c["cores"]]
+    if mode == "dense":
+        res["grads"] = O.tt_backward(g, O.OPTIM_DENSE, c["B"], c["D"], 0, 0, c["indices"], rowidx, tableidx, c["d_out"], cores)
+    elif mode == "sgd":
+        O.tt_backward(g, O.OPTIM_SGD, c["B"], c["D"], LR, 0, c["indices"], rowidx, tableidx, c["d_out"], cores)
+    elif mode == "adagrad":
+        res["state"] = [np.zeros_like(x) for x in cores]
+        O.tt_backward(g, O.OPTIM_ADAGRAD, c["B"], c["D"], LR, EPS, c["indices"], rowidx, tableidx, c["d_out"], cores, res["state"])
+    res["cores"] = cores
+    return res
+
+
+CASES = [
+    # (tables, p, q, ranks, B, pooling, duplicate fraction)
+    (1, [20, 22, 25], [4, 4, 4], [16, 16], 300, 10, 0.7),     # specialised kernels, ~70 % of the lookups on a few rows
+    (1, [200, 220, 250], [4, 4, 4], [32, 32], 512, 10, 0.6),  # the benchmark geometry (24-bit keys: three sort passes)
+    (3, [7, 9, 11], [3, 4, 5], [13, 12], 120, 6, 0.5),        # generic kernels, three tables, D % 4 == 0
+    (2, [5, 8], [3, 5], [6], 90, 5, 0.8),                     # T = 2, D = 15 (scalar pooling / gradient sums)
+    (1, [6, 5, 7, 4], [2, 3, 2, 2], [4, 5, 3], 200, 8, 0.9),  # T = 4, 840 rows: nearly every lookup is a duplicate
+    (1, [20, 22, 25], [4, 4, 4], [16, 16], 40, 3, 0.0),       # no duplicates to speak of, tiny batch (nnz < 1024)
+    (1, [40, 50, 60], [4, 4, 4], [16, 16], 1400, 11, 0.95),   # ~15k lookups (the map's limit is 16384), three rows hot
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_dedup_vs_oracle_and_plain_path(case):
+    tables, p, q, r, B, pf, frac = CASES[case]
+    c = make_case(100 + case, tables, p, q, r, B, pf, frac)
+    nnz = c["indices"].size
+    assert nnz <= 16384
+    distinct = np.unique(c["indices"] + np.repeat(np.arange(tables), np.diff(c["offsets"][::B])) * int(np.prod(np.array(p, dtype=np.int64)))).size
+    for mode in ("dense", "sgd", "adagrad"):
+        got, again, plain, orc = run(c, mode, True), run(c, mode, True), run(c, mode, False), oracle(c, mode)
+        assert got["nu"] == distinct, "number of distinct (table, index) pairs"
+        if frac >= 0.5:
+            assert distinct <= 0.62 * nnz, "the case must hold at least ~40-50 % duplicates"
+        assert np.array_equal(got["out"], plain["out"]), "forward must be bit-identical to the plain path"
+        assert_close(got["out"], orc["out"], f"case {case} out")
+        gref = oracle(c, "dense")["grads"] if mode == "adagrad" else None
+        for k in range(len(p)):
+            if mode == "dense":
+                assert_close(got["grads"][k], orc["grads"][k], f"case {case} grad{k}")
+                assert np.array_equal(got["grads"][k], again["grads"][k]), "not deterministic"
+            elif mode == "sgd":
+                assert_close(got["cores"][k], orc["cores"][k], f"case {case} sgd core{k}")
+                assert np.array_equal(got["cores"][k], again["cores"][k]), "not deterministic"
+            else:
+                assert_close(got["state"][k], orc["state"][k], f"case {case} adagrad state{k}")
+                assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"case {case} adagrad core{k}")
+
+
+def test_batches_the_map_does_not_take_fall_back_to_the_plain_plan():
+    import tt_embeddings as E
+
+    p, q, r = [20, 22, 25], [4, 4, 4], [1, 16, 16, 1]
+    idx = t(np.random.RandomState(0).randint(0, 11000, size=20000).astype(np.int64))
+    tb = torch.zeros_like(idx)
+    plan = E.make_plan(1, p, q, r, idx.numel(), idx, tb, None, dedup=True)  # > 16384 lookups
+    assert plan is not None and not isinstance(plan, E.DedupPlan)
+    big = [70000, 70000, 70000]  # 3.4e14 rows: keys do not fit 32 bits
+    plan = E.make_plan(1, big, q, r, 100, idx[:100], tb[:100], None, dedup=True)
+    assert plan is not None and not isinstance(plan, E.DedupPlan)
+
+
+@pytest.mark.parametrize("route", ["native-present", "python-only"])
+def test_module_with_dedup_tracks_the_plain_module(route, monkeypatch):
+    """TTEmbeddingBag(dedup=True) over a Zipf stream (cfg3's, before the cache is populated): same outputs as the
+    plain module bit for bit, same cores after several fused-SGD steps to tolerance; the frequency table counts
+    every occurrence."""
+    import tt_embeddings_ops as ops
+
+    if route == "python-only":
+        monkeypatch.setenv("TTX_NO_NATIVE_NODE", "1")
+    p, q, r = [200, 220, 250], [4, 4, 4], [32, 32]
+    E_, D, B, Lp = 11_000_000, 64, 512, 20
+    kw = dict(num_embeddings=E_, embedding_dim=D, tt_ranks=r, tt_p_shapes=p, tt_q_shapes=q, weight_dist="uniform", device=DEV,
+              sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, use_cache=True, cache_size=1024, hashtbl_size=1 << 16)
+    torch.manual_seed(3)
+    a = ops.TTEmbeddingBag(dedup=True, **kw)
+    b = ops.TTEmbeddingBag(dedup=False, **kw)
+    with torch.no_grad():
+        for x, y in zip(b.tt_cores, a.tt_cores):
+            x.copy_(y)
+    rs = np.random.RandomState(4)
+    off = t(np.arange(0, B * Lp + 1, Lp, dtype=np.int64))
+    grad = t((rs.rand(B, D) * 0.1).astype(np.float32))
+    for step in range(4):
+        idx = t((rs.zipf(1.2, size=B * Lp).astype(np.int64)) % E_)
+        oa, ob = a(idx, off), b(idx, off)
+        if step == 0:
+            assert torch.equal(oa, ob), "first forward: identical cores -> identical output"
+        assert_close(oa.detach().cpu().numpy(), ob.detach().cpu().numpy(), f"step {step} output", rtol=1e-4, atol_scale=2e-5)
+        oa.backward(grad)
+        ob.backward(grad)
+    for k in range(3):
+        assert_close(a.tt_cores[k].detach().cpu().numpy(), b.tt_cores[k].detach().cpu().numpy(), f"core{k} after 4 steps",
+                     rtol=1e-4, atol_scale=2e-5)
+    fa, fb = a.cache_freq.cpu().numpy(), b.cache_freq.cpu().numpy()
+    assert int(fa.sum()) == int(fb.sum()) == 4 * B * Lp or abs(int(fa.sum()) - int(fb.sum())) < 8
