@@ -63,6 +63,8 @@ int make_dims(const ttx_geom* g, Dims* d);  // TTX_OK or TTX_EINVAL (+message)
 // Device-resident lookup plan (see include/ttx.h).  All arrays int32.
 //   sid[t][n]   = table*p_t + i_t                      (original order)
 //   perm[t][*]  = lookups n sorted (stably) by sid[t]
+//   ipos[t][n]  = position of lookup n in perm[t]: the row of its partial gradient (the backward kernels store
+//                 thin-core partials in SORTED order, so a slice's rows are contiguous for reduce_apply)
 //   off[t][s]   = first position in perm[t] of slice s  (S_t + 1 entries)
 //   chunk_rec[c]= {pivot slice, start in the sorted order, lookups in chunk, partial slot}: the work
 //                 list of the pivot core (core 1), each slice's run of lookups
@@ -73,6 +75,7 @@ struct Plan {
   int* hdr;  // [0] = number of chunks, [1] = MC, [2] = nnz, [3] = lrow valid
   int* sid[TTX_MAX_CORES];
   int* perm[TTX_MAX_CORES];
+  int* ipos[TTX_MAX_CORES];  // inverse of perm: position of lookup n in core t's sorted order (thin cores)
   int* off[TTX_MAX_CORES];
   int* chunk_off;    // [S_1 + 1]
   int4* chunk_rec;   // [max_chunks]

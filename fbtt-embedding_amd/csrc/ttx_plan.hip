@@ -51,7 +51,7 @@ static size_t cnt_ints(const Dims& d, long long nnz) {  // (+ a row per table gr
 
 static size_t plan_ints(const Dims& d, long long nnz, int MC) {
   size_t n = r64(64);                                               // hdr
-  for (int t = 0; t < d.T; ++t) n += r64(nnz) * 5 + r64((size_t)d.S[t] + 1);  // sid, perm, 3 scratch, off
+  for (int t = 0; t < d.T; ++t) n += r64(nnz) * 6 + r64((size_t)d.S[t] + 1);  // sid, perm, ipos, 3 scratch, off
   n += r64((size_t)d.S[1] + 1);                                     // chunk_off
   n += r64((size_t)max_chunks(d, nnz, MC) * 4);                     // chunk_rec
   n += r64((size_t)nnz * 4);                                        // lrec
@@ -79,6 +79,7 @@ Plan carve_plan(const Dims& d, long long nnz, void* base) {
   for (int t = 0; t < d.T; ++t) {
     P.sid[t] = take(nnz);
     P.perm[t] = take(nnz);
+    P.ipos[t] = take(nnz);
     P.off[t] = take((size_t)d.S[t] + 1);
     for (int i = 0; i < 3; ++i) P.scratch[t][i] = take(nnz);
   }
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
   // ---- 3. stores: perm, slice offsets (run heads of the sorted keys) -----------
   if (t != 1) {  // the pivot's consumers read lrec / chunk_rec / chunk_off only
     int* pm = P.perm[t];
-    for (int i = tid; i < N; i += kPlanThreads) pm[i] = valL[i];
+    for (int i = tid; i < N; i += kPlanThreads) { pm[i] = valL[i]; P.ipos[t][valL[i]] = i; }
     int* off = P.off[t];
     const int S = d.S[t];
     for (int i = tid; i <= N; i += kPlanThreads) {
@@ -488,10 +489,28 @@ __device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg,
   const int ftot = call >> 12, ptot = call & 4095;
   const int ctot = ftot + ptot;
   const int ex = fbase + pbase;                     // first slot of this slice
+  // the records are written by ALL threads, one full chunk each per round (a skewed stream puts hundreds of full
+  // chunks on one slice: its thread writing them one after the other was the tail of the launch): slice dg
+  // publishes {first full chunk, first position, first slot} and every thread finds its chunk's slice by binary
+  // search over the full-chunk prefix
+  __shared__ int cf_base[257], cf_pos[256], cf_slot[256];
   if (dg < S) {
     P.chunk_off[dg] = ex;
-    for (int j = 0; j < nf; ++j) P.chunk_rec[fbase + j] = make_int4(dg, dbase + j * MC, MC, ex + j);
+    cf_base[dg] = fbase;
+    cf_pos[dg] = dbase;
+    cf_slot[dg] = ex;
     if (np) P.chunk_rec[ftot + pbase] = make_int4(dg, dbase + nf * MC, pr, ex + nf);
+  }
+  if (dg == 0) cf_base[S] = ftot;
+  __syncthreads();
+  for (int c = threadIdx.x; c < ftot; c += blockDim.x) {
+    int lo = 0, hi = S;  // the last slice with cf_base <= c (slices without full chunks share their successor's base)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (cf_base[mid] <= c) lo = mid; else hi = mid;
+    }
+    const int j = c - cf_base[lo];
+    P.chunk_rec[c] = make_int4(lo, cf_pos[lo] + j * MC, MC, cf_slot[lo] + j);
   }
   for (int cc = ctot + dg; cc < P.max_chunks; cc += blockDim.x) P.chunk_rec[cc] = make_int4(0, 0, 0, 0);
   if (dg == 0) {
@@ -522,15 +541,15 @@ struct Prologue {
   int64_t* hashtbl;
   int64_t* cache_freq;
 };
-#ifndef TTX_PLAN_KU
-#define TTX_PLAN_KU 4
-#endif
 constexpr int kOneThreads = 1024;                 // 16 waves: the histogram of all N keys is 4x shorter per thread
 constexpr int kOneWaves = kOneThreads / kWave;
 template <bool PRO>
 __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
     Dims d, int Nmax, const int* __restrict__ n_dev, const int64_t* __restrict__ indices,
     const int64_t* __restrict__ tableidx, const int64_t* __restrict__ rowidx, Plan P, Prologue pg) {
+  // (a ballot-grouped histogram -- wave_match8 per batch, the group's first lane adding the group size to a
+  //  wave-private row -- was measured against these LDS atomics: 17.5 vs 12.5 us uniform, 30.7 vs 28.3 us on a
+  //  skewed stream: the ~60 VALU instructions of a match cost more than the atomics' conflicts)
   __shared__ int htot[256], hbef[256], hrun[kOneWaves][256];
   const int N = live_n(Nmax, n_dev);
   __shared__ int wt5[kMbUnits + 1];
@@ -538,28 +557,57 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
   const int t = blockIdx.y, tid = threadIdx.x;
   const int lane = lane_id(), w = tid / kWave;
   const CoreDec ct = core_dec(d, t);
+  if (PRO) tableidx = nullptr;
+  // ---- every global load of the launch is issued here: all N keys (batch m = positions [1024 m, 1024 m + 1024),
+  // this thread's key of the batch at 1024 m + tid), then the offsets
+  constexpr int kMaxB = kOneMaxN / kOneThreads;  // 16 batches
+  const int nbat = (N + kOneThreads - 1) / kOneThreads;
+  long long ix[kMaxB];
+  int tb[kMaxB];
+#pragma unroll
+  for (int m = 0; m < kMaxB; ++m) {
+    const int i = m * kOneThreads + tid;
+    ix[m] = (m < nbat && i < N) ? indices[i] : 0;
+    tb[m] = (m < nbat && i < N && tableidx) ? (int)tableidx[i] : 0;
+  }
   if (PRO) {
-    tableidx = nullptr;
     if (t <= 1)  // only core 0 (rowidx out) and the pivot (lrow) need bag rows
       for (int e = tid; e <= pg.nb; e += kOneThreads) offs[e] = (int)min(pg.offsets[e], (int64_t)0x7fffffff);
   }
   if (tid < 256) { htot[tid] = 0; hbef[tid] = 0; }
   for (int e = tid; e < kOneWaves * 256; e += kOneThreads) (&hrun[0][0])[e] = 0;
   __syncthreads();
-  const int bbeg = blockIdx.x * (kOneWaves * kOneUnit), bend = min(N, bbeg + kOneWaves * kOneUnit);
+  const int bx = blockIdx.x;
+  const int bbeg = bx * (kOneWaves * kOneUnit), bend = min(N, bbeg + kOneWaves * kOneUnit);
+  // this thread's own position (the one it ranks and scatters): batch bx
+  const int i = bbeg + tid;
+  const bool valid = i < bend;
+  int kv = 0, tbv = 0, row = 0;
+  long long idx = 0;
+#pragma unroll
+  for (int m = 0; m < kMaxB; ++m) {
+    if (m < nbat) {  // (work-group-uniform)
+      const int im = m * kOneThreads + tid;
+      if (im < N) {
+        const int km = min(tb[m] * ct.p + decode_core(ct, ix[m]), 255);  // tableidx is not validated
+        atomicAdd(&htot[km], 1);
+        if (m < bx) atomicAdd(&hbef[km], 1);
+        else if (m == bx) atomicAdd(&hrun[w][km], 1);
+        if (m == bx) { kv = km; idx = ix[m]; tbv = tb[m]; }
+      }
+    }
+  }
   // Frequency update of this wave's 64 keys (work-groups of the last core, which have no bag rows to find),
-  // split in two so that its CAS round trip (random 8-byte slots in HBM) overlaps the histogram below:
+  // split in two so that its CAS round trip (random 8-byte slots in HBM) overlaps the work below:
   // here equal keys of the wave are combined (hashtbl_count_wave's grouping) and the group leaders issue
-  // the CAS; its result is looked at after the histogram.
+  // the CAS; its result is looked at before the scatter.
   bool h_lead = false;
   long long h_key = 0;
   unsigned long long h_times = 0, h_old = 0;
   int h_idx = 0;
   const bool h_on = PRO && pg.H && t == (d.T >= 3 ? 2 : 0);
   if (h_on) {
-    const int i = bbeg + w * kOneUnit + lane;
-    const bool valid = i < bend;
-    h_key = valid ? indices[i] : 0;
+    h_key = valid ? idx : 0;
     const unsigned h = valid ? hash64(h_key, pg.H) : 0u;
     const unsigned long long peers = wave_match8(h & 255u, valid);
     const int leader = valid ? __ffsll((long long)peers) - 1 : 0;
@@ -573,55 +621,23 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
       h_old = atomicCAS((unsigned long long*)&pg.hashtbl[h_idx], (unsigned long long)(-1ll), (unsigned long long)h_key);
     }
   }
-  // this wave's own 64 positions: index, key and bag row are fetched / searched HERE, before the histogram,
-  // so that their latency (and the rowidx / tableidx stores) overlaps it; ranking needs the scan below
-  const int i = bbeg + w * kOneUnit + lane;
-  const bool valid = i < bend;
-  int kv = 0, tbv = 0, row = 0;
-  long long idx = 0;
-  if (valid) {
-    idx = indices[i];
-    tbv = tableidx ? (int)tableidx[i] : 0;
-    kv = min(tbv * ct.p + decode_core(ct, idx), 255);
-    if (PRO && t <= 1) {  // bag of position i: the last b with offsets[b] <= i (empty bags skipped)
-      int lo = 0, hi = pg.nb;  // answer in [lo, hi)
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (offs[mid] <= i) lo = mid; else hi = mid;
-      }
-      row = lo;
-      if (t == 0) {
-        pg.rowidx[i] = row;
-        pg.tableidx[i] = 0;
-      }
+  if (valid && PRO && t <= 1) {  // bag of position i: the last b with offsets[b] <= i (empty bags skipped)
+    int lo = 0, hi = pg.nb;  // answer in [lo, hi)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (offs[mid] <= i) lo = mid; else hi = mid;
     }
-  }
-  constexpr int kU = TTX_PLAN_KU;  // loads in flight per thread (every work-group reads all N indices: latency, not bandwidth)
-  for (int i0 = tid; i0 < N; i0 += kOneThreads * kU) {
-    long long ix[kU];
-    int tb[kU];
-#pragma unroll
-    for (int j = 0; j < kU; ++j) {
-      const int i = i0 + j * kOneThreads;
-      ix[j] = i < N ? indices[i] : 0;
-      tb[j] = (i < N && tableidx) ? (int)tableidx[i] : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < kU; ++j) {
-      const int i = i0 + j * kOneThreads;
-      if (i < N) {
-        const int kv = min(tb[j] * ct.p + decode_core(ct, ix[j]), 255);  // tableidx is not validated
-        atomicAdd(&htot[kv], 1);
-        if (i < bbeg) atomicAdd(&hbef[kv], 1);
-        else if (i < bend) atomicAdd(&hrun[(i - bbeg) / kOneUnit][kv], 1);
-      }
+    row = lo;
+    if (t == 0) {
+      pg.rowidx[i] = row;
+      pg.tableidx[i] = 0;
     }
   }
   __syncthreads();
   // digit dg = tid (first 256 threads): total, exclusive prefix over digits, first position per wave
   const int dg = tid;
   const bool isd = tid < 256;
-  const int tot = isd ? htot[dg] : 0;
+  const int tot = isd ? htot[dg] : 0, bef = isd ? hbef[dg] : 0;
   const int inc = wave_incl_scan(tot);
   if (isd && lane == kWave - 1) wt5[w] = inc;
   int mine[kOneWaves];
@@ -633,13 +649,13 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
     for (int k = 0; k < w; ++k) wbase += wt5[k];
   const int dbase = wbase + inc - tot;
   if (isd) {
-    int b = dbase + hbef[dg];
+    int b = dbase + bef;
 #pragma unroll
     for (int k = 0; k < kOneWaves; ++k) { hrun[k][dg] = b; b += mine[k]; }
   }
   __syncthreads();
   if (blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, N, PRO || rowidx != nullptr, P, wt5);
-  // rank + scatter this wave's 64 positions (key, bag row: computed before the histogram, see above)
+  // rank + scatter this wave's 64 positions
   if (h_lead) {  // second half of the frequency update: count, or keep probing (hashtbl_cuda_utils.cuh:102-133)
     for (int pr = 0;; ++pr) {
       if ((long long)h_old == -1 || (long long)h_old == h_key) {
@@ -656,6 +672,7 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
     const int pos = hrun[w][kv] + __popcll(peers & lanemask_lt());
     if (t != 1) {
       P.perm[t][pos] = i;
+      P.ipos[t][i] = pos;
     } else {
       const int s0 = tbv * d.p[0] + decode_core(d, 0, idx);
       const int s2 = d.T > 2 ? tbv * d.p[2] + decode_core(d, 2, idx) : 0;
@@ -736,6 +753,7 @@ __global__ __launch_bounds__(kMbThreads) void mb_scatter_kernel(
         const int pos = before + __popcll(peers & lanemask_lt());
         if (!pivot) {
           P.perm[t][pos] = i;
+          P.ipos[t][i] = pos;
         } else {  // the pivot's final order lives in lrec.x
           const int s0 = slice_id(d, core_dec(d, 0), 0, tb[k], ix[k]);
           const int s2 = d.T > 2 ? slice_id(d, core_dec(d, 2), 2, tb[k], ix[k]) : 0;
@@ -1012,6 +1030,7 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
       if ((peers[k] & lanemask_lt()) == 0) hrun[w][kv[k]] = before + __popcll(peers[k]);
       if (t != 1) {
         P.perm[t][pos] = i;
+        P.ipos[t][i] = pos;
       } else {
         const int s0 = slice_id(d, core_dec(d, 0), 0, tb[k], ix[k]);
         const int s2 = d.T > 2 ? slice_id(d, core_dec(d, 2), 2, tb[k], ix[k]) : 0;
@@ -1167,6 +1186,7 @@ __global__ __launch_bounds__(kWideThreads) void mbp_scatter_kernel(
       const int pos = before + __popcll(peers[k] & lanemask_lt());
       if ((peers[k] & lanemask_lt()) == 0) hrun[w][dg] = before + __popcll(peers[k]);
       if (!(last && pivot)) dst[pos] = it[k].val;  // the pivot's final order lives in lrec.x
+      if (last && !pivot) P.ipos[t][it[k].val] = pos;
       if (last) {
         sk[pos] = it[k].kv;
         if (pivot) {

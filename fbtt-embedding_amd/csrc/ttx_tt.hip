@@ -130,7 +130,7 @@ static Lds make_lds(const Dims& d, int MC, bool bwd) {
   L.oX1 = take(sc * L.szX1);
   L.oG = take(bwd && d.T >= 3 ? MC * d.D : 0);
   L.oC = take(L.cLds ? sc * sl2 : 0);
-  L.oI = take(MC * 4);  // int4 lookup records
+  L.oI = take(MC * (bwd ? 8 : 4));  // int4 lookup records (+ backward: the rows of their thin-core partials)
   L.bytes = o * 4;
   L.fdD = make_fd(d.D);
   L.fdN1 = make_fd(N1);
@@ -688,99 +688,124 @@ __global__ __launch_bounds__(kThreads) void pool_gather_kernel(int N, int B, int
     sl += 16;
   }
   V* o = out + ((size_t)tb * B + r) * DV;
-  for (int e = l; e < DV; e += 16) {
-    V acc = o[e];
-    int j = 0;
-    for (; j + 4 <= sl; j += 4) {  // four rows in flight, added in index order
-      int u[4];
-      V v[4];
+  for (int eb = 0; eb < DV; eb += 16) {
+    const int e = eb + l;
+    const bool ev = e < DV;
+    V acc;
+    vzero(acc);
+    if (ev) acc = o[e];
+    for (int base = 0; base < sl; base += 16) {  // the lanes fetch 16 lookups' map entries at once, then 16 rows in flight
+      const int j = base + l;
+      const int u = j < sl ? uid[n + j] : 0;
+      const float w = (psw && j < sl) ? psw[n + j] : 1.f;
+      const int cnt = min(16, sl - base);
+      V v[16];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) u[q] = uid[n + j + q];
+      for (int q = 0; q < 16; ++q) {
+        const int uq = __shfl(u, q, 16);
+        if (q < cnt && ev) v[q] = rows[(size_t)uq * DV + e];
+      }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = rows[(size_t)u[q] * DV + e];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (psw) vfma(acc, psw[n + j + q], v[q]);
-        else vadd(acc, v[q]);
+      for (int q = 0; q < 16; ++q) {  // added in index order
+        const float wq = __shfl(w, q, 16);
+        if (q < cnt && ev) {
+          if (psw) vfma(acc, wq, v[q]);
+          else vadd(acc, v[q]);
+        }
       }
     }
-    for (; j < sl; ++j) {
-      const V v = rows[(size_t)uid[n + j] * DV + e];
-      if (psw) vfma(acc, psw[n + j], v);
-      else vadd(acc, v);
-    }
-    o[e] = acc;
+    if (ev) o[e] = acc;
   }
 }
 
 // Gu[u, :] = sum over the occurrences n of distinct pair u, in index order, of (psw[n] *) d_output[table(n), row(n), :].
-// A work-group owns 16 pairs: pairs with fewer than kGsumCoop occurrences are summed by one 16-lane group each;
-// a pair hit more often (a hot row of a skewed stream takes a sixth of the batch) is then summed by all 16 groups,
-// group g taking the g-th sixteenth of its occurrence list, the 16 part sums folded in group order through LDS --
-// a fixed order either way: deterministic.
+// A 1024-thread work-group = 64 groups of 16 lanes.  Pairs with fewer than kGsumCoop occurrences are summed by one
+// group each (work-group b takes pairs [64 b, 64 b + 64)); a pair hit more often -- a hot row of a skewed stream takes
+// a sixth of the batch -- is summed by ALL 64 groups of one work-group, group g taking the g-th part of its occurrence
+// list, the part sums folded in group order through LDS: a fixed order either way, deterministic.  Hot pairs are
+// dealt round-robin over the work-groups (the map orders pairs by key, so a Zipf stream's hot rows 1, 2, 3, .. are
+// neighbours: pair u goes to work-group u % gridDim).  A group's lanes fetch 16 occurrences' bag rows at once and
+// keep 16 gradient-row loads in flight.
 constexpr int kGsumCoop = 64;
+constexpr int kGsumThreads = 1024;
+constexpr int kGsumGroups = kGsumThreads / 16;
 template <typename V>
-__device__ __forceinline__ V gsum_range(int lo, int hi, int e, int B, int DV, const int* __restrict__ occ,
-                                        const int64_t* __restrict__ rowidx, const int64_t* __restrict__ tableidx,
-                                        const float* __restrict__ psw, const V* __restrict__ dout) {
-  V acc;
-  vzero(acc);
-  int k = lo;
-  for (; k + 4 <= hi; k += 4) {
-    int n[4];
-    V v[4];
+__device__ __forceinline__ void gsum_group(int lo, int hi, int B, int DV, const int* __restrict__ occ,
+                                           const int64_t* __restrict__ rowidx, const int64_t* __restrict__ tableidx,
+                                           const float* __restrict__ psw, const V* __restrict__ dout, V* dst) {
+  const int l = threadIdx.x & 15;
+  for (int eb = 0; eb < DV; eb += 16) {
+    const int e = eb + l;
+    const bool ev = e < DV;
+    V acc;
+    vzero(acc);
+    for (int base = lo; base < hi; base += 16) {
+      const int k = base + l;
+      int off = 0;
+      float w = 1.f;
+      if (k < hi) {
+        const int n = occ[k];
+        off = (int)(tableidx[n] * B + rowidx[n]);
+        if (psw) w = psw[n];
+      }
+      const int cnt = min(16, hi - base);
+      V v[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) n[q] = occ[k + q];
+      for (int q = 0; q < 16; ++q) {
+        const int oq = __shfl(off, q, 16);
+        if (q < cnt && ev) v[q] = dout[(size_t)oq * DV + e];
+      }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = dout[((size_t)tableidx[n[q]] * B + rowidx[n[q]]) * DV + e];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (psw) vfma(acc, psw[n[q]], v[q]);
-      else vadd(acc, v[q]);
+      for (int q = 0; q < 16; ++q) {
+        const float wq = __shfl(w, q, 16);
+        if (q < cnt && ev) {
+          if (psw) vfma(acc, wq, v[q]);
+          else vadd(acc, v[q]);
+        }
+      }
     }
+    if (ev) dst[e] = acc;
   }
-  for (; k < hi; ++k) {
-    const int n = occ[k];
-    const V v = dout[((size_t)tableidx[n] * B + rowidx[n]) * DV + e];
-    if (psw) vfma(acc, psw[n], v);
-    else vadd(acc, v);
-  }
-  return acc;
 }
 
 template <typename V>
-__global__ __launch_bounds__(kThreads) void gsum_kernel(DedupMap M, int B, int DV, const int64_t* __restrict__ rowidx,
-                                                       const int64_t* __restrict__ tableidx,
-                                                       const float* __restrict__ psw, const V* __restrict__ dout,
-                                                       V* __restrict__ Gu) {
+__global__ __launch_bounds__(kGsumThreads) void gsum_kernel(DedupMap M, int B, int DV, const int64_t* __restrict__ rowidx,
+                                                           const int64_t* __restrict__ tableidx,
+                                                           const float* __restrict__ psw, const V* __restrict__ dout,
+                                                           V* __restrict__ Gu) {
   extern __shared__ __attribute__((aligned(16))) float gs_lds[];
-  V* part = (V*)gs_lds;  // [16][DV]
+  __shared__ int hot[kDedupMaxN / kGsumCoop], nhot;
+  V* part = (V*)gs_lds;  // [kGsumGroups][DV]
   const int nu = M.nu[0];
-  const int u0 = blockIdx.x * 16;
-  if (u0 >= nu) return;
-  const int g = threadIdx.x / 16, l = threadIdx.x & 15;
-  {
-    const int u = u0 + g;
+  const int g = threadIdx.x / 16;
+  if (threadIdx.x == 0) nhot = 0;
+  __syncthreads();
+  {  // this work-group's hot pairs: u = b, b + G, b + 2G, .. (one test per thread)
+    for (int u = blockIdx.x + threadIdx.x * gridDim.x; u < nu; u += kGsumThreads * gridDim.x)
+      if (M.occ_off[u + 1] - M.occ_off[u] >= kGsumCoop) hot[atomicAdd(&nhot, 1)] = u;
+  }
+  {  // pairs [64 b, 64 b + 64), one group each
+    const int u = blockIdx.x * kGsumGroups + g;
     if (u < nu) {
       const int lo = M.occ_off[u], hi = M.occ_off[u + 1];
-      if (hi - lo < kGsumCoop)
-        for (int e = l; e < DV; e += 16) Gu[(size_t)u * DV + e] = gsum_range<V>(lo, hi, e, B, DV, M.occ, rowidx, tableidx, psw, dout);
+      if (hi - lo < kGsumCoop) gsum_group<V>(lo, hi, B, DV, M.occ, rowidx, tableidx, psw, dout, Gu + (size_t)u * DV);
     }
   }
-  for (int uu = 0; uu < 16 && u0 + uu < nu; ++uu) {  // (work-group-uniform control flow)
-    const int u = u0 + uu;
+  __syncthreads();
+  const int nh = nhot;
+  for (int hh = 0; hh < nh; ++hh) {  // (work-group-uniform; which of its hot pairs a work-group takes first does not matter)
+    const int u = hot[hh];
     const int lo = M.occ_off[u], hi = M.occ_off[u + 1];
-    if (hi - lo < kGsumCoop) continue;
-    const int per = (hi - lo + 15) / 16;
+    const int per = (hi - lo + kGsumGroups - 1) / kGsumGroups;
     const int a = min(hi, lo + g * per), b = min(hi, a + per);
+    gsum_group<V>(a, b, B, DV, M.occ, rowidx, tableidx, psw, dout, part + (size_t)g * DV);
     __syncthreads();
-    for (int e = l; e < DV; e += 16) part[g * DV + e] = gsum_range<V>(a, b, e, B, DV, M.occ, rowidx, tableidx, psw, dout);
-    __syncthreads();
-    for (int e = threadIdx.x; e < DV; e += kThreads) {
+    for (int e = threadIdx.x; e < DV; e += kGsumThreads) {
       V acc = part[e];
-      for (int q = 1; q < 16; ++q) vadd(acc, part[q * DV + e]);
+      for (int q = 1; q < kGsumGroups; ++q) vadd(acc, part[(size_t)q * DV + e]);
       Gu[(size_t)u * DV + e] = acc;
     }
+    __syncthreads();
   }
 }
 
@@ -811,7 +836,7 @@ __device__ __forceinline__ void zero_hot_counters(const Partials& PC) {
 template <int NT>
 __device__ __forceinline__ void bwd_stage_fused(int lenS, int j0, int k, int na, int nb, int sJ, int sA,
                                                 int sB, float* X, const float* G, int gJ, int gBase,
-                                                const float* Cg, int slice, const int4* I, int which,
+                                                const float* Cg, int slice, const int4* I, const int4* IP, int which,
                                                 float* __restrict__ pc) {
   const FastDiv fk = make_fd(k);
   for (int e = threadIdx.x; e < lenS * k; e += kThreads) {
@@ -841,7 +866,7 @@ __device__ __forceinline__ void bwd_stage_fused(int lenS, int j0, int k, int na,
         g += NT;
       }
     }
-    float* o = pc + (size_t)rec.x * slice + kk * NT;
+    float* o = pc + (size_t)(which == 2 ? IP[j0 + jl].z : IP[j0 + jl].w) * slice + kk * NT;
 #pragma unroll
     for (int x = 0; x < NT; ++x) o[x] = acc[x];
   }
@@ -850,7 +875,7 @@ __device__ __forceinline__ void bwd_stage_fused(int lenS, int j0, int k, int na,
 // generic two-phase version (any n): (a) partial, barrier, (b) d x in place
 __device__ __forceinline__ void bwd_stage_any(int lenS, int j0, int m, int k, int n, int nb, int sJ, int sA,
                                               int sB, float* X, const float* G, int gJ, int gBase,
-                                              const float* Cg, int slice, const int4* I, int which,
+                                              const float* Cg, int slice, const int4* I, const int4* IP, int which,
                                               float* __restrict__ pc) {
   const FastDiv fn = make_fd(n), fnb = make_fd(nb);
   {
@@ -865,7 +890,7 @@ __device__ __forceinline__ void bwd_stage_any(int lenS, int j0, int m, int k, in
       int row = 0;
       for (int a = 0; a * nb < m; ++a)
         for (int b = 0; b < nb; ++b, ++row) acc = fmaf(xj[a * sA + b * sB], gi[row * n], acc);
-      pc[(size_t)I[j0 + jl].x * slice + rem] = acc;
+      pc[(size_t)(which == 2 ? IP[j0 + jl].z : IP[j0 + jl].w) * slice + rem] = acc;
     }
   }
   __syncthreads();
@@ -1003,7 +1028,7 @@ __device__ __forceinline__ void da_group(const Dims& d, const Lds& L, const floa
     unsigned a_;
     const unsigned jl = fdivmod((unsigned)row, L.fdQ0, a_);
     if ((int)jl < lenS) {
-      float* o = pc + (size_t)I[j0 + jl].x * sl0 + a_ * K0;
+      float* o = pc + (size_t)I[L.MC + j0 + jl].x * sl0 + a_ * K0;  // (row of the partial: position in core 0's sorted order)
 #pragma unroll
       for (int y = 0; y < KB; ++y) {
         const int kk = (k0t + y) * 16 + i16;
@@ -1041,6 +1066,7 @@ __device__ __forceinline__ void bwd_pass_front(const Dims& d, const CorePtrs& C,
   const int tid = threadIdx.x;
   const int T = d.T, q0 = d.q[0], D = d.D;
   const int4* I = (const int4*)(smem + L.oI);
+  const int4* IP = I + L.MC;  // rows of the lookups' thin-core partials (bwd_kernel)
   float* X0 = smem + L.oX0;
   float* X1 = smem + L.oX1;
   float* Gb = smem + L.oG;
@@ -1077,11 +1103,11 @@ __device__ __forceinline__ void bwd_pass_front(const Dims& d, const CorePtrs& C,
     // stage t = 2 on x_1 [m2 x k2] with G = bag gradient [m2 x n2]
     const int m2 = d.m[2], k2 = d.k[2], n2 = d.n[2];
     if (n2 <= 8) {
-#define CALL(NT) bwd_stage_fused<NT>(lenS, j0, k2, 1, m2, L.szX1, 0, k2, X1, Gb, D, j0, C.c[3], d.slice[3], I, 3, PC.pc[3])
+#define CALL(NT) bwd_stage_fused<NT>(lenS, j0, k2, 1, m2, L.szX1, 0, k2, X1, Gb, D, j0, C.c[3], d.slice[3], I, IP, 3, PC.pc[3])
       TTX_NT_SWITCH(n2, CALL)
 #undef CALL
     } else {
-      bwd_stage_any(lenS, j0, m2, k2, n2, m2, L.szX1, 0, k2, X1, Gb, D, j0, C.c[3], d.slice[3], I, 3, PC.pc[3]);
+      bwd_stage_any(lenS, j0, m2, k2, n2, m2, L.szX1, 0, k2, X1, Gb, D, j0, C.c[3], d.slice[3], I, IP, 3, PC.pc[3]);
     }
     __syncthreads();
   }
@@ -1092,11 +1118,11 @@ __device__ __forceinline__ void bwd_pass_front(const Dims& d, const CorePtrs& C,
     const int gJ = (T == 3) ? D : L.szX1;
     const int gBase = (T == 3) ? j0 : 0;
     if (n1 <= 8) {
-#define CALL(NT) bwd_stage_fused<NT>(lenS, j0, k1, q0, q1, q0 * L.ld, L.ld, k1, X0, Gin, gJ, gBase, C.c[2], d.slice[2], I, 2, PC.pc[2])
+#define CALL(NT) bwd_stage_fused<NT>(lenS, j0, k1, q0, q1, q0 * L.ld, L.ld, k1, X0, Gin, gJ, gBase, C.c[2], d.slice[2], I, IP, 2, PC.pc[2])
       TTX_NT_SWITCH(n1, CALL)
 #undef CALL
     } else {
-      bwd_stage_any(lenS, j0, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, Gin, gJ, gBase, C.c[2], d.slice[2], I, 2, PC.pc[2]);
+      bwd_stage_any(lenS, j0, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, Gin, gJ, gBase, C.c[2], d.slice[2], I, IP, 2, PC.pc[2]);
     }
     __syncthreads();
   }
@@ -1156,6 +1182,10 @@ __global__ __launch_bounds__(kThreads, 3) void bwd_kernel(Dims d, Plan P, CorePt
   STAMP(2);
   if (L.dbg & 16) return;
   const int4* I = (const int4*)(smem + L.oI);
+  if (tid < len) {  // partial gradients of the thin cores are stored in the cores' SORTED order (Plan::ipos)
+    const int n = I[tid].x;
+    ((int4*)(smem + L.oI))[L.MC + tid] = make_int4(P.ipos[0][n], 0, d.T > 2 ? P.ipos[2][n] : 0, d.T > 3 ? P.ipos[3][n] : 0);
+  }
   const int table = PC.tableidx ? (int)PC.tableidx[I[0].x] : s / d.p[1];
   if (d.T >= 3) {
     // bag gradients of the chunk's lookups
@@ -1399,7 +1429,7 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Pl
       const int slot = (sbeg > p0) ? 1 : 0;
       float* dst = PC.seg[t] + (size_t)(2 * b + slot) * sl;
       if (t == 1) sum_rows4(pc, sl, beg, end, red, IotaRow{}, StoreEmit{dst});
-      else sum_rows4(pc, sl, beg, end, red, ListRow{P.perm[t]}, StoreEmit{dst});
+      else sum_rows4(pc, sl, beg, end, red, IotaRow{}, StoreEmit{dst});  // (thin cores too: partials lie in sorted order)
       // arrival (the "last block" pattern): every thread publishes its stores device-wide, one thread
       // counts the work-group in, and the work-group that completes the count folds the segment sums
       __threadfence();
@@ -1432,7 +1462,7 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Pl
   int beg, end;
   const int* __restrict__ list;
   if (t == 1) { beg = P.chunk_off[s]; end = P.chunk_off[s + 1]; list = nullptr; }
-  else { beg = P.off[t][s]; end = P.off[t][s + 1]; list = P.perm[t]; }
+  else { beg = P.off[t][s]; end = P.off[t][s + 1]; list = nullptr; }  // partial rows = positions of the sorted order
   const size_t base = (size_t)s * sl;
   float* __restrict__ dw = DW.c[t];
   float* __restrict__ wt = W.c[t];
@@ -1891,13 +1921,14 @@ int ttx_tt_backward_dd(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, f
   float* Gu = (float*)workspace;
   {
     ProfScope ps(TTX_PROF_POOL, st);
-    const int blocks = ((int)nnz + 15) / 16;  // (upper bound: work-groups beyond the distinct pairs leave at once)
+    const int blocks = ((int)nnz + kGsumGroups - 1) / kGsumGroups;  // (upper bound: a work-group without pairs only looks for hot ones)
+    const size_t lds = (size_t)kGsumGroups * d.D * sizeof(float);
     if (d.D % 4 == 0 && (((uintptr_t)d_output) & 15) == 0)
-      hipLaunchKernelGGL(gsum_kernel<float4>, dim3(blocks), dim3(kThreads), (size_t)16 * d.D * sizeof(float), st, M, B, d.D / 4,
-                         rowidx, tableidx, psw, (const float4*)d_output, (float4*)Gu);
+      hipLaunchKernelGGL(gsum_kernel<float4>, dim3(blocks), dim3(kGsumThreads), lds, st, M, B, d.D / 4, rowidx, tableidx, psw,
+                         (const float4*)d_output, (float4*)Gu);
     else
-      hipLaunchKernelGGL(gsum_kernel<float>, dim3(blocks), dim3(kThreads), (size_t)16 * d.D * sizeof(float), st, M, B, d.D,
-                         rowidx, tableidx, psw, d_output, Gu);
+      hipLaunchKernelGGL(gsum_kernel<float>, dim3(blocks), dim3(kGsumThreads), lds, st, M, B, d.D, rowidx, tableidx, psw, d_output,
+                         Gu);
     TTX_HIP(hipGetLastError());
   }
   // the distinct pairs as a batch of their own: bag row of pair u is u, its bag gradient Gu[u] (B = 0: no table term)

@@ -487,7 +487,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             raise ValueError(f"offsets must describe num_tables * B bags, got {offsets.numel() - 1} bags for "
                              f"{self.num_tables} tables")
         fast = _native_node()
-        if self.dedup and self.warmup and indices.is_cuda and indices.numel() > 0 and per_sample_weights is None \
+        if getattr(self, "dedup", False) and self.warmup and indices.is_cuda and indices.numel() > 0 and per_sample_weights is None \
                 and getattr(_engine, "DedupPlan", None) is not None:
             # duplicate lookups share their contraction: frequency update + bag rows as usual, then the map and the
             # plan of the distinct pairs (one work-group sorts the batch's keys), through the reference-shaped route

@@ -1,0 +1,19 @@
+#!/bin/bash
+# per-kernel durations (rocprofv3 --kernel-trace --stats) of one or more bench workloads, ttx kernels only.
+# usage (GPU box, repo root): scripts/kprof.sh <tag> <workload> [<workload> ...]   -> gpurun_out/kprof_<tag>/<workload>.md
+set -u
+TAG=$1; shift
+REPO=$(pwd); OUT=$REPO/gpurun_out/kprof_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
+for W in "$@"; do
+  cd /tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$W" -- python "$REPO/bench.py" --workload "$W" --steps 30 --warmup 5 \
+      --repeats 1 --no-cpu-baseline --no-graph ${KPROF_ARGS:-} > "$OUT/$W.log" 2>&1
+  cd "$REPO"
+  F=$(find "$OUT/$W" -name "*kernel_stats.csv" | head -1)
+  { echo "## $W"; python scripts/stats_csv_to_md.py "$F" "$W" | grep -E "ttx::|^\| kernel|^\|---"; tail -1 "$OUT/$W.log" | python -c "
+import json,sys
+try:
+    j=json.loads(sys.stdin.read()); print('eager ms/step', j['eager_ms_per_step'], '| kernel_us (event brackets)', j['kernel_us'])
+except Exception as e: print('no bench line', e)
+"; } | tee "$OUT/$W.md"
+done

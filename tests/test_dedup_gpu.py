@@ -111,15 +111,18 @@ def test_dedup_vs_oracle_and_plain_path(case):
         assert np.array_equal(got["out"], plain["out"]), "forward must be bit-identical to the plain path"
         assert_close(got["out"], orc["out"], f"case {case} out")
         gref = oracle(c, "dense")["grads"] if mode == "adagrad" else None
+        # a hot row's gradient is an fp32 sum over thousands of occurrences, added in an order of its own by either
+        # side (the oracle: sequentially): the rounding random walk is ~sqrt(n) ulp
+        tol = dict(rtol=1e-4, atol_scale=2e-5) if frac >= 0.9 else {}
         for k in range(len(p)):
             if mode == "dense":
-                assert_close(got["grads"][k], orc["grads"][k], f"case {case} grad{k}")
+                assert_close(got["grads"][k], orc["grads"][k], f"case {case} grad{k}", **tol)
                 assert np.array_equal(got["grads"][k], again["grads"][k]), "not deterministic"
             elif mode == "sgd":
-                assert_close(got["cores"][k], orc["cores"][k], f"case {case} sgd core{k}")
+                assert_close(got["cores"][k], orc["cores"][k], f"case {case} sgd core{k}", **tol)
                 assert np.array_equal(got["cores"][k], again["cores"][k]), "not deterministic"
             else:
-                assert_close(got["state"][k], orc["state"][k], f"case {case} adagrad state{k}")
+                assert_close(got["state"][k], orc["state"][k], f"case {case} adagrad state{k}", **(dict(rtol=2e-4, atol_scale=4e-5) if tol else {}))
                 assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"case {case} adagrad core{k}")
 
 
