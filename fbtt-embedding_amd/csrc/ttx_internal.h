@@ -71,8 +71,19 @@ int make_dims(const ttx_geom* g, Dims* d);  // TTX_OK or TTX_EINVAL (+message)
 //                 cut into chunks of <= MC lookups; chunk_off[s] = first chunk of s
 //   lrec[i]     = {n, sid_0, sid_2, sid_3} of the i-th lookup in pivot order
 //   lrow[i]     = bag row (rowidx[n]) of that lookup; valid iff hdr[3] != 0
+// reduce_apply_kernel's hot-slice thresholds (ttx_tt.hip); the plan kernels that know the slice sizes leave the number
+// of hot slices per core in hdr[8 + t] (-1: unknown), so that the launch's hot-slice work-groups can leave at once
+#ifndef TTX_SEG_THIN
+#define TTX_SEG_THIN 256
+#endif
+#ifndef TTX_HOT_PIVOT
+#define TTX_HOT_PIVOT 16
+#endif
+constexpr int kSegThin = TTX_SEG_THIN;    // partial rows per segment of a thin core's sorted order; hot: > 2 segments
+constexpr int kHotRowsPivot = TTX_HOT_PIVOT;  // chunk partials beyond which a pivot slice is hot
+
 struct Plan {
-  int* hdr;  // [0] = number of chunks, [1] = MC, [2] = nnz, [3] = lrow valid
+  int* hdr;  // [0] = number of chunks, [1] = MC, [2] = nnz, [3] = lrow valid, [8 + t] = hot slices of core t (-1: unknown)
   int* sid[TTX_MAX_CORES];
   int* perm[TTX_MAX_CORES];
   int* ipos[TTX_MAX_CORES];  // inverse of perm: position of lookup n in core t's sorted order (thin cores)

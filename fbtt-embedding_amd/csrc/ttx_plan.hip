@@ -370,6 +370,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
       P.hdr[1] = MC;
       P.hdr[2] = N;
       P.hdr[3] = rowidx ? 1 : 0;
+      for (int tt = 0; tt < TTX_MAX_CORES; ++tt) P.hdr[8 + tt] = -1;  // hot slices per core: unknown (reduce_apply looks)
     }
     PSTAMP(5);
   }
@@ -464,6 +465,8 @@ __device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg,
   const int lane = lane_id(), w = threadIdx.x / kWave;
   const int S = d.S[t];
   if (t != 1) {
+    const int nhot = __syncthreads_count(dg < S && tot > 2 * kSegThin);  // (reduce_apply's hot slices, ttx_internal.h)
+    if (dg == 0) P.hdr[8 + t] = nhot;
     if (dg <= S) P.off[t][dg] = (dg == S) ? N : dbase;
     if (dg == 0 && S == 256) P.off[t][256] = N;
     return;
@@ -477,6 +480,8 @@ __device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg,
   const int nf = dg < S ? tot / MC : 0;            // full chunks
   const int pr = dg < S ? tot - nf * MC : 0;       // lookups in the partial chunk
   const int np = pr ? 1 : 0;
+  const int nhot = __syncthreads_count(nf + np > kHotRowsPivot);
+  if (dg == 0) P.hdr[8 + 1] = nhot;
   const int packed = (nf << 12) | np;              // slices <= 256: np sums stay < 4096
   const int cinc = wave_incl_scan(packed);
   __syncthreads();
@@ -584,17 +589,39 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
   const bool valid = i < bend;
   int kv = 0, tbv = 0, row = 0;
   long long idx = 0;
+  bool peel_on = true;
 #pragma unroll
   for (int m = 0; m < kMaxB; ++m) {
     if (m < nbat) {  // (work-group-uniform)
       const int im = m * kOneThreads + tid;
-      if (im < N) {
-        const int km = min(tb[m] * ct.p + decode_core(ct, ix[m]), 255);  // tableidx is not validated
+      const bool vm = im < N;
+      const int km = vm ? min(tb[m] * ct.p + decode_core(ct, ix[m]), 255) : 0;  // tableidx is not validated
+      // Same-address LDS atomics of one wave instruction serialise, and a skewed stream puts most of a batch on one
+      // digit (cfg3's: 90 % of core 0's keys, 70 % of the pivot's): the wave then peels the first lane's digit off --
+      // one ballot, that lane adds the whole group's count -- and leaves the rest to one atomic per lane (plan kernel
+      // 21.3 -> 14.2 us on cfg3's stream).  The ballot costs 1.4 us per launch on a uniform stream, so a wave peels
+      // only while its previous batch had a group of >= 12 lanes (its first batch always tries).  A full ballot
+      // grouping of all digits (wave_match8) costs more than it saves.
+      unsigned long long rest = __ballot(vm);
+      if (peel_on && rest != 0) {  // (wave-uniform)
+        const int src = __ffsll((long long)rest) - 1;
+        const int d0 = __shfl(km, src, kWave);
+        const unsigned long long grp = __ballot(vm && km == d0) & rest;
+        const int c = __popcll(grp);
+        if (lane == src) {
+          atomicAdd(&htot[d0], c);
+          if (m < bx) atomicAdd(&hbef[d0], c);
+          else if (m == bx) atomicAdd(&hrun[w][d0], c);
+        }
+        rest &= ~grp;
+        peel_on = c >= 12;
+      }
+      if ((rest >> lane) & 1ull) {
         atomicAdd(&htot[km], 1);
         if (m < bx) atomicAdd(&hbef[km], 1);
         else if (m == bx) atomicAdd(&hrun[w][km], 1);
-        if (m == bx) { kv = km; idx = ix[m]; tbv = tb[m]; }
       }
+      if (vm && m == bx) { kv = km; idx = ix[m]; tbv = tb[m]; }
     }
   }
   // Frequency update of this wave's 64 keys (work-groups of the last core, which have no bag rows to find),
@@ -923,6 +950,7 @@ __device__ __forceinline__ void finish_wide(const Dims& d, int t, const int (&to
     P.hdr[1] = MC;
     P.hdr[2] = N;
     P.hdr[3] = has_row ? 1 : 0;
+    for (int tt = 0; tt < TTX_MAX_CORES; ++tt) P.hdr[8 + tt] = -1;  // hot slices per core: unknown (reduce_apply looks)
   }
 }
 
@@ -1268,6 +1296,7 @@ __global__ __launch_bounds__(1024) void mb_chunks_kernel(Dims d, int Nmax, const
     P.hdr[1] = MC;
     P.hdr[2] = N;
     P.hdr[3] = has_row;
+    for (int tt = 0; tt < TTX_MAX_CORES; ++tt) P.hdr[8 + tt] = -1;  // hot slices per core: unknown (reduce_apply looks)
   }
 }
 

@@ -1251,16 +1251,35 @@ __device__ __forceinline__ float apply_one(int optim, float g, float w, float lr
 // g+G, .. in index order, the G group sums are then added in group order
 // through LDS.  Long slices: 4 floats per thread, partials summed in order.
 constexpr int kReduceThreads = 1024;  // upper bound; launched with 512 when the largest slice is <= 4096 floats
-#ifndef TTX_SEG_THIN
-#define TTX_SEG_THIN 512
-#endif
-constexpr int kSegThin = TTX_SEG_THIN;         // partial rows per segment of a thin core's sorted order
 constexpr int kSegPivot = 32;         // chunk partials per segment of the pivot core
 // A slice is HOT when it holds more than two segments' worth of partials (a skewed index stream puts
 // a third of a batch on one slice): one work-group per SEGMENT then sums its share, and the last one
 // to arrive folds the segment sums in segment order and applies the optimizer -- all other slices keep
 // their single owner.  Deterministic either way (fixed partition, fixed order).
 __device__ __forceinline__ int seg_len(int t) { return t == 1 ? kSegPivot : kSegThin; }
+// The PIVOT core's hot slices (few rows, 4096 floats each) are split by COLUMNS instead: work-group j takes float4
+// columns [j C, (j + 1) C) of every hot slice, its threads form nthreads / C row groups, group g sums rows g, g + G,
+// .. (eight in flight), the group sums are folded in group order through LDS and the optimizer is applied to those
+// columns -- no second pass, no arrival counter, no fence.  (Row segments of 32 chunk partials plus the last
+// arriver's fold of the segment sums were the tail of the launch on a skewed stream: 16 + 6 us of serial load
+// rounds.  The thin cores keep row segments: many rows of 128 floats -- column blocks of 64 bytes would leave
+// eight work-groups to read 4.7 MB, measured 43 us.)
+#ifndef TTX_HOT_COLS
+#define TTX_HOT_COLS 8
+#endif
+#ifndef TTX_HOT_NF
+#define TTX_HOT_NF 4
+#endif
+#ifndef TTX_RTHREADS_SMALL
+#define TTX_RTHREADS_SMALL 512
+#endif
+constexpr int kHotNF = TTX_HOT_NF;  // rows in flight per lane on the hot-slice paths
+constexpr int kHotColsPivot = TTX_HOT_COLS;  // (kHotRowsPivot, kSegThin: ttx_internal.h)
+// column work-groups of the launch: one per block of kHotColsPivot float4 columns, each walks ALL hot slices of the pivot
+// (a launch without hot slices pays for V / C work-groups that look at the offsets once and leave)
+__host__ __device__ __forceinline__ int hot_wgs(int total_max, int sl, int t) {
+  return (sl & 3) ? 0 : (sl / 4 + kHotColsPivot - 1) / kHotColsPivot;
+}
 
 struct ApplyEmit {
   int optim;
@@ -1301,7 +1320,7 @@ struct StoreEmit {
 
 // sum rows row(beg) .. row(end-1) of `pc` (sl floats each, sl % 4 == 0) in a fixed order and hand every
 // float4 lane of the result to emit(v, sum).  Whole work-group; contains block barriers.
-template <class RowFn, class Emit>
+template <class RowFn, class Emit, bool DEEP = false>
 __device__ __forceinline__ void sum_rows4(const float* __restrict__ pc, int sl, int beg, int end, float4* red,
                                           RowFn row, Emit emit) {
   const int nthreads = blockDim.x, tid = threadIdx.x;
@@ -1317,6 +1336,15 @@ __device__ __forceinline__ void sum_rows4(const float* __restrict__ pc, int sl, 
     if (g == 0) pre = emit.prefetch(v);
     if (g < G) {
       int i = beg + g;
+      if (DEEP || cnt >= 16 * G) {  // many rows per group (a hot slice's segment, a warm slice's owner): the load rounds ARE the time
+        for (; i + (kHotNF - 1) * G < end; i += kHotNF * G) {
+          float4 x[kHotNF];
+#pragma unroll
+          for (int u = 0; u < kHotNF; ++u) x[u] = ((const float4*)(pc + row(i + u * G) * sl))[v];
+#pragma unroll
+          for (int u = 0; u < kHotNF; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+        }
+      }
       for (; i + 3 * G < end; i += 4 * G) {  // four rows in flight per lane (eight: slower, 13.7 vs 12.3 us at cfg2)
         const size_t r0 = row(i), r1 = row(i + G), r2 = row(i + 2 * G), r3 = row(i + 3 * G);
         const float4 x0 = ((const float4*)(pc + r0 * sl))[v], x1 = ((const float4*)(pc + r1 * sl))[v];
@@ -1375,12 +1403,17 @@ struct SegRow {  // final fold of a hot slice: segment j's slot (1 = the slice s
   __device__ __forceinline__ size_t operator()(int i) const { return (size_t)(2 * (j_first + i) + (i == 0 ? first_slot : 0)); }
 };
 
-__global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Plan P, Partials PC,
+#ifndef TTX_REDUCE_WAVES
+#define TTX_REDUCE_WAVES 6
+#endif
+// (second launch bound = waves per SIMD the register allocation has to leave room for: the hot-slice paths pushed the
+//  kernel from 77 to 89-99 VGPRs, i.e. from three to two 512-thread work-groups per CU, +1.5 us at the benchmark batch)
+__global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply_kernel(Dims d, Plan P, Partials PC,
                                                                int optim, float lr, float eps,
                                                                CorePtrs W, CorePtrs St,
                                                                CorePtrs DW, int nslices, int rows_max) {
   __shared__ float4 red[kReduceThreads];
-  __shared__ int s_last;
+  __shared__ int s_last, s_nhot, s_hot[kReduceThreads];
   const int nthreads = blockDim.x, tid = threadIdx.x;
   int b = blockIdx.x;
   if (b >= nslices) {
@@ -1388,10 +1421,60 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Pl
     b -= nslices;
     int t = 0;
     for (;; ++t) {
-      const int total_max = (t == 1) ? P.max_chunks : rows_max;
-      const int nseg = (total_max + seg_len(t) - 1) / seg_len(t);
+      const int nseg = (t == 1) ? hot_wgs(P.max_chunks, d.slice[1], 1) : (rows_max + seg_len(t) - 1) / seg_len(t);
       if (b < nseg || t == d.T - 1) break;
       b -= nseg;
+    }
+    if (P.hdr[8 + t] == 0) return;  // the plan kernel found no hot slice in this core (-1: it did not look)
+    if (t == 1) {  // ---- pivot: column work-group j -- float4 columns [j C, (j + 1) C) of EVERY hot slice ----
+      const int sl = d.slice[1], V = sl / 4, C = kHotColsPivot;
+      const int c0 = b * C, c1 = min(V, c0 + C);
+      if (c0 >= c1) return;
+      const int* off = P.chunk_off;
+      const int S = d.S[1];
+      const int G = nthreads / C, g = tid / C, v = c0 + (tid - g * C);
+      const bool act = g < G && v < c1;
+      const float* __restrict__ pc = PC.pc[1];
+      for (int s0 = 0; s0 < S; s0 += nthreads) {  // (work-group-uniform control flow throughout)
+        if (tid == 0) s_nhot = 0;
+        __syncthreads();
+        const int sidx = s0 + tid;
+        if (sidx < S && off[sidx + 1] - off[sidx] > kHotRowsPivot) s_hot[atomicAdd(&s_nhot, 1)] = sidx;
+        __syncthreads();
+        const int nh = s_nhot;
+        for (int h = 0; h < nh; ++h) {  // (the order in which a work-group takes its hot slices does not matter)
+          const int sh = s_hot[h];
+          const int beg = off[sh], end = off[sh + 1];
+          const size_t base = (size_t)sh * sl;
+          const ApplyEmit ap{optim, lr, eps, W.c[1] + base, St.c[1] ? St.c[1] + base : nullptr, DW.c[1] ? DW.c[1] + base : nullptr};
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          typename ApplyEmit::Pre pre{};
+          if (act && g == 0) pre = ap.prefetch(v);
+          if (act) {
+            for (int i = beg + g; i < end; i += kHotNF * G) {  // kHotNF rows in flight per lane (the tail predicated, not serialised)
+              float4 x[kHotNF];
+#pragma unroll
+              for (int u = 0; u < kHotNF; ++u) {
+                const int r = i + u * G;
+                x[u] = r < end ? ((const float4*)(pc + (size_t)r * sl))[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+              }
+#pragma unroll
+              for (int u = 0; u < kHotNF; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+            }
+            red[tid] = acc;
+          }
+          __syncthreads();
+          if (act && g == 0) {
+            for (int q = 1; q < G; ++q) {
+              const float4 x = red[q * C + (v - c0)];
+              acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+            }
+            ap(v, acc, pre);
+          }
+          __syncthreads();
+        }
+      }
+      return;
     }
     const int SEG = seg_len(t), sl = d.slice[t];
     if ((sl & 3) != 0) return;  // (odd slice sizes stay with their single owner)
@@ -1429,21 +1512,25 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Pl
       const int slot = (sbeg > p0) ? 1 : 0;
       float* dst = PC.seg[t] + (size_t)(2 * b + slot) * sl;
       if (t == 1) sum_rows4(pc, sl, beg, end, red, IotaRow{}, StoreEmit{dst});
-      else sum_rows4(pc, sl, beg, end, red, IotaRow{}, StoreEmit{dst});  // (thin cores too: partials lie in sorted order)
-      // arrival (the "last block" pattern): every thread publishes its stores device-wide, one thread
-      // counts the work-group in, and the work-group that completes the count folds the segment sums
-      __threadfence();
+      else sum_rows4<IotaRow, StoreEmit, true>(pc, sl, beg, end, red, IotaRow{}, StoreEmit{dst});  // (partials lie in sorted order)
+      // arrival (the "last block" pattern).  Producer: the work-group's plain stores are complete at the barrier
+      // (work-group scope), then ONE lane writes the XCD's dirty L2 lines back (agent-scope release: buffer_wbl2
+      // works on the cache, not on a thread's own stores) and counts the work-group in; the work-group that
+      // completes the count folds the segment sums after ONE lane's agent-scope acquire (invalidates this CU's L1).
+      // (Every thread calling __threadfence() -- 512 release + acquire pairs per work-group -- cost 2-4x one lane's,
+      // MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility".)
       __syncthreads();
       if (tid == 0) {
         int idx = s;
         for (int tt = 0; tt < t; ++tt) idx += d.S[tt];
         const int j_first = sbeg / SEG, j_last = (send - 1) / SEG;
-        const int old = atomicAdd(&PC.hot_cnt[idx], 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const int old = __hip_atomic_fetch_add(&PC.hot_cnt[idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (old == j_last - j_first);
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
       __syncthreads();
       if (s_last) {
-        __threadfence();  // acquire: the other work-groups' segment sums
         const int j_first = sbeg / SEG, j_last = (send - 1) / SEG;
         const size_t base = (size_t)s * sl;
         const ApplyEmit ap{optim, lr, eps, W.c[t] + base, St.c[t] ? St.c[t] + base : nullptr,
@@ -1474,7 +1561,7 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_apply_kernel(Dims d, Pl
   }
   const float* __restrict__ pc = PC.pc[t];
   if ((sl & 3) == 0) {
-    if (end - beg > 2 * seg_len(t) && PC.hot_cnt) return;  // hot: the segment work-groups own it
+    if (end - beg > (t == 1 ? kHotRowsPivot : 2 * seg_len(t)) && PC.hot_cnt) return;  // hot: the segment / column work-groups own it
     const ApplyEmit ap{optim, lr, eps, wt + base, stt ? stt + base : nullptr, dw ? dw + base : nullptr};
     if (list) sum_rows4(pc, sl, beg, end, red, ListRow{list}, ap);
     else sum_rows4(pc, sl, beg, end, red, IotaRow{}, ap);
@@ -1697,6 +1784,7 @@ int ttx_tt_rows(const ttx_geom* g, int32_t D, int64_t nnz, const int64_t* indice
 }
 
 static int num_segments(const Dims& d, long long nnz, int MC, int t) {
+  if (t == 1) return 0;  // (the pivot's hot slices are split by columns: hot_wgs)
   const long long total = (t == 1) ? (long long)max_chunks(d, nnz, MC) : nnz;
   const int SEG = (t == 1) ? kSegPivot : kSegThin;
   return (int)((total + SEG - 1) / SEG);
@@ -1788,7 +1876,7 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
   for (int t = 0; t < d.T; ++t) {
     PC.seg[t] = (float*)(ws + offs[d.T + t]);
     nslices += d.S[t];
-    nsegs += num_segments(d, nnz, MC, t);
+    nsegs += (t == 1) ? hot_wgs(P.max_chunks, d.slice[1], 1) : num_segments(d, nnz, MC, t);
   }
   for (int t = d.T; t < TTX_MAX_CORES; ++t) PC.seg[t] = nullptr;
   PC.hot_cnt = (int*)(ws + offs[2 * d.T]);
@@ -1818,7 +1906,7 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
     const int blocks = nslices + nsegs;  // slice owners, then the segment work-groups of hot slices
     int smax = 0;
     for (int t = 0; t < d.T; ++t) smax = d.slice[t] > smax ? d.slice[t] : smax;
-    const int rthreads = smax <= 4096 ? 512 : kReduceThreads;  // (measured: 512 is 1.7 us faster at r = 32, 1024 at r = 64)
+    const int rthreads = smax <= 4096 ? TTX_RTHREADS_SMALL : kReduceThreads;  // (measured: 512 is 1.7 us faster at r = 32, 1024 at r = 64)
     ProfScope ps(TTX_PROF_APPLY, st);
     hipLaunchKernelGGL(reduce_apply_kernel, dim3(blocks), dim3(rthreads), 0, st, d, P, PC, optim, lr,
                        eps, C, S, DW, nslices, (int)nnz);
