@@ -555,7 +555,9 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
   // (a ballot-grouped histogram -- wave_match8 per batch, the group's first lane adding the group size to a
   //  wave-private row -- was measured against these LDS atomics: 17.5 vs 12.5 us uniform, 30.7 vs 28.3 us on a
   //  skewed stream: the ~60 VALU instructions of a match cost more than the atomics' conflicts)
-  __shared__ int htot[256], hbef[256], hrun[kOneWaves][256];
+  // one LDS atomic per key: digit counts of the keys in front of this work-group's window (hbef), inside it per wave
+  // slot (hrun) and behind it (haft); a digit's total is their sum
+  __shared__ int haft[256], hbef[256], hrun[kOneWaves][256];
   const int N = live_n(Nmax, n_dev);
   __shared__ int wt5[kMbUnits + 1];
   __shared__ int offs[PRO ? kProMaxBags + 1 : 1];
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
     if (t <= 1)  // only core 0 (rowidx out) and the pivot (lrow) need bag rows
       for (int e = tid; e <= pg.nb; e += kOneThreads) offs[e] = (int)min(pg.offsets[e], (int64_t)0x7fffffff);
   }
-  if (tid < 256) { htot[tid] = 0; hbef[tid] = 0; }
+  if (tid < 256) { haft[tid] = 0; hbef[tid] = 0; }
   for (int e = tid; e < kOneWaves * 256; e += kOneThreads) (&hrun[0][0])[e] = 0;
   __syncthreads();
   const int bx = blockIdx.x;
@@ -608,19 +610,11 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
         const int d0 = __shfl(km, src, kWave);
         const unsigned long long grp = __ballot(vm && km == d0) & rest;
         const int c = __popcll(grp);
-        if (lane == src) {
-          atomicAdd(&htot[d0], c);
-          if (m < bx) atomicAdd(&hbef[d0], c);
-          else if (m == bx) atomicAdd(&hrun[w][d0], c);
-        }
+        if (lane == src) atomicAdd(m < bx ? &hbef[d0] : (m == bx ? &hrun[w][d0] : &haft[d0]), c);
         rest &= ~grp;
         peel_on = c >= 12;
       }
-      if ((rest >> lane) & 1ull) {
-        atomicAdd(&htot[km], 1);
-        if (m < bx) atomicAdd(&hbef[km], 1);
-        else if (m == bx) atomicAdd(&hrun[w][km], 1);
-      }
+      if ((rest >> lane) & 1ull) atomicAdd(m < bx ? &hbef[km] : (m == bx ? &hrun[w][km] : &haft[km]), 1);
       if (vm && m == bx) { kv = km; idx = ix[m]; tbv = tb[m]; }
     }
   }
@@ -664,12 +658,15 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
   // digit dg = tid (first 256 threads): total, exclusive prefix over digits, first position per wave
   const int dg = tid;
   const bool isd = tid < 256;
-  const int tot = isd ? htot[dg] : 0, bef = isd ? hbef[dg] : 0;
-  const int inc = wave_incl_scan(tot);
-  if (isd && lane == kWave - 1) wt5[w] = inc;
   int mine[kOneWaves];
 #pragma unroll
   for (int k = 0; k < kOneWaves; ++k) mine[k] = isd ? hrun[k][dg] : 0;
+  const int bef = isd ? hbef[dg] : 0;
+  int tot = isd ? bef + haft[dg] : 0;
+#pragma unroll
+  for (int k = 0; k < kOneWaves; ++k) tot += mine[k];
+  const int inc = wave_incl_scan(tot);
+  if (isd && lane == kWave - 1) wt5[w] = inc;
   __syncthreads();
   int wbase = 0;
   if (isd)

@@ -123,11 +123,17 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
     for (int t = 0; t < g.T; ++t) cp[t] = cores[t].data_ptr<float>();
     const size_t wb = ttx_tt_forward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
     Tensor ws = bytes_on(indices, wb);
-    check(ttx_tt_forward_w(&g, (int32_t)B, (int32_t)D, nnz, indices.data_ptr<int64_t>(), rowidx.data_ptr<int64_t>(),
-                           tableidx.data_ptr<int64_t>(), weighted ? psw->data_ptr<float>() : nullptr, cp,
-                           out.data_ptr<float>(), nnz > 0 ? plan.data_ptr() : nullptr, ws.data_ptr(), wb, stream));
+    // a gradient for the weights needs the lookups' rows in backward: d_psw[n] = <d_out[bag(n)], row_n>
+    const bool psw_grad = weighted && psw->requires_grad() && nnz > 0;
+    Tensor rows_keep;
+    if (psw_grad) rows_keep = at::empty({nnz, D}, cores[0].options());
+    check(ttx_tt_forward_wr(&g, (int32_t)B, (int32_t)D, nnz, indices.data_ptr<int64_t>(), rowidx.data_ptr<int64_t>(),
+                            tableidx.data_ptr<int64_t>(), weighted ? psw->data_ptr<float>() : nullptr, cp,
+                            out.data_ptr<float>(), psw_grad ? rows_keep.data_ptr<float>() : nullptr,
+                            nnz > 0 ? plan.data_ptr() : nullptr, ws.data_ptr(), wb, stream));
 
     if (weighted) ctx->saved_data["psw"] = psw->detach();
+    if (psw_grad) ctx->saved_data["rows"] = rows_keep;
     ctx->saved_data["p"] = p;
     ctx->saved_data["q"] = q;
     ctx->saved_data["r"] = r;
@@ -199,6 +205,13 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
                             keep.size() > 3 ? keep[3].data_ptr() : nullptr, ws.data_ptr(), wb, stream));
     if (optim == TTX_OPTIM_DENSE)
       for (int t = 0; t < T; ++t) grads[kHead + nstate + t] = dense[t];
+    if (ctx->saved_data.count("rows")) {  // gradient of the per_sample_weights (argument slot 11)
+      const Tensor rows = ctx->saved_data["rows"].toTensor();
+      Tensor d_psw = at::empty({nnz}, rows.options());
+      check(ttx_psw_backward((int32_t)B, (int32_t)D, nnz, rows.data_ptr<float>(), rowidx.data_ptr<int64_t>(),
+                             tableidx.data_ptr<int64_t>(), go.data_ptr<float>(), d_psw.data_ptr<float>(), stream));
+      grads[11] = d_psw;
+    }
     return grads;
   }
 };
@@ -207,8 +220,7 @@ Tensor lookup(const Tensor& indices, const Tensor& offsets, int64_t num_tables, 
               std::vector<int64_t> q, std::vector<int64_t> r, int64_t optim, double lr, double eps,
               c10::optional<Tensor> hashtbl, c10::optional<Tensor> cache_freq, std::vector<Tensor> state,
               std::vector<Tensor> cores, c10::optional<Tensor> per_sample_weights) {
-  // (the weights are detached: no gradient flows to them)
-  if (per_sample_weights.has_value() && per_sample_weights->defined()) per_sample_weights = per_sample_weights->detach();
+  // (weights that require a gradient get one: d_psw[n] = <d_out[bag(n)], row_n>; the rows are kept for it)
   return TTLookupOp::apply(indices, offsets, num_tables, std::move(p), std::move(q), std::move(r), optim, lr, eps,
                            hashtbl, cache_freq, per_sample_weights, at::TensorList(state), at::TensorList(cores));
 }

@@ -809,6 +809,25 @@ __global__ __launch_bounds__(kGsumThreads) void gsum_kernel(DedupMap M, int B, i
   }
 }
 
+// gradient with respect to nn.EmbeddingBag's per_sample_weights: out[bag] = sum_n w_n row_n  ->  dL/dw_n = <d_out[bag(n)], row_n>.
+// One 16-lane group per lookup (rows are the forward's, kept by ttx_tt_forward_wr).
+__global__ __launch_bounds__(kThreads) void psw_grad_kernel(int N, int B, int D, const float* __restrict__ rows,
+                                                           const int64_t* __restrict__ rowidx,
+                                                           const int64_t* __restrict__ tableidx,
+                                                           const float* __restrict__ dout, float* __restrict__ d_psw) {
+  const int n = blockIdx.x * (kThreads / 16) + threadIdx.x / 16;
+  const int l = threadIdx.x & 15;
+  float acc = 0.f;
+  if (n < N) {
+    const float* r = rows + (size_t)n * D;
+    const float* g = dout + ((size_t)tableidx[n] * B + rowidx[n]) * D;
+    for (int e = l; e < D; e += 16) acc = fmaf(r[e], g[e], acc);
+  }
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 16);
+  if (n < N && l == 0) d_psw[n] = acc;
+}
+
 struct Partials {
   float* pc[TTX_MAX_CORES];  // pc[1] is per CHUNK, the others per lookup
   const float* psw;          // per_sample_weights by lookup (nn.EmbeddingBag), or NULL: the bag gradient of
@@ -1717,6 +1736,14 @@ int ttx_tt_forward_w(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const
                      const int64_t* rowidx, const int64_t* tableidx, const float* psw,
                      const float* const* tt_cores, float* output, const void* plan, void* workspace,
                      size_t workspace_bytes, ttx_stream_t stream) {
+  return ttx_tt_forward_wr(g, B, D, nnz, indices, rowidx, tableidx, psw, tt_cores, output, nullptr, plan, workspace,
+                           workspace_bytes, stream);
+}
+
+int ttx_tt_forward_wr(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const int64_t* indices,
+                      const int64_t* rowidx, const int64_t* tableidx, const float* psw,
+                      const float* const* tt_cores, float* output, float* rows_keep, const void* plan, void* workspace,
+                      size_t workspace_bytes, ttx_stream_t stream) {
   Dims d;
   int rc = make_dims(g, &d);
   if (rc) return rc;
@@ -1743,7 +1770,8 @@ int ttx_tt_forward_w(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const
     if (rc) return rc;
     ws += pb;
   }
-  float* rows = (float*)ws;
+  if (rows_keep && (((uintptr_t)rows_keep) & 15)) TTX_FAIL(TTX_EINVAL, "rows_keep must be 16-byte aligned");
+  float* rows = rows_keep ? rows_keep : (float*)ws;
   rc = run_rows(d, nnz, P, tt_cores, rows, output, nout, st);  // also zeroes `output`
   if (rc) return rc;
   {
@@ -1912,6 +1940,18 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
                        eps, C, S, DW, nslices, (int)nnz);
     TTX_HIP(hipGetLastError());
   }
+  return TTX_OK;
+}
+
+int ttx_psw_backward(int32_t B, int32_t D, int64_t nnz, const float* rows, const int64_t* rowidx,
+                     const int64_t* tableidx, const float* d_output, float* d_psw, ttx_stream_t stream) {
+  (void)hipGetLastError();
+  if (nnz == 0) return TTX_OK;
+  if (B <= 0 || D <= 0 || nnz < 0 || nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "bad B / D / nnz");
+  if (!rows || !rowidx || !tableidx || !d_output || !d_psw) TTX_FAIL(TTX_EINVAL, "NULL input");
+  hipLaunchKernelGGL(psw_grad_kernel, dim3(((int)nnz + kThreads / 16 - 1) / (kThreads / 16)), dim3(kThreads), 0,
+                     (hipStream_t)stream, (int)nnz, B, D, rows, rowidx, tableidx, d_output, d_psw);
+  TTX_HIP(hipGetLastError());
   return TTX_OK;
 }
 

@@ -471,13 +471,14 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         which uses self.warmup, :822,:841.)  int32 indices / offsets are accepted; with
         include_last_offset=False the closing offset (nnz) is appended here."""
         if per_sample_weights is not None:
-            # nn.EmbeddingBag(mode="sum") semantics, forward and the cores' gradients; no gradient to the weights.
-            # Served by the C++ node while the cache is not live (cache rows are gathered unweighted).
+            # nn.EmbeddingBag(mode="sum") semantics: forward, the cores' gradients / fused optimizers and -- if the
+            # weights require it -- their own gradient.  Served by the C++ node while the cache is not live (cache
+            # rows are gathered unweighted).
             if _native_node() is None or not self.warmup or not indices.is_cuda:
                 raise NotImplementedError("per_sample_weights needs ttx_torch.so and a cache that is not live")
             if per_sample_weights.shape != indices.shape:
                 raise ValueError("per_sample_weights must have the shape of indices")
-            per_sample_weights = per_sample_weights.detach().float().contiguous()
+            per_sample_weights = per_sample_weights.float().contiguous()  # (keeps the autograd graph of the weights)
         if indices.dim() != 1 or offsets.dim() != 1:
             raise ValueError("indices and offsets must be 1-D (the 2-D fixed-length form of nn.EmbeddingBag is not supported)")
         indices, offsets = indices.long(), offsets.long()

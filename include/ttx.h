@@ -113,12 +113,23 @@ int ttx_tt_forward(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz,
 
 /* nn.EmbeddingBag's per_sample_weights (not in the reference): lookup n enters its
  * bag scaled by per_sample_weights[n], and its share of the bag gradient is scaled the same way in
- * ttx_tt_backward_w.  NULL = the plain entry point.  (No gradient with respect to the weights.) */
+ * ttx_tt_backward_w.  NULL = the plain entry point. */
 int ttx_tt_forward_w(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz,
                      const int64_t* indices, const int64_t* rowidx, const int64_t* tableidx,
                      const float* per_sample_weights, const float* const* tt_cores,
                      float* output, const void* plan, void* workspace, size_t workspace_bytes,
                      ttx_stream_t stream);
+
+/* ... and with a gradient for the weights: ttx_tt_forward_wr leaves the lookups' rows (unweighted, [nnz, D], 16-byte
+ * aligned) in rows_keep (NULL = ttx_tt_forward_w), and ttx_psw_backward turns them into
+ * d_psw[n] = <d_output[tableidx[n], rowidx[n], :], rows[n, :]>, what autograd gives nn.EmbeddingBag(mode="sum"). */
+int ttx_tt_forward_wr(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz,
+                      const int64_t* indices, const int64_t* rowidx, const int64_t* tableidx,
+                      const float* per_sample_weights, const float* const* tt_cores,
+                      float* output, float* rows_keep, const void* plan, void* workspace,
+                      size_t workspace_bytes, ttx_stream_t stream);
+int ttx_psw_backward(int32_t B, int32_t D, int64_t nnz, const float* rows, const int64_t* rowidx,
+                     const int64_t* tableidx, const float* d_output, float* d_psw, ttx_stream_t stream);
 
 /* decompress rows: rows[n, :] = TT row of indices[n] in table tableidx[n]
  * (tableidx == NULL -> table 0).  This is the contraction alone, the part of

@@ -220,6 +220,17 @@ def test_per_sample_weights_vs_nn_embedding_bag(node, p, q, r):
     ms(t(idx), t(off), per_sample_weights=t(psw)).backward(t(d_out))
     for k in range(len(p)):
         assert_close(ms.tt_cores[k].detach().cpu().numpy(), cores[k] - LR * ref_cores[k].grad.cpu().numpy(), f"weighted sgd{k}")
+    # the weights' own gradient (d_psw[n] = <d_out[bag(n)], row_n>), dense and fused-optimizer modes
+    w_ref = t(psw).clone().requires_grad_(True)
+    full2 = ops.tt_matrix_to_full(p, q, [1] + r + [1], [t(c) for c in cores], [1, 0, 2, 3])
+    torch.nn.functional.embedding_bag(t(idx), full2, t(off), mode="sum", per_sample_weights=w_ref,
+                                      include_last_offset=True).backward(t(d_out))
+    for extra in (dict(sparse=False), dict(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=LR)):
+        mw = fresh(**extra)
+        w = t(psw).clone().requires_grad_(True)
+        mw(t(idx), t(off), per_sample_weights=w).backward(t(d_out))
+        assert w.grad is not None, "per_sample_weights that require a gradient must get one"
+        assert_close(w.grad.cpu().numpy(), w_ref.grad.cpu().numpy(), f"gradient of per_sample_weights ({extra})")
 
 
 @pytest.mark.parametrize("optim", ["sgd", "adagrad"])
