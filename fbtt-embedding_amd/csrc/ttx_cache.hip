@@ -229,6 +229,79 @@ __global__ __launch_bounds__(kCT) void cache_forward_kernel(int N, int D, const 
   }
 }
 
+// The same sums for D % 4 == 0, wave64-native (the 32-lane-group kernel above keeps 1 group in 20 busy at 20 lookups
+// per bag: the others are not run heads and leave).  A wave owns 64 consecutive cached lookups: one coalesced load of
+// their bag rows and cache locations, run heads by one ballot, and the wave's four 16-lane groups take the runs
+// round-robin -- a row of 64 floats is ONE 16-byte load per lane, a run is summed in index order by one group with
+// eight rows in flight.  The last run of a span may go on behind it (its group keeps walking); a run that began in
+// the previous span belongs to that span's wave.  Locations travel through LDS (a cross-lane read would need the
+// source lane active: the groups' loops diverge).
+__global__ __launch_bounds__(kCT) void cache_forward4_kernel(int N, int D4, const int* __restrict__ skip_dev,
+                                                            const int64_t* __restrict__ rowidx,
+                                                            const int32_t* __restrict__ loc,
+                                                            const float4* __restrict__ w, float4* out) {
+  __shared__ unsigned char hpos[kCT / kWave][kWave];
+  __shared__ int lloc[kCT / kWave][kWave];
+  __shared__ int lrow[kCT / kWave][kWave];
+  const int wv = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  if (skip_dev) { const int k = max(0, min(N, *skip_dev)); N -= k; rowidx += k; loc += k; }
+  const int n0 = (blockIdx.x * (kCT / kWave) + wv) * kWave;
+  if (n0 >= N) return;  // (wave-uniform)
+  const int n = n0 + lane;
+  const int r = n < N ? (int)rowidx[n] : -1;
+  lloc[wv][lane] = n < N ? loc[n] : 0;
+  int rprev = __shfl_up(r, 1, kWave);
+  if (lane == 0) rprev = n0 > 0 ? (int)rowidx[n0 - 1] : -1;
+  const bool head = n < N && (n == 0 || rprev != r);
+  const unsigned long long heads = __ballot(head);
+  if (head) {
+    const int k = __popcll(heads & ((1ull << lane) - 1ull));
+    hpos[wv][k] = (unsigned char)lane;
+    lrow[wv][k] = r;
+  }
+  const int nheads = __popcll(heads);
+  const int g = lane >> 4, l = lane & 15, sh = lane & 48;
+  for (int k = g; k < nheads; k += 4) {
+    const int pos = hpos[wv][k];
+    const int hn = n0 + pos;
+    const int row = lrow[wv][k];
+    int sl;
+    if (k + 1 < nheads) {
+      sl = hpos[wv][k + 1] - pos;
+    } else {  // the span's last run may go on behind it: 16 candidates per ballot (one group gets here)
+      sl = min(N, n0 + kWave) - hn;
+      if (hn + sl < N)
+        for (;;) {
+          const int c = hn + sl + l;
+          const bool same = c < N && (int)rowidx[c] == row;
+          const unsigned m = (unsigned)(__ballot(!same) >> sh) & 0xffffu;
+          if (m) { sl += __builtin_ctz(m); break; }
+          sl += 16;
+        }
+    }
+    const int inspan = kWave - pos;  // lookups of the run whose location sits in LDS
+    float4* o = out + (size_t)row * D4;
+    for (int e = l; e < D4; e += 16) {
+      float4 acc = o[e];
+      for (int j0 = 0; j0 < sl; j0 += 8) {
+        int lc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u;
+          lc[u] = j < sl ? (j < inspan ? lloc[wv][pos + j] : loc[hn + j]) : -1;
+        }
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = lc[u] >= 0 ? w[(size_t)lc[u] * D4 + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j0 + u < sl) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      }
+      o[e] = acc;
+    }
+  }
+}
+
 // cache_backward_sgd_kernel cu:1574-1621 / dense cu:1659-1697: hardware fp32
 // atomic add (the same row can be hit from several bags).  scale = -lr (SGD)
 // or +1 (dense gradient).
@@ -619,6 +692,10 @@ int ttx_preprocess_indices_async(int64_t nnz, const int64_t* colidx, int64_t nb,
   return TTX_OK;
 }
 
+// (A/B knob of scripts/bench_cache.py: 1 = the 32-lane-group kernel for every D)
+static int g_cache_fwd_lookup_groups = 0;
+int ttx_debug_cache_fwd(int32_t lookup_groups) { g_cache_fwd_lookup_groups = lookup_groups; return TTX_OK; }
+
 int ttx_cache_forward(int32_t B, int64_t nnz, const int32_t* loc, const int64_t* rowidx, int32_t D,
                       const float* cache_weight, float* output, ttx_stream_t stream) {
   return ttx_cache_forward_n(B, nnz, nullptr, loc, rowidx, D, cache_weight, output, stream);
@@ -632,8 +709,12 @@ int ttx_cache_forward_n(int32_t B, int64_t nnz, const int32_t* skip_dev, const i
   if (nnz == 0) return TTX_OK;
   if (!loc || !rowidx || !cache_weight || !output) TTX_FAIL(TTX_EINVAL, "NULL input");
   ProfScope ps(TTX_PROF_CACHE_FWD, (hipStream_t)stream);
-  hipLaunchKernelGGL(cache_forward_kernel, dim3((unsigned)((nnz + kCT / 32 - 1) / (kCT / 32))), dim3(kCT), 0,
-                     (hipStream_t)stream, (int)nnz, D, skip_dev, rowidx, loc, cache_weight, output);
+  if (D % 4 == 0 && ((((uintptr_t)cache_weight) | ((uintptr_t)output)) & 15) == 0 && !g_cache_fwd_lookup_groups)
+    hipLaunchKernelGGL(cache_forward4_kernel, dim3((unsigned)((nnz + kCT - 1) / kCT)), dim3(kCT), 0, (hipStream_t)stream,
+                       (int)nnz, D / 4, skip_dev, rowidx, loc, (const float4*)cache_weight, (float4*)output);
+  else
+    hipLaunchKernelGGL(cache_forward_kernel, dim3((unsigned)((nnz + kCT / 32 - 1) / (kCT / 32))), dim3(kCT), 0,
+                       (hipStream_t)stream, (int)nnz, D, skip_dev, rowidx, loc, cache_weight, output);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }

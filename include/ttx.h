@@ -377,6 +377,8 @@ int ttx_set_chunk(int32_t indices_per_chunk);
 /* ablation knob (scripts/ablate.py only): bit mask of kernel phases to skip;
  * results are INVALID while it is non-zero.  0 = normal operation. */
 int ttx_debug_skip(int32_t mask);
+/* A/B knob (scripts/bench_cache.py only): 1 = ttx_cache_forward uses the one-group-per-lookup kernel for every D */
+int ttx_debug_cache_fwd(int32_t lookup_groups);
 /* debug (scripts/phase_times.py only): device buffer receiving 16 int64 wall-clock
  * stamps per backward work-group; NULL (default) = off. */
 int ttx_debug_stamps(void* device_buffer);

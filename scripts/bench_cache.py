@@ -27,8 +27,14 @@ def timed(fn, iters=20):
 
 
 out = []
+# `--only NNZ,ROWS`: one configuration (so that a rocprofv3 --stats average over the run belongs to one size)
+only = None
+if "--only" in sys.argv:
+    only = tuple(int(x) for x in sys.argv[sys.argv.index("--only") + 1].split(","))
 for nnz in (10240, 1 << 20):
     for cache_rows in (1 << 18, 1 << 22):
+        if only and (nnz, cache_rows) != only:
+            continue
         g = torch.Generator(device="cpu").manual_seed(1)
         B = nnz // L
         nnz = B * L  # whole bags
@@ -38,6 +44,9 @@ for nnz in (10240, 1 << 20):
         outp = torch.zeros(B, D, device=dev)
         grad = torch.rand(B, D, device=dev)
         t_f = timed(lambda: E.cache_forward(B, nnz, loc, rowidx, w, outp))
+        E.lib().ttx_debug_cache_fwd(1)
+        t_f_old = timed(lambda: E.cache_forward(B, nnz, loc, rowidx, w, outp))
+        E.lib().ttx_debug_cache_fwd(0)
         t_b = timed(lambda: E.cache_backward_sgd(nnz, grad, loc, rowidx, 0.0, w))
         H = 1 << 22
         idx = torch.randint(0, 11_000_000, (nnz,), generator=g, dtype=torch.int64).to(dev)
@@ -49,6 +58,7 @@ for nnz in (10240, 1 << 20):
         t_l = timed(lambda: E.preprocess_indices_sync(idx, off, 1, False, ht, st))  # incl. the host read-back
         rec = {"nnz": nnz, "cache_rows": cache_rows, "cache_MiB": cache_rows * D * 4 >> 20}
         for name, t, bytes_ in (("gather_fwd", t_f, nnz * (4 * D + 12) + B * 4 * D),
+                                ("gather_fwd_one_group_per_lookup", t_f_old, nnz * (4 * D + 12) + B * 4 * D),
                                 ("scatter_sgd_bwd", t_b, nnz * (2 * 4 * D + 12) + B * 4 * D),
                                 ("hash_update", t_u, nnz * 24), ("lookup_partition_sync", t_l, nnz * 25 + nnz * 3 * 20)):
             gbs = bytes_ / t / 1e9
