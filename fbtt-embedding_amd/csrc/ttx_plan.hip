@@ -546,6 +546,9 @@ struct Prologue {
   int64_t* hashtbl;
   int64_t* cache_freq;
 };
+#ifndef TTX_PLAN_XWG
+#define TTX_PLAN_XWG 1
+#endif
 constexpr int kOneThreads = 1024;                 // 16 waves: the histogram of all N keys is 4x shorter per thread
 constexpr int kOneWaves = kOneThreads / kWave;
 template <bool PRO>
@@ -678,7 +681,9 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
     for (int k = 0; k < kOneWaves; ++k) { hrun[k][dg] = b; b += mine[k]; }
   }
   __syncthreads();
-  if (blockIdx.x == 0) finish_single_pass(d, t, dg, tot, dbase, N, PRO || rowidx != nullptr, P, wt5);
+  // offsets / chunk list: by an EXTRA work-group per core (the last of the grid, whose window lies behind the batch), so
+  // that no work-group has both the list and 1024 positions to scatter on its critical path
+  if (blockIdx.x == gridDim.x - 1) finish_single_pass(d, t, dg, tot, dbase, N, PRO || rowidx != nullptr, P, wt5);
   // rank + scatter this wave's 64 positions
   if (h_lead) {  // second half of the frequency update: count, or keep probing (hashtbl_cuda_utils.cuh:102-133)
     for (int pr = 0;; ++pr) {
@@ -1321,7 +1326,7 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
     }
   }
   if (maxp == 1 && N <= kOneMaxN && !d.tab) {
-    hipLaunchKernelGGL(mb_single_kernel<false>, dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit), d.T),
+    hipLaunchKernelGGL(mb_single_kernel<false>, dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit) + TTX_PLAN_XWG, d.T),
                        dim3(kOneThreads), 0, stream, d, N, n_dev, indices, tableidx, rowidx, P, Prologue{});
     TTX_HIP(hipGetLastError());
     return TTX_OK;
@@ -1605,7 +1610,7 @@ bool prologue_fusable(const Dims& d, long long nnz, long long nb) {
 
 int prologue_launch(const Dims& d, int N, const int64_t* indices, const Prologue& pg, const Plan& P, hipStream_t stream) {
   ProfScope ps(TTX_PROF_PLAN, stream);
-  hipLaunchKernelGGL(mb_single_kernel<true>, dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit), d.T),
+  hipLaunchKernelGGL(mb_single_kernel<true>, dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit) + TTX_PLAN_XWG, d.T),
                      dim3(kOneThreads), 0, stream, d, N, (const int*)nullptr, indices, nullptr, nullptr, P, pg);
   TTX_HIP(hipGetLastError());
   return TTX_OK;

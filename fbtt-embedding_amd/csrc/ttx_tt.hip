@@ -726,7 +726,7 @@ __global__ __launch_bounds__(kThreads) void pool_gather_kernel(int N, int B, int
 // dealt round-robin over the work-groups (the map orders pairs by key, so a Zipf stream's hot rows 1, 2, 3, .. are
 // neighbours: pair u goes to work-group u % gridDim).  A group's lanes fetch 16 occurrences' bag rows at once and
 // keep 16 gradient-row loads in flight.
-constexpr int kGsumCoop = 64;
+constexpr int kGsumCoop = 16;
 constexpr int kGsumThreads = 1024;
 constexpr int kGsumGroups = kGsumThreads / 16;
 template <typename V>

@@ -10,7 +10,7 @@ for W in "$@"; do
       --repeats 1 --no-cpu-baseline --no-graph ${KPROF_ARGS:-} > "$OUT/$W.log" 2>&1
   cd "$REPO"
   F=$(find "$OUT/$W" -name "*kernel_stats.csv" | head -1)
-  { echo "## $W"; python scripts/stats_csv_to_md.py "$F" "$W" | grep -E "ttx::|^\| kernel|^\|---"; tail -1 "$OUT/$W.log" | python -c "
+  { echo "## $W"; python scripts/stats_csv_to_md.py "$F" "$W" | grep -E "ttx::|^\| kernel|^\|---"; grep "^{\"metric" "$OUT/$W.log" | tail -1 | python -c "
 import json,sys
 try:
     j=json.loads(sys.stdin.read()); print('eager ms/step', j['eager_ms_per_step'], '| kernel_us (event brackets)', j['kernel_us'])
