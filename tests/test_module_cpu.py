@@ -318,32 +318,3 @@ def test_geometry_struct_layout_matches_the_header(tmp_path):
     g = E._geom(3, [[4, 5, 5], [8, 9, 10], [4, 5, 5]], [2, 3, 2], [1, 4, 5, 1])
     assert g.num_tables == 3 and g.T == 3 and [g.p_tables[i] for i in range(9)] == [4, 5, 5, 8, 9, 10, 4, 5, 5]
     assert not bool(E._geom(3, [4, 5, 5], [2, 3, 2], [1, 4, 5, 1]).p_tables)
-
-
-def test_dedup_wrapper_equals_plain_module(ops):
-    """ttx_dedup.DedupTTEmbeddingBag: every distinct index contracted once, rows gathered and pooled by torch --
-    same outputs and the same core gradients as the plain module on a batch full of repeats"""
-    import ttx_dedup
-
-    p, q, r, B = [4, 5, 5], [2, 3, 2], [4, 5], 30
-    E_, D = 100, 12
-    rs = np.random.RandomState(2)
-    for include_last in (True, False):
-        kw = dict(sparse=False, use_cache=False, weight_dist="uniform", device="cpu", include_last_offset=include_last)
-        plain, inner = ops.TTEmbeddingBag(E_, D, r, p, q, **kw), ops.TTEmbeddingBag(E_, D, r, p, q, **kw)
-        with torch.no_grad():
-            for a, b in zip(inner.tt_cores, plain.tt_cores):
-                a.copy_(b)
-        wrapped = ttx_dedup.DedupTTEmbeddingBag(inner)
-        lens = rs.randint(0, 9, size=B)
-        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        idx = torch.from_numpy(np.where(rs.rand(int(off[-1])) < 0.6, 7, rs.randint(0, E_, size=int(off[-1]))).astype(np.int64))
-        off_t = torch.from_numpy(off if include_last else off[:-1])
-        g = torch.from_numpy(rs.rand(B, D).astype(np.float32))
-        o1, o2 = plain(idx, off_t), wrapped(idx, off_t)
-        assert wrapped.last_unique < idx.numel()
-        assert_close(o2.detach().numpy(), o1.detach().numpy(), "dedup forward")
-        o1.backward(g)
-        o2.backward(g)
-        for k in range(3):
-            assert_close(inner.tt_cores[k].grad.numpy(), plain.tt_cores[k].grad.numpy(), f"dedup grad{k}", rtol=5e-5)

@@ -380,36 +380,6 @@ def test_var_table_batched_lookup(node, optimizer, shape):
                 assert_close(sv[k].cpu().numpy(), one.optimizer_state[c][0].cpu().numpy(), f"table {k} state{c}")
 
 
-def test_dedup_wrapper_fused_sgd(node):
-    """ttx_dedup.DedupTTEmbeddingBag on the GPU: a Zipf batch (a third of it distinct), fused-SGD steps through the
-    wrapper leave the cores where the plain module leaves them"""
-    import tt_embeddings_ops as ops
-    import ttx_dedup
-
-    p, q, r = [20, 22, 25], [4, 4, 4], [16, 16]
-    E_, D, B = 20 * 22 * 25, 64, 256
-    kw = dict(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, use_cache=False, weight_dist="uniform", device=DEV)
-    plain, inner = ops.TTEmbeddingBag(E_, D, r, p, q, **kw), ops.TTEmbeddingBag(E_, D, r, p, q, **kw)
-    with torch.no_grad():
-        for a, b in zip(inner.tt_cores, plain.tt_cores):
-            a.copy_(b)
-    wrapped = ttx_dedup.DedupTTEmbeddingBag(inner)
-    rs = np.random.RandomState(4)
-    for step in range(2):
-        lens = rs.randint(0, 30, size=B)
-        off = t(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64))
-        idx = t(((rs.zipf(1.2, size=int(lens.sum())) - 1) % E_).astype(np.int64))
-        g = t((rs.rand(B, D) * 0.1).astype(np.float32))
-        o1, o2 = plain(idx, off), wrapped(idx, off)
-        assert wrapped.last_unique < 0.6 * idx.numel()
-        assert_close(o2.detach().cpu().numpy(), o1.detach().cpu().numpy(), f"step {step} dedup forward", rtol=5e-5)
-        o1.backward(g)
-        o2.backward(g)
-    for k in range(3):
-        assert_close(inner.tt_cores[k].detach().cpu().numpy(), plain.tt_cores[k].detach().cpu().numpy(),
-                     f"core{k} after two steps", rtol=1e-4, atol_scale=1e-5)
-
-
 @pytest.mark.parametrize("streams", [False, True])
 def test_mixed_cardinality_tables(node, streams):
     """ttx_mixed.MixedTTEmbeddingBag: five tables of three different TT row shapes ->
