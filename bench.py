@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--no-cache", action="store_true", help="use_cache=False (skip the hash-table frequency update)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager Python path only (no hipGraph replay)")
+    ap.add_argument("--prefetch", default="round", choices=["round", "next", "none"],
+                    help="captured round: lookup prologues of the round's batches in one launch up front (round, default), "
+                         "of the next batch on a side stream under the current backward (next), or in line (none)")
     ap.add_argument("--optimizer", default=None, choices=["sgd", "adagrad"])
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--run-baseline", action="store_true",
@@ -320,6 +323,12 @@ def main():
             graph_txt = "; timed as hipGraph replay of the captured module fwd+bwd steps (one graph per round of the 10 request batches)"
             if "rccl" in mode:
                 graph_txt += "; all-to-all exchanges issued on RCCL directly, inside the graph"
+            if "prefetch-round" in mode:
+                graph_txt += ("; the lookup prologues (frequency update, bag rows, plan) of the round's 10 batches are enqueued "
+                              "up front in one launch (module.prefetch_many), every replay plans them again")
+            elif "prefetch-next" in mode:
+                graph_txt += ("; the lookup prologue of batch k+1 runs on a side stream under the backward of batch k "
+                              "(module.prefetch), captured as a forked branch")
         line = {
             "metric": ("fwd+bwd GFLOPS (true algorithmic: 3 x fwd FLOP / time), TT-EmbeddingBag E=11M "
                        f"D={D} ranks={RANKS} nnz={nnz_step_total // world if not cfg5 else nnz_step_total}"),
@@ -334,6 +343,10 @@ def main():
             "repeats": len(regions),
             "spread": {"ms_per_step_min": round(min(regions) / args.steps * 1e3, 4), "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
                        "region_ms": [round(r * 1e3, 3) for r in regions]},
+            "no_prefetch": (None if not plain_regions else
+                            {"ms_per_step": round(statistics.median(plain_regions) / args.steps * 1e3, 4),
+                             "value": round(3.0 * fl_fwd * nnz_step_total / (statistics.median(plain_regions) / args.steps) / 1e9, 2),
+                             "what": "the same captured round with every step's prologue in line (no side stream)"}),
             "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
             "eager_value": round(3.0 * fl_fwd * nnz_step_total / (eager_elapsed / args.steps) / 1e9, 2),
             "us_per_nnz": round(elapsed / args.steps / nnz_step_total * 1e6, 5),
@@ -358,7 +371,7 @@ def main():
     # the remainder, so exactly K steps run either way.  N > 1: the exchanges go through RCCL directly
     # (ttx_sharded.DirectExchange: current stream, capturable; torch.distributed's own collectives are not).
     # Falls back to the eager timing if capture is unavailable.
-    mode, regions = "eager", None
+    mode, regions, plain_regions = "eager", None, None
     can_graph = not args.no_graph and (not wl["populate"] or ops._native_node() is not None)
     if sharded:
         can_graph = can_graph and ops._native_node() is not None and not os.environ.get("TTX_NO_DIRECT_RCCL")
@@ -382,9 +395,23 @@ def main():
                 mod.enable_direct_exchange()
                 eager_steps(5)
                 sync()
+            # The captured round plans its batches ahead where the module supports it (cache not live, one GPU): the lookup
+            # prologues of the round's batches -- frequency update, bag rows, lookup plan: index work that depends on a
+            # batch's indices only, not on the cores -- are enqueued up front in ONE launch (module.prefetch_many ->
+            # ttx_lookup_prologue_multi; a prologue occupies 30 of the 256 CUs for ~12 us of dependent loads, ten of them
+            # take about as long as one), the steps' forward / backward follow without them.  Same kernels' work, same
+            # results (bit-identical, tested); every replay plans its ten batches again, inside the timed region.  The
+            # plain round (every step's prologue in line) is timed beside it (`no_prefetch`).  `--prefetch next`: the
+            # prologue of batch k+1 on a side stream under the backward of batch k instead (a forked branch in the graph:
+            # measured slower than in line at this step size, the cross-stream edges cost more than the overlap saves).
+            pipelined = (not sharded) and args.prefetch != "none" and mod.prefetch(*reqs[0])
+            if pipelined:
+                mod._prefetched.clear()
+                mk = ttx_graph.planned_round if args.prefetch == "round" else ttx_graph.pipelined_round
+                round_fn = mk(mod, reqs, lambda out, k: out.backward(grad))
             E.profile_reset()
             E.profile_mask(1 << E.PROF_BWD)  # the event pairs around the backward kernel become graph nodes
-            g_round = ttx_graph.GraphedRound(step, reqs, warmup=3)
+            g_round = ttx_graph.GraphedRound(round_fn, [()], warmup=3) if pipelined else ttx_graph.GraphedRound(step, reqs, warmup=3)
             E.profile_mask(0)
             singles = [ttx_graph.GraphedRound(step, [b], warmup=0) for b in reqs[:args.steps % iters]]
 
@@ -398,7 +425,13 @@ def main():
                 dog.start()
             graph_steps(max(args.warmup, iters))
             regions = [timed(graph_steps, args.steps) for _ in range(max(1, args.repeats))]
-            mode = "hipgraph+direct-rccl" if sharded else "hipgraph"
+            mode = "hipgraph+direct-rccl" if sharded else (f"hipgraph+prefetch-{args.prefetch}" if pipelined else "hipgraph")
+            if pipelined:  # the same round without the overlap, for the record
+                g_plain = ttx_graph.GraphedRound(step, reqs, warmup=1)
+                pipelined_round_replay, g_round = g_round, g_plain
+                graph_steps(iters)
+                plain_regions = [timed(graph_steps, args.steps) for _ in range(max(1, min(3, args.repeats)))]
+                g_round = pipelined_round_replay
             # the captured event pairs hold the times of the LAST replay of each of the round's steps: the live
             # duration of the dominant kernel inside the timed region, without the host's launch latency that an
             # eager event bracket picks up when the host, not the GPU, is the bottleneck

@@ -456,19 +456,25 @@ __global__ __launch_bounds__(kMbThreads) void mb_count_kernel(
     for (int e = lane; e < 256; e += kWave) A.cnt[((size_t)t * A.U + u) * 256 + e] = hist[w][e];
 }
 
+template <typename T>
+__device__ __forceinline__ T* shifted(T* p, long long bytes) { return (T*)((char*)p + bytes); }
+
 // Single 8-bit pass (every S[t] <= 256): digit == slice id, so the digit prefix IS the slice
 // offset table and the pivot's chunk list follows from the digit totals -- what mb_finish would
 // recompute from the sorted keys.  One 256-thread work-group per core, thread = digit dg;
 // tot = lookups of the slice, dbase = its first position.  wt5: LDS int[kMbUnits + 1].
 __device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg, int tot, int dbase, int N,
-                                                   bool has_row, const Plan& P, int* wt5) {
+                                                   bool has_row, const Plan& P, int* wt5, long long psh = 0) {
+  int* const hdr = (int*)((char*)P.hdr + psh);
+  int* const chunk_off = (int*)((char*)P.chunk_off + psh);
+  int4* const chunk_rec = (int4*)((char*)P.chunk_rec + psh);
   const int lane = lane_id(), w = threadIdx.x / kWave;
   const int S = d.S[t];
   if (t != 1) {
     const int nhot = __syncthreads_count(dg < S && tot > 2 * kSegThin);  // (reduce_apply's hot slices, ttx_internal.h)
-    if (dg == 0) P.hdr[8 + t] = nhot;
-    if (dg <= S) P.off[t][dg] = (dg == S) ? N : dbase;
-    if (dg == 0 && S == 256) P.off[t][256] = N;
+    if (dg == 0) hdr[8 + t] = nhot;
+    if (dg <= S) shifted(P.off[t], psh)[dg] = (dg == S) ? N : dbase;
+    if (dg == 0 && S == 256) shifted(P.off[t], psh)[256] = N;
     return;
   }
   // chunk SLOTS (where a chunk's d core_1 partial lives) are contiguous per slice; the DISPATCH
@@ -481,7 +487,7 @@ __device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg,
   const int pr = dg < S ? tot - nf * MC : 0;       // lookups in the partial chunk
   const int np = pr ? 1 : 0;
   const int nhot = __syncthreads_count(nf + np > kHotRowsPivot);
-  if (dg == 0) P.hdr[8 + 1] = nhot;
+  if (dg == 0) hdr[8 + 1] = nhot;
   const int packed = (nf << 12) | np;              // slices <= 256: np sums stay < 4096
   const int cinc = wave_incl_scan(packed);
   __syncthreads();
@@ -500,11 +506,11 @@ __device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg,
   // search over the full-chunk prefix
   __shared__ int cf_base[257], cf_pos[256], cf_slot[256];
   if (dg < S) {
-    P.chunk_off[dg] = ex;
+    chunk_off[dg] = ex;
     cf_base[dg] = fbase;
     cf_pos[dg] = dbase;
     cf_slot[dg] = ex;
-    if (np) P.chunk_rec[ftot + pbase] = make_int4(dg, dbase + nf * MC, pr, ex + nf);
+    if (np) chunk_rec[ftot + pbase] = make_int4(dg, dbase + nf * MC, pr, ex + nf);
   }
   if (dg == 0) cf_base[S] = ftot;
   __syncthreads();
@@ -515,15 +521,15 @@ __device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg,
       if (cf_base[mid] <= c) lo = mid; else hi = mid;
     }
     const int j = c - cf_base[lo];
-    P.chunk_rec[c] = make_int4(lo, cf_pos[lo] + j * MC, MC, cf_slot[lo] + j);
+    chunk_rec[c] = make_int4(lo, cf_pos[lo] + j * MC, MC, cf_slot[lo] + j);
   }
-  for (int cc = ctot + dg; cc < P.max_chunks; cc += blockDim.x) P.chunk_rec[cc] = make_int4(0, 0, 0, 0);
+  for (int cc = ctot + dg; cc < P.max_chunks; cc += blockDim.x) chunk_rec[cc] = make_int4(0, 0, 0, 0);
   if (dg == 0) {
-    P.chunk_off[S] = ctot;
-    P.hdr[0] = ctot;
-    P.hdr[1] = MC;
-    P.hdr[2] = N;
-    P.hdr[3] = has_row ? 1 : 0;
+    chunk_off[S] = ctot;
+    hdr[0] = ctot;
+    hdr[1] = MC;
+    hdr[2] = N;
+    hdr[3] = has_row ? 1 : 0;
   }
 }
 
@@ -546,6 +552,15 @@ struct Prologue {
   int64_t* hashtbl;
   int64_t* cache_freq;
 };
+// Several batches in ONE launch (ttx_lookup_prologue_multi: a round of training batches planned ahead): grid.z = batch.
+// Batch z reads its own indices / offsets and writes rowidx / tableidx / plan at a constant stride behind batch 0's.
+constexpr int kMaxMulti = 16;
+struct ProBatch {
+  const int64_t* indices[kMaxMulti];
+  const int64_t* offsets[kMaxMulti];
+  long long out_stride;    // elements between the batches' rowidx / tableidx arrays
+  long long plan_stride;   // bytes between the batches' plan buffers
+};
 #ifndef TTX_PLAN_XWG
 #define TTX_PLAN_XWG 1
 #endif
@@ -554,7 +569,24 @@ constexpr int kOneWaves = kOneThreads / kWave;
 template <bool PRO>
 __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
     Dims d, int Nmax, const int* __restrict__ n_dev, const int64_t* __restrict__ indices,
-    const int64_t* __restrict__ tableidx, const int64_t* __restrict__ rowidx, Plan P, Prologue pg) {
+    const int64_t* __restrict__ tableidx, const int64_t* __restrict__ rowidx, Plan P, Prologue pg, ProBatch mb) {
+  if (PRO && blockIdx.z > 0) {  // (work-group-uniform) a later batch of a multi-batch launch
+    const int z = blockIdx.z;
+    // (a switch over constant subscripts: a run-time subscript into the by-value struct sends it -- and the kernel's other
+    //  arguments with it -- through scratch memory: measured +10 us on every launch, multi-batch or not)
+    switch (z) {
+#define TTX_PICK(K) case K: indices = mb.indices[K]; pg.offsets = mb.offsets[K]; break;
+      TTX_PICK(1) TTX_PICK(2) TTX_PICK(3) TTX_PICK(4) TTX_PICK(5) TTX_PICK(6) TTX_PICK(7) TTX_PICK(8)
+      TTX_PICK(9) TTX_PICK(10) TTX_PICK(11) TTX_PICK(12) TTX_PICK(13) TTX_PICK(14) TTX_PICK(15)
+#undef TTX_PICK
+      default: break;
+    }
+    pg.rowidx += (long long)z * mb.out_stride;
+    pg.tableidx += (long long)z * mb.out_stride;
+  }
+  // batch z's plan lies z * plan_stride bytes behind batch 0's: applied where a pointer is used (modifying the by-value
+  // Plan would make it a local copy, and its run-time subscripts P.perm[t] .. would go through scratch memory)
+  const long long psh = PRO ? (long long)blockIdx.z * mb.plan_stride : 0;
   // (a ballot-grouped histogram -- wave_match8 per batch, the group's first lane adding the group size to a
   //  wave-private row -- was measured against these LDS atomics: 17.5 vs 12.5 us uniform, 30.7 vs 28.3 us on a
   //  skewed stream: the ~60 VALU instructions of a match cost more than the atomics' conflicts)
@@ -683,7 +715,7 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
   __syncthreads();
   // offsets / chunk list: by an EXTRA work-group per core (the last of the grid, whose window lies behind the batch), so
   // that no work-group has both the list and 1024 positions to scatter on its critical path
-  if (blockIdx.x == gridDim.x - 1) finish_single_pass(d, t, dg, tot, dbase, N, PRO || rowidx != nullptr, P, wt5);
+  if (blockIdx.x == gridDim.x - 1) finish_single_pass(d, t, dg, tot, dbase, N, PRO || rowidx != nullptr, P, wt5, psh);
   // rank + scatter this wave's 64 positions
   if (h_lead) {  // second half of the frequency update: count, or keep probing (hashtbl_cuda_utils.cuh:102-133)
     for (int pr = 0;; ++pr) {
@@ -700,14 +732,14 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
   if (valid) {
     const int pos = hrun[w][kv] + __popcll(peers & lanemask_lt());
     if (t != 1) {
-      P.perm[t][pos] = i;
-      P.ipos[t][i] = pos;
+      shifted(P.perm[t], psh)[pos] = i;
+      shifted(P.ipos[t], psh)[i] = pos;
     } else {
       const int s0 = tbv * d.p[0] + decode_core(d, 0, idx);
       const int s2 = d.T > 2 ? tbv * d.p[2] + decode_core(d, 2, idx) : 0;
       const int s3 = d.T > 3 ? tbv * d.p[3] + decode_core(d, 3, idx) : 0;
-      P.lrec[pos] = make_int4(i, s0, s2, s3);
-      if (PRO) P.lrow[pos] = row;
+      shifted(P.lrec, psh)[pos] = make_int4(i, s0, s2, s3);
+      if (PRO) shifted(P.lrow, psh)[pos] = row;
       else if (rowidx) P.lrow[pos] = (int)rowidx[i];
     }
   }
@@ -1327,7 +1359,7 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
   }
   if (maxp == 1 && N <= kOneMaxN && !d.tab) {
     hipLaunchKernelGGL(mb_single_kernel<false>, dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit) + TTX_PLAN_XWG, d.T),
-                       dim3(kOneThreads), 0, stream, d, N, n_dev, indices, tableidx, rowidx, P, Prologue{});
+                       dim3(kOneThreads), 0, stream, d, N, n_dev, indices, tableidx, rowidx, P, Prologue{}, ProBatch{});
     TTX_HIP(hipGetLastError());
     return TTX_OK;
   }
@@ -1608,10 +1640,13 @@ bool prologue_fusable(const Dims& d, long long nnz, long long nb) {
   return true;
 }
 
-int prologue_launch(const Dims& d, int N, const int64_t* indices, const Prologue& pg, const Plan& P, hipStream_t stream) {
+int prologue_launch(const Dims& d, int N, const int64_t* indices, const Prologue& pg, const Plan& P, hipStream_t stream,
+                    const ProBatch* mb = nullptr, int nbatch = 1) {
   ProfScope ps(TTX_PROF_PLAN, stream);
-  hipLaunchKernelGGL(mb_single_kernel<true>, dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit) + TTX_PLAN_XWG, d.T),
-                     dim3(kOneThreads), 0, stream, d, N, (const int*)nullptr, indices, nullptr, nullptr, P, pg);
+  hipLaunchKernelGGL(mb_single_kernel<true>,
+                     dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit) + TTX_PLAN_XWG, d.T, nbatch),
+                     dim3(kOneThreads), 0, stream, d, N, (const int*)nullptr, indices, nullptr, nullptr, P, pg,
+                     mb ? *mb : ProBatch{});
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }
@@ -1647,6 +1682,47 @@ int ttx_lookup_prologue(const ttx_geom* g, int64_t nnz, const int64_t* colidx, i
   // (the bags are table-major by construction here: the plan may sort table groups on their own)
   return ttx::plan_build(d, nnz, colidx, tableidx, rowidx, P, (hipStream_t)stream, nullptr, offsets,
                          (int)(nb / d.num_tables));
+}
+
+int ttx_lookup_prologue_multi(const ttx_geom* g, int32_t nbatch, int64_t nnz, const int64_t* const* colidx_host,
+                              int64_t nb, const int64_t* const* offsets_host, int64_t H, int64_t* upd_hashtbl,
+                              int64_t* upd_cache_freq, int64_t* rowidx, int64_t* tableidx, void* plans,
+                              size_t plan_stride, ttx_stream_t stream) {
+  ttx::Dims d;
+  int rc = ttx::make_dims(g, &d);
+  if (rc != TTX_OK) return rc;
+  if (nbatch <= 0 || nnz == 0) return TTX_OK;
+  if (!colidx_host || !offsets_host || !rowidx || !tableidx || !plans) TTX_FAIL(TTX_EINVAL, "NULL input");
+  if (nb <= 0 || nb % d.num_tables != 0) TTX_FAIL(TTX_EINVAL, "offsets must hold num_tables * B + 1 entries");
+  const size_t pb = ttx::plan_bytes(d, nnz);
+  if (plan_stride < pb || plan_stride % 256 != 0)
+    TTX_FAIL(TTX_EWORKSPACE, "plan stride %zu: need a multiple of 256 of at least %zu bytes", plan_stride, pb);
+  const bool upd = upd_hashtbl && upd_cache_freq;
+  if (upd && (H <= 0 || H >= (1ll << 31))) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
+  for (int z = 0; z < nbatch; ++z)
+    if (!colidx_host[z] || !offsets_host[z]) TTX_FAIL(TTX_EINVAL, "batch %d: NULL indices / offsets", z);
+  if (!ttx::prologue_fusable(d, nnz, nb)) {  // general shape: batch after batch, same results
+    for (int z = 0; z < nbatch; ++z) {
+      rc = ttx_lookup_prologue(g, nnz, colidx_host[z], nb, offsets_host[z], H, upd_hashtbl, upd_cache_freq,
+                               rowidx + (size_t)z * nnz, tableidx + (size_t)z * nnz, (char*)plans + (size_t)z * plan_stride,
+                               plan_stride, stream);
+      if (rc != TTX_OK) return rc;
+    }
+    return TTX_OK;
+  }
+  for (int z0 = 0; z0 < nbatch; z0 += ttx::kMaxMulti) {  // kMaxMulti batches per launch
+    const int nz = nbatch - z0 < ttx::kMaxMulti ? nbatch - z0 : ttx::kMaxMulti;
+    ttx::ProBatch mb{};
+    for (int z = 0; z < nz; ++z) { mb.indices[z] = colidx_host[z0 + z]; mb.offsets[z] = offsets_host[z0 + z]; }
+    mb.out_stride = nnz;
+    mb.plan_stride = (long long)plan_stride;
+    ttx::Plan P = ttx::carve_plan(d, nnz, (char*)plans + (size_t)z0 * plan_stride);
+    ttx::Prologue pg{offsets_host[z0], (int)nb, rowidx + (size_t)z0 * nnz, tableidx + (size_t)z0 * nnz, upd ? (int)H : 0,
+                     upd_hashtbl, upd_cache_freq};
+    rc = ttx::prologue_launch(d, (int)nnz, colidx_host[z0], pg, P, (hipStream_t)stream, &mb, nz);
+    if (rc != TTX_OK) return rc;
+  }
+  return TTX_OK;
 }
 
 size_t ttx_plan_bytes(const ttx_geom* g, int64_t nnz) {

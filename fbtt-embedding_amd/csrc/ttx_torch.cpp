@@ -83,12 +83,15 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
                         std::vector<int64_t> p, std::vector<int64_t> q, std::vector<int64_t> r, int64_t optim,
                         double lr, double eps, const c10::optional<Tensor>& hashtbl,
                         const c10::optional<Tensor>& cache_freq, const c10::optional<Tensor>& psw,
-                        at::TensorList state, at::TensorList cores) {
+                        const c10::optional<Tensor>& pre_rowidx, const c10::optional<Tensor>& pre_tableidx,
+                        const c10::optional<Tensor>& pre_plan, at::TensorList state, at::TensorList cores) {
     Geom G;
     make_geom(G, num_tables, p, q, r);
     const ttx_geom& g = G.g;
     check_cores(g, cores, "tt_cores");
     const bool weighted = psw.has_value() && psw->defined();
+    // the lookup prologue of this batch may have run ahead on another stream (`prologue` below; the module's prefetch)
+    const bool pre = pre_plan.has_value() && pre_plan->defined();
     if (weighted)
       TORCH_CHECK(psw->is_cuda() && psw->scalar_type() == at::kFloat && psw->is_contiguous() &&
                       psw->numel() == indices.numel(),
@@ -106,9 +109,19 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
     auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
 
     Tensor out = at::empty({num_tables, B, D}, cores[0].options());
-    Tensor rowidx = at::empty_like(indices), tableidx = at::empty_like(indices);
-    Tensor plan;
-    if (nnz > 0) {
+    Tensor rowidx, tableidx, plan;
+    if (pre) {
+      TORCH_CHECK(pre_rowidx.has_value() && pre_tableidx.has_value() && pre_rowidx->numel() == nnz &&
+                      pre_tableidx->numel() == nnz && (size_t)pre_plan->numel() >= ttx_plan_bytes(&g, nnz),
+                  "tt_embeddings: the prefetched prologue does not belong to this batch");
+      rowidx = *pre_rowidx;
+      tableidx = *pre_tableidx;
+      plan = *pre_plan;
+    } else {
+      rowidx = at::empty_like(indices);
+      tableidx = at::empty_like(indices);
+    }
+    if (nnz > 0 && !pre) {
       const size_t pb = ttx_plan_bytes(&g, nnz);
       plan = bytes_on(indices, pb);
       const bool upd = hashtbl.has_value() && hashtbl->defined() && hashtbl->numel() > 0 && cache_freq.has_value() &&
@@ -171,8 +184,8 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
     const int64_t nnz = indices.numel();
 
     // one slot per forward argument (lists expanded): indices, offsets, num_tables, p, q, r, optim, lr, eps,
-    // hashtbl, cache_freq, per_sample_weights, state.., cores..
-    constexpr int64_t kHead = 12;
+    // hashtbl, cache_freq, per_sample_weights, pre_rowidx, pre_tableidx, pre_plan, state.., cores..
+    constexpr int64_t kHead = 15;
     const Tensor psw = ctx->saved_data.count("psw") ? ctx->saved_data["psw"].toTensor() : Tensor();
     variable_list grads(kHead + nstate + T);
     Tensor go = grad_outputs[0];
@@ -219,10 +232,79 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
 Tensor lookup(const Tensor& indices, const Tensor& offsets, int64_t num_tables, std::vector<int64_t> p,
               std::vector<int64_t> q, std::vector<int64_t> r, int64_t optim, double lr, double eps,
               c10::optional<Tensor> hashtbl, c10::optional<Tensor> cache_freq, std::vector<Tensor> state,
-              std::vector<Tensor> cores, c10::optional<Tensor> per_sample_weights) {
+              std::vector<Tensor> cores, c10::optional<Tensor> per_sample_weights, c10::optional<Tensor> pre_rowidx,
+              c10::optional<Tensor> pre_tableidx, c10::optional<Tensor> pre_plan) {
   // (weights that require a gradient get one: d_psw[n] = <d_out[bag(n)], row_n>; the rows are kept for it)
   return TTLookupOp::apply(indices, offsets, num_tables, std::move(p), std::move(q), std::move(r), optim, lr, eps,
-                           hashtbl, cache_freq, per_sample_weights, at::TensorList(state), at::TensorList(cores));
+                           hashtbl, cache_freq, per_sample_weights, pre_rowidx, pre_tableidx, pre_plan,
+                           at::TensorList(state), at::TensorList(cores));
+}
+
+// The lookup prologue alone (cache not live): frequency update, offsets -> bag rows, lookup plan -- everything of a
+// step that depends on the batch's indices only, not on the cores.  Enqueued on the CURRENT stream: the module's
+// prefetch runs it on a side stream while the previous step's backward still occupies the main one, and hands the
+// three tensors to `lookup`.  -> {rowidx, tableidx, plan}
+std::vector<Tensor> prologue(const Tensor& indices, const Tensor& offsets, int64_t num_tables, std::vector<int64_t> p,
+                             std::vector<int64_t> q, std::vector<int64_t> r, c10::optional<Tensor> hashtbl,
+                             c10::optional<Tensor> cache_freq) {
+  Geom G;
+  make_geom(G, num_tables, p, q, r);
+  const ttx_geom& g = G.g;
+  TORCH_CHECK(indices.is_cuda() && indices.scalar_type() == at::kLong && indices.is_contiguous() && offsets.is_cuda() &&
+                  offsets.scalar_type() == at::kLong && offsets.is_contiguous(),
+              "tt_embeddings: indices / offsets must be contiguous int64 GPU tensors");
+  const int64_t nnz = indices.numel(), nb = offsets.numel() - 1;
+  TORCH_CHECK(nnz > 0 && nb > 0 && nb % num_tables == 0, "tt_embeddings: offsets must hold num_tables * B + 1 entries");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(indices.device());
+  auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  Tensor rowidx = at::empty_like(indices), tableidx = at::empty_like(indices);
+  const size_t pb = ttx_plan_bytes(&g, nnz);
+  Tensor plan = bytes_on(indices, pb);
+  const bool upd = hashtbl.has_value() && hashtbl->defined() && hashtbl->numel() > 0 && cache_freq.has_value() &&
+                   cache_freq->defined();
+  if (upd) TORCH_CHECK(hashtbl->numel() == cache_freq->numel(), "tt_embeddings: hashtbl must match cache_freq");
+  check(ttx_lookup_prologue(&g, nnz, indices.data_ptr<int64_t>(), nb, offsets.data_ptr<int64_t>(),
+                            upd ? hashtbl->numel() : 0, upd ? hashtbl->data_ptr<int64_t>() : nullptr,
+                            upd ? cache_freq->data_ptr<int64_t>() : nullptr, rowidx.data_ptr<int64_t>(),
+                            tableidx.data_ptr<int64_t>(), plan.data_ptr(), pb, stream));
+  return {rowidx, tableidx, plan};
+}
+
+// ... and of several batches at once (ttx_lookup_prologue_multi: one launch per 16 batches): every batch with the same
+// number of indices and offsets.  -> {rowidx [nbatch, nnz], tableidx [nbatch, nnz], plans [nbatch, stride]}; row k of each is
+// what `lookup(pre_*=)` takes for batch k.
+std::vector<Tensor> prologue_multi(std::vector<Tensor> indices, std::vector<Tensor> offsets, int64_t num_tables,
+                                   std::vector<int64_t> p, std::vector<int64_t> q, std::vector<int64_t> r,
+                                   c10::optional<Tensor> hashtbl, c10::optional<Tensor> cache_freq) {
+  Geom G;
+  make_geom(G, num_tables, p, q, r);
+  const ttx_geom& g = G.g;
+  const int64_t nbatch = (int64_t)indices.size();
+  TORCH_CHECK(nbatch > 0 && offsets.size() == indices.size(), "tt_embeddings: one offsets tensor per indices tensor");
+  const int64_t nnz = indices[0].numel(), nb = offsets[0].numel() - 1;
+  std::vector<const int64_t*> ip(nbatch), op(nbatch);
+  for (int64_t k = 0; k < nbatch; ++k) {
+    TORCH_CHECK(indices[k].is_cuda() && indices[k].scalar_type() == at::kLong && indices[k].is_contiguous() &&
+                    offsets[k].is_cuda() && offsets[k].scalar_type() == at::kLong && offsets[k].is_contiguous() &&
+                    indices[k].numel() == nnz && offsets[k].numel() == nb + 1,
+                "tt_embeddings: the batches of a multi-batch prologue must be contiguous int64 GPU tensors of one size");
+    ip[k] = indices[k].data_ptr<int64_t>();
+    op[k] = offsets[k].data_ptr<int64_t>();
+  }
+  TORCH_CHECK(nnz > 0 && nb > 0 && nb % num_tables == 0, "tt_embeddings: offsets must hold num_tables * B + 1 entries");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(indices[0].device());
+  auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  Tensor rowidx = at::empty({nbatch, nnz}, indices[0].options()), tableidx = at::empty({nbatch, nnz}, indices[0].options());
+  const size_t stride = (ttx_plan_bytes(&g, nnz) + 255) / 256 * 256;
+  Tensor plans = at::empty({nbatch, (int64_t)stride}, indices[0].options().dtype(at::kByte));
+  const bool upd = hashtbl.has_value() && hashtbl->defined() && hashtbl->numel() > 0 && cache_freq.has_value() &&
+                   cache_freq->defined();
+  if (upd) TORCH_CHECK(hashtbl->numel() == cache_freq->numel(), "tt_embeddings: hashtbl must match cache_freq");
+  check(ttx_lookup_prologue_multi(&g, (int32_t)nbatch, nnz, ip.data(), nb, op.data(), upd ? hashtbl->numel() : 0,
+                                  upd ? hashtbl->data_ptr<int64_t>() : nullptr,
+                                  upd ? cache_freq->data_ptr<int64_t>() : nullptr, rowidx.data_ptr<int64_t>(),
+                                  tableidx.data_ptr<int64_t>(), plans.data_ptr(), stride, stream));
+  return {rowidx, tableidx, plans};
 }
 
 // ---- cache live (one table): tt_embeddings_ops.py:821-874 with self.warmup == False ----------------
@@ -496,7 +578,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         pybind11::arg("indices"), pybind11::arg("offsets"), pybind11::arg("num_tables"), pybind11::arg("p"),
         pybind11::arg("q"), pybind11::arg("r"), pybind11::arg("optim"), pybind11::arg("lr"), pybind11::arg("eps"),
         pybind11::arg("hashtbl"), pybind11::arg("cache_freq"), pybind11::arg("state"), pybind11::arg("cores"),
-        pybind11::arg("per_sample_weights") = pybind11::none());
+        pybind11::arg("per_sample_weights") = pybind11::none(), pybind11::arg("pre_rowidx") = pybind11::none(),
+        pybind11::arg("pre_tableidx") = pybind11::none(), pybind11::arg("pre_plan") = pybind11::none());
+  m.def("prologue", &prologue, "the lookup prologue alone, on the current stream: -> [rowidx, tableidx, plan] for lookup(pre_*=)",
+        pybind11::arg("indices"), pybind11::arg("offsets"), pybind11::arg("num_tables"), pybind11::arg("p"),
+        pybind11::arg("q"), pybind11::arg("r"), pybind11::arg("hashtbl") = pybind11::none(),
+        pybind11::arg("cache_freq") = pybind11::none());
+  m.def("prologue_multi", &prologue_multi, "the prologues of several equal-sized batches in one launch: -> [rowidx, tableidx, plans], row k for batch k");
   m.def("lookup_cached", &lookup_cached, "cache-live lookup of one table: partition, contraction of the misses, gather of the hits");
   m.def("rccl_unique_id", &rccl_unique_id, "ncclGetUniqueId (rank 0; broadcast the bytes to the others)");
   m.def("rccl_comm_init", &rccl_comm_init, "ncclCommInitRank on the given device (collective; releases the GIL)");

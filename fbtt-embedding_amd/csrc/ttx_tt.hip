@@ -741,18 +741,18 @@ __device__ __forceinline__ void gsum_group(int lo, int hi, int B, int DV, const 
     vzero(acc);
     for (int base = lo; base < hi; base += 16) {
       const int k = base + l;
-      int off = 0;
+      long long off = 0;  // bag of the occurrence: table * B + row (64-bit: tables * B may exceed 2^31)
       float w = 1.f;
       if (k < hi) {
         const int n = occ[k];
-        off = (int)(tableidx[n] * B + rowidx[n]);
+        off = (long long)tableidx[n] * B + rowidx[n];
         if (psw) w = psw[n];
       }
       const int cnt = min(16, hi - base);
       V v[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int oq = __shfl(off, q, 16);
+        const long long oq = ((long long)__shfl((int)(off >> 32), q, 16) << 32) | (unsigned)__shfl((int)off, q, 16);
         if (q < cnt && ev) v[q] = dout[(size_t)oq * DV + e];
       }
 #pragma unroll

@@ -464,6 +464,98 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         if self.use_cache:
             _engine.update_cache_state(indices, self.hashtbl, self.cache_freq)
 
+    # -------------------------------------------------------------- prefetch
+    def _normalise(self, indices: torch.Tensor, offsets: torch.Tensor):
+        indices, offsets = indices.long(), offsets.long()
+        if not self.include_last_offset:
+            offsets = torch.cat([offsets, offsets.new_full((1,), indices.numel())])
+        return indices, offsets
+
+    def prefetch(self, indices: torch.Tensor, offsets: torch.Tensor) -> bool:
+        """Not in the reference.  Run the lookup prologue of a COMING batch now, on a side stream: hash-table frequency
+        update, offsets -> bag rows and the lookup plan depend on the batch's indices only, not on the cores, so they
+        can overlap the backward of the step before (call it once the next batch's tensors exist, before
+        `loss.backward()`; the next `forward(indices, offsets)` with the same tensors picks the result up).  HIP streams
+        and events only; captures into a hipGraph as a forked branch.  Returns False (and does nothing) whenever the
+        overlap does not apply: cache live, no C++ node, CPU tensors, empty batch, duplicate sharing."""
+        fast = _native_node()
+        if (fast is None or not self.warmup or not indices.is_cuda or indices.numel() == 0 or getattr(self, "dedup", False)
+                or indices.dim() != 1 or offsets.dim() != 1):
+            return False
+        key = (indices.data_ptr(), offsets.data_ptr(), indices.numel(), offsets.numel())
+        idx, off = self._normalise(indices, offsets)
+        idx, off = idx.contiguous(), off.contiguous()
+        cur = torch.cuda.current_stream(indices.device)
+        side = self.prefetch_stream(indices.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)  # the batch's tensors exist at this point of the caller's stream
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            rowidx, tableidx, plan = fast.prologue(idx, off, self.num_tables, getattr(self, "_p_flat", self.tt_p_shapes),
+                                                   self.tt_q_shapes, self.tt_ranks,
+                                                   self.hashtbl if self.use_cache else None,
+                                                   self.cache_freq if self.use_cache else None)
+            done = torch.cuda.Event()
+            done.record(side)
+        if len(self._prefetched) >= 8:  # (batches that never came: drop the oldest)
+            self._prefetched.pop(next(iter(self._prefetched)))
+        self._prefetched[key] = (idx, off, rowidx, tableidx, plan, done)
+        return True
+
+    def prefetch_many(self, batches) -> bool:
+        """Not in the reference.  The lookup prologues of SEVERAL coming batches -- `[(indices, offsets), ...]`, all of
+        one size -- in one launch on the current stream (`ttx_lookup_prologue_multi`): a prologue occupies 30 of the chip's
+        256 CUs for its ~12 us of dependent loads, sixteen of them take about as long as one.  Each batch's next
+        `forward(indices, offsets)` picks its result up, as after prefetch().  Returns False (and does nothing) where
+        prefetch() would."""
+        fast = _native_node()
+        batches = list(batches)
+        if fast is None or not self.warmup or not batches or getattr(self, "dedup", False):
+            return False
+        norm, keys = [], []
+        for indices, offsets in batches:
+            if not indices.is_cuda or indices.numel() == 0 or indices.dim() != 1 or offsets.dim() != 1:
+                return False
+            keys.append((indices.data_ptr(), offsets.data_ptr(), indices.numel(), offsets.numel()))
+            idx, off = self._normalise(indices, offsets)
+            norm.append((idx.contiguous(), off.contiguous()))
+        if len({(i.numel(), o.numel()) for i, o in norm}) != 1:
+            return False
+        self.prefetch_stream(norm[0][0].device)
+        rowidx, tableidx, plans = fast.prologue_multi([i for i, _ in norm], [o for _, o in norm], self.num_tables,
+                                                      getattr(self, "_p_flat", self.tt_p_shapes), self.tt_q_shapes, self.tt_ranks,
+                                                      self.hashtbl if self.use_cache else None,
+                                                      self.cache_freq if self.use_cache else None)
+        for k, key in enumerate(keys):
+            while len(self._prefetched) >= 64:
+                self._prefetched.pop(next(iter(self._prefetched)))
+            self._prefetched[key] = (norm[k][0], norm[k][1], rowidx[k], tableidx[k], plans[k], None)
+        return True
+
+    def prefetch_stream(self, device: Optional[torch.device] = None) -> "torch.cuda.Stream":
+        """the side stream of prefetch() (created at first use; call this before a hipGraph capture that prefetches)"""
+        side = getattr(self, "_pf_stream", None)
+        if side is None:
+            side = self._pf_stream = torch.cuda.Stream(device=device if device is not None else self.tt_cores[0].device)
+            self._prefetched = {}
+        return side
+
+    def _take_prefetched(self, indices: torch.Tensor, offsets: torch.Tensor):
+        pf = getattr(self, "_prefetched", None)
+        if not pf:
+            return None
+        hit = pf.pop(getattr(self, "_pf_key", None), None)
+        self._pf_key = None
+        if hit is None:
+            return None
+        _, _, rowidx, tableidx, plan, done = hit
+        if done is not None:  # (prefetch(): ran on the side stream; prefetch_many(): same stream, stream-ordered)
+            cur = torch.cuda.current_stream(indices.device)
+            cur.wait_event(done)
+            for t in (rowidx, tableidx, plan):  # allocated on the side stream, used (and freed) on this one
+                t.record_stream(cur)
+        return rowidx, tableidx, plan
+
     # --------------------------------------------------------------- forward
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True,
                 per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -481,9 +573,14 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             per_sample_weights = per_sample_weights.float().contiguous()  # (keeps the autograd graph of the weights)
         if indices.dim() != 1 or offsets.dim() != 1:
             raise ValueError("indices and offsets must be 1-D (the 2-D fixed-length form of nn.EmbeddingBag is not supported)")
-        indices, offsets = indices.long(), offsets.long()
-        if not self.include_last_offset:
-            offsets = torch.cat([offsets, offsets.new_full((1,), indices.numel())])
+        self._pf_key = None
+        if getattr(self, "_prefetched", None):  # a prefetch() for exactly these tensors?
+            k = (indices.data_ptr(), offsets.data_ptr(), indices.numel(), offsets.numel())
+            if k in self._prefetched:
+                self._pf_key = k
+                indices, offsets = self._prefetched[k][0], self._prefetched[k][1]  # (already in the int64 / closing-offset form)
+        if self._pf_key is None:
+            indices, offsets = self._normalise(indices, offsets)
         if (offsets.numel() - 1) % self.num_tables != 0:
             raise ValueError(f"offsets must describe num_tables * B bags, got {offsets.numel() - 1} bags for "
                              f"{self.num_tables} tables")
@@ -507,11 +604,13 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             # is the C++ autograd node of csrc/ttx_torch.cpp -- same C ABI calls, no interpreter in between
             use_state = self.sparse and self.optimizer not in _SGD_LIKE
             optim = 2 if not self.sparse else (1 if use_state else 0)
+            pre = self._take_prefetched(indices, offsets)  # (rowidx, tableidx, plan) if prefetch() ran for this batch
             return fast.lookup(indices.contiguous(), offsets.contiguous(), self.num_tables,
                                getattr(self, "_p_flat", self.tt_p_shapes),  # (per-table factors: flattened)
                                self.tt_q_shapes, self.tt_ranks, optim, self.learning_rate, self.eps,
                                self.hashtbl if self.use_cache else None, self.cache_freq if self.use_cache else None,
-                               list(self.optimizer_state) if use_state else [], list(self.tt_cores), per_sample_weights)
+                               list(self.optimizer_state) if use_state else [], list(self.tt_cores), per_sample_weights,
+                               *(pre if pre is not None else (None, None, None)))
         if (fast is not None and not self.warmup and self.use_cache and self.num_tables == 1 and indices.is_cuda
                 and indices.numel() > 0):
             # cache live: frequency update + hash lookup + stable partition (split point kept on the device),

@@ -11,8 +11,41 @@ from typing import Callable, Sequence
 import torch
 
 
+def planned_round(module, batches: Sequence[tuple], backward: Callable) -> Callable:
+    """A round of training steps over `batches` whose lookup prologues (frequency update, bag rows, lookup plan: index
+    work that depends on a batch's indices only) are all enqueued up front in one launch (`module.prefetch_many`), the
+    steps' forward / backward following without them.  Returns a zero-argument callable for GraphedRound."""
+    batches = list(batches)
+
+    def run() -> None:
+        module.prefetch_many(batches)
+        for k, (i, o) in enumerate(batches):
+            backward(module(i, o), k)
+
+    return run
+
+
+def pipelined_round(module, batches: Sequence[tuple], backward: Callable) -> Callable:
+    """A round of training steps over `batches` in which the lookup prologue of batch k+1 (`module.prefetch`: frequency
+    update, bag rows, lookup plan -- index work that does not depend on the cores) is enqueued on a side stream before
+    the backward of batch k, so that the two overlap.  `backward(out, k)` runs the step's backward (e.g.
+    `lambda out, k: out.backward(grad)`).  Returns a zero-argument callable for GraphedRound (or to call eagerly)."""
+    batches = list(batches)
+
+    def run() -> None:
+        for k, (i, o) in enumerate(batches):
+            out = module(i, o)
+            if k + 1 < len(batches):
+                module.prefetch(*batches[k + 1])
+            backward(out, k)
+
+    return run
+
+
 class GraphedRound:
     def __init__(self, step: Callable, batches: Sequence[tuple], warmup: int = 3) -> None:
+        """step(*batch) for every batch -- or, with batches == [()], one zero-argument round function such as
+        pipelined_round(...)."""
         assert len(batches) > 0
         self.batches = list(batches)  # keep the captured tensors alive
         self._stream = torch.cuda.Stream()

@@ -301,6 +301,17 @@ int ttx_lookup_prologue(const ttx_geom* g, int64_t nnz, const int64_t* colidx,
                         int64_t* upd_hashtbl, int64_t* upd_cache_freq, int64_t* rowidx,
                         int64_t* tableidx, void* plan, size_t plan_bytes, ttx_stream_t stream);
 
+/* The prologues of SEVERAL batches in one launch (plan a round of training batches ahead: a batch's prologue depends on
+ * its indices only, not on the cores).  colidx_host / offsets_host: HOST arrays of nbatch device pointers, every batch
+ * with nnz indices and nb + 1 offsets; rowidx / tableidx: [nbatch][nnz]; plans: nbatch plan buffers plan_stride bytes
+ * apart (a multiple of 256, >= ttx_plan_bytes(g, nnz)).  Batch z's results are exactly ttx_lookup_prologue's for that
+ * batch; the frequency table counts all batches (counts commute).  One launch per 16 batches when the batch qualifies
+ * for the single-launch prologue, the per-batch calls otherwise. */
+int ttx_lookup_prologue_multi(const ttx_geom* g, int32_t nbatch, int64_t nnz, const int64_t* const* colidx_host,
+                              int64_t num_bags_total, const int64_t* const* offsets_host, int64_t hashtbl_size,
+                              int64_t* upd_hashtbl, int64_t* upd_cache_freq, int64_t* rowidx, int64_t* tableidx,
+                              void* plans, size_t plan_stride, ttx_stream_t stream);
+
 /* replaces cache_populate_cuda (tt_embeddings.cpp:76-86,
  * tt_embeddings_cuda.cu:1260-1336): stable descending radix sort of the slots
  * by frequency, the top cache_size keys get cache rows (cache_state[slot] =

@@ -1,0 +1,63 @@
+"""Register / scratch budget of the step's kernels at the benchmark shape, from the compiler's own resource report
+(hipcc cross-compiles gfx950 without a GPU).  Two regressions of round 2 were invisible to the parity tests and cost
+1.5 and 10 us per step: reduce_apply dropping from three to two 512-thread work-groups per CU (77 -> 89 VGPRs), and the plan
+kernel's by-value arguments going through scratch memory after a run-time subscript into one of them."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "fbtt-embedding_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def resources(src):
+    """{mangled kernel name: {VGPRs, ScratchSize, Occupancy, ...}}"""
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-function",
+                          "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(CSRC, src)],
+                         capture_output=True, text=True, timeout=900).stderr
+    res, cur = {}, None
+    for line in out.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = res.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return res
+
+
+def pick(res, *needles):
+    hits = [v for k, v in res.items() if all(n in k for n in needles)]
+    assert len(hits) == 1, f"{needles}: {len(hits)} kernels match"
+    return hits[0]
+
+
+@pytest.fixture(scope="module")
+def plan_res():
+    return resources("ttx_plan.hip")
+
+
+@pytest.fixture(scope="module")
+def tt_res():
+    return resources("ttx_tt.hip")
+
+
+def test_plan_kernel_keeps_its_arguments_out_of_scratch(plan_res):
+    for pro in ("ILb1E", "ILb0E"):
+        r = pick(plan_res, "mb_single_kernel", pro)
+        assert r["ScratchSize"] == 0, f"mb_single_kernel<{pro}>: {r}"
+        assert r["VGPRs"] <= 80, r
+
+
+def test_contraction_and_reduce_kernels_budget(tt_res):
+    cfg2 = "Shape3ILi32ELi4ELi32ELi4ELi2ELi16EEELb0"
+    fwd, bwd = pick(tt_res, "spec_fwd_kernel", cfg2), pick(tt_res, "spec_bwd_kernel", cfg2)
+    assert fwd["ScratchSize"] == 0 and bwd["ScratchSize"] == 0, (fwd, bwd)
+    assert bwd["VGPRs"] <= 104, bwd  # four 256-thread work-groups per CU need <= 128; round 2 shipped 98
+    red = pick(tt_res, "reduce_apply_kernel")
+    assert red["Occupancy"] >= 6, f"reduce_apply_kernel must leave room for three 512-thread work-groups per CU: {red}"
+    assert pick(tt_res, "pool4_small_kernel")["ScratchSize"] == 0

@@ -478,3 +478,76 @@ def test_direct_rccl_exchange_one_rank():
     worker = os.path.join(os.path.dirname(__file__), "_direct_exchange_worker.py")
     res = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=240)
     assert "DIRECT-EXCHANGE-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+@pytest.mark.parametrize("use_cache", [False, True])
+def test_prefetched_prologue_is_bit_identical_eager_and_captured(node, use_cache):
+    """module.prefetch(): the lookup prologue of the NEXT batch on a side stream while this step's backward runs.
+    Same kernels on the same inputs -> outputs, cores and frequency table bit-identical to the plain sequence, eagerly
+    and as one captured round (ttx_graph.pipelined_round inside a GraphedRound)."""
+    import tt_embeddings_ops as ops
+    import ttx_graph
+
+    if node == "python":
+        m = ops.TTEmbeddingBag(11000, 64, [16, 16], [20, 22, 25], [4, 4, 4], use_cache=False, weight_dist="uniform", device=DEV)
+        assert m.prefetch(torch.zeros(4, dtype=torch.int64, device=DEV), torch.tensor([0, 4], device=DEV)) is False
+        return
+    p, q, r = [200, 220, 250], [4, 4, 4], [32, 32]
+    E_, D, B, Lp = 11_000_000, 64, 512, 20
+    kw = dict(num_embeddings=E_, embedding_dim=D, tt_ranks=r, tt_p_shapes=p, tt_q_shapes=q, weight_dist="uniform", device=DEV,
+              sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, use_cache=use_cache, cache_size=1024, hashtbl_size=1 << 23)  # (sparse table: no key is dropped, whatever the insert order)
+    torch.manual_seed(5)
+    a, b, c = ops.TTEmbeddingBag(**kw), ops.TTEmbeddingBag(**kw), ops.TTEmbeddingBag(**kw)
+    with torch.no_grad():
+        for other in (b, c):
+            for x, y in zip(other.tt_cores, a.tt_cores):
+                x.copy_(y)
+    reqs = [(t(i), t(o)) for i, o in G.make_requests(31, 6, B, 1, Lp, E_)]
+    grad = t(G.make_grad(32, 1, B, D)[0])
+    outs_init = [x.detach().clone() for x in a.tt_cores]
+    outs_a, outs_b = [], []
+    for k, (i, o) in enumerate(reqs):  # plain
+        out = a(i, o)
+        outs_a.append(out.detach().clone())
+        out.backward(grad)
+    for k, (i, o) in enumerate(reqs):  # prefetched, eager
+        out = b(i, o)
+        if k + 1 < len(reqs):
+            assert b.prefetch(*reqs[k + 1]) is True
+        outs_b.append(out.detach().clone())
+        out.backward(grad)
+    torch.cuda.synchronize()
+    for x, y in zip(outs_a, outs_b):
+        assert torch.equal(x, y), "prefetched forward differs"
+    for x, y in zip(a.tt_cores, b.tt_cores):
+        assert torch.equal(x, y), "cores differ after the prefetched steps"
+    c.prefetch_stream()  # (the side stream exists before the capture begins)
+    rnd = ttx_graph.GraphedRound(ttx_graph.pipelined_round(c, reqs, lambda out, k: out.backward(grad)), [()], warmup=0)
+    torch.cuda.synchronize()  # (warmup=0 and a capture does not execute: c still holds the initial cores)
+    rnd.replay()
+    torch.cuda.synchronize()
+    for x, y in zip(a.tt_cores, c.tt_cores):
+        assert torch.equal(x, y), "cores differ after the captured pipelined round"
+    # ... and all six prologues in ONE launch up front (prefetch_many), eagerly and as a captured round
+    d, e = ops.TTEmbeddingBag(**kw), ops.TTEmbeddingBag(**kw)
+    with torch.no_grad():
+        for other in (d, e):
+            for x, y in zip(other.tt_cores, outs_init):
+                x.copy_(y)
+    assert d.prefetch_many(reqs) is True
+    for k, (i, o) in enumerate(reqs):
+        out = d(i, o)
+        assert torch.equal(out.detach(), outs_a[k]), "forward after prefetch_many differs"
+        out.backward(grad)
+    e.prefetch_stream()
+    rnd2 = ttx_graph.GraphedRound(ttx_graph.planned_round(e, reqs, lambda out, k: out.backward(grad)), [()], warmup=0)
+    torch.cuda.synchronize()
+    rnd2.replay()
+    torch.cuda.synchronize()
+    for x, y, z in zip(a.tt_cores, d.tt_cores, e.tt_cores):
+        assert torch.equal(x, y) and torch.equal(x, z), "cores differ after the planned rounds"
+    if use_cache:
+        def table(m):
+            k_, f_ = m.hashtbl.cpu().numpy(), m.cache_freq.cpu().numpy()
+            return sorted(zip(k_[k_ >= 0].tolist(), f_[k_ >= 0].tolist()))
+        assert table(a) == table(b) == table(c) == table(d) == table(e), "frequency tables differ"
