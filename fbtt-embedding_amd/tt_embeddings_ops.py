@@ -475,14 +475,15 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         """Not in the reference.  Run the lookup prologue of a COMING batch now, on a side stream: hash-table frequency
         update, offsets -> bag rows and the lookup plan depend on the batch's indices only, not on the cores, so they
         can overlap the backward of the step before (call it once the next batch's tensors exist, before
-        `loss.backward()`; the next `forward(indices, offsets)` with the same tensors picks the result up).  HIP streams
+        `loss.backward()`; the next `forward(indices, offsets)` with the same tensor OBJECTS, unmodified, picks the
+        result up -- anything else runs the prologue in line).  HIP streams
         and events only; captures into a hipGraph as a forked branch.  Returns False (and does nothing) whenever the
         overlap does not apply: cache live, no C++ node, CPU tensors, empty batch, duplicate sharing."""
         fast = _native_node()
         if (fast is None or not self.warmup or not indices.is_cuda or indices.numel() == 0 or getattr(self, "dedup", False)
                 or indices.dim() != 1 or offsets.dim() != 1):
             return False
-        key = (indices.data_ptr(), offsets.data_ptr(), indices.numel(), offsets.numel())
+        key = (id(indices), id(offsets))  # (identity: the entry keeps both objects alive, so neither id nor memory is reused)
         idx, off = self._normalise(indices, offsets)
         idx, off = idx.contiguous(), off.contiguous()
         cur = torch.cuda.current_stream(indices.device)
@@ -499,7 +500,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             done.record(side)
         if len(self._prefetched) >= 8:  # (batches that never came: drop the oldest)
             self._prefetched.pop(next(iter(self._prefetched)))
-        self._prefetched[key] = (idx, off, rowidx, tableidx, plan, done)
+        self._prefetched[key] = (idx, off, rowidx, tableidx, plan, done, indices, offsets, indices._version, offsets._version)
         return True
 
     def prefetch_many(self, batches) -> bool:
@@ -516,7 +517,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         for indices, offsets in batches:
             if not indices.is_cuda or indices.numel() == 0 or indices.dim() != 1 or offsets.dim() != 1:
                 return False
-            keys.append((indices.data_ptr(), offsets.data_ptr(), indices.numel(), offsets.numel()))
+            keys.append((id(indices), id(offsets)))
             idx, off = self._normalise(indices, offsets)
             norm.append((idx.contiguous(), off.contiguous()))
         if len({(i.numel(), o.numel()) for i, o in norm}) != 1:
@@ -529,7 +530,8 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         for k, key in enumerate(keys):
             while len(self._prefetched) >= 64:
                 self._prefetched.pop(next(iter(self._prefetched)))
-            self._prefetched[key] = (norm[k][0], norm[k][1], rowidx[k], tableidx[k], plans[k], None)
+            self._prefetched[key] = (norm[k][0], norm[k][1], rowidx[k], tableidx[k], plans[k], None, batches[k][0], batches[k][1],
+                                     batches[k][0]._version, batches[k][1]._version)
         return True
 
     def prefetch_stream(self, device: Optional[torch.device] = None) -> "torch.cuda.Stream":
@@ -548,7 +550,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         self._pf_key = None
         if hit is None:
             return None
-        _, _, rowidx, tableidx, plan, done = hit
+        rowidx, tableidx, plan, done = hit[2:6]
         if done is not None:  # (prefetch(): ran on the side stream; prefetch_many(): same stream, stream-ordered)
             cur = torch.cuda.current_stream(indices.device)
             cur.wait_event(done)
@@ -574,11 +576,16 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         if indices.dim() != 1 or offsets.dim() != 1:
             raise ValueError("indices and offsets must be 1-D (the 2-D fixed-length form of nn.EmbeddingBag is not supported)")
         self._pf_key = None
-        if getattr(self, "_prefetched", None):  # a prefetch() for exactly these tensors?
-            k = (indices.data_ptr(), offsets.data_ptr(), indices.numel(), offsets.numel())
-            if k in self._prefetched:
+        if getattr(self, "_prefetched", None):  # a prefetch() for exactly these tensor objects, not written to since?
+            k = (id(indices), id(offsets))
+            hit = self._prefetched.get(k)
+            if hit is not None and (hit[6] is not indices or hit[7] is not offsets or hit[8] != indices._version
+                                    or hit[9] != offsets._version):
+                self._prefetched.pop(k)  # stale: the batch was modified in place after its prefetch
+                hit = None
+            if hit is not None:
                 self._pf_key = k
-                indices, offsets = self._prefetched[k][0], self._prefetched[k][1]  # (already in the int64 / closing-offset form)
+                indices, offsets = hit[0], hit[1]  # (already in the int64 / closing-offset form)
         if self._pf_key is None:
             indices, offsets = self._normalise(indices, offsets)
         if (offsets.numel() - 1) % self.num_tables != 0:

@@ -551,3 +551,27 @@ def test_prefetched_prologue_is_bit_identical_eager_and_captured(node, use_cache
             k_, f_ = m.hashtbl.cpu().numpy(), m.cache_freq.cpu().numpy()
             return sorted(zip(k_[k_ >= 0].tolist(), f_[k_ >= 0].tolist()))
         assert table(a) == table(b) == table(c) == table(d) == table(e), "frequency tables differ"
+
+
+def test_prefetch_of_a_batch_that_changed_is_not_used(node):
+    """a prefetched prologue belongs to the tensor OBJECTS it was made for, as they were: a batch written to after its
+    prefetch, or another tensor, runs the prologue in line (no stale plan)"""
+    import tt_embeddings_ops as ops
+
+    if node == "python":
+        return
+    p, q, r = [20, 22, 25], [4, 4, 4], [16, 16]
+    m = ops.TTEmbeddingBag(11000, 64, r, p, q, sparse=False, use_cache=False, weight_dist="uniform", device=DEV)
+    idx, off = (t(a) for a in G.make_bags(3, 300, 11000, 6, 2, 1))
+    ref = m(idx, off).detach().clone()
+    assert m.prefetch(idx, off) is True
+    idx2 = idx.clone()
+    assert torch.equal(m(idx2, off).detach(), ref) and len(m._prefetched) == 1, "another tensor object: in-line prologue"
+    idx.add_(1).remainder_(11000)  # written to after the prefetch
+    out = m(idx, off).detach()
+    assert len(m._prefetched) == 0, "the stale entry must be dropped"
+    fresh = ops.TTEmbeddingBag(11000, 64, r, p, q, sparse=False, use_cache=False, weight_dist="uniform", device=DEV)
+    with torch.no_grad():
+        for x, y in zip(fresh.tt_cores, m.tt_cores):
+            x.copy_(y)
+    assert torch.equal(out, fresh(idx, off).detach()), "a modified batch must be planned again"
