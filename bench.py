@@ -395,7 +395,8 @@ def main():
                 mod.enable_direct_exchange()
                 eager_steps(5)
                 sync()
-            # The captured round plans its batches ahead where the module supports it (cache not live, one GPU): the lookup
+            # The captured round plans its batches ahead where the module supports it (one GPU; cache not live, or live over
+            # one table: then the frequency updates, cache lookups, hit / miss partitions and miss plans): the lookup
             # prologues of the round's batches -- frequency update, bag rows, lookup plan: index work that depends on a
             # batch's indices only, not on the cores -- are enqueued up front in ONE launch (module.prefetch_many ->
             # ttx_lookup_prologue_multi; a prologue occupies 30 of the 256 CUs for ~12 us of dependent loads, ten of them
@@ -404,7 +405,8 @@ def main():
             # plain round (every step's prologue in line) is timed beside it (`no_prefetch`).  `--prefetch next`: the
             # prologue of batch k+1 on a side stream under the backward of batch k instead (a forked branch in the graph:
             # measured slower than in line at this step size, the cross-stream edges cost more than the overlap saves).
-            pipelined = (not sharded) and args.prefetch != "none" and mod.prefetch(*reqs[0])
+            pipelined = (not sharded) and args.prefetch != "none" and hasattr(mod, "prefetch_many") and bool(
+                mod.prefetch_many(reqs[:1]) if args.prefetch == "round" else mod.prefetch(*reqs[0]))
             if pipelined:
                 mod._prefetched.clear()
                 mk = ttx_graph.planned_round if args.prefetch == "round" else ttx_graph.pipelined_round

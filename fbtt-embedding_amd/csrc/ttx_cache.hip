@@ -48,8 +48,15 @@ __global__ __launch_bounds__(kCT) void rowidx_update_kernel(int64_t nb, int32_t 
                                                            int64_t* upd_hashtbl, int64_t* cache_freq,
                                                            const int64_t* __restrict__ hashtbl,
                                                            const int32_t* __restrict__ cache_state, int32_t* loc,
-                                                           int* unit_cnt) {
+                                                           int* unit_cnt, ProBatch mb, long long ws_stride) {
   __shared__ int wc[kCT / kWave];
+  if (blockIdx.y > 0) {  // batch z of ttx_lookup_prologue_cached_multi (ws_stride: ints between the batches' loc / unit_cnt)
+    const int z = blockIdx.y;
+    TTX_PICK_BATCH(mb, z, colidx, offsets)
+    rowidx += (long long)z * mb.out_stride;
+    tableidx += (long long)z * mb.out_stride;
+    if (loc) { loc += (long long)z * ws_stride; unit_cnt += (long long)z * ws_stride; }
+  }
   const int64_t gt = (int64_t)blockIdx.x * kCT + threadIdx.x;
   const int64_t b = gt >> 3;
   if (b < nb) {
@@ -127,8 +134,18 @@ __global__ __launch_bounds__(1024) void scan_units_kernel(int U, int* unit_cnt, 
 __global__ __launch_bounds__(kCT) void partition_scatter_kernel(
     int N, int U, int scanned, const int64_t* __restrict__ colidx, const int64_t* __restrict__ rowidx,
     const int32_t* __restrict__ loc, const int* __restrict__ unit_cnt, int64_t* pcol, int64_t* prow,
-    int32_t* ploc, int* total_out, int32_t* num_tt_dev) {
+    int32_t* ploc, int* total_out, int32_t* num_tt_dev, ProBatch mb, long long ws_stride) {
   __shared__ int wsum[kCT / kWave], wbase[kCT / kWave];
+  if (blockIdx.y > 0) {  // batch z of ttx_lookup_prologue_cached_multi
+    const int z = blockIdx.y;
+    const int64_t* unused = nullptr;
+    TTX_PICK_BATCH(mb, z, colidx, unused)
+    (void)unused;
+    const long long sh = (long long)z * mb.out_stride;
+    rowidx += sh; pcol += sh; prow += sh; ploc += sh;
+    loc += (long long)z * ws_stride; unit_cnt += (long long)z * ws_stride; total_out += (long long)z * ws_stride;
+    if (num_tt_dev) num_tt_dev += z;
+  }
   const int g = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid / kWave;
   int part = 0;  // TT entries before this unit
   if (scanned) {
@@ -665,7 +682,7 @@ int ttx_preprocess_indices_async(int64_t nnz, const int64_t* colidx, int64_t nb,
     const int64_t threads = nb * 8 > nnz ? nb * 8 : nnz;
     hipLaunchKernelGGL(rowidx_update_kernel, dim3((unsigned)((threads + kCT - 1) / kCT)), dim3(kCT), 0, st, nb, B,
                        offsets, rowidx, tableidx, nnz, colidx, (int32_t)H, upd ? upd_hashtbl : nullptr,
-                       upd ? upd_cache_freq : nullptr, hashtbl, cache_state, loc, unit_cnt);
+                       upd ? upd_cache_freq : nullptr, hashtbl, cache_state, loc, unit_cnt, ProBatch{}, 0ll);
   } else {
     hipLaunchKernelGGL(compute_rowidx_kernel, dim3((unsigned)((nb + kCT / 8 - 1) / (kCT / 8))), dim3(kCT), 0,
                        st, nb, B, offsets, rowidx, tableidx);
@@ -681,7 +698,7 @@ int ttx_preprocess_indices_async(int64_t nnz, const int64_t* colidx, int64_t nb,
   const int scanned = U > kScanUnits ? 1 : 0;
   if (scanned) hipLaunchKernelGGL(scan_units_kernel, dim3(1), dim3(1024), 0, st, U, unit_cnt, total);
   hipLaunchKernelGGL(partition_scatter_kernel, dim3(U), dim3(kCT), 0, st, N, U, scanned, colidx, rowidx, loc,
-                     unit_cnt, pcol, prow, ploc, total, num_tt_dev);
+                     unit_cnt, pcol, prow, ploc, total, num_tt_dev, ProBatch{}, 0ll);
   TTX_HIP(hipGetLastError());
   *partitioned_host = 1;
   if (num_tt_dev) return TTX_OK;  // the split point stays on the device: no host synchronisation at all
@@ -690,6 +707,74 @@ int ttx_preprocess_indices_async(int64_t nnz, const int64_t* colidx, int64_t nb,
   TTX_HIP(hipMemcpyAsync(num_tt_host, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   TTX_HIP(hipStreamSynchronize(st));
   return TTX_OK;
+}
+
+size_t ttx_lookup_prologue_cached_multi_workspace_bytes(int32_t nbatch, int64_t nnz) {
+  return (size_t)(nbatch > 0 ? nbatch : 0) * align_up(ttx_preprocess_workspace_bytes(nnz));
+}
+
+int ttx_lookup_prologue_cached_multi(const ttx_geom* g, int32_t nbatch, int64_t nnz, const int64_t* const* colidx_host,
+                                     int64_t nb, const int64_t* const* offsets_host, int64_t H, int64_t* hashtbl,
+                                     int64_t* cache_freq, const int32_t* cache_state, int64_t* rowidx,
+                                     int64_t* tableidx, int64_t* pcol, int64_t* prow, int32_t* ploc,
+                                     int32_t* num_tt_dev, void* plans, size_t plan_stride, void* workspace,
+                                     size_t workspace_bytes, ttx_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Dims d;
+  int rc = make_dims(g, &d);
+  if (rc != TTX_OK) return rc;
+  if (nbatch <= 0 || nnz == 0) return TTX_OK;
+  if (d.num_tables != 1) TTX_FAIL(TTX_EINVAL, "the cache serves one table (num_tables=%d)", d.num_tables);
+  if (nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz too large");
+  if (!colidx_host || !offsets_host || !hashtbl || !cache_freq || !cache_state || !rowidx || !tableidx || !pcol ||
+      !prow || !ploc || !num_tt_dev || !plans)
+    TTX_FAIL(TTX_EINVAL, "NULL input");
+  if (nb <= 0) TTX_FAIL(TTX_EINVAL, "offsets must hold B + 1 entries");
+  if (H <= 0 || H >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
+  const size_t pb = plan_bytes(d, nnz);
+  if (plan_stride < pb || plan_stride % 256 != 0)
+    TTX_FAIL(TTX_EWORKSPACE, "plan stride %zu: need a multiple of 256 of at least %zu bytes", plan_stride, pb);
+  const size_t wsb = align_up(ttx_preprocess_workspace_bytes(nnz));
+  if (!workspace || workspace_bytes < (size_t)nbatch * wsb) TTX_FAIL(TTX_EWORKSPACE, "prologue workspace too small");
+  for (int z = 0; z < nbatch; ++z)
+    if (!colidx_host[z] || !offsets_host[z]) TTX_FAIL(TTX_EINVAL, "batch %d: NULL indices / offsets", z);
+  const int N = (int)nnz, U = num_units(nnz);
+  if (!plan_batches_ok(d, nnz) || U > kScanUnits) {  // general shape: batch after batch, same results
+    for (int z = 0; z < nbatch; ++z) {
+      int32_t n_host = 0, part = 0;
+      rc = ttx_preprocess_indices_async(nnz, colidx_host[z], nb, offsets_host[z], 1, 0, H, hashtbl, cache_state,
+                                        rowidx + (size_t)z * nnz, tableidx + (size_t)z * nnz, pcol + (size_t)z * nnz,
+                                        prow + (size_t)z * nnz, ploc + (size_t)z * nnz, &n_host, &part, num_tt_dev + z,
+                                        hashtbl, cache_freq, (char*)workspace + (size_t)z * wsb, wsb, stream);
+      if (rc != TTX_OK) return rc;
+      rc = plan_build(d, nnz, pcol + (size_t)z * nnz, tableidx + (size_t)z * nnz, prow + (size_t)z * nnz,
+                      carve_plan(d, nnz, (char*)plans + (size_t)z * plan_stride), st, num_tt_dev + z);
+      if (rc != TTX_OK) return rc;
+    }
+    return TTX_OK;
+  }
+  const long long ws_stride = (long long)(wsb / 4);
+  for (int z0 = 0; z0 < nbatch; z0 += kMaxMulti) {  // kMaxMulti batches per launch (the pointer table of ProBatch)
+    const int nz = nbatch - z0 < kMaxMulti ? nbatch - z0 : kMaxMulti;
+    ProBatch mb{};
+    for (int z = 0; z < nz; ++z) { mb.indices[z] = colidx_host[z0 + z]; mb.offsets[z] = offsets_host[z0 + z]; }
+    mb.out_stride = nnz;
+    mb.plan_stride = (long long)plan_stride;
+    int32_t* loc = (int32_t*)((char*)workspace + (size_t)z0 * wsb);
+    int* unit_cnt = (int*)((char*)loc + align_up((size_t)nnz * 4));
+    int* total = unit_cnt + U;
+    const int64_t threads = nb * 8 > nnz ? nb * 8 : nnz;
+    hipLaunchKernelGGL(rowidx_update_kernel, dim3((unsigned)((threads + kCT - 1) / kCT), nz), dim3(kCT), 0, st, nb,
+                       (int32_t)nb, offsets_host[z0], rowidx + (size_t)z0 * nnz, tableidx + (size_t)z0 * nnz, nnz,
+                       colidx_host[z0], (int32_t)H, hashtbl, cache_freq, hashtbl, cache_state, loc, unit_cnt, mb,
+                       ws_stride);
+    TTX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(partition_scatter_kernel, dim3(U, nz), dim3(kCT), 0, st, N, U, 0, colidx_host[z0],
+                       rowidx + (size_t)z0 * nnz, loc, unit_cnt, pcol + (size_t)z0 * nnz, prow + (size_t)z0 * nnz,
+                       ploc + (size_t)z0 * nnz, total, num_tt_dev + z0, mb, ws_stride);
+    TTX_HIP(hipGetLastError());
+  }
+  return plan_build_batches(d, nbatch, nnz, num_tt_dev, pcol, tableidx, prow, plans, plan_stride, st);
 }
 
 // (A/B knob of scripts/bench_cache.py: 1 = the 32-lane-group kernel for every D)

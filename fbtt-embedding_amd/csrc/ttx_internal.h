@@ -109,6 +109,42 @@ int plan_build(const Dims& d, long long nnz, const int64_t* indices,
 // (offsets != NULL: the caller vouches that the lookups are table-major with table k at positions
 //  [offsets[k * bags_per_table], offsets[(k + 1) * bags_per_table)) -- the module's bag offsets)  // n_dev: device-side lookup count <= nnz (nnz is then an upper bound)
 
+// Several batches in ONE launch (ttx_lookup_prologue_multi / _cached_multi: a round of training batches planned ahead):
+// grid.z (or .y) = batch.  Batch z reads its own indices / offsets and writes its outputs at a constant stride behind
+// batch 0's.
+constexpr int kMaxMulti = 16;
+struct ProBatch {
+  const int64_t* indices[kMaxMulti];
+  const int64_t* offsets[kMaxMulti];
+  long long out_stride;    // elements between the batches' rowidx / tableidx (/ pcol / prow / ploc) arrays
+  long long plan_stride;   // bytes between the batches' plan buffers
+};
+// indices / offsets of batch Z > 0.  (A switch over constant subscripts: a run-time subscript into the by-value struct
+// sends it -- and the kernel's other arguments with it -- through scratch memory: measured +10 us on every launch.)
+#define TTX_PICK_BATCH(MB, Z, IND, OFF)                                                                   \
+  switch (Z) {                                                                                            \
+    case 1: IND = MB.indices[1]; OFF = MB.offsets[1]; break;                                              \
+    case 2: IND = MB.indices[2]; OFF = MB.offsets[2]; break;                                              \
+    case 3: IND = MB.indices[3]; OFF = MB.offsets[3]; break;                                              \
+    case 4: IND = MB.indices[4]; OFF = MB.offsets[4]; break;                                              \
+    case 5: IND = MB.indices[5]; OFF = MB.offsets[5]; break;                                              \
+    case 6: IND = MB.indices[6]; OFF = MB.offsets[6]; break;                                              \
+    case 7: IND = MB.indices[7]; OFF = MB.offsets[7]; break;                                              \
+    case 8: IND = MB.indices[8]; OFF = MB.offsets[8]; break;                                              \
+    case 9: IND = MB.indices[9]; OFF = MB.offsets[9]; break;                                              \
+    case 10: IND = MB.indices[10]; OFF = MB.offsets[10]; break;                                           \
+    case 11: IND = MB.indices[11]; OFF = MB.offsets[11]; break;                                           \
+    case 12: IND = MB.indices[12]; OFF = MB.offsets[12]; break;                                           \
+    case 13: IND = MB.indices[13]; OFF = MB.offsets[13]; break;                                           \
+    case 14: IND = MB.indices[14]; OFF = MB.offsets[14]; break;                                           \
+    case 15: IND = MB.indices[15]; OFF = MB.offsets[15]; break;                                           \
+    default: break;                                                                                       \
+  }
+bool plan_batches_ok(const Dims& d, long long nnz);
+int plan_build_batches(const Dims& d, int nbatch, long long nnz, const int* n_dev, const int64_t* indices,
+                       const int64_t* tableidx, const int64_t* rowidx, void* plans, size_t plan_stride,
+                       hipStream_t stream);
+
 long long* debug_stamps();  // debug stamp buffer (ttx_debug_stamps), or nullptr
 
 // --------------------------------------------------- duplicate lookups ----

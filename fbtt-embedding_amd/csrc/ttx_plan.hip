@@ -552,15 +552,6 @@ struct Prologue {
   int64_t* hashtbl;
   int64_t* cache_freq;
 };
-// Several batches in ONE launch (ttx_lookup_prologue_multi: a round of training batches planned ahead): grid.z = batch.
-// Batch z reads its own indices / offsets and writes rowidx / tableidx / plan at a constant stride behind batch 0's.
-constexpr int kMaxMulti = 16;
-struct ProBatch {
-  const int64_t* indices[kMaxMulti];
-  const int64_t* offsets[kMaxMulti];
-  long long out_stride;    // elements between the batches' rowidx / tableidx arrays
-  long long plan_stride;   // bytes between the batches' plan buffers
-};
 #ifndef TTX_PLAN_XWG
 #define TTX_PLAN_XWG 1
 #endif
@@ -572,21 +563,20 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
     const int64_t* __restrict__ tableidx, const int64_t* __restrict__ rowidx, Plan P, Prologue pg, ProBatch mb) {
   if (PRO && blockIdx.z > 0) {  // (work-group-uniform) a later batch of a multi-batch launch
     const int z = blockIdx.z;
-    // (a switch over constant subscripts: a run-time subscript into the by-value struct sends it -- and the kernel's other
-    //  arguments with it -- through scratch memory: measured +10 us on every launch, multi-batch or not)
-    switch (z) {
-#define TTX_PICK(K) case K: indices = mb.indices[K]; pg.offsets = mb.offsets[K]; break;
-      TTX_PICK(1) TTX_PICK(2) TTX_PICK(3) TTX_PICK(4) TTX_PICK(5) TTX_PICK(6) TTX_PICK(7) TTX_PICK(8)
-      TTX_PICK(9) TTX_PICK(10) TTX_PICK(11) TTX_PICK(12) TTX_PICK(13) TTX_PICK(14) TTX_PICK(15)
-#undef TTX_PICK
-      default: break;
-    }
+    TTX_PICK_BATCH(mb, z, indices, pg.offsets)
     pg.rowidx += (long long)z * mb.out_stride;
     pg.tableidx += (long long)z * mb.out_stride;
   }
+  if (!PRO && blockIdx.z > 0) {  // batch z of plan_build_batches: its arrays lie at a constant stride behind batch 0's
+    const long long sh = (long long)blockIdx.z * mb.out_stride;
+    indices += sh;
+    if (tableidx) tableidx += sh;
+    if (rowidx) rowidx += sh;
+    if (n_dev) n_dev += blockIdx.z;
+  }
   // batch z's plan lies z * plan_stride bytes behind batch 0's: applied where a pointer is used (modifying the by-value
   // Plan would make it a local copy, and its run-time subscripts P.perm[t] .. would go through scratch memory)
-  const long long psh = PRO ? (long long)blockIdx.z * mb.plan_stride : 0;
+  const long long psh = (long long)blockIdx.z * mb.plan_stride;
   // (a ballot-grouped histogram -- wave_match8 per batch, the group's first lane adding the group size to a
   //  wave-private row -- was measured against these LDS atomics: 17.5 vs 12.5 us uniform, 30.7 vs 28.3 us on a
   //  skewed stream: the ~60 VALU instructions of a match cost more than the atomics' conflicts)
@@ -740,7 +730,7 @@ __global__ __launch_bounds__(kOneThreads) void mb_single_kernel(
       const int s3 = d.T > 3 ? tbv * d.p[3] + decode_core(d, 3, idx) : 0;
       shifted(P.lrec, psh)[pos] = make_int4(i, s0, s2, s3);
       if (PRO) shifted(P.lrow, psh)[pos] = row;
-      else if (rowidx) P.lrow[pos] = (int)rowidx[i];
+      else if (rowidx) shifted(P.lrow, psh)[pos] = (int)rowidx[i];
     }
   }
 }
@@ -1449,6 +1439,32 @@ int plan_build(const Dims& d, long long nnz, const int64_t* indices,
     else TTX_PLAN_LAUNCH(16);
 #undef TTX_PLAN_LAUNCH
   }
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
+// The plans of `nbatch` batches of one size in ONE launch (grid.z = batch): batch z reads indices / tableidx / rowidx at
+// z * nnz elements, its live count at n_dev[z], and writes its plan z * plan_stride bytes behind `plans`.  Only the
+// single-launch plan does this (plan_batches_ok); same plans as plan_build(.., n_dev + z) batch by batch.
+bool plan_batches_ok(const Dims& d, long long nnz) {
+  if (nnz > kOneMaxN || d.tab) return false;
+  for (int t = 0; t < d.T; ++t) if (d.S[t] > 256) return false;
+  return true;
+}
+
+int plan_build_batches(const Dims& d, int nbatch, long long nnz, const int* n_dev, const int64_t* indices,
+                       const int64_t* tableidx, const int64_t* rowidx, void* plans, size_t plan_stride,
+                       hipStream_t stream) {
+  if (!plan_batches_ok(d, nnz)) TTX_FAIL(TTX_EINVAL, "plan_build_batches: batch shape needs the multi-launch plans");
+  ProfScope ps(TTX_PROF_PLAN, stream);
+  const Plan P = carve_plan(d, nnz, plans);
+  ProBatch mb{};
+  mb.out_stride = nnz;
+  mb.plan_stride = (long long)plan_stride;
+  const int N = (int)nnz;
+  hipLaunchKernelGGL(mb_single_kernel<false>,
+                     dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit) + TTX_PLAN_XWG, d.T, nbatch),
+                     dim3(kOneThreads), 0, stream, d, N, n_dev, indices, tableidx, rowidx, P, Prologue{}, mb);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }

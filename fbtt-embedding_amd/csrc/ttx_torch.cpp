@@ -310,13 +310,14 @@ std::vector<Tensor> prologue_multi(std::vector<Tensor> indices, std::vector<Tens
 // ---- cache live (one table): tt_embeddings_ops.py:821-874 with self.warmup == False ----------------
 struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
   // args: indices, offsets, p, q, r, optim, lr, eps, hashtbl, cache_freq, cache_state,
-  //       cache_optimizer_state (undefined unless Adagrad), cache_weight, state.., cores..
-  static constexpr int64_t kHead = 13;
+  //       cache_optimizer_state (undefined unless Adagrad), cache_weight, pre (the batch's row of prologue_cached_multi's
+  //       results: {tableidx, pcol, prow, ploc, n_tt, plan}, or empty), state.., cores..
+  static constexpr int64_t kHead = 13;  // (then one slot per tensor of pre, state, cores)
   static Tensor forward(AutogradContext* ctx, const Tensor& indices, const Tensor& offsets, std::vector<int64_t> p,
                         std::vector<int64_t> q, std::vector<int64_t> r, int64_t optim, double lr, double eps,
                         const Tensor& hashtbl, const Tensor& cache_freq, const Tensor& cache_state,
                         const c10::optional<Tensor>& cache_opt_state, const Tensor& cache_weight,
-                        at::TensorList state, at::TensorList cores) {
+                        at::TensorList pre, at::TensorList state, at::TensorList cores) {
     Geom G;
     make_geom(G, 1, p, q, r);
     const ttx_geom& g = G.g;
@@ -336,28 +337,40 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(indices.device());
     auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
 
-    Tensor rowidx = at::empty_like(indices), tableidx = at::empty_like(indices);
-    Tensor pcol = at::empty_like(indices), prow = at::empty_like(indices);
-    Tensor ploc = at::empty({nnz}, indices.options().dtype(at::kInt));
-    const size_t pwb = ttx_preprocess_workspace_bytes(nnz);
-    Tensor pws = bytes_on(indices, pwb);
-    // the split point (number of TT entries) stays on the device: the kernels below read it there,
-    // nnz only sizes grids and workspaces -- no host synchronisation, the step can be graph-captured
-    Tensor n_tt = at::empty({1}, indices.options().dtype(at::kInt));
-    int32_t n_host = 0, part = 0;
-    check(ttx_preprocess_indices_async(nnz, indices.data_ptr<int64_t>(), B, offsets.data_ptr<int64_t>(), 1, 0, H,
-                                       hashtbl.data_ptr<int64_t>(), cache_state.data_ptr<int32_t>(),
-                                       rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(), pcol.data_ptr<int64_t>(),
-                                       prow.data_ptr<int64_t>(), ploc.data_ptr<int32_t>(), &n_host, &part,
-                                       n_tt.data_ptr<int32_t>(), hashtbl.data_ptr<int64_t>(),
-                                       cache_freq.data_ptr<int64_t>(), pws.data_ptr(), pwb, stream));
-    TORCH_CHECK(part == 1, "tt_embeddings: the cache-live preprocessing did not partition");
+    Tensor tableidx, pcol, prow, ploc, n_tt, plan;
+    const size_t pb = ttx_plan_bytes(&g, nnz);
+    if (pre.size() == 6) {  // planned ahead (prologue_cached_multi): frequency update, lookup, partition and plan are done
+      tableidx = pre[0]; pcol = pre[1]; prow = pre[2]; ploc = pre[3]; n_tt = pre[4]; plan = pre[5];
+      TORCH_CHECK(tableidx.numel() == nnz && pcol.numel() == nnz && prow.numel() == nnz && ploc.numel() == nnz &&
+                      n_tt.numel() == 1 && (size_t)plan.numel() >= pb && pcol.scalar_type() == at::kLong &&
+                      ploc.scalar_type() == at::kInt && n_tt.scalar_type() == at::kInt && plan.is_contiguous(),
+                  "tt_embeddings: the planned-ahead prologue does not match this batch");
+    } else {
+      TORCH_CHECK(pre.size() == 0, "tt_embeddings: pre must be prologue_cached_multi's six tensors of the batch, or empty");
+      Tensor rowidx = at::empty_like(indices);
+      tableidx = at::empty_like(indices);
+      pcol = at::empty_like(indices);
+      prow = at::empty_like(indices);
+      ploc = at::empty({nnz}, indices.options().dtype(at::kInt));
+      const size_t pwb = ttx_preprocess_workspace_bytes(nnz);
+      Tensor pws = bytes_on(indices, pwb);
+      // the split point (number of TT entries) stays on the device: the kernels below read it there,
+      // nnz only sizes grids and workspaces -- no host synchronisation, the step can be graph-captured
+      n_tt = at::empty({1}, indices.options().dtype(at::kInt));
+      int32_t n_host = 0, part = 0;
+      check(ttx_preprocess_indices_async(nnz, indices.data_ptr<int64_t>(), B, offsets.data_ptr<int64_t>(), 1, 0, H,
+                                         hashtbl.data_ptr<int64_t>(), cache_state.data_ptr<int32_t>(),
+                                         rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(), pcol.data_ptr<int64_t>(),
+                                         prow.data_ptr<int64_t>(), ploc.data_ptr<int32_t>(), &n_host, &part,
+                                         n_tt.data_ptr<int32_t>(), hashtbl.data_ptr<int64_t>(),
+                                         cache_freq.data_ptr<int64_t>(), pws.data_ptr(), pwb, stream));
+      TORCH_CHECK(part == 1, "tt_embeddings: the cache-live preprocessing did not partition");
+      plan = bytes_on(indices, pb);
+      check(ttx_plan_build_n(&g, nnz, n_tt.data_ptr<int32_t>(), pcol.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
+                             prow.data_ptr<int64_t>(), plan.data_ptr(), pb, stream));
+    }
 
     Tensor out = at::empty({1, B, D}, cores[0].options());
-    const size_t pb = ttx_plan_bytes(&g, nnz);
-    Tensor plan = bytes_on(indices, pb);
-    check(ttx_plan_build_n(&g, nnz, n_tt.data_ptr<int32_t>(), pcol.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
-                           prow.data_ptr<int64_t>(), plan.data_ptr(), pb, stream));
     const float* cp[TTX_MAX_CORES] = {};
     for (int t = 0; t < g.T; ++t) cp[t] = cores[t].data_ptr<float>();
     const size_t wb = ttx_tt_forward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
@@ -377,6 +390,7 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     ctx->saved_data["eps"] = eps;
     ctx->saved_data["T"] = (int64_t)g.T;
     ctx->saved_data["nstate"] = (int64_t)state.size();
+    ctx->saved_data["npre"] = (int64_t)pre.size();
     std::vector<Tensor> keep = {pcol, prow, tableidx, ploc, cache_weight, n_tt};
     ctx->saved_data["keep"] = keep;
     if (cache_opt_state.has_value() && cache_opt_state->defined()) ctx->saved_data["copt"] = *cache_opt_state;
@@ -392,7 +406,7 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     const auto r = ctx->saved_data["r"].toIntVector();
     const int64_t optim = ctx->saved_data["optim"].toInt();
     const double lr = ctx->saved_data["lr"].toDouble(), eps = ctx->saved_data["eps"].toDouble();
-    const int64_t T = ctx->saved_data["T"].toInt(), nstate = ctx->saved_data["nstate"].toInt();
+    const int64_t T = ctx->saved_data["T"].toInt(), nstate = ctx->saved_data["nstate"].toInt() + ctx->saved_data["npre"].toInt();
     auto keep = ctx->saved_data["keep"].toTensorVector();
     auto cores = ctx->saved_data["cores"].toTensorVector();
     auto state = ctx->saved_data["state"].toTensorVector();
@@ -460,10 +474,55 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
 Tensor lookup_cached(const Tensor& indices, const Tensor& offsets, std::vector<int64_t> p, std::vector<int64_t> q,
                      std::vector<int64_t> r, int64_t optim, double lr, double eps, const Tensor& hashtbl,
                      const Tensor& cache_freq, const Tensor& cache_state, c10::optional<Tensor> cache_opt_state,
-                     const Tensor& cache_weight, std::vector<Tensor> state, std::vector<Tensor> cores) {
+                     const Tensor& cache_weight, std::vector<Tensor> state, std::vector<Tensor> cores,
+                     std::vector<Tensor> pre) {
   return TTCachedLookupOp::apply(indices, offsets, std::move(p), std::move(q), std::move(r), optim, lr, eps, hashtbl,
-                                 cache_freq, cache_state, cache_opt_state, cache_weight, at::TensorList(state),
-                                 at::TensorList(cores));
+                                 cache_freq, cache_state, cache_opt_state, cache_weight, at::TensorList(pre),
+                                 at::TensorList(state), at::TensorList(cores));
+}
+
+// The cache-live prologues of several batches at once (ttx_lookup_prologue_cached_multi: three launches per 16 batches):
+// -> {tableidx, pcol, prow [nbatch, nnz] int64, ploc [nbatch, nnz] int32, n_tt [nbatch, 1] int32, plans [nbatch, stride]};
+// the rows k of the six are what `lookup_cached(pre=)` takes for batch k.  Void after the next cache_populate.
+std::vector<Tensor> prologue_cached_multi(std::vector<Tensor> indices, std::vector<Tensor> offsets, std::vector<int64_t> p,
+                                          std::vector<int64_t> q, std::vector<int64_t> r, const Tensor& hashtbl,
+                                          const Tensor& cache_freq, const Tensor& cache_state) {
+  Geom G;
+  make_geom(G, 1, p, q, r);
+  const ttx_geom& g = G.g;
+  const int64_t nbatch = (int64_t)indices.size();
+  TORCH_CHECK(nbatch > 0 && offsets.size() == indices.size(), "tt_embeddings: one offsets tensor per indices tensor");
+  const int64_t nnz = indices[0].numel(), nb = offsets[0].numel() - 1;
+  std::vector<const int64_t*> ip(nbatch), op(nbatch);
+  for (int64_t k = 0; k < nbatch; ++k) {
+    TORCH_CHECK(indices[k].is_cuda() && indices[k].scalar_type() == at::kLong && indices[k].is_contiguous() &&
+                    offsets[k].is_cuda() && offsets[k].scalar_type() == at::kLong && offsets[k].is_contiguous() &&
+                    indices[k].numel() == nnz && offsets[k].numel() == nb + 1,
+                "tt_embeddings: the batches of a multi-batch prologue must be contiguous int64 GPU tensors of one size");
+    ip[k] = indices[k].data_ptr<int64_t>();
+    op[k] = offsets[k].data_ptr<int64_t>();
+  }
+  TORCH_CHECK(nnz > 0 && nb > 0, "tt_embeddings: empty batch");
+  const int64_t H = hashtbl.numel();
+  TORCH_CHECK(H > 0 && cache_freq.numel() == H && cache_state.numel() == H && hashtbl.scalar_type() == at::kLong &&
+                  cache_freq.scalar_type() == at::kLong && cache_state.scalar_type() == at::kInt,
+              "tt_embeddings: hashtbl / cache_freq (int64) and cache_state (int32) must have hashtbl_size entries");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(indices[0].device());
+  auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  const auto lopt = indices[0].options(), iopt = indices[0].options().dtype(at::kInt);
+  Tensor rowidx = at::empty({nbatch, nnz}, lopt), tableidx = at::empty({nbatch, nnz}, lopt);
+  Tensor pcol = at::empty({nbatch, nnz}, lopt), prow = at::empty({nbatch, nnz}, lopt);
+  Tensor ploc = at::empty({nbatch, nnz}, iopt), n_tt = at::empty({nbatch, 1}, iopt);
+  const size_t stride = (ttx_plan_bytes(&g, nnz) + 255) / 256 * 256;
+  Tensor plans = at::empty({nbatch, (int64_t)stride}, lopt.dtype(at::kByte));
+  const size_t wb = ttx_lookup_prologue_cached_multi_workspace_bytes((int32_t)nbatch, nnz);
+  Tensor ws = bytes_on(indices[0], wb);
+  check(ttx_lookup_prologue_cached_multi(&g, (int32_t)nbatch, nnz, ip.data(), nb, op.data(), H, hashtbl.data_ptr<int64_t>(),
+                                         cache_freq.data_ptr<int64_t>(), cache_state.data_ptr<int32_t>(),
+                                         rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(), pcol.data_ptr<int64_t>(),
+                                         prow.data_ptr<int64_t>(), ploc.data_ptr<int32_t>(), n_tt.data_ptr<int32_t>(),
+                                         plans.data_ptr(), stride, ws.data_ptr(), wb, stream));
+  return {tableidx, pcol, prow, ploc, n_tt, plans};
 }
 
 // ---- direct RCCL exchange (table-sharded multi-GPU lookup, ttx_sharded.py) -----------------------------
@@ -585,7 +644,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         pybind11::arg("q"), pybind11::arg("r"), pybind11::arg("hashtbl") = pybind11::none(),
         pybind11::arg("cache_freq") = pybind11::none());
   m.def("prologue_multi", &prologue_multi, "the prologues of several equal-sized batches in one launch: -> [rowidx, tableidx, plans], row k for batch k");
-  m.def("lookup_cached", &lookup_cached, "cache-live lookup of one table: partition, contraction of the misses, gather of the hits");
+  m.def("lookup_cached", &lookup_cached, "cache-live lookup of one table: partition, contraction of the misses, gather of the hits",
+        pybind11::arg("indices"), pybind11::arg("offsets"), pybind11::arg("p"), pybind11::arg("q"), pybind11::arg("r"),
+        pybind11::arg("optim"), pybind11::arg("lr"), pybind11::arg("eps"), pybind11::arg("hashtbl"),
+        pybind11::arg("cache_freq"), pybind11::arg("cache_state"), pybind11::arg("cache_optimizer_state"),
+        pybind11::arg("cache_weight"), pybind11::arg("state"), pybind11::arg("cores"),
+        pybind11::arg("pre") = std::vector<Tensor>());
+  m.def("prologue_cached_multi", &prologue_cached_multi,
+        "the cache-live prologues of several equal-sized batches: -> [tableidx, pcol, prow, ploc, n_tt, plans], row k for batch k");
   m.def("rccl_unique_id", &rccl_unique_id, "ncclGetUniqueId (rank 0; broadcast the bytes to the others)");
   m.def("rccl_comm_init", &rccl_comm_init, "ncclCommInitRank on the given device (collective; releases the GIL)");
   m.def("rccl_comm_destroy", &rccl_comm_destroy);

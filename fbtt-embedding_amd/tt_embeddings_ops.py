@@ -452,6 +452,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             self.cache_freq.fill_(0)
             self.cache_state.fill_(-1)
             self.warmup = True
+            self._drop_prefetched()
 
     def cache_populate(self) -> None:
         if self.use_cache:
@@ -459,6 +460,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                                    list(self.tt_cores), self.L, self.hashtbl, self.cache_freq, self.cache_state,
                                    self.cache_weight)
             self.warmup = False
+            self._drop_prefetched()  # (a planned-ahead batch was split into hits / misses by the OLD cache contents)
 
     def update_cache(self, indices: torch.Tensor) -> None:
         if self.use_cache:
@@ -500,18 +502,23 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             done.record(side)
         if len(self._prefetched) >= 8:  # (batches that never came: drop the oldest)
             self._prefetched.pop(next(iter(self._prefetched)))
-        self._prefetched[key] = (idx, off, rowidx, tableidx, plan, done, indices, offsets, indices._version, offsets._version)
+        self._prefetched[key] = (idx, off, (rowidx, tableidx, plan), done, indices, offsets, indices._version,
+                                 offsets._version, False)
         return True
 
     def prefetch_many(self, batches) -> bool:
         """Not in the reference.  The lookup prologues of SEVERAL coming batches -- `[(indices, offsets), ...]`, all of
         one size -- in one launch on the current stream (`ttx_lookup_prologue_multi`): a prologue occupies 30 of the chip's
         256 CUs for its ~12 us of dependent loads, sixteen of them take about as long as one.  Each batch's next
-        `forward(indices, offsets)` picks its result up, as after prefetch().  Returns False (and does nothing) where
-        prefetch() would."""
+        `forward(indices, offsets)` picks its result up, as after prefetch().  With a LIVE cache (one table) the round's
+        frequency updates, cache lookups, hit / miss partitions and miss plans are done the same way
+        (`ttx_lookup_prologue_cached_multi`, three launches); cache_populate() / reset_cache() drop what was planned.
+        Returns False (and does nothing) where the prologue cannot be planned ahead: no C++ node, CPU tensors, empty
+        batches, batches of different sizes, duplicate sharing, a live cache over several tables."""
         fast = _native_node()
         batches = list(batches)
-        if fast is None or not self.warmup or not batches or getattr(self, "dedup", False):
+        live = not self.warmup
+        if fast is None or not batches or getattr(self, "dedup", False) or (live and not (self.use_cache and self.num_tables == 1)):
             return False
         norm, keys = [], []
         for indices, offsets in batches:
@@ -523,16 +530,24 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         if len({(i.numel(), o.numel()) for i, o in norm}) != 1:
             return False
         self.prefetch_stream(norm[0][0].device)
-        rowidx, tableidx, plans = fast.prologue_multi([i for i, _ in norm], [o for _, o in norm], self.num_tables,
-                                                      getattr(self, "_p_flat", self.tt_p_shapes), self.tt_q_shapes, self.tt_ranks,
-                                                      self.hashtbl if self.use_cache else None,
-                                                      self.cache_freq if self.use_cache else None)
+        if live:
+            res = fast.prologue_cached_multi([i for i, _ in norm], [o for _, o in norm], self.tt_p_shapes, self.tt_q_shapes,
+                                             self.tt_ranks, self.hashtbl, self.cache_freq, self.cache_state)
+        else:
+            res = fast.prologue_multi([i for i, _ in norm], [o for _, o in norm], self.num_tables,
+                                      getattr(self, "_p_flat", self.tt_p_shapes), self.tt_q_shapes, self.tt_ranks,
+                                      self.hashtbl if self.use_cache else None,
+                                      self.cache_freq if self.use_cache else None)
         for k, key in enumerate(keys):
             while len(self._prefetched) >= 64:
                 self._prefetched.pop(next(iter(self._prefetched)))
-            self._prefetched[key] = (norm[k][0], norm[k][1], rowidx[k], tableidx[k], plans[k], None, batches[k][0], batches[k][1],
-                                     batches[k][0]._version, batches[k][1]._version)
+            self._prefetched[key] = (norm[k][0], norm[k][1], tuple(t[k] for t in res), None, batches[k][0], batches[k][1],
+                                     batches[k][0]._version, batches[k][1]._version, live)
         return True
+
+    def _drop_prefetched(self) -> None:
+        if getattr(self, "_prefetched", None):
+            self._prefetched.clear()
 
     def prefetch_stream(self, device: Optional[torch.device] = None) -> "torch.cuda.Stream":
         """the side stream of prefetch() (created at first use; call this before a hipGraph capture that prefetches)"""
@@ -542,21 +557,23 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             self._prefetched = {}
         return side
 
-    def _take_prefetched(self, indices: torch.Tensor, offsets: torch.Tensor):
+    def _take_prefetched(self, indices: torch.Tensor, offsets: torch.Tensor, live: bool = False):
+        """the planned-ahead prologue of this batch -- (rowidx, tableidx, plan), or with a live cache (tableidx, pcol, prow,
+        ploc, n_tt, plan) -- or None"""
         pf = getattr(self, "_prefetched", None)
         if not pf:
             return None
         hit = pf.pop(getattr(self, "_pf_key", None), None)
         self._pf_key = None
-        if hit is None:
+        if hit is None or hit[8] != live:  # (planned for the other state of the cache: run the prologue in line)
             return None
-        rowidx, tableidx, plan, done = hit[2:6]
+        pre, done = hit[2], hit[3]
         if done is not None:  # (prefetch(): ran on the side stream; prefetch_many(): same stream, stream-ordered)
             cur = torch.cuda.current_stream(indices.device)
             cur.wait_event(done)
-            for t in (rowidx, tableidx, plan):  # allocated on the side stream, used (and freed) on this one
+            for t in pre:  # allocated on the side stream, used (and freed) on this one
                 t.record_stream(cur)
-        return rowidx, tableidx, plan
+        return pre
 
     # --------------------------------------------------------------- forward
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True,
@@ -579,8 +596,8 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         if getattr(self, "_prefetched", None):  # a prefetch() for exactly these tensor objects, not written to since?
             k = (id(indices), id(offsets))
             hit = self._prefetched.get(k)
-            if hit is not None and (hit[6] is not indices or hit[7] is not offsets or hit[8] != indices._version
-                                    or hit[9] != offsets._version):
+            if hit is not None and (hit[4] is not indices or hit[5] is not offsets or hit[6] != indices._version
+                                    or hit[7] != offsets._version):
                 self._prefetched.pop(k)  # stale: the batch was modified in place after its prefetch
                 hit = None
             if hit is not None:
@@ -624,11 +641,12 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             # contraction of the misses, gather of the hits, and the matching backward -- the C++ node again
             use_state = self.sparse and self.optimizer not in _SGD_LIKE
             optim = 2 if not self.sparse else (1 if use_state else 0)
+            pre = self._take_prefetched(indices, offsets, live=True)  # planned ahead by prefetch_many()?
             return fast.lookup_cached(indices.contiguous(), offsets.contiguous(), self.tt_p_shapes, self.tt_q_shapes,
                                       self.tt_ranks, optim, self.learning_rate, self.eps, self.hashtbl, self.cache_freq,
                                       self.cache_state, self.cache_optimizer_state if use_state else None,
                                       self.cache_weight, list(self.optimizer_state) if use_state else [],
-                                      list(self.tt_cores))
+                                      list(self.tt_cores), list(pre) if pre is not None else [])
         prologue = getattr(_engine, "lookup_prologue", None)
         if prologue is not None and self.warmup and indices.numel() > 0:
             # cache not live: frequency update, offsets -> bag rows and the lookup plan in one native call

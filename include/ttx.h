@@ -312,6 +312,23 @@ int ttx_lookup_prologue_multi(const ttx_geom* g, int32_t nbatch, int64_t nnz, co
                               int64_t* upd_hashtbl, int64_t* upd_cache_freq, int64_t* rowidx, int64_t* tableidx,
                               void* plans, size_t plan_stride, ttx_stream_t stream);
 
+/* The same for a LIVE cache (one table; tt_embeddings_ops.py:827-846 with self.warmup == False, then the plan of the
+ * misses): per batch z exactly ttx_preprocess_indices_async(num_tables = 1, warmup = 0, frequency update on the same
+ * table, split point to num_tt_dev[z]) followed by ttx_plan_build_n(.., num_tt_dev + z, pcol_z, tableidx_z, prow_z) --
+ * as three launches per 16 batches when the batch qualifies for the single-launch plan (every p_t <= 256, nnz <= 16384),
+ * batch after batch otherwise.  rowidx / tableidx / pcol / prow / ploc: [nbatch][nnz]; num_tt_dev: [nbatch].  A cached
+ * lookup's location depends on (hashtbl, cache_state) as the last ttx_cache_populate left them, not on the frequency
+ * counts, so batch z's results do not depend on which other batches were counted first; they are void once the cache
+ * is populated again. */
+size_t ttx_lookup_prologue_cached_multi_workspace_bytes(int32_t nbatch, int64_t nnz);
+int ttx_lookup_prologue_cached_multi(const ttx_geom* g, int32_t nbatch, int64_t nnz, const int64_t* const* colidx_host,
+                                     int64_t num_bags, const int64_t* const* offsets_host, int64_t hashtbl_size,
+                                     int64_t* hashtbl, int64_t* cache_freq, const int32_t* cache_state,
+                                     int64_t* rowidx, int64_t* tableidx, int64_t* partitioned_colidx,
+                                     int64_t* partitioned_rowidx, int32_t* cache_locations, int32_t* num_tt_dev,
+                                     void* plans, size_t plan_stride, void* workspace, size_t workspace_bytes,
+                                     ttx_stream_t stream);
+
 /* replaces cache_populate_cuda (tt_embeddings.cpp:76-86,
  * tt_embeddings_cuda.cu:1260-1336): stable descending radix sort of the slots
  * by frequency, the top cache_size keys get cache rows (cache_state[slot] =

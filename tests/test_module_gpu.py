@@ -575,3 +575,125 @@ def test_prefetch_of_a_batch_that_changed_is_not_used(node):
         for x, y in zip(fresh.tt_cores, m.tt_cores):
             x.copy_(y)
     assert torch.equal(out, fresh(idx, off).detach()), "a modified batch must be planned again"
+
+
+def _cache_live_pair(ops, p, q, r, E_, D, B, Lp, optimizer, n_req=5, cache_size=512):
+    """two modules with the same cores whose caches went live on the same warm-up stream, and a round of requests"""
+    kw = dict(num_embeddings=E_, embedding_dim=D, tt_ranks=r, tt_p_shapes=p, tt_q_shapes=q, weight_dist="uniform", device=DEV,
+              sparse=optimizer is not None, optimizer=optimizer or ops.OptimType.SGD, learning_rate=0.05, use_cache=True,
+              cache_size=cache_size, hashtbl_size=1 << 20)
+    torch.manual_seed(11)
+    a, b = ops.TTEmbeddingBag(**kw), ops.TTEmbeddingBag(**kw)
+    warm = [(t(i), t(o)) for i, o in G.make_requests(70, 3, B, 1, Lp, E_, alpha=1.2)]
+    with torch.no_grad():
+        for i, o in warm:
+            a(i, o)
+    a.cache_populate()
+    # (b takes a's table and cache as they are: two tables filled by the same stream may seat colliding keys in a different
+    #  order -- as in the reference -- and then break frequency ties at the cache's edge differently)
+    b.load_state_dict(a.state_dict())
+    b.warmup = False
+    reqs = [(t(i), t(o)) for i, o in G.make_requests(71, n_req, B, 1, Lp, E_, alpha=1.2)]
+    return a, b, reqs
+
+
+@pytest.mark.parametrize("shape", ["single-launch", "small", "general"])
+def test_cache_live_round_planned_ahead_equals_the_in_line_prologue(node, shape):
+    """prefetch_many() with a LIVE cache (ttx_lookup_prologue_cached_multi): per batch the same partition (misses first
+    in index order, hits behind them reversed), cache locations, split point and -- through the forward it drives --
+    plan as the in-line route (ttx_preprocess_indices_async + ttx_plan_build_n)"""
+    import tt_embeddings as E
+    import tt_embeddings_ops as ops
+
+    if node == "python":
+        return
+    p, q, r, E_, D, B, Lp = {"single-launch": ([200, 220, 250], [4, 4, 4], [32, 32], 11_000_000, 64, 512, 20),
+                             "small": ([20, 22, 25], [4, 4, 4], [16, 16], 11_000, 64, 96, 5),
+                             "general": ([300, 20, 20], [4, 4, 4], [8, 8], 120_000, 64, 128, 12)}[shape]
+    a, b, reqs = _cache_live_pair(ops, p, q, r, E_, D, B, Lp, None)
+    assert b.prefetch_many(reqs) is True and len(b._prefetched) == len(reqs)
+    hits = 0
+    for i, o in reqs:
+        key = (id(i), id(o))
+        tableidx, pcol, prow, ploc, n_tt, plan = b._prefetched[key][2]
+        off = torch.cat([o, o.new_full((1,), i.numel())]) if not a.include_last_offset else o
+        ecol, erow, etab, e_ntt, eloc = E.preprocess_indices_sync(i, off, 1, False, a.hashtbl, a.cache_state, a.cache_freq)
+        assert int(n_tt.item()) == e_ntt
+        assert torch.equal(pcol, ecol) and torch.equal(prow, erow) and torch.equal(ploc, eloc)
+        assert torch.equal(tableidx, torch.zeros_like(tableidx))
+        hits += i.numel() - e_ntt
+        out_b = b(i, o)   # planned (consumes the entry)
+        a_out = a(i, o)   # in line (counts the batch a second time in a's table: lookups do not depend on the counts)
+        assert torch.equal(out_b.detach(), a_out.detach()), "forward through the planned-ahead plan differs"
+    assert hits > 0 and len(b._prefetched) == 0
+
+
+@pytest.mark.parametrize("optim", ["sgd", "adagrad"])
+def test_cache_live_training_round_planned_ahead_eager_and_captured(node, optim):
+    """a round of cache-live training steps with the prologues planned ahead, eagerly and replayed from a hipGraph,
+    against the plain sequence: first output bit-identical, the rest to rounding (the cache rows' fused SGD updates are
+    float atomics whose order is not fixed, here as in the reference); the frequency table counts the same.  With
+    Adagrad the cache rows' step sizes depend on which lookup of a row arrives first (cu:1735-1795, `old` of the
+    atomic) -- two plain runs differ in the second step already -- so only the first output and the table are held."""
+    import tt_embeddings_ops as ops
+    import ttx_graph
+
+    if node == "python":
+        return
+    p, q, r, E_, D, B, Lp = [200, 220, 250], [4, 4, 4], [32, 32], 11_000_000, 64, 512, 20
+    optimizer = ops.OptimType.SGD if optim == "sgd" else ops.OptimType.EXACT_ADAGRAD
+    a, b, reqs = _cache_live_pair(ops, p, q, r, E_, D, B, Lp, optimizer, n_req=4)
+    c = ops.TTEmbeddingBag(num_embeddings=E_, embedding_dim=D, tt_ranks=r, tt_p_shapes=p, tt_q_shapes=q, weight_dist="uniform",
+                           device=DEV, sparse=True, optimizer=optimizer, learning_rate=0.05, use_cache=True, cache_size=512,
+                           hashtbl_size=1 << 20)
+    c.load_state_dict(a.state_dict())
+    c.warmup = False
+    grad = t(G.make_grad(72, 1, B, D)[0])
+    outs_a = []
+    for i, o in reqs:
+        out = a(i, o)
+        outs_a.append(out.detach().clone())
+        out.backward(grad)
+    assert b.prefetch_many(reqs) is True
+    for k, (i, o) in enumerate(reqs):
+        out = b(i, o)
+        if k == 0:
+            assert torch.equal(out.detach(), outs_a[0])
+        if optim == "sgd":
+            assert torch.allclose(out.detach(), outs_a[k], rtol=2e-5, atol=2e-6), f"step {k}"
+        assert bool(torch.isfinite(out).all())
+        out.backward(grad)
+    c.prefetch_stream()
+    rnd = ttx_graph.GraphedRound(ttx_graph.planned_round(c, reqs, lambda out, k: out.backward(grad)), [()], warmup=0)
+    torch.cuda.synchronize()
+    rnd.replay()
+    torch.cuda.synchronize()
+    if optim == "sgd":
+        for x, y, z in zip(a.tt_cores, b.tt_cores, c.tt_cores):
+            assert torch.allclose(x, y, rtol=2e-5, atol=2e-6) and torch.allclose(x, z, rtol=2e-5, atol=2e-6)
+        assert torch.allclose(a.cache_weight, b.cache_weight, rtol=2e-5, atol=2e-6)
+        assert torch.allclose(a.cache_weight, c.cache_weight, rtol=2e-5, atol=2e-6)
+
+    def table(m):
+        k_, f_ = m.hashtbl.cpu().numpy(), m.cache_freq.cpu().numpy()
+        return sorted(zip(k_[k_ >= 0].tolist(), f_[k_ >= 0].tolist()))
+    assert table(a) == table(b) == table(c)
+
+
+def test_cache_populate_drops_what_was_planned_ahead(node):
+    """a batch planned ahead was split into hits and misses by the cache contents of that moment: cache_populate() and
+    reset_cache() void it, a prologue planned while the cache was warming up is not used once it is live"""
+    import tt_embeddings_ops as ops
+
+    if node == "python":
+        return
+    a, b, reqs = _cache_live_pair(ops, [20, 22, 25], [4, 4, 4], [16, 16], 11_000, 64, 96, 5, None, n_req=2)
+    assert b.prefetch_many(reqs) is True and len(b._prefetched) == 2
+    b.cache_populate()
+    assert len(b._prefetched) == 0
+    for (i, o) in reqs:  # (b's second populate may cache other rows than a's first: same values to rounding)
+        assert torch.allclose(a(i, o).detach(), b(i, o).detach(), rtol=1e-5, atol=1e-6)
+    b.reset_cache()  # warming up again
+    assert len(b._prefetched) == 0 and b.prefetch_many(reqs[:1]) is True
+    b.warmup = False  # (an entry planned for the warming-up cache is not of the kind the live route takes)
+    assert torch.allclose(b(*reqs[0]).detach(), a(*reqs[0]).detach(), rtol=1e-5, atol=1e-6)
