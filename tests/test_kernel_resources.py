@@ -50,7 +50,7 @@ def test_plan_kernel_keeps_its_arguments_out_of_scratch(plan_res):
     for pro in ("ILb1E", "ILb0E"):
         r = pick(plan_res, "mb_single_kernel", pro)
         assert r["ScratchSize"] == 0, f"mb_single_kernel<{pro}>: {r}"
-        assert r["VGPRs"] <= 80, r
+        assert r["VGPRs"] <= 128, r  # (a 1024-thread work-group is four waves per SIMD: 128 registers each)
 
 
 def test_contraction_and_reduce_kernels_budget(tt_res):
