@@ -326,6 +326,8 @@ def main():
             if "prefetch-round" in mode:
                 graph_txt += ("; the lookup prologues (frequency update, bag rows, plan) of the round's 10 batches are enqueued "
                               "up front in one launch (module.prefetch_many), every replay plans them again")
+                if "rccl" in mode:
+                    graph_txt += "; the round's index exchange too: one all-to-all for the 10 batches"
             elif "prefetch-next" in mode:
                 graph_txt += ("; the lookup prologue of batch k+1 runs on a side stream under the backward of batch k "
                               "(module.prefetch), captured as a forked branch")
@@ -405,12 +407,30 @@ def main():
             # plain round (every step's prologue in line) is timed beside it (`no_prefetch`).  `--prefetch next`: the
             # prologue of batch k+1 on a side stream under the backward of batch k instead (a forked branch in the graph:
             # measured slower than in line at this step size, the cross-stream edges cost more than the overlap saves).
-            pipelined = (not sharded) and args.prefetch != "none" and hasattr(mod, "prefetch_many") and bool(
-                mod.prefetch_many(reqs[:1]) if args.prefetch == "round" else mod.prefetch(*reqs[0]))
+            # N > 1 (sharded module, `--prefetch round`): the round's index exchange is planned ahead as well -- ONE all-to-all
+            # carries the ten batches' lookups, the owners' prologues follow in one launch, every step is left with the
+            # pooled exchange forward and the gradient exchange backward (ShardedTableBatchedTTEmbeddingBag.prefetch_many).
+            # Planning ahead pays where the prologue is latency-bound (small batches); at 327k+ lookups per step it costs:
+            # ten batches' plans and exchanged indices are written up front and read back from HBM instead of from the
+            # caches they were just written through (cfg5 on one rank: 4.31 -> 4.89 ms/step), so large steps stay in line.
+            pf_kw = {"fixed_pooling": POOL} if sharded else {}
+            small = reqs[0][0].numel() <= 65536
+            if not small:
+                pipelined = False
+            elif sharded:
+                pipelined = args.prefetch == "round" and bool(mod.prefetch_many(reqs[:1], **pf_kw))
+                if pipelined:
+                    mod._planned.clear()
+                    if mod.local is not None and getattr(mod.local, "_prefetched", None):
+                        mod.local._prefetched.clear()
+            else:
+                pipelined = args.prefetch != "none" and hasattr(mod, "prefetch_many") and bool(
+                    mod.prefetch_many(reqs[:1]) if args.prefetch == "round" else mod.prefetch(*reqs[0]))
+                if pipelined:
+                    mod._prefetched.clear()
             if pipelined:
-                mod._prefetched.clear()
                 mk = ttx_graph.planned_round if args.prefetch == "round" else ttx_graph.pipelined_round
-                round_fn = mk(mod, reqs, lambda out, k: out.backward(grad))
+                round_fn = mk(mod, reqs, lambda out, k: out.backward(grad), **pf_kw)
             E.profile_reset()
             E.profile_mask(1 << E.PROF_BWD)  # the event pairs around the backward kernel become graph nodes
             g_round = ttx_graph.GraphedRound(round_fn, [()], warmup=3) if pipelined else ttx_graph.GraphedRound(step, reqs, warmup=3)
@@ -427,7 +447,8 @@ def main():
                 dog.start()
             graph_steps(max(args.warmup, iters))
             regions = [timed(graph_steps, args.steps) for _ in range(max(1, args.repeats))]
-            mode = "hipgraph+direct-rccl" if sharded else (f"hipgraph+prefetch-{args.prefetch}" if pipelined else "hipgraph")
+            mode = (("hipgraph+direct-rccl" + ("+prefetch-round" if pipelined else "")) if sharded
+                    else (f"hipgraph+prefetch-{args.prefetch}" if pipelined else "hipgraph"))
             if pipelined:  # the same round without the overlap, for the record
                 g_plain = ttx_graph.GraphedRound(step, reqs, warmup=1)
                 pipelined_round_replay, g_round = g_round, g_plain

@@ -11,16 +11,17 @@ from typing import Callable, Sequence
 import torch
 
 
-def planned_round(module, batches: Sequence[tuple], backward: Callable) -> Callable:
+def planned_round(module, batches: Sequence[tuple], backward: Callable, **forward_kw) -> Callable:
     """A round of training steps over `batches` whose lookup prologues (frequency update, bag rows, lookup plan: index
     work that depends on a batch's indices only) are all enqueued up front in one launch (`module.prefetch_many`), the
-    steps' forward / backward following without them.  Returns a zero-argument callable for GraphedRound."""
+    steps' forward / backward following without them.  `forward_kw` goes to both calls (the sharded module's
+    `fixed_pooling=L`: its index exchange is planned ahead as well).  Returns a zero-argument callable for GraphedRound."""
     batches = list(batches)
 
     def run() -> None:
-        module.prefetch_many(batches)
+        module.prefetch_many(batches, **forward_kw)
         for k, (i, o) in enumerate(batches):
-            backward(module(i, o), k)
+            backward(module(i, o, **forward_kw), k)
 
     return run
 

@@ -175,6 +175,52 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
     def _a2a(self, out, inp, out_splits=None, in_splits=None):
         _a2a(self.group, out, inp, out_splits, in_splits)
 
+    def prefetch_many(self, batches, fixed_pooling: Optional[int] = None) -> bool:
+        """Plan a round of batches ahead (collective: every rank calls it with its batches of the same round).  The
+        lookups' way in -- which depends on the batches' indices only -- is done for ALL of them at once: ONE index
+        exchange carries the round (K times the bytes of a step's exchange, which is latency-bound), one copy brings it
+        into table-major order, and the owners' lookup prologues run in one launch (`local.prefetch_many`).  Each batch's
+        next `forward(indices, offsets, fixed_pooling=L)` -- same tensor objects, unmodified -- then starts at the local
+        lookup: two exchanges per step instead of three.  Fixed pooling only (the split sizes are known without a host
+        read-back); returns False, and does nothing, otherwise."""
+        batches = list(batches)
+        W, NT = self.world, self.num_tables
+        if fixed_pooling is None or not batches or (W == 1 and not _FORCE_EXCHANGE):
+            return False
+        Lp, K = int(fixed_pooling), len(batches)
+        B = (batches[0][1].numel() - 1) // NT
+        for i, o in batches:
+            if i.dim() != 1 or o.dim() != 1 or i.numel() != NT * B * Lp or (o.numel() - 1) // NT != B:
+                return False
+        dev = batches[0][0].device
+        n_own = [len(o) for o in self.owned]
+        n_me = n_own[self.rank]
+        order = self._cached(("order", dev), lambda: torch.tensor(self._order, device=dev))
+        # send: [table (owner-major)][batch][B * Lp] -- the block of destination d is its tables' rows, contiguous
+        stack = torch.stack([i.long().view(NT, B * Lp) for i, _ in batches], dim=1)   # [NT, K, B*Lp]
+        send_idx = (stack if self._identity else stack[order]).contiguous().view(-1)
+        in_splits = [k * K * B * Lp for k in n_own]
+        out_splits = [n_me * K * B * Lp] * W
+        recv_idx = send_idx.new_empty(sum(out_splits))
+        if self.direct is not None:
+            self.direct.all_to_all(recv_idx, send_idx, out_splits, in_splits)
+        else:
+            self._a2a(recv_idx, send_idx, out_splits, in_splits)
+        # wire order [src][k][batch][b][l] -> per batch table-major [k][src][b][l]
+        loc = recv_idx.view(W, n_me, K, B * Lp).permute(2, 1, 0, 3).contiguous().view(K, -1)
+        loc_off = self._cached(("off", dev, n_me * W * B, Lp), lambda: torch.arange(
+            0, n_me * W * B * Lp + 1, Lp, device=dev, dtype=torch.int64))
+        loc_idx = [loc[j] for j in range(K)]
+        if n_me and hasattr(self.local, "prefetch_many"):
+            self.local.prefetch_many([(x, loc_off) for x in loc_idx])  # (False on CPU tensors: prologues then run in line)
+        if not hasattr(self, "_planned"):
+            self._planned = {}
+        for j, (i, o) in enumerate(batches):
+            while len(self._planned) >= 64:
+                self._planned.pop(next(iter(self._planned)))
+            self._planned[(id(i), id(o))] = (i, o, i._version, o._version, Lp, loc_idx[j], loc_off)
+        return True
+
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, fixed_pooling: Optional[int] = None) -> torch.Tensor:
         W, NT, D = self.world, self.num_tables, self.embedding_dim
         indices, offsets = indices.long(), offsets.long()
@@ -186,7 +232,13 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         n_me = n_own[self.rank]
         order = self._cached(("order", dev), lambda: torch.tensor(self._order, device=dev))
         # ---- 1. lookups in -------------------------------------------------
-        if fixed_pooling is not None:
+        hit = getattr(self, "_planned", {}).pop((id(indices), id(offsets)), None) if getattr(self, "_planned", None) else None
+        if hit is not None and not (hit[0] is indices and hit[1] is offsets and hit[2] == indices._version
+                                    and hit[3] == offsets._version and fixed_pooling is not None and hit[4] == int(fixed_pooling)):
+            hit = None  # (another tensor, or written to since: exchange in line)
+        if hit is not None:  # planned ahead (prefetch_many): the index exchange of this batch is done
+            loc_idx, loc_off = hit[5], hit[6]
+        elif fixed_pooling is not None:
             Lp = int(fixed_pooling)
             send_idx = indices if self._identity else indices.view(NT, B * Lp)[order].contiguous().view(-1)
             in_splits = [k * B * Lp for k in n_own]

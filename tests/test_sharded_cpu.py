@@ -126,3 +126,86 @@ def test_two_rank_table_sharding_matches_single_process(fixed, NT, direct):
         assert mine == [t for t in range(NT) if t % world == r]
         for t in range(3 if mine else 0):
             np.testing.assert_allclose(cr[t], new_cores[t][mine], rtol=1e-5, atol=1e-7)
+
+
+def _worker_round(rank, world, port, q, NT, direct):
+    try:
+        for p in (HERE, os.path.join(ROOT, "fbtt-embedding_amd")):
+            sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import gen_inputs as G
+        import oracle_engine
+        import tt_embeddings_ops as ops
+        import ttx_sharded
+
+        ops._engine = oracle_engine
+        cores_all = G.make_cores(5, NT, P, Q, R)
+        fixed, K = 3, 3
+
+        def fresh():
+            m = ttx_sharded.ShardedTableBatchedTTEmbeddingBag(
+                NT, int(np.prod(P)), D, R, tt_p_shapes=P, tt_q_shapes=Q, sparse=True, optimizer=ops.OptimType.SGD,
+                learning_rate=0.1, weight_dist="uniform", device="cpu")
+            if direct:
+                m.enable_direct_exchange(ttx_sharded.CollectiveExchange(None))
+            if m.local is not None:
+                with torch.no_grad():
+                    for t, core in enumerate(m.local.tt_cores):
+                        core.copy_(torch.from_numpy(cores_all[t][m.my_tables]))
+            return m
+
+        a, b = fresh(), fresh()
+        batches, grads = [], []
+        for k in range(K):
+            idx, off, grad = _make_inputs(10 * k + rank, fixed, NT)
+            batches.append((torch.from_numpy(idx), torch.from_numpy(off)))
+            grads.append(torch.from_numpy(grad))
+        outs_a = []
+        for (i, o), g in zip(batches, grads):  # every step's index exchange in line
+            out = a(i, o, fixed_pooling=fixed)
+            outs_a.append(out.detach().clone())
+            out.backward(g)
+        assert b.prefetch_many(batches, fixed_pooling=fixed) is True and len(b._planned) == K
+        same = True
+        for k, ((i, o), g) in enumerate(zip(batches, grads)):  # the round's index exchange done up front
+            out = b(i, o, fixed_pooling=fixed)
+            same = same and torch.equal(out.detach(), outs_a[k])
+            out.backward(g)
+        assert len(b._planned) == 0
+        if a.local is not None:
+            for x, y in zip(a.local.tt_cores, b.local.tt_cores):
+                same = same and torch.equal(x, y)
+        # a batch written to after the planning is exchanged in line again
+        b.prefetch_many(batches[:1], fixed_pooling=fixed)
+        batches[0][0].add_(1).remainder_(int(np.prod(P)))
+        out_b = b(*batches[0], fixed_pooling=fixed).detach()
+        out_a = a(*batches[0], fixed_pooling=fixed).detach()
+        same = same and torch.equal(out_a, out_b) and len(b._planned) == 0
+        assert b.prefetch_many(batches, fixed_pooling=None) is False  # ragged bags: not planned ahead
+        q.put((rank, bool(same), "", None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "ERROR", traceback.format_exc(), None))
+
+
+@pytest.mark.parametrize("NT,direct", [(2, True), (5, True), (5, False), (1, True)])
+def test_two_rank_round_planned_ahead_equals_in_line(NT, direct):
+    """ShardedTableBatchedTTEmbeddingBag.prefetch_many: ONE index exchange for a round of batches, then the steps with the
+    pooled / gradient exchanges only -- outputs and cores identical to exchanging every step's indices in line"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_round, args=(r, world, port, q, NT, direct)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for _ in range(world):
+        r = q.get(timeout=180)
+        assert r[1] is True, f"rank {r[0]}: {r[1]}\n{r[2]}"
+    for p in procs:
+        p.join(timeout=60)
