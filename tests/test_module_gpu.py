@@ -697,3 +697,27 @@ def test_cache_populate_drops_what_was_planned_ahead(node):
     assert len(b._prefetched) == 0 and b.prefetch_many(reqs[:1]) is True
     b.warmup = False  # (an entry planned for the warming-up cache is not of the kind the live route takes)
     assert torch.allclose(b(*reqs[0]).detach(), a(*reqs[0]).detach(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("live", [False, True])
+def test_more_batches_than_one_prologue_launch_holds(node, live):
+    """prefetch_many with 18 batches: the multi-batch prologues take 16 batches per launch (the pointer table of
+    ProBatch) -- the 17th and 18th go through a second one; every batch's forward equals the in-line one"""
+    import tt_embeddings_ops as ops
+
+    if node == "python":
+        return
+    p, q, r, E_, D, B, Lp = [20, 22, 25], [4, 4, 4], [16, 16], 11_000, 64, 300, 6
+    if live:
+        a, b, reqs = _cache_live_pair(ops, p, q, r, E_, D, B, Lp, None, n_req=18, cache_size=256)
+    else:
+        kw = dict(num_embeddings=E_, embedding_dim=D, tt_ranks=r, tt_p_shapes=p, tt_q_shapes=q, weight_dist="uniform",
+                  device=DEV, sparse=False, use_cache=True, cache_size=256, hashtbl_size=1 << 20)
+        torch.manual_seed(3)
+        a, b = ops.TTEmbeddingBag(**kw), ops.TTEmbeddingBag(**kw)
+        b.load_state_dict(a.state_dict())
+        reqs = [(t(i), t(o)) for i, o in G.make_requests(75, 18, B, 1, Lp, E_, alpha=1.2)]
+    assert b.prefetch_many(reqs) is True and len(b._prefetched) == 18
+    for i, o in reqs:
+        assert torch.equal(b(i, o).detach(), a(i, o).detach())
+    assert len(b._prefetched) == 0
