@@ -134,7 +134,8 @@ __global__ __launch_bounds__(1024) void scan_units_kernel(int U, int* unit_cnt, 
 __global__ __launch_bounds__(kCT) void partition_scatter_kernel(
     int N, int U, int scanned, const int64_t* __restrict__ colidx, const int64_t* __restrict__ rowidx,
     const int32_t* __restrict__ loc, const int* __restrict__ unit_cnt, int64_t* pcol, int64_t* prow,
-    int32_t* ploc, int* total_out, int32_t* num_tt_dev, ProBatch mb, long long ws_stride) {
+    int32_t* ploc, int* total_out, int32_t* num_tt_dev, ProBatch mb, long long ws_stride,
+    const float* __restrict__ psw, float* ppsw, int32_t* porig) {
   __shared__ int wsum[kCT / kWave], wbase[kCT / kWave];
   if (blockIdx.y > 0) {  // batch z of ttx_lookup_prologue_cached_multi
     const int z = blockIdx.y;
@@ -177,6 +178,8 @@ __global__ __launch_bounds__(kCT) void partition_scatter_kernel(
     pcol[dst] = colidx[i];
     prow[dst] = rowidx[i];
     ploc[dst] = cl;
+    if (psw) ppsw[dst] = psw[i];  // nn.EmbeddingBag per_sample_weights travel with their lookups ...
+    if (porig) porig[dst] = i;    // ... and the way back (the weights' gradient is returned in the caller's order)
   }
 }
 
@@ -244,6 +247,68 @@ __global__ __launch_bounds__(kCT) void cache_forward_kernel(int N, int D, const 
     for (int j = 0; j < sl; ++j) acc += w[(size_t)loc[n + j] * D + e];
     o[e] = acc;
   }
+}
+
+// ... with nn.EmbeddingBag's per_sample_weights: out[row] += sum_j psw[n + j] * w[loc[n + j]], in index order (one
+// 32-lane group per run head; the weighted form is the rare one and stays simple)
+__global__ __launch_bounds__(kCT) void cache_forward_w_kernel(int N, int D, const int* __restrict__ skip_dev,
+                                                             const int64_t* __restrict__ rowidx,
+                                                             const int32_t* __restrict__ loc,
+                                                             const float* __restrict__ psw,
+                                                             const float* __restrict__ w, float* out) {
+  const int n = blockIdx.x * (kCT / 32) + threadIdx.x / 32;
+  const int l = threadIdx.x & 31;
+  if (skip_dev) { const int k = max(0, min(N, *skip_dev)); N -= k; rowidx += k; loc += k; psw += k; }
+  if (n >= N) return;
+  const int64_t r = rowidx[n];
+  if (n > 0 && rowidx[n - 1] == r) return;
+  const unsigned long long half = (threadIdx.x & 32) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+  int sl = 1;
+  for (;;) {
+    const int c = n + sl + l;
+    const bool same = c < N && rowidx[c] == r;
+    const unsigned long long m = (__ballot(!same) & half) >> (threadIdx.x & 32);
+    if (m) { sl += __builtin_ctzll(m); break; }
+    sl += 32;
+  }
+  float* o = out + (size_t)r * D;
+  for (int e = l; e < D; e += 32) {
+    float acc = o[e];
+    for (int j = 0; j < sl; ++j) acc = fmaf(psw[n + j], w[(size_t)loc[n + j] * D + e], acc);
+    o[e] = acc;
+  }
+}
+
+// rows[n] = w[loc[n]] for the cached entries (behind the split point): the forward's rows of the hits, kept for the
+// gradient of the per_sample_weights (ttx_psw_backward reads them like the contraction's rows of the misses)
+__global__ __launch_bounds__(kCT) void cache_rows_gather_kernel(int N, int D, const int* __restrict__ skip_dev,
+                                                               const int32_t* __restrict__ loc,
+                                                               const float* __restrict__ w, float* __restrict__ rows) {
+  const int k = skip_dev ? max(0, min(N, *skip_dev)) : 0;
+  const int n = k + blockIdx.x * (kCT / 32) + threadIdx.x / 32;
+  const int l = threadIdx.x & 31;
+  if (n >= N) return;
+  const float* src = w + (size_t)loc[n] * D;
+  float* dst = rows + (size_t)n * D;
+  for (int e = l; e < D; e += 32) dst[e] = src[e];
+}
+
+// scaled[n] = psw[n] * grad[rowidx[n]] and iota[n] = n for the cached entries: the cache backward kernels then take
+// (scaled, iota) in place of (grad_output, rowidx) -- every lookup brings its own weighted gradient row
+__global__ __launch_bounds__(kCT) void cache_scale_grad_kernel(int N, int D, const int* __restrict__ skip_dev,
+                                                              const float* __restrict__ grad,
+                                                              const int64_t* __restrict__ rowidx,
+                                                              const float* __restrict__ psw,
+                                                              float* __restrict__ scaled, int64_t* __restrict__ iota) {
+  const int k = skip_dev ? max(0, min(N, *skip_dev)) : 0;
+  const int n = k + blockIdx.x * (kCT / 32) + threadIdx.x / 32;
+  const int l = threadIdx.x & 31;
+  if (n >= N) return;
+  const float* g = grad + (size_t)rowidx[n] * D;
+  const float wn = psw[n];
+  float* dst = scaled + (size_t)n * D;
+  for (int e = l; e < D; e += 32) dst[e] = wn * g[e];
+  if (l == 0) iota[n] = n;
 }
 
 // The same sums for D % 4 == 0, wave64-native (the 32-lane-group kernel above keeps 1 group in 20 busy at 20 lookups
@@ -775,7 +840,22 @@ int ttx_preprocess_indices_async(int64_t nnz, const int64_t* colidx, int64_t nb,
                                  int32_t* ploc, int32_t* num_tt_host, int32_t* partitioned_host,
                                  int32_t* num_tt_dev, int64_t* upd_hashtbl, int64_t* upd_cache_freq,
                                  void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
+  return ttx_preprocess_indices_async_w(nnz, colidx, nb, offsets, num_tables, warmup, H, hashtbl, cache_state, rowidx,
+                                        tableidx, pcol, prow, ploc, num_tt_host, partitioned_host, num_tt_dev,
+                                        upd_hashtbl, upd_cache_freq, nullptr, nullptr, nullptr, workspace,
+                                        workspace_bytes, stream);
+}
+
+int ttx_preprocess_indices_async_w(int64_t nnz, const int64_t* colidx, int64_t nb,
+                                   const int64_t* offsets, int32_t num_tables, int32_t warmup,
+                                   int64_t H, const int64_t* hashtbl, const int32_t* cache_state,
+                                   int64_t* rowidx, int64_t* tableidx, int64_t* pcol, int64_t* prow,
+                                   int32_t* ploc, int32_t* num_tt_host, int32_t* partitioned_host,
+                                   int32_t* num_tt_dev, int64_t* upd_hashtbl, int64_t* upd_cache_freq,
+                                   const float* psw, float* ppsw, int32_t* porig,
+                                   void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (psw && !ppsw) TTX_FAIL(TTX_EINVAL, "per_sample_weights without a buffer for the partitioned weights");
   if (!num_tt_host || !partitioned_host) TTX_FAIL(TTX_EINVAL, "NULL output");
   *num_tt_host = (int32_t)nnz;
   *partitioned_host = 0;
@@ -820,7 +900,7 @@ int ttx_preprocess_indices_async(int64_t nnz, const int64_t* colidx, int64_t nb,
   const int scanned = U > kScanUnits ? 1 : 0;
   if (scanned) hipLaunchKernelGGL(scan_units_kernel, dim3(1), dim3(1024), 0, st, U, unit_cnt, total);
   hipLaunchKernelGGL(partition_scatter_kernel, dim3(U), dim3(kCT), 0, st, N, U, scanned, colidx, rowidx, loc,
-                     unit_cnt, pcol, prow, ploc, total, num_tt_dev, ProBatch{}, 0ll);
+                     unit_cnt, pcol, prow, ploc, total, num_tt_dev, ProBatch{}, 0ll, psw, ppsw, porig);
   TTX_HIP(hipGetLastError());
   *partitioned_host = 1;
   if (num_tt_dev) return TTX_OK;  // the split point stays on the device: no host synchronisation at all
@@ -893,7 +973,8 @@ int ttx_lookup_prologue_cached_multi(const ttx_geom* g, int32_t nbatch, int64_t 
     TTX_HIP(hipGetLastError());
     hipLaunchKernelGGL(partition_scatter_kernel, dim3(U, nz), dim3(kCT), 0, st, N, U, 0, colidx_host[z0],
                        rowidx + (size_t)z0 * nnz, loc, unit_cnt, pcol + (size_t)z0 * nnz, prow + (size_t)z0 * nnz,
-                       ploc + (size_t)z0 * nnz, total, num_tt_dev + z0, mb, ws_stride);
+                       ploc + (size_t)z0 * nnz, total, num_tt_dev + z0, mb, ws_stride, (const float*)nullptr,
+                       (float*)nullptr, (int32_t*)nullptr);
     TTX_HIP(hipGetLastError());
   }
   return plan_build_batches(d, nbatch, nnz, num_tt_dev, pcol, tableidx, prow, plans, plan_stride, st);
@@ -922,6 +1003,43 @@ int ttx_cache_forward_n(int32_t B, int64_t nnz, const int32_t* skip_dev, const i
   else
     hipLaunchKernelGGL(cache_forward_kernel, dim3((unsigned)((nnz + kCT / 32 - 1) / (kCT / 32))), dim3(kCT), 0,
                        (hipStream_t)stream, (int)nnz, D, skip_dev, rowidx, loc, cache_weight, output);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
+int ttx_cache_forward_nw(int32_t B, int64_t nnz, const int32_t* skip_dev, const int32_t* loc, const int64_t* rowidx,
+                         const float* psw, int32_t D, const float* cache_weight, float* output, ttx_stream_t stream) {
+  if (!psw) return ttx_cache_forward_n(B, nnz, skip_dev, loc, rowidx, D, cache_weight, output, stream);
+  if (B <= 0) TTX_FAIL(TTX_EINVAL, "B=%d must be > 0", B);
+  if (D <= 0) TTX_FAIL(TTX_EINVAL, "D=%d must be > 0", D);
+  if (nnz == 0) return TTX_OK;
+  if (!loc || !rowidx || !cache_weight || !output) TTX_FAIL(TTX_EINVAL, "NULL input");
+  ProfScope ps(TTX_PROF_CACHE_FWD, (hipStream_t)stream);
+  hipLaunchKernelGGL(cache_forward_w_kernel, dim3((unsigned)((nnz + kCT / 32 - 1) / (kCT / 32))), dim3(kCT), 0,
+                     (hipStream_t)stream, (int)nnz, D, skip_dev, rowidx, loc, psw, cache_weight, output);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
+int ttx_cache_rows_n(int64_t nnz, const int32_t* skip_dev, const int32_t* loc, int32_t D, const float* cache_weight,
+                     float* rows, ttx_stream_t stream) {
+  if (nnz == 0) return TTX_OK;
+  if (D <= 0) TTX_FAIL(TTX_EINVAL, "D=%d must be > 0", D);
+  if (!loc || !cache_weight || !rows) TTX_FAIL(TTX_EINVAL, "NULL input");
+  hipLaunchKernelGGL(cache_rows_gather_kernel, dim3((unsigned)((nnz + kCT / 32 - 1) / (kCT / 32))), dim3(kCT), 0,
+                     (hipStream_t)stream, (int)nnz, D, skip_dev, loc, cache_weight, rows);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
+int ttx_cache_weighted_grad_n(int64_t nnz, const int32_t* skip_dev, int32_t D, const float* grad_output,
+                              const int64_t* rowidx, const float* psw, float* scaled, int64_t* iota,
+                              ttx_stream_t stream) {
+  if (nnz == 0) return TTX_OK;
+  if (D <= 0) TTX_FAIL(TTX_EINVAL, "D=%d must be > 0", D);
+  if (!grad_output || !rowidx || !psw || !scaled || !iota) TTX_FAIL(TTX_EINVAL, "NULL input");
+  hipLaunchKernelGGL(cache_scale_grad_kernel, dim3((unsigned)((nnz + kCT / 32 - 1) / (kCT / 32))), dim3(kCT), 0,
+                     (hipStream_t)stream, (int)nnz, D, skip_dev, grad_output, rowidx, psw, scaled, iota);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }

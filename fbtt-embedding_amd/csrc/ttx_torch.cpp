@@ -310,14 +310,16 @@ std::vector<Tensor> prologue_multi(std::vector<Tensor> indices, std::vector<Tens
 // ---- cache live (one table): tt_embeddings_ops.py:821-874 with self.warmup == False ----------------
 struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
   // args: indices, offsets, p, q, r, optim, lr, eps, hashtbl, cache_freq, cache_state,
-  //       cache_optimizer_state (undefined unless Adagrad), cache_weight, pre (the batch's row of prologue_cached_multi's
-  //       results: {tableidx, pcol, prow, ploc, n_tt, plan}, or empty), state.., cores..
-  static constexpr int64_t kHead = 13;  // (then one slot per tensor of pre, state, cores)
+  //       cache_optimizer_state (undefined unless Adagrad), cache_weight, per_sample_weights (optional),
+  //       pre (the batch's row of prologue_cached_multi's results: {tableidx, pcol, prow, ploc, n_tt, plan}, or empty),
+  //       state.., cores..
+  static constexpr int64_t kHead = 14;  // (then one slot per tensor of pre, state, cores)
   static Tensor forward(AutogradContext* ctx, const Tensor& indices, const Tensor& offsets, std::vector<int64_t> p,
                         std::vector<int64_t> q, std::vector<int64_t> r, int64_t optim, double lr, double eps,
                         const Tensor& hashtbl, const Tensor& cache_freq, const Tensor& cache_state,
                         const c10::optional<Tensor>& cache_opt_state, const Tensor& cache_weight,
-                        at::TensorList pre, at::TensorList state, at::TensorList cores) {
+                        const c10::optional<Tensor>& psw, at::TensorList pre, at::TensorList state,
+                        at::TensorList cores) {
     Geom G;
     make_geom(G, 1, p, q, r);
     const ttx_geom& g = G.g;
@@ -337,7 +339,14 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(indices.device());
     auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
 
-    Tensor tableidx, pcol, prow, ploc, n_tt, plan;
+    const bool weighted = psw.has_value() && psw->defined();
+    if (weighted)
+      TORCH_CHECK(psw->is_cuda() && psw->scalar_type() == at::kFloat && psw->is_contiguous() && psw->numel() == nnz &&
+                      pre.size() == 0,
+                  "tt_embeddings: per_sample_weights must be a contiguous float32 GPU tensor, one weight per index "
+                  "(and the batch's prologue runs in line)");
+    const bool psw_grad = weighted && psw->requires_grad();
+    Tensor tableidx, pcol, prow, ploc, n_tt, plan, ppsw, porig;
     const size_t pb = ttx_plan_bytes(&g, nnz);
     if (pre.size() == 6) {  // planned ahead (prologue_cached_multi): frequency update, lookup, partition and plan are done
       tableidx = pre[0]; pcol = pre[1]; prow = pre[2]; ploc = pre[3]; n_tt = pre[4]; plan = pre[5];
@@ -358,12 +367,18 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
       // nnz only sizes grids and workspaces -- no host synchronisation, the step can be graph-captured
       n_tt = at::empty({1}, indices.options().dtype(at::kInt));
       int32_t n_host = 0, part = 0;
-      check(ttx_preprocess_indices_async(nnz, indices.data_ptr<int64_t>(), B, offsets.data_ptr<int64_t>(), 1, 0, H,
-                                         hashtbl.data_ptr<int64_t>(), cache_state.data_ptr<int32_t>(),
-                                         rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(), pcol.data_ptr<int64_t>(),
-                                         prow.data_ptr<int64_t>(), ploc.data_ptr<int32_t>(), &n_host, &part,
-                                         n_tt.data_ptr<int32_t>(), hashtbl.data_ptr<int64_t>(),
-                                         cache_freq.data_ptr<int64_t>(), pws.data_ptr(), pwb, stream));
+      if (weighted) {  // the weights follow their lookups through the partition; the origins bring their gradient back
+        ppsw = at::empty({nnz}, cores[0].options());
+        if (psw_grad) porig = at::empty({nnz}, indices.options().dtype(at::kInt));
+      }
+      check(ttx_preprocess_indices_async_w(nnz, indices.data_ptr<int64_t>(), B, offsets.data_ptr<int64_t>(), 1, 0, H,
+                                           hashtbl.data_ptr<int64_t>(), cache_state.data_ptr<int32_t>(),
+                                           rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
+                                           pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(), ploc.data_ptr<int32_t>(),
+                                           &n_host, &part, n_tt.data_ptr<int32_t>(), hashtbl.data_ptr<int64_t>(),
+                                           cache_freq.data_ptr<int64_t>(), weighted ? psw->data_ptr<float>() : nullptr,
+                                           weighted ? ppsw.data_ptr<float>() : nullptr,
+                                           psw_grad ? porig.data_ptr<int32_t>() : nullptr, pws.data_ptr(), pwb, stream));
       TORCH_CHECK(part == 1, "tt_embeddings: the cache-live preprocessing did not partition");
       plan = bytes_on(indices, pb);
       check(ttx_plan_build_n(&g, nnz, n_tt.data_ptr<int32_t>(), pcol.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
@@ -375,12 +390,19 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     for (int t = 0; t < g.T; ++t) cp[t] = cores[t].data_ptr<float>();
     const size_t wb = ttx_tt_forward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
     Tensor ws = bytes_on(indices, wb);
-    check(ttx_tt_forward(&g, (int32_t)B, (int32_t)D, nnz, pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(),
-                         tableidx.data_ptr<int64_t>(), cp, out.data_ptr<float>(), plan.data_ptr(), ws.data_ptr(), wb,
-                         stream));
-    check(ttx_cache_forward_n((int32_t)B, nnz, n_tt.data_ptr<int32_t>(), ploc.data_ptr<int32_t>(),
-                              prow.data_ptr<int64_t>(), (int32_t)D, cache_weight.data_ptr<float>(), out.data_ptr<float>(),
-                              stream));
+    // (a gradient for the weights needs every lookup's forward row: the contraction's for the misses, the cache's for the hits)
+    Tensor rows_keep;
+    if (psw_grad) rows_keep = at::empty({nnz, D}, cores[0].options());
+    check(ttx_tt_forward_wr(&g, (int32_t)B, (int32_t)D, nnz, pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(),
+                            tableidx.data_ptr<int64_t>(), weighted ? ppsw.data_ptr<float>() : nullptr, cp,
+                            out.data_ptr<float>(), psw_grad ? rows_keep.data_ptr<float>() : nullptr, plan.data_ptr(),
+                            ws.data_ptr(), wb, stream));
+    check(ttx_cache_forward_nw((int32_t)B, nnz, n_tt.data_ptr<int32_t>(), ploc.data_ptr<int32_t>(),
+                               prow.data_ptr<int64_t>(), weighted ? ppsw.data_ptr<float>() : nullptr, (int32_t)D,
+                               cache_weight.data_ptr<float>(), out.data_ptr<float>(), stream));
+    if (psw_grad)
+      check(ttx_cache_rows_n(nnz, n_tt.data_ptr<int32_t>(), ploc.data_ptr<int32_t>(), (int32_t)D,
+                             cache_weight.data_ptr<float>(), rows_keep.data_ptr<float>(), stream));
 
     ctx->saved_data["p"] = p;
     ctx->saved_data["q"] = q;
@@ -391,6 +413,11 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     ctx->saved_data["T"] = (int64_t)g.T;
     ctx->saved_data["nstate"] = (int64_t)state.size();
     ctx->saved_data["npre"] = (int64_t)pre.size();
+    if (weighted) ctx->saved_data["ppsw"] = ppsw;
+    if (psw_grad) {
+      ctx->saved_data["rows"] = rows_keep;
+      ctx->saved_data["porig"] = porig;
+    }
     std::vector<Tensor> keep = {pcol, prow, tableidx, ploc, cache_weight, n_tt};
     ctx->saved_data["keep"] = keep;
     if (cache_opt_state.has_value() && cache_opt_state->defined()) ctx->saved_data["copt"] = *cache_opt_state;
@@ -443,19 +470,39 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     }
     const size_t wb = ttx_tt_backward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
     Tensor ws = bytes_on(pcol, wb);
-    check(ttx_tt_backward(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz,
-                          pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
-                          go.data_ptr<float>(), cp, optim == TTX_OPTIM_ADAGRAD ? sp : nullptr,
-                          optim == TTX_OPTIM_DENSE ? gp : nullptr, plan.defined() ? plan.data_ptr() : nullptr,
-                          ws.data_ptr(), wb, stream));
+    const Tensor ppsw = ctx->saved_data.count("ppsw") ? ctx->saved_data["ppsw"].toTensor() : Tensor();
+    check(ttx_tt_backward_w(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz,
+                            pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
+                            ppsw.defined() ? ppsw.data_ptr<float>() : nullptr, go.data_ptr<float>(), cp,
+                            optim == TTX_OPTIM_ADAGRAD ? sp : nullptr, optim == TTX_OPTIM_DENSE ? gp : nullptr,
+                            plan.defined() ? plan.data_ptr() : nullptr, ws.data_ptr(), wb, stream));
+    if (ctx->saved_data.count("rows")) {  // gradient of the per_sample_weights (argument slot 13), in the caller's order
+      const Tensor rows_keep = ctx->saved_data["rows"].toTensor(), porig = ctx->saved_data["porig"].toTensor();
+      Tensor d_part = at::empty({nnz}, rows_keep.options());
+      check(ttx_psw_backward((int32_t)B, (int32_t)D, nnz, rows_keep.data_ptr<float>(), prow.data_ptr<int64_t>(),
+                             tableidx.data_ptr<int64_t>(), go.data_ptr<float>(), d_part.data_ptr<float>(), stream));
+      Tensor d_psw = at::empty({nnz}, rows_keep.options());
+      d_psw.index_copy_(0, porig.to(at::kLong), d_part);
+      grads[13] = d_psw;
+    }
     const int32_t* loc = ploc.data_ptr<int32_t>();
     const int64_t* rows = prow.data_ptr<int64_t>();
+    const float* gcache = go.data_ptr<float>();  // (weighted: every cached lookup's own scaled gradient row)
+    Tensor scaled, iota;
+    if (ppsw.defined()) {
+      scaled = at::empty({nnz, D}, go.options());
+      iota = at::empty({nnz}, prow.options());
+      check(ttx_cache_weighted_grad_n(nnz, n_tt, (int32_t)D, go.data_ptr<float>(), rows, ppsw.data_ptr<float>(),
+                                      scaled.data_ptr<float>(), iota.data_ptr<int64_t>(), stream));
+      gcache = scaled.data_ptr<float>();
+      rows = iota.data_ptr<int64_t>();
+    }
     if (optim == TTX_OPTIM_SGD) {
-      check(ttx_cache_backward_sgd_n(nnz, n_tt, (int32_t)D, go.data_ptr<float>(), loc, rows, (float)lr,
+      check(ttx_cache_backward_sgd_n(nnz, n_tt, (int32_t)D, gcache, loc, rows, (float)lr,
                                      cache_weight.data_ptr<float>(), stream));
     } else if (optim == TTX_OPTIM_ADAGRAD) {
       TORCH_CHECK(cache_opt_state.defined(), "tt_embeddings: Adagrad with a live cache needs cache_optimizer_state");
-      check(ttx_cache_backward_rowwise_adagrad_approx_n(nnz, n_tt, (int32_t)D, go.data_ptr<float>(), loc, rows, (float)lr,
+      check(ttx_cache_backward_rowwise_adagrad_approx_n(nnz, n_tt, (int32_t)D, gcache, loc, rows, (float)lr,
                                                         (float)eps, cache_opt_state.data_ptr<float>(),
                                                         cache_weight.data_ptr<float>(), stream));
     } else {
@@ -463,7 +510,7 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
       // (the reference returns no cache gradient when nothing was hit, tt_embeddings_ops.py:349-353;
       // with the split point on the device this node always returns one -- zeros in that case)
       Tensor gcw = at::empty_like(cache_weight);
-      check(ttx_cache_backward_dense_n(nnz, n_tt, (int32_t)D, go.data_ptr<float>(), loc, rows, cache_weight.size(0),
+      check(ttx_cache_backward_dense_n(nnz, n_tt, (int32_t)D, gcache, loc, rows, cache_weight.size(0),
                                        gcw.data_ptr<float>(), stream));
       grads[12] = gcw;  // cache_weight
     }
@@ -475,10 +522,10 @@ Tensor lookup_cached(const Tensor& indices, const Tensor& offsets, std::vector<i
                      std::vector<int64_t> r, int64_t optim, double lr, double eps, const Tensor& hashtbl,
                      const Tensor& cache_freq, const Tensor& cache_state, c10::optional<Tensor> cache_opt_state,
                      const Tensor& cache_weight, std::vector<Tensor> state, std::vector<Tensor> cores,
-                     std::vector<Tensor> pre) {
+                     std::vector<Tensor> pre, c10::optional<Tensor> per_sample_weights) {
   return TTCachedLookupOp::apply(indices, offsets, std::move(p), std::move(q), std::move(r), optim, lr, eps, hashtbl,
-                                 cache_freq, cache_state, cache_opt_state, cache_weight, at::TensorList(pre),
-                                 at::TensorList(state), at::TensorList(cores));
+                                 cache_freq, cache_state, cache_opt_state, cache_weight, per_sample_weights,
+                                 at::TensorList(pre), at::TensorList(state), at::TensorList(cores));
 }
 
 // The cache-live prologues of several batches at once (ttx_lookup_prologue_cached_multi: three launches per 16 batches):
@@ -649,7 +696,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         pybind11::arg("optim"), pybind11::arg("lr"), pybind11::arg("eps"), pybind11::arg("hashtbl"),
         pybind11::arg("cache_freq"), pybind11::arg("cache_state"), pybind11::arg("cache_optimizer_state"),
         pybind11::arg("cache_weight"), pybind11::arg("state"), pybind11::arg("cores"),
-        pybind11::arg("pre") = std::vector<Tensor>());
+        pybind11::arg("pre") = std::vector<Tensor>(), pybind11::arg("per_sample_weights") = pybind11::none());
   m.def("prologue_cached_multi", &prologue_cached_multi,
         "the cache-live prologues of several equal-sized batches: -> [tableidx, pcol, prow, ploc, n_tt, plans], row k for batch k");
   m.def("rccl_unique_id", &rccl_unique_id, "ncclGetUniqueId (rank 0; broadcast the bytes to the others)");

@@ -583,10 +583,11 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         include_last_offset=False the closing offset (nnz) is appended here."""
         if per_sample_weights is not None:
             # nn.EmbeddingBag(mode="sum") semantics: forward, the cores' gradients / fused optimizers and -- if the
-            # weights require it -- their own gradient.  Served by the C++ node while the cache is not live (cache
-            # rows are gathered unweighted).
-            if _native_node() is None or not self.warmup or not indices.is_cuda:
-                raise NotImplementedError("per_sample_weights needs ttx_torch.so and a cache that is not live")
+            # weights require it -- their own gradient.  Served by the C++ nodes: cache not live, or live over one table
+            # (the weights follow their lookups through the hit / miss partition; cache rows are gathered and updated
+            # weighted).
+            if _native_node() is None or not indices.is_cuda or (not self.warmup and not (self.use_cache and self.num_tables == 1)):
+                raise NotImplementedError("per_sample_weights needs ttx_torch.so (GPU tensors)")
             if per_sample_weights.shape != indices.shape:
                 raise ValueError("per_sample_weights must have the shape of indices")
             per_sample_weights = per_sample_weights.float().contiguous()  # (keeps the autograd graph of the weights)
@@ -642,11 +643,13 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             use_state = self.sparse and self.optimizer not in _SGD_LIKE
             optim = 2 if not self.sparse else (1 if use_state else 0)
             pre = self._take_prefetched(indices, offsets, live=True)  # planned ahead by prefetch_many()?
+            if per_sample_weights is not None:
+                pre = None  # (the planned-ahead partition does not carry weights: this batch's prologue runs in line)
             return fast.lookup_cached(indices.contiguous(), offsets.contiguous(), self.tt_p_shapes, self.tt_q_shapes,
                                       self.tt_ranks, optim, self.learning_rate, self.eps, self.hashtbl, self.cache_freq,
                                       self.cache_state, self.cache_optimizer_state if use_state else None,
                                       self.cache_weight, list(self.optimizer_state) if use_state else [],
-                                      list(self.tt_cores), list(pre) if pre is not None else [])
+                                      list(self.tt_cores), list(pre) if pre is not None else [], per_sample_weights)
         prologue = getattr(_engine, "lookup_prologue", None)
         if prologue is not None and self.warmup and indices.numel() > 0:
             # cache not live: frequency update, offsets -> bag rows and the lookup plan in one native call

@@ -290,6 +290,33 @@ int ttx_cache_backward_rowwise_adagrad_approx_n(int64_t nnz, const int32_t* skip
                                                 float* cache_optimizer_state, float* cache_weight,
                                                 ttx_stream_t stream);
 
+/* nn.EmbeddingBag's per_sample_weights with a LIVE cache (not in the reference, which has no weights at all):
+ *  - ttx_preprocess_indices_async_w: as ttx_preprocess_indices_async; the weights travel with their lookups into
+ *    partitioned_weights and every partitioned entry's original position goes to partitioned_origin (either may be
+ *    NULL), so that the gradient of the weights can be handed back in the caller's order;
+ *  - ttx_cache_forward_nw: output[rowidx[n]] += per_sample_weights[n] * cache_weight[loc[n]] for the cached entries
+ *    (per_sample_weights == NULL: ttx_cache_forward_n);
+ *  - ttx_cache_rows_n: rows[n] = cache_weight[loc[n]] for the cached entries -- with the contraction's rows of the
+ *    misses in front (ttx_tt_forward_wr) ttx_psw_backward then yields d per_sample_weights for the whole batch;
+ *  - ttx_cache_weighted_grad_n: scaled[n] = per_sample_weights[n] * grad_output[rowidx[n]], iota[n] = n for the
+ *    cached entries: ttx_cache_backward_*_n(.., grad_output = scaled, rowidx = iota, ..) is the weighted backward. */
+int ttx_preprocess_indices_async_w(int64_t nnz, const int64_t* colidx, int64_t num_bags_total, const int64_t* offsets,
+                                   int32_t num_tables, int32_t warmup, int64_t hashtbl_size, const int64_t* hashtbl,
+                                   const int32_t* cache_state, int64_t* rowidx, int64_t* tableidx,
+                                   int64_t* partitioned_colidx, int64_t* partitioned_rowidx, int32_t* cache_locations,
+                                   int32_t* num_tt_host, int32_t* partitioned_host, int32_t* num_tt_dev,
+                                   int64_t* upd_hashtbl, int64_t* upd_cache_freq, const float* per_sample_weights,
+                                   float* partitioned_weights, int32_t* partitioned_origin, void* workspace,
+                                   size_t workspace_bytes, ttx_stream_t stream);
+int ttx_cache_forward_nw(int32_t B, int64_t nnz, const int32_t* skip_dev, const int32_t* cache_locations,
+                         const int64_t* rowidx, const float* per_sample_weights, int32_t D, const float* cache_weight,
+                         float* output, ttx_stream_t stream);
+int ttx_cache_rows_n(int64_t nnz, const int32_t* skip_dev, const int32_t* cache_locations, int32_t D,
+                     const float* cache_weight, float* rows, ttx_stream_t stream);
+int ttx_cache_weighted_grad_n(int64_t nnz, const int32_t* skip_dev, int32_t D, const float* grad_output,
+                              const int64_t* rowidx, const float* per_sample_weights, float* scaled, int64_t* iota,
+                              ttx_stream_t stream);
+
 /* Lookup prologue of a batch while the cache is not live (warmup): what the module does
  * before the contraction -- update_cache_state (tt_embeddings_ops.py:827-833) when
  * upd_hashtbl / upd_cache_freq are non-NULL, preprocess_indices_sync with warmup = true

@@ -721,3 +721,64 @@ def test_more_batches_than_one_prologue_launch_holds(node, live):
     for i, o in reqs:
         assert torch.equal(b(i, o).detach(), a(i, o).detach())
     assert len(b._prefetched) == 0
+
+
+@pytest.mark.parametrize("optim", ["dense", "sgd", "adagrad"])
+def test_per_sample_weights_with_a_live_cache(node, optim):
+    """nn.EmbeddingBag's per_sample_weights while the row cache is live (the part the reference has no
+    counterpart for at all): against torch's embedding_bag + autograd on the table the module serves at that moment --
+    the TT rows with the cached rows laid over them.  Forward, the weights' own gradient, the dense gradients of the cores
+    (misses only) and of the cache rows (hits only); with the fused optimizers the cache rows' and cores' steps."""
+    import tt_embeddings as E
+    import tt_embeddings_ops as ops
+
+    if node == "python":
+        return
+    p, q, r, E_, D, B, Lp = [20, 22, 25], [4, 4, 4], [16, 16], 11_000, 64, 96, 6
+    optimizer = {"dense": None, "sgd": ops.OptimType.SGD, "adagrad": ops.OptimType.EXACT_ADAGRAD}[optim]
+    a, _, reqs = _cache_live_pair(ops, p, q, r, E_, D, B, Lp, optimizer, n_req=1, cache_size=200)
+    idx, off = reqs[0]
+    rs = np.random.RandomState(4)
+    psw = t((rs.rand(idx.numel()) * 2 - 0.5).astype(np.float32))
+    d_out = t(G.make_grad(9, 1, B, D)[0])
+    # the table the module serves now, as a function of the cores and the cache rows
+    keys, state = a.hashtbl.cpu().numpy(), a.cache_state.cpu().numpy()
+    slot_ok = (keys >= 0) & (state >= 0)
+    ck, crow = torch.from_numpy(keys[slot_ok]).to(DEV), torch.from_numpy(state[slot_ok].astype(np.int64)).to(DEV)
+    cached = torch.zeros(E_, dtype=torch.bool, device=DEV)
+    cached[ck] = True
+    hit = cached[idx]
+    assert 0 < int(hit.sum()) < idx.numel(), "the batch must hold hits and misses"
+    ref_cores = [c.detach().clone().requires_grad_(True) for c in a.tt_cores]
+    ref_cw = a.cache_weight.detach().clone().requires_grad_(True)
+    full = ops.tt_matrix_to_full(p, q, [1] + r + [1], ref_cores, [1, 0, 2, 3])
+    table = full.index_put((ck,), ref_cw[crow])  # cached rows laid over the TT rows
+    w_ref = psw.clone().requires_grad_(True)
+    ref = torch.nn.functional.embedding_bag(idx, table, off, mode="sum", per_sample_weights=w_ref, include_last_offset=True)
+    ref.backward(d_out)
+    cores0 = [c.detach().clone() for c in a.tt_cores]
+    cw0 = a.cache_weight.detach().clone()
+    w = psw.clone().requires_grad_(True)
+    out = a(idx, off, per_sample_weights=w)
+    assert_close(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), "weighted forward, cache live")
+    out.backward(d_out)
+    assert w.grad is not None
+    assert_close(w.grad.cpu().numpy(), w_ref.grad.cpu().numpy(), "gradient of per_sample_weights, cache live")
+    if optim == "dense":
+        for k in range(3):
+            assert_close(a.tt_cores[k].grad.cpu().numpy(), ref_cores[k].grad.cpu().numpy(), f"core {k} gradient (misses)")
+        assert_close(a.cache_weight.grad.cpu().numpy(), ref_cw.grad.cpu().numpy(), "cache row gradient (hits)")
+    elif optim == "sgd":
+        for k in range(3):
+            assert_close(a.tt_cores[k].detach().cpu().numpy(), (cores0[k] - 0.05 * ref_cores[k].grad).cpu().numpy(), f"core {k} after SGD")
+        assert_close(a.cache_weight.detach().cpu().numpy(), (cw0 - 0.05 * ref_cw.grad).cpu().numpy(), "cache rows after SGD",
+                     rtol=2e-5, atol_scale=4e-6)
+    else:  # Adagrad: the rows that were not hit stay, the rows that were hit move against their gradient
+        moved = (a.cache_weight.detach() - cw0).abs().sum(dim=1) > 0
+        touched = ref_cw.grad.abs().sum(dim=1) > 0
+        assert torch.equal(moved, touched)
+        step = a.cache_weight.detach() - cw0
+        assert bool(((step * ref_cw.grad).sum(dim=1)[touched] < 0).all())
+    # without a gradient for the weights, and an unweighted call afterwards, the module keeps working
+    a(idx, off, per_sample_weights=psw).backward(d_out)
+    a(idx, off).backward(d_out)
