@@ -259,13 +259,14 @@ def test_hot_slices_are_reduced_by_several_work_groups(p, q, r):
                 assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"hot {p} adagrad core{k}")
 
 
-def test_benchmark_shape_large_batch_variant():
-    """the benchmark shape at a batch that no longer fits the single-launch plan (> 16384 lookups): forward,
-    dense gradients and fused SGD against the oracle"""
-    p, q, r = [9, 8, 7], [4, 4, 4], [1, 32, 32, 1]
-    E_, D, B = int(np.prod(p)), 64, 6800
+@pytest.mark.parametrize("q", [[4, 4, 4], [2, 4, 4]])
+def test_benchmark_shape_large_batch_variant(q):
+    """the benchmark shape (and its q0 = 2 sibling) at a batch that no longer fits the single-launch plan
+    (> 16384 lookups): forward, dense gradients and fused SGD against the oracle"""
+    p, r = [9, 8, 7], [1, 32, 32, 1]
+    E_, D, B = int(np.prod(p)), int(np.prod(q)), 6800
     idx, off = G.make_bags(51, B, E_, 20, 2, 1)
-    assert idx.size > 131072  # ... and the plan's chunks hold four 16-lookup sub-chunks (kernel variant MULTI)
+    assert idx.size > 131072  # ... and the plan's chunks hold four 16- / 32-lookup sub-chunks (kernel variant MULTI)
     c = dict(tables=1, T=3, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
              cores=G.make_cores(52, 1, p, q, r, "signed"), d_out=G.make_grad(53, 1, B, D))
     for mode in ("dense", "sgd"):
@@ -279,12 +280,13 @@ def test_benchmark_shape_large_batch_variant():
 
 
 @pytest.mark.parametrize("ranks,q", [([32, 32], [4, 4, 4]), ([16, 16], [4, 4, 4]), ([32, 32], [4, 4, 8]), ([16, 16], [4, 4, 8]),
-                                      ([64, 64], [4, 4, 8]), ([64, 64], [4, 4, 4])])
+                                      ([64, 64], [4, 4, 8]), ([64, 64], [4, 4, 4]), ([32, 32], [2, 4, 4]), ([16, 16], [2, 4, 4]), ([64, 64], [2, 4, 4])])
 def test_specialised_shapes_vs_oracle_and_generic(ranks, q):
     """the shape-specialised wave-independent kernels (ttx_tt_spec.inc): against the oracle,
     and against the generic kernels (forced with the debug knob) on the same inputs;
     slices with 1..70 lookups exercise partial groups of 4 and chunks of 32 (16 for r = 64, which
-    also walks core 1 in four column passes)"""
+    also walks core 1 in four column passes); q0 = 2 (the reference's default factoring of D = 32): a 16-row
+    tile is eight lookups of two rows, a lane's accumulator rows belong to two lookups"""
     import tt_embeddings as E
 
     p = [6, 5, 7]
