@@ -35,6 +35,7 @@ constexpr int kPlanThreads = 1024;
 constexpr int kPlanWaves = kPlanThreads / kWave;
 
 int max_chunks(const Dims& d, long long nnz, int MC) {
+  if (MC <= 0) MC = 1;  // (a shape no kernel variant fits: the sizes stay defined, the launch reports TTX_EUNSUPPORTED)
   long long a = nnz < d.S[1] ? nnz : d.S[1];
   long long v = a + nnz / MC + 1;
   return (int)v;
@@ -1414,6 +1415,7 @@ int plan_build(const Dims& d, long long nnz, const int64_t* indices,
                const int64_t* tableidx, const int64_t* rowidx, const Plan& P, hipStream_t stream,
                const int* n_dev, const int64_t* offsets, int bags_per_table) {
   if (nnz < 0 || nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz=%lld out of range", nnz);
+  if (P.MC <= 0) TTX_FAIL(TTX_EUNSUPPORTED, "TT shape does not fit the LDS of any kernel variant (core-1 slice %d x %d floats)", d.k[0], d.n[0]);
   ProfScope ps(TTX_PROF_PLAN, stream);
   if (nnz > 1024 || !d.idx32 || n_dev)
     return plan_build_mb(d, (int)nnz, n_dev, indices, tableidx, rowidx, P, stream, offsets, bags_per_table);
@@ -1685,6 +1687,7 @@ int ttx_lookup_prologue(const ttx_geom* g, int64_t nnz, const int64_t* colidx, i
   const bool upd = upd_hashtbl && upd_cache_freq;
   if (upd && (H <= 0 || H >= (1ll << 31))) TTX_FAIL(TTX_EINVAL, "hashtbl_size=%lld must be in (0, 2^31)", (long long)H);
   ttx::Plan P = ttx::carve_plan(d, nnz, plan);
+  if (P.MC <= 0) TTX_FAIL(TTX_EUNSUPPORTED, "TT shape does not fit the LDS of any kernel variant (core-1 slice %d x %d floats)", d.k[0], d.n[0]);
   if (ttx::prologue_fusable(d, nnz, nb)) {
     ttx::Prologue pg{offsets, (int)nb, rowidx, tableidx, upd ? (int)H : 0, upd_hashtbl, upd_cache_freq};
     return ttx::prologue_launch(d, (int)nnz, colidx, pg, P, (hipStream_t)stream);

@@ -280,7 +280,8 @@ def test_benchmark_shape_large_batch_variant(q):
 
 
 @pytest.mark.parametrize("ranks,q", [([32, 32], [4, 4, 4]), ([16, 16], [4, 4, 4]), ([32, 32], [4, 4, 8]), ([16, 16], [4, 4, 8]),
-                                      ([64, 64], [4, 4, 8]), ([64, 64], [4, 4, 4]), ([32, 32], [2, 4, 4]), ([16, 16], [2, 4, 4]), ([64, 64], [2, 4, 4])])
+                                      ([64, 64], [4, 4, 8]), ([64, 64], [4, 4, 4]), ([32, 32], [2, 4, 4]), ([16, 16], [2, 4, 4]), ([64, 64], [2, 4, 4]),
+                                      ([32, 32], [4, 8, 8]), ([64, 64], [4, 8, 8])])
 def test_specialised_shapes_vs_oracle_and_generic(ranks, q):
     """the shape-specialised wave-independent kernels (ttx_tt_spec.inc): against the oracle,
     and against the generic kernels (forced with the debug knob) on the same inputs;
@@ -302,6 +303,9 @@ def test_specialised_shapes_vs_oracle_and_generic(ranks, q):
             E.lib().ttx_debug_skip(256)  # generic kernels
             try:
                 gen = run_case(c, mode, plan_shared=False)
+            except RuntimeError as ex:  # (r = 64 with q1 = 8: a 128 KB core_1 slice does not fit the generic kernels' LDS)
+                assert "LDS" in str(ex) and ranks == [64, 64] and q[1] == 8, ex
+                gen = got
             finally:
                 E.lib().ttx_debug_skip(0)
             assert_close(got["out"], orc["out"], f"spec {ranks}{q} out vs oracle")
