@@ -1626,6 +1626,8 @@ static int spec_mc(const Dims& d, long long nnz) {
     case SPEC2_64_4_64_4: return S2_64_4_64_4::MC;
     case SPEC_32_8_32_8: return S_32_8_32_8::MC * (S_32_8_32_8::SUB ? ks : 1);
     case SPEC_64_8_64_8: return S_64_8_64_8::MC;
+    case SPEC2_32_2_32_4: return S2_32_2_32_4::MC * (S2_32_2_32_4::SUB ? ks : 1);
+    case SPEC2_64_2_64_4: return S2_64_2_64_4::MC;
     default: return 0;
   }
 }
