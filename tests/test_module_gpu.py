@@ -597,7 +597,7 @@ def _cache_live_pair(ops, p, q, r, E_, D, B, Lp, optimizer, n_req=5, cache_size=
     return a, b, reqs
 
 
-@pytest.mark.parametrize("shape", ["single-launch", "small", "general"])
+@pytest.mark.parametrize("shape", ["single-launch", "small", "general", "q0=2"])
 def test_cache_live_round_planned_ahead_equals_the_in_line_prologue(node, shape):
     """prefetch_many() with a LIVE cache (ttx_lookup_prologue_cached_multi): per batch the same partition (misses first
     in index order, hits behind them reversed), cache locations, split point and -- through the forward it drives --
@@ -609,7 +609,8 @@ def test_cache_live_round_planned_ahead_equals_the_in_line_prologue(node, shape)
         return
     p, q, r, E_, D, B, Lp = {"single-launch": ([200, 220, 250], [4, 4, 4], [32, 32], 11_000_000, 64, 512, 20),
                              "small": ([20, 22, 25], [4, 4, 4], [16, 16], 11_000, 64, 96, 5),
-                             "general": ([300, 20, 20], [4, 4, 4], [8, 8], 120_000, 64, 128, 12)}[shape]
+                             "general": ([300, 20, 20], [4, 4, 4], [8, 8], 120_000, 64, 128, 12),
+                             "q0=2": ([20, 22, 25], [2, 4, 4], [16, 16], 11_000, 32, 96, 5)}[shape]
     a, b, reqs = _cache_live_pair(ops, p, q, r, E_, D, B, Lp, None)
     assert b.prefetch_many(reqs) is True and len(b._prefetched) == len(reqs)
     hits = 0
