@@ -1628,6 +1628,8 @@ static int spec_mc(const Dims& d, long long nnz) {
     case SPEC_64_8_64_8: return S_64_8_64_8::MC;
     case SPEC2_32_2_32_4: return S2_32_2_32_4::MC * (S2_32_2_32_4::SUB ? ks : 1);
     case SPEC2_64_2_64_4: return S2_64_2_64_4::MC;
+    case SPEC2_16_2_16_4: return S2_16_2_16_4::MC * (S2_16_2_16_4::SUB ? ks : 1);
+    case SPEC_16_8_16_8: return S_16_8_16_8::MC * (S_16_8_16_8::SUB ? ks : 1);
     default: return 0;
   }
 }

@@ -281,7 +281,8 @@ def test_benchmark_shape_large_batch_variant(q):
 
 @pytest.mark.parametrize("ranks,q", [([32, 32], [4, 4, 4]), ([16, 16], [4, 4, 4]), ([32, 32], [4, 4, 8]), ([16, 16], [4, 4, 8]),
                                       ([64, 64], [4, 4, 8]), ([64, 64], [4, 4, 4]), ([32, 32], [2, 4, 4]), ([16, 16], [2, 4, 4]), ([64, 64], [2, 4, 4]),
-                                      ([32, 32], [4, 8, 8]), ([64, 64], [4, 8, 8]), ([32, 32], [2, 2, 4]), ([64, 64], [2, 2, 4])])
+                                      ([32, 32], [4, 8, 8]), ([64, 64], [4, 8, 8]), ([32, 32], [2, 2, 4]), ([64, 64], [2, 2, 4]), ([16, 16], [2, 2, 4]),
+                                      ([16, 16], [4, 8, 8])])
 def test_specialised_shapes_vs_oracle_and_generic(ranks, q):
     """the shape-specialised wave-independent kernels (ttx_tt_spec.inc): against the oracle,
     and against the generic kernels (forced with the debug knob) on the same inputs;
