@@ -36,8 +36,9 @@ def run_plan_cases(seed=0, max_cases=None, budget=None):
         tables = int(rs.choice([1, 1, 2, 3, 5, 9, 20, 40]))
         spec = T == 3 and rs.rand() < 0.4
         if spec:
-            q, r = [4, 4, int(rs.choice([4, 8]))], [1] + [int(rs.choice([16, 32]))] * 2 + [1]
-            r[2] = r[1]
+            # the shape-specialised kernels' families: q0 = 4 / 2, q1 = 2 / 4 / 8 (ttx_tt_spec.inc)
+            q = [[4, 4, 4], [4, 4, 8], [2, 4, 4], [2, 2, 4], [4, 8, 8]][int(rs.randint(0, 5))]
+            r = [1] + [int(rs.choice([16, 32]))] * 2 + [1]
         else:
             q = [int(rs.randint(1, 5)) for _ in range(T)]
             r = [1] + [int(rs.randint(1, 9)) for _ in range(T - 1)] + [1]
