@@ -63,403 +63,31 @@ __device__ __forceinline__ unsigned fdivmod(unsigned n, const FastDiv f, unsigne
   return q;
 }
 
-// LDS carve of the contraction kernels (float offsets) + padded GEMM extents.
-// A CHUNK is <= MC lookups of one pivot slice: they share one staged B1 and one d core_1
-// partial.  A PASS is <= SC of those lookups: one X0 tile of rS rows (SC*q0 padded to 32).
-// Keeping X0 per pass small is what lets three work-groups share a CU at the benchmark shape.
-struct Lds {
-  int MC, SC;
-  int rS;    // rows of one pass
-  int nsub;  // passes of a full chunk
-  int K0p;   // r1 padded to a multiple of 32
-  int K0t;   // 16-wide tiles covering r1
-  int N1t;   // 16-wide tiles covering N1
-  int ld;    // row stride of Bs and X0 (>= 16*N1t, == 2 mod 32)
-  int ldA;   // row stride of As (>= K0p, == 2 mod 32)
-  int persist;  // d core_1 accumulates in registers across passes
-  int oB, oA, oX0, oX1, oG, oC, oI;
-  int szX1;  // per-lookup floats of X1 (T == 4)
-  int cLds;  // forward: last-core slices of a pass are staged in LDS
-  int bytes;
-  int dbg;   // ablation mask (bench/ablate only): phases to skip, results invalid when != 0
-  long long* stamps;  // debug: per work-group phase timestamps (100 MHz wall clock), or NULL
-  FastDiv fdD, fdD4, fdN1, fdN4, fdSl0, fdSl04, fdK0, fdK04, fdQ0, fdSl2, fdSC;
+struct Partials {
+  float* pc[TTX_MAX_CORES];  // pc[1] is per CHUNK, the others per lookup
+  const float* psw;          // per_sample_weights by lookup (nn.EmbeddingBag), or NULL: the bag gradient of
+                             // lookup n enters the backward scaled by psw[n]
+  const int64_t* tableidx;   // tables of different row factors (Dims::tab): the table of a pivot slice is read
+                             // from one of its lookups; NULL otherwise (table = slice / p_1)
+  // hot slices (reduce_apply_kernel): arrival counters, one per core slice (zeroed by the backward
+  // contraction kernel), and the segment partial sums, two slots per segment
+  int* hot_cnt;
+  int n_hot_cnt;
+  float* seg[TTX_MAX_CORES];
 };
 
-static int g_chunk_override = 0;
-static int g_debug_skip = 0;
-static int g_disable_spec = 0;
-static bool spec_shape(const Dims& d);  // ttx_tt_spec.inc covers this geometry
-static int spec_mc(const Dims& d, long long nnz);  // ... with this many lookups per chunk
-static long long* g_stamps = nullptr;
-
-long long* debug_stamps() { return g_stamps; }
-
-static int stride2(int n) {  // smallest s >= n with s % 32 == 2
-  int s = (n + 29) / 32 * 32 + 2;
-  return s;
+// zero the hot-slice arrival counters (called by work-group 0 of the backward contraction kernels,
+// which always run right before reduce_apply_kernel on the same stream)
+__device__ __forceinline__ void zero_hot_counters(const Partials& PC) {
+  if (blockIdx.x == 0 && PC.hot_cnt)
+    for (int i = threadIdx.x; i < PC.n_hot_cnt; i += blockDim.x) PC.hot_cnt[i] = 0;
 }
-
-static Lds make_lds(const Dims& d, int MC, bool bwd) {
-  Lds L;
-  memset(&L, 0, sizeof(L));
-  const int K0 = d.k[0], N1 = d.n[0], q0 = d.q[0];
-  L.MC = MC;
-  L.K0p = (K0 + 31) / 32 * 32;
-  L.K0t = (K0 + 15) / 16;
-  L.N1t = (N1 + 15) / 16;
-  L.ld = stride2(L.N1t * 16);
-  L.ldA = stride2(L.K0p);
-  // register-resident d core_1 needs <= 2 (N-pair) jobs per wave and one group of <= 4 r1 tiles
-  const int npairs = (L.N1t + 1) / 2;
-  L.persist = (L.K0t <= 4 && npairs <= 2 * kWaves) ? 1 : 0;
-  int sc = 32 / q0;
-  if (sc < 1) sc = 1;
-  if (sc > MC || (bwd && !L.persist)) sc = MC;
-  L.SC = sc;
-  L.rS = (sc * q0 + 31) / 32 * 32;
-  L.nsub = (MC + sc - 1) / sc;
-  L.szX1 = (d.T == 4) ? d.m[1] * d.n[1] : 0;
-  const int sl2 = d.T > 2 ? d.slice[2] : 0;
-  L.cLds = (!bwd && d.T > 2 && d.n[1] <= 8 && sc * sl2 <= 4096) ? 1 : 0;
-  int o = 0;
-  auto take = [&](int n) { int r = o; o += (n + 3) / 4 * 4; return r; };
-  L.oB = take(L.K0p * L.ld);
-  L.oA = take(L.nsub * L.rS * L.ldA);
-  L.oX0 = take(L.rS * L.ld);
-  L.oX1 = take(sc * L.szX1);
-  L.oG = take(bwd && d.T >= 3 ? MC * d.D : 0);
-  L.oC = take(L.cLds ? sc * sl2 : 0);
-  L.oI = take(MC * (bwd ? 8 : 4));  // int4 lookup records (+ backward: the rows of their thin-core partials)
-  L.bytes = o * 4;
-  L.fdD = make_fd(d.D);
-  L.fdN1 = make_fd(N1);
-  L.fdSl0 = make_fd(d.slice[0]);
-  L.fdK0 = make_fd(K0);
-  L.fdQ0 = make_fd(q0);
-  L.fdD4 = make_fd(d.D / 4 > 0 ? d.D / 4 : 1);
-  L.fdN4 = make_fd(N1 / 4 > 0 ? N1 / 4 : 1);
-  L.fdSl04 = make_fd(d.slice[0] / 4 > 0 ? d.slice[0] / 4 : 1);
-  L.fdK04 = make_fd(K0 / 4 > 0 ? K0 / 4 : 1);
-  L.fdSl2 = make_fd(sl2 > 0 ? sl2 : 1);
-  L.fdSC = make_fd(sc);
-  L.dbg = g_debug_skip;
-  L.stamps = g_stamps;
-  return L;
-}
-
-int choose_chunk(const Dims& d, long long nnz) {
-  if (spec_shape(d)) return spec_mc(d, nnz);  // wave-independent kernels: Shape3::MC of the variant picked for nnz
-  if (g_chunk_override > 0) return g_chunk_override;
-  // three, then two work-groups per CU (160 KiB of LDS), else whatever fits
-  for (int mc = 16; mc >= 8; mc >>= 1)
-    if (make_lds(d, mc, true).bytes <= 53 * 1024) return mc;
-  for (int mc = 32; mc >= 8; mc >>= 1)
-    if (make_lds(d, mc, true).bytes <= 80 * 1024) return mc;
-  for (int mc = 16; mc >= 1; mc >>= 1)
-    if (make_lds(d, mc, true).bytes <= 160 * 1024) return mc;
-  return 0;
-}
-
-// ------------------------------------------------------------- kernels -----
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// As row of (lookup j of the chunk, core-0 row a)
-__device__ __forceinline__ int a_row(const Lds& L, int q0, unsigned j, unsigned a) {
-  unsigned jl;
-  const unsigned h = fdivmod(j, L.fdSC, jl);
-  return h * L.rS + jl * q0 + a;
-}
-
-// chunk prologue shared by forward and backward: stage B1, the lookup records and the
-// stacked core-0 slices (pass-major, zero padded to the MFMA tile extents) in LDS.
-// Dependent global loads: chunk_rec -> lrec -> core-0 rows (B1 needs only chunk_rec).
-__device__ __forceinline__ void stage_chunk(const Dims& d, const Plan& P, const CorePtrs& C,
-                                            const Lds& L, float* smem, int s, int start, int len) {
-  const int tid = threadIdx.x;
-  const int K0 = d.k[0], N1 = d.n[0], q0 = d.q[0];
-  int4* I = (int4*)(smem + L.oI);
-  float* Bs = smem + L.oB;
-  float* As = smem + L.oA;
-  const float* __restrict__ B1 = C.c[1] + (size_t)s * d.slice[1];
-  const bool padB = (L.K0p != K0) || (L.N1t * 16 != N1);
-  if (tid < len) I[tid] = P.lrec[start + tid];
-  if (padB) {
-    for (int e = tid; e < L.K0p * L.ld; e += kThreads) Bs[e] = 0.f;
-    __syncthreads();
-  }
-  if ((N1 & 3) == 0) {
-    const int nv = K0 * N1 / 4;
-    for (int e = tid; e < nv; e += kThreads) {
-      const float4 v = ((const float4*)B1)[e];
-      unsigned c4;
-      const unsigned row = fdivmod((unsigned)e, L.fdN4, c4);
-      float2* dst = (float2*)(Bs + row * L.ld + c4 * 4);  // ld is even: 8-byte aligned
-      dst[0] = make_float2(v.x, v.y);
-      dst[1] = make_float2(v.z, v.w);
-    }
-  } else {
-    for (int e = tid; e < K0 * N1; e += kThreads) {
-      unsigned col;
-      const unsigned row = fdivmod((unsigned)e, L.fdN1, col);
-      Bs[row * L.ld + col] = B1[e];
-    }
-  }
-  // zero A: rows past the chunk / columns past r1 feed the MFMA as zeros
-  const int npass = (len + L.SC - 1) / L.SC;
-  for (int e = tid; e < npass * L.rS * L.ldA; e += kThreads) As[e] = 0.f;
-  __syncthreads();
-  const int sl0 = d.slice[0];  // q0 * r1
-  if ((K0 & 3) == 0) {
-    const int per = sl0 / 4;
-    for (int e = tid; e < len * per; e += kThreads) {
-      unsigned rem, c4;
-      const unsigned j = fdivmod((unsigned)e, L.fdSl04, rem);
-      const unsigned a = fdivmod(rem, L.fdK04, c4);
-      const float4 v = ((const float4*)(C.c[0] + (size_t)I[j].y * sl0))[rem];
-      float2* dst = (float2*)(As + a_row(L, q0, j, a) * L.ldA + c4 * 4);
-      dst[0] = make_float2(v.x, v.y);
-      dst[1] = make_float2(v.z, v.w);
-    }
-  } else {
-    for (int e = tid; e < len * sl0; e += kThreads) {
-      unsigned rem, k;
-      const unsigned j = fdivmod((unsigned)e, L.fdSl0, rem);
-      const unsigned a = fdivmod(rem, L.fdK0, k);
-      As[a_row(L, q0, j, a) * L.ldA + k] = (C.c[0] + (size_t)I[j].y * sl0)[rem];
-    }
-  }
-  __syncthreads();
-}
-
-// ---- GEMM 1:  one 16-row tile of X0 x NB column tiles = As * Bs, k-step {k, k+8, k+16, k+24} ----
-// arow0: As row of the tile; xrow0: X0 row of the tile (within the pass)
-template <int NB>
-__device__ __forceinline__ void x0_group(const Dims& d, const Lds& L, float* smem, int arow0, int xrow0,
-                                         int n0, float* rows_out, int j0, int lenS) {
-  const int lane = lane_id();
-  const int i16 = lane & 15, kq = lane >> 4;
-  const float* arow = smem + L.oA + (arow0 + i16) * L.ldA + 8 * kq;
-  const float* bbase = smem + L.oB + 8 * kq * L.ld + n0 * 16 + i16;
-  f32x4 acc[NB];
-#pragma unroll
-  for (int x = 0; x < NB; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // software pipeline: the B fragments of k-step t+1 are read from LDS while the
-  // MFMAs of k-step t issue
-  float bcur[NB];
-#pragma unroll
-  for (int x = 0; x < NB; ++x) bcur[x] = bbase[x * 16];
-  for (int kb = 0; kb < L.K0p; kb += 32) {
-    float a[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) a[t] = arow[kb + t];
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the 8 A fragments (4 x ds_read2)
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int kn = (t < 7) ? kb + t + 1 : kb + 32;  // k-steps of a block are kb+0..7 (+8*kq)
-      const float* bn = bbase + (kn < L.K0p ? kn : 0) * L.ld;  // last prefetch wraps (unused)
-      float bnxt[NB];
-#pragma unroll
-      for (int x = 0; x < NB; ++x) bnxt[x] = bn[x * 16];
-#pragma unroll
-      for (int x = 0; x < NB; ++x) acc[x] = mfma4(a[t], bcur[x], acc[x]);
-#pragma unroll
-      for (int x = 0; x < NB; ++x) bcur[x] = bnxt[x];
-      __builtin_amdgcn_sched_group_barrier(0x100, (NB + 1) / 2, 0);  // DS reads of step t+1
-      __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);            // MFMAs of step t
-    }
-  }
-  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + r
-  if (rows_out) {  // T == 2 forward: rows straight to HBM
-    const int4* I = (const int4*)(smem + L.oI);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = xrow0 + kq * 4 + r;
-      unsigned a_;
-      const unsigned jl = fdivmod((unsigned)row, L.fdQ0, a_);
-      if ((int)jl < lenS) {
-        float* o = rows_out + (size_t)I[j0 + jl].x * d.D + a_ * d.n[0];
-#pragma unroll
-        for (int x = 0; x < NB; ++x) {
-          const int col = (n0 + x) * 16 + i16;
-          if (col < d.n[0]) o[col] = acc[x][r];
-        }
-      }
-    }
-  } else {
-    float* xo = smem + L.oX0 + (xrow0 + kq * 4) * L.ld + n0 * 16 + i16;
-#pragma unroll
-    for (int x = 0; x < NB; ++x)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xo[r * L.ld + x * 16] = acc[x][r];
-  }
-}
-
-// X0 of pass h (all rS rows: rows past the pass come out as zeros)
-__device__ __forceinline__ void gemm_x0(const Dims& d, const Lds& L, float* smem, int h,
-                                        float* rows_out, int j0, int lenS) {
-  const int w = threadIdx.x / kWave;
-  const int mtiles = L.rS / 16;
-  // column-group width: the widest of 8/4/2/1 tiles that still gives every wave a job
-  int NB = 8;
-  while (NB > 1 && mtiles * ((L.N1t + NB - 1) / NB) < kWaves) NB >>= 1;
-  const int ngroups = (L.N1t + NB - 1) / NB;
-  for (int job = w; job < mtiles * ngroups; job += kWaves) {
-    const int mt = job / ngroups, g = job - mt * ngroups;
-    int n0 = g * NB;
-    int cnt = min(NB, L.N1t - n0);
-    const int ar = h * L.rS + mt * 16, xr = mt * 16;
-    while (cnt > 0) {
-      if (cnt >= 8) { x0_group<8>(d, L, smem, ar, xr, n0, rows_out, j0, lenS); n0 += 8; cnt -= 8; }
-      else if (cnt >= 4) { x0_group<4>(d, L, smem, ar, xr, n0, rows_out, j0, lenS); n0 += 4; cnt -= 4; }
-      else if (cnt >= 2) { x0_group<2>(d, L, smem, ar, xr, n0, rows_out, j0, lenS); n0 += 2; cnt -= 2; }
-      else { x0_group<1>(d, L, smem, ar, xr, n0, rows_out, j0, lenS); n0 += 1; cnt -= 1; }
-    }
-  }
-}
-
-// ---- forward tail stage: out[m x NT] = x[m x k] * C[k x NT] per lookup, C from LDS or HBM ----
-// item = (lookup jl of the pass, row); x addressing: row = a*nb + b -> X + jl*sJ + a*sA + b*sB
-template <int NT>
-__device__ __forceinline__ void fwd_stage(int lenS, int j0, int m, int k, int nb, int sJ, int sA, int sB,
-                                          const float* X, const float* Cs, int cJ, bool c_lds,
-                                          const float* Cg, int slice, const int4* I, int which,
-                                          float* out_lds, int oJ, float* __restrict__ rows, int D) {
-  const FastDiv fm = make_fd(m), fnb = make_fd(nb);
-  for (int e = threadIdx.x; e < lenS * m; e += kThreads) {
-    unsigned row, b;
-    const unsigned jl = fdivmod((unsigned)e, fm, row);
-    const unsigned a = fdivmod(row, fnb, b);
-    const float* xi = X + jl * sJ + a * sA + b * sB;
-    const int4 rec = I[j0 + jl];
-    const int sid = which == 2 ? rec.z : rec.w;
-    const float* c = c_lds ? Cs + jl * cJ : Cg + (size_t)sid * slice;
-    float acc[NT];
-#pragma unroll
-    for (int x = 0; x < NT; ++x) acc[x] = 0.f;
-#pragma unroll 4
-    for (int kk = 0; kk < k; ++kk) {
-      const float xv = xi[kk];
-#pragma unroll
-      for (int x = 0; x < NT; ++x) acc[x] = fmaf(xv, c[kk * NT + x], acc[x]);
-    }
-    float* o = rows ? rows + (size_t)rec.x * D + row * NT : out_lds + jl * oJ + row * NT;
-#pragma unroll
-    for (int x = 0; x < NT; ++x) o[x] = acc[x];
-  }
-}
-
-// generic (any n) version: item = (jl, row, col), C from HBM
-__device__ __forceinline__ void fwd_stage_any(int lenS, int j0, int m, int k, int n, int nb, int sJ, int sA,
-                                              int sB, const float* X, const float* Cg, int slice,
-                                              const int4* I, int which, float* out_lds, int oJ,
-                                              float* __restrict__ rows, int D) {
-  const FastDiv fper = make_fd(m * n), fn = make_fd(n), fnb = make_fd(nb);
-  for (int e = threadIdx.x; e < lenS * m * n; e += kThreads) {
-    unsigned rem, col, b;
-    const unsigned jl = fdivmod((unsigned)e, fper, rem);
-    const unsigned row = fdivmod(rem, fn, col);
-    const unsigned a = fdivmod(row, fnb, b);
-    const float* xi = X + jl * sJ + a * sA + b * sB;
-    const int4 rec = I[j0 + jl];
-    const int sid = which == 2 ? rec.z : rec.w;
-    const float* c = Cg + (size_t)sid * slice + col;
-    float acc = 0.f;
-    for (int kk = 0; kk < k; ++kk) acc = fmaf(xi[kk], c[kk * n], acc);
-    if (rows) rows[(size_t)rec.x * D + rem] = acc;
-    else out_lds[jl * oJ + rem] = acc;
-  }
-}
-
-#define TTX_NT_SWITCH(nt, CALL)          \
-  switch (nt) {                          \
-    case 1: { CALL(1); } break;          \
-    case 2: { CALL(2); } break;          \
-    case 3: { CALL(3); } break;          \
-    case 4: { CALL(4); } break;          \
-    case 5: { CALL(5); } break;          \
-    case 6: { CALL(6); } break;          \
-    case 7: { CALL(7); } break;          \
-    case 8: { CALL(8); } break;          \
-    default: break;                      \
-  }
-
-// the grid also zeroes the pooled output (the bag-pooling kernel that follows accumulates
-// onto it): saves a memset launch
-__device__ __forceinline__ void zero_output(float* __restrict__ out, long long n) {
-  if (!out) return;
-  for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < n; e += (long long)gridDim.x * kThreads) out[e] = 0.f;
-}
-
-__global__ __launch_bounds__(kThreads, 3) void fwd_kernel(Dims d, Plan P, CorePtrs C,
-                                                         float* __restrict__ rows, Lds L,
-                                                         float* __restrict__ zout, long long nzero) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  zero_output(zout, nzero);
-  const int chunk = blockIdx.x;
-  const int4 cr = P.chunk_rec[chunk];
-  const int s = cr.x, start = cr.y, len = cr.z;
-  if (len == 0) return;
-  const int tid = threadIdx.x;
-  const int q0 = d.q[0];
-  stage_chunk(d, P, C, L, smem, s, start, len);
-  const int4* I = (const int4*)(smem + L.oI);
-  const float* X0 = smem + L.oX0;
-  float* X1 = smem + L.oX1;
-  float* Cs = smem + L.oC;
-  const int npass = (len + L.SC - 1) / L.SC;
-  for (int h = 0; h < npass; ++h) {
-    const int j0 = h * L.SC;
-    const int lenS = min(L.SC, len - j0);
-    if (d.T == 2) {
-      gemm_x0(d, L, smem, h, rows, j0, lenS);
-      continue;
-    }
-    if (h > 0) __syncthreads();  // the previous pass is done with X0 / X1 / Cs
-    if (L.cLds) {  // last-core slices of this pass -> LDS (overlaps the GEMM)
-      const int sl2 = d.slice[2];
-      for (int e = tid; e < lenS * sl2; e += kThreads) {
-        unsigned rem;
-        const unsigned jl = fdivmod((unsigned)e, L.fdSl2, rem);
-        Cs[e] = (C.c[2] + (size_t)I[j0 + jl].z * sl2)[rem];
-      }
-    }
-    if (!(L.dbg & 1)) gemm_x0(d, L, smem, h, nullptr, j0, lenS);
-    __syncthreads();
-    if (L.dbg & 2) continue;
-    // tail stage t = 1: x_1[m1 x n1] = x_0[m1 x k1] * core_2[i_2][k1 x n1]
-    {
-      const int k1 = d.k[1], n1 = d.n[1], m1 = d.m[1], q1 = d.q[1];
-      const bool last = (d.T == 3);
-      const int sl2 = d.slice[2];
-      if (n1 <= 8) {
-#define CALL(NT) fwd_stage<NT>(lenS, j0, m1, k1, q1, q0 * L.ld, L.ld, k1, X0, Cs, sl2, L.cLds != 0, C.c[2], sl2, I, 2, \
-                               X1, L.szX1, last ? rows : nullptr, d.D)
-        TTX_NT_SWITCH(n1, CALL)
-#undef CALL
-      } else {
-        fwd_stage_any(lenS, j0, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, C.c[2], sl2, I, 2, X1, L.szX1,
-                      last ? rows : nullptr, d.D);
-      }
-    }
-    if (d.T == 4) {
-      __syncthreads();
-      // tail stage t = 2: row[m2 x n2] = x_1[m2 x k2] * core_3[i_3][k2 x n2]
-      const int k2 = d.k[2], n2 = d.n[2], m2 = d.m[2];
-      if (n2 <= 8) {
-#define CALL(NT) fwd_stage<NT>(lenS, j0, m2, k2, m2, L.szX1, 0, k2, X1, nullptr, 0, false, C.c[3], d.slice[3], I, 3, \
-                               nullptr, 0, rows, d.D)
-        TTX_NT_SWITCH(n2, CALL)
-#undef CALL
-      } else {
-        fwd_stage_any(lenS, j0, m2, k2, n2, m2, L.szX1, 0, k2, X1, C.c[3], d.slice[3], I, 3, nullptr, 0, rows, d.D);
-      }
-    }
-  }
-}
+#include "ttx_tt_generic.inc"
 
 // out[table,row,:] += sum of the run's rows, in index order (run = consecutive
 // lookups with equal (rowidx, tableidx); reference reduce_output_kernel
@@ -826,433 +454,6 @@ __global__ __launch_bounds__(kThreads) void psw_grad_kernel(int N, int B, int D,
 #pragma unroll
   for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 16);
   if (n < N && l == 0) d_psw[n] = acc;
-}
-
-struct Partials {
-  float* pc[TTX_MAX_CORES];  // pc[1] is per CHUNK, the others per lookup
-  const float* psw;          // per_sample_weights by lookup (nn.EmbeddingBag), or NULL: the bag gradient of
-                             // lookup n enters the backward scaled by psw[n]
-  const int64_t* tableidx;   // tables of different row factors (Dims::tab): the table of a pivot slice is read
-                             // from one of its lookups; NULL otherwise (table = slice / p_1)
-  // hot slices (reduce_apply_kernel): arrival counters, one per core slice (zeroed by the backward
-  // contraction kernel), and the segment partial sums, two slots per segment
-  int* hot_cnt;
-  int n_hot_cnt;
-  float* seg[TTX_MAX_CORES];
-};
-
-// zero the hot-slice arrival counters (called by work-group 0 of the backward contraction kernels,
-// which always run right before reduce_apply_kernel on the same stream)
-__device__ __forceinline__ void zero_hot_counters(const Partials& PC) {
-  if (blockIdx.x == 0 && PC.hot_cnt)
-    for (int i = threadIdx.x; i < PC.n_hot_cnt; i += blockDim.x) PC.hot_cnt[i] = 0;
-}
-
-// ---- backward tail stage, fused: for one (lookup, column kk) pair walk the rows once,
-//   d core partial[kk][0..NT) = sum_row x[row][kk] * G[row][0..NT)     -> HBM
-//   d x[row][kk]              = sum_c   G[row][c]  * C[kk][c]          -> over x in place
-// (only this thread ever reads x[.][kk] of that lookup, so in place is safe without a barrier)
-template <int NT>
-__device__ __forceinline__ void bwd_stage_fused(int lenS, int j0, int k, int na, int nb, int sJ, int sA,
-                                                int sB, float* X, const float* G, int gJ, int gBase,
-                                                const float* Cg, int slice, const int4* I, const int4* IP, int which,
-                                                float* __restrict__ pc) {
-  const FastDiv fk = make_fd(k);
-  for (int e = threadIdx.x; e < lenS * k; e += kThreads) {
-    unsigned kk;
-    const unsigned jl = fdivmod((unsigned)e, fk, kk);
-    const int4 rec = I[j0 + jl];
-    const int sid = which == 2 ? rec.z : rec.w;
-    const float* cg = Cg + (size_t)sid * slice + kk * NT;
-    float c[NT], acc[NT];
-#pragma unroll
-    for (int x = 0; x < NT; ++x) { c[x] = cg[x]; acc[x] = 0.f; }
-    float* xb = X + jl * sJ + kk;
-    const float* g = G + (gBase + jl) * gJ;
-    for (int a = 0; a < na; ++a) {
-      float* xa = xb + a * sA;
-#pragma unroll 4
-      for (int b = 0; b < nb; ++b) {
-        const float xv = xa[b * sB];
-        float dx = 0.f;
-#pragma unroll
-        for (int x = 0; x < NT; ++x) {
-          const float gv = g[x];
-          acc[x] = fmaf(xv, gv, acc[x]);
-          dx = fmaf(gv, c[x], dx);
-        }
-        xa[b * sB] = dx;
-        g += NT;
-      }
-    }
-    float* o = pc + (size_t)(which == 2 ? IP[j0 + jl].z : IP[j0 + jl].w) * slice + kk * NT;
-#pragma unroll
-    for (int x = 0; x < NT; ++x) o[x] = acc[x];
-  }
-}
-
-// generic two-phase version (any n): (a) partial, barrier, (b) d x in place
-__device__ __forceinline__ void bwd_stage_any(int lenS, int j0, int m, int k, int n, int nb, int sJ, int sA,
-                                              int sB, float* X, const float* G, int gJ, int gBase,
-                                              const float* Cg, int slice, const int4* I, const int4* IP, int which,
-                                              float* __restrict__ pc) {
-  const FastDiv fn = make_fd(n), fnb = make_fd(nb);
-  {
-    const FastDiv fp = make_fd(k * n);
-    for (int e = threadIdx.x; e < lenS * k * n; e += kThreads) {
-      unsigned rem, col;
-      const unsigned jl = fdivmod((unsigned)e, fp, rem);
-      const unsigned kk = fdivmod(rem, fn, col);
-      const float* gi = G + (gBase + jl) * gJ + col;
-      const float* xj = X + jl * sJ + kk;
-      float acc = 0.f;
-      int row = 0;
-      for (int a = 0; a * nb < m; ++a)
-        for (int b = 0; b < nb; ++b, ++row) acc = fmaf(xj[a * sA + b * sB], gi[row * n], acc);
-      pc[(size_t)(which == 2 ? IP[j0 + jl].z : IP[j0 + jl].w) * slice + rem] = acc;
-    }
-  }
-  __syncthreads();
-  {
-    const FastDiv fp = make_fd(m * k), fk = make_fd(k);
-    for (int e = threadIdx.x; e < lenS * m * k; e += kThreads) {
-      unsigned rem, kk, b;
-      const unsigned jl = fdivmod((unsigned)e, fp, rem);
-      const unsigned row = fdivmod(rem, fk, kk);
-      const unsigned a = fdivmod(row, fnb, b);
-      const int4 rec = I[j0 + jl];
-      const int sid = which == 2 ? rec.z : rec.w;
-      const float* ct = Cg + (size_t)sid * slice + kk * n;
-      const float* gi = G + (gBase + jl) * gJ + row * n;
-      float acc = 0.f;
-      for (int c = 0; c < n; ++c) acc = fmaf(gi[c], ct[c], acc);
-      X[jl * sJ + a * sA + b * sB + kk] = acc;
-    }
-  }
-}
-
-// ---- GEMM 2: d core_1 tiles += As^T * dX0 over one pass, k-step rows {m, m+8, m+16, m+24} ----
-// acc[x][y]: x = column tile of the pair (np*2 + x), y = r1 tile k0t + y
-template <int KB, bool TWO>
-__device__ __forceinline__ void db1_accum(const Lds& L, const float* smem, int h, int np, int k0t,
-                                          f32x4 (&acc)[2][KB]) {
-  const int lane = lane_id();
-  const int i16 = lane & 15, kq = lane >> 4;
-  const float* xr = smem + L.oX0 + 8 * kq * L.ld + np * 32 + i16;
-  const float* ar = smem + L.oA + (h * L.rS + 8 * kq) * L.ldA + k0t * 16 + i16;
-  // software pipeline: operands of k-step t+1 are read while the MFMAs of step t issue
-  float bc0 = xr[0], bc1 = TWO ? xr[16] : 0.f, ac[KB];
-#pragma unroll
-  for (int y = 0; y < KB; ++y) ac[y] = ar[y * 16];
-  for (int mb = 0; mb < L.rS; mb += 32) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int mx = (t < 7) ? mb + t + 1 : mb + 32;  // row steps of a block are mb+0..7 (+8*kq)
-      const int mn = (mx < L.rS) ? mx : 0;            // last prefetch wraps (unused)
-      const float bn0 = xr[mn * L.ld];
-      const float bn1 = TWO ? xr[mn * L.ld + 16] : 0.f;
-      float an[KB];
-#pragma unroll
-      for (int y = 0; y < KB; ++y) an[y] = ar[mn * L.ldA + y * 16];
-#pragma unroll
-      for (int y = 0; y < KB; ++y) {
-        acc[0][y] = mfma4(ac[y], bc0, acc[0][y]);
-        if (TWO) acc[1][y] = mfma4(ac[y], bc1, acc[1][y]);
-      }
-      bc0 = bn0;
-      bc1 = bn1;
-#pragma unroll
-      for (int y = 0; y < KB; ++y) ac[y] = an[y];
-      __builtin_amdgcn_sched_group_barrier(0x100, 1 + (KB + 1) / 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, (TWO ? 2 : 1) * KB, 0);
-    }
-  }
-}
-
-template <int KB>
-__device__ __forceinline__ void db1_store(const Dims& d, const Lds& L, int np, int k0t,
-                                          const f32x4 (&acc)[2][KB], float* __restrict__ pc) {
-  const int lane = lane_id();
-  const int i16 = lane & 15, kq = lane >> 4;
-  const int K0 = d.k[0], N1 = d.n[0];
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {
-    const int col = (np * 2 + x) * 16 + i16;
-#pragma unroll
-    for (int y = 0; y < KB; ++y)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kk = (k0t + y) * 16 + kq * 4 + r;
-        if (kk < K0 && col < N1) pc[kk * N1 + col] = acc[x][y][r];
-      }
-  }
-}
-
-template <int KB>
-__device__ __forceinline__ void db1_zero(f32x4 (&acc)[2][KB]) {
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < KB; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
-}
-
-// ---- GEMM 3: d core_0 partial rows = dX0 * Bs^T, k-step columns {c, c+1, c+2, c+3} ----
-template <int KB>
-__device__ __forceinline__ void da_group(const Dims& d, const Lds& L, const float* smem, int mt,
-                                         int k0t, int j0, int lenS, float* __restrict__ pc) {
-  const int lane = lane_id();
-  const int i16 = lane & 15, kq = lane >> 4;
-  const float* xr = smem + L.oX0 + (mt * 16 + i16) * L.ld + kq;
-  const float* br = smem + L.oB + (k0t * 16 + i16) * L.ld + kq;
-  const int ncols = L.N1t * 16;
-  f32x4 acc[KB];
-#pragma unroll
-  for (int y = 0; y < KB; ++y) acc[y] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // software pipeline over 16-column blocks: the 4 k-steps of block c+16 are read while
-  // the MFMAs of block c issue
-  float ac[4], bc[4][KB];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    ac[u] = xr[u * 4];
-#pragma unroll
-    for (int y = 0; y < KB; ++y) bc[u][y] = br[y * 16 * L.ld + u * 4];
-  }
-  for (int c = 0; c < ncols; c += 16) {
-    const int cn = (c + 16 < ncols) ? c + 16 : 0;  // last prefetch wraps (unused)
-    float an[4], bn[4][KB];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      an[u] = xr[cn + u * 4];
-#pragma unroll
-      for (int y = 0; y < KB; ++y) bn[u][y] = br[y * 16 * L.ld + cn + u * 4];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int y = 0; y < KB; ++y) acc[y] = mfma4(ac[u], bc[u][y], acc[y]);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      ac[u] = an[u];
-#pragma unroll
-      for (int y = 0; y < KB; ++y) bc[u][y] = bn[u][y];
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * KB, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * KB, 0);
-  }
-  const int4* I = (const int4*)(smem + L.oI);
-  const int K0 = d.k[0], sl0 = d.slice[0];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = mt * 16 + kq * 4 + r;
-    unsigned a_;
-    const unsigned jl = fdivmod((unsigned)row, L.fdQ0, a_);
-    if ((int)jl < lenS) {
-      float* o = pc + (size_t)I[L.MC + j0 + jl].x * sl0 + a_ * K0;  // (row of the partial: position in core 0's sorted order)
-#pragma unroll
-      for (int y = 0; y < KB; ++y) {
-        const int kk = (k0t + y) * 16 + i16;
-        if (kk < K0) o[kk] = acc[y][r];
-      }
-    }
-  }
-}
-
-// all d core_0 tiles of one pass, spread over the waves
-__device__ __forceinline__ void gemm_da(const Dims& d, const Lds& L, const float* smem, int j0, int lenS,
-                                        float* __restrict__ pc) {
-  const int w = threadIdx.x / kWave;
-  const int mtiles = (lenS * d.q[0] + 15) / 16;
-  int KB = 4;
-  while (KB > 1 && mtiles * ((L.K0t + KB - 1) / KB) < kWaves) KB >>= 1;
-  const int ngroups = (L.K0t + KB - 1) / KB;
-  for (int job = w; job < mtiles * ngroups; job += kWaves) {
-    const int mt = job / ngroups, g = job - mt * ngroups;
-    int k0t = g * KB;
-    int cnt = min(KB, L.K0t - k0t);
-    while (cnt > 0) {
-      if (cnt >= 4) { da_group<4>(d, L, smem, mt, k0t, j0, lenS, pc); k0t += 4; cnt -= 4; }
-      else if (cnt >= 2) { da_group<2>(d, L, smem, mt, k0t, j0, lenS, pc); k0t += 2; cnt -= 2; }
-      else { da_group<1>(d, L, smem, mt, k0t, j0, lenS, pc); k0t += 1; cnt -= 1; }
-    }
-  }
-}
-
-// everything of one pass up to and including the per-lookup tail: leaves dX0 in LDS
-__device__ __forceinline__ void bwd_pass_front(const Dims& d, const CorePtrs& C, const Lds& L, float* smem,
-                                               int B, int table, const int64_t* __restrict__ rowidx,
-                                               const float* __restrict__ d_output, const Partials& PC,
-                                               int h, int j0, int lenS) {
-  const int tid = threadIdx.x;
-  const int T = d.T, q0 = d.q[0], D = d.D;
-  const int4* I = (const int4*)(smem + L.oI);
-  const int4* IP = I + L.MC;  // rows of the lookups' thin-core partials (bwd_kernel)
-  float* X0 = smem + L.oX0;
-  float* X1 = smem + L.oX1;
-  float* Gb = smem + L.oG;
-  if (T == 2) {
-    // dX0 is the bag gradient itself: [q0 x q1]; zero the MFMA padding
-    for (int e = tid; e < L.rS * L.ld; e += kThreads) X0[e] = 0.f;
-    __syncthreads();
-    for (int e = tid; e < lenS * D; e += kThreads) {
-      unsigned rem, col;
-      const unsigned jl = fdivmod((unsigned)e, L.fdD, rem);
-      const unsigned a = fdivmod(rem, L.fdN1, col);
-      X0[(jl * q0 + a) * L.ld + col] = d_output[((size_t)table * B + rowidx[I[j0 + jl].x]) * D + rem] *
-                                       (PC.psw ? PC.psw[I[j0 + jl].x] : 1.f);
-    }
-    __syncthreads();
-    return;
-  }
-  // recompute the forward intermediate x_0 of this pass
-  if (!(L.dbg & 1)) gemm_x0(d, L, smem, h, nullptr, j0, lenS);
-  __syncthreads();
-  if (L.dbg & 2) return;
-  if (T == 4) {
-    // x_1 = x_0 * core_2[i_2]  (needed by the gradient of core 3)
-    const int k1 = d.k[1], n1 = d.n[1], m1 = d.m[1], q1 = d.q[1];
-    if (n1 <= 8) {
-#define CALL(NT) fwd_stage<NT>(lenS, j0, m1, k1, q1, q0 * L.ld, L.ld, k1, X0, nullptr, 0, false, C.c[2], d.slice[2], I, 2, \
-                               X1, L.szX1, nullptr, D)
-      TTX_NT_SWITCH(n1, CALL)
-#undef CALL
-    } else {
-      fwd_stage_any(lenS, j0, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, C.c[2], d.slice[2], I, 2, X1, L.szX1, nullptr, D);
-    }
-    __syncthreads();
-    // stage t = 2 on x_1 [m2 x k2] with G = bag gradient [m2 x n2]
-    const int m2 = d.m[2], k2 = d.k[2], n2 = d.n[2];
-    if (n2 <= 8) {
-#define CALL(NT) bwd_stage_fused<NT>(lenS, j0, k2, 1, m2, L.szX1, 0, k2, X1, Gb, D, j0, C.c[3], d.slice[3], I, IP, 3, PC.pc[3])
-      TTX_NT_SWITCH(n2, CALL)
-#undef CALL
-    } else {
-      bwd_stage_any(lenS, j0, m2, k2, n2, m2, L.szX1, 0, k2, X1, Gb, D, j0, C.c[3], d.slice[3], I, IP, 3, PC.pc[3]);
-    }
-    __syncthreads();
-  }
-  // stage t = 1 on x_0 (row = a*q1 + b at a*ld + b*k1) with G1 = bag gradient (T == 3) or d x_1
-  {
-    const int m1 = d.m[1], k1 = d.k[1], n1 = d.n[1], q1 = d.q[1];
-    const float* Gin = (T == 3) ? Gb : X1;
-    const int gJ = (T == 3) ? D : L.szX1;
-    const int gBase = (T == 3) ? j0 : 0;
-    if (n1 <= 8) {
-#define CALL(NT) bwd_stage_fused<NT>(lenS, j0, k1, q0, q1, q0 * L.ld, L.ld, k1, X0, Gin, gJ, gBase, C.c[2], d.slice[2], I, IP, 2, PC.pc[2])
-      TTX_NT_SWITCH(n1, CALL)
-#undef CALL
-    } else {
-      bwd_stage_any(lenS, j0, m1, k1, n1, q1, q0 * L.ld, L.ld, k1, X0, Gin, gJ, gBase, C.c[2], d.slice[2], I, IP, 2, PC.pc[2]);
-    }
-    __syncthreads();
-  }
-}
-
-// the chunk loop with d core_1 held in registers across passes (KB = r1 tiles, <= 2 jobs/wave)
-template <int KB>
-__device__ __forceinline__ void bwd_passes(const Dims& d, const CorePtrs& C, const Lds& L, float* smem, int B,
-                                           int table, const int64_t* __restrict__ rowidx,
-                                           const float* __restrict__ d_output, const Partials& PC, int chunk,
-                                           int len) {
-  const int w = threadIdx.x / kWave;
-  const int npairs = (L.N1t + 1) / 2;
-  f32x4 acc0[2][KB], acc1[2][KB];
-  db1_zero<KB>(acc0);
-  db1_zero<KB>(acc1);
-  const int np0 = w, np1 = w + kWaves;
-  const int npass = (len + L.SC - 1) / L.SC;
-  for (int h = 0; h < npass; ++h) {
-    const int j0 = h * L.SC;
-    const int lenS = min(L.SC, len - j0);
-    if (h > 0) __syncthreads();  // the previous pass is done with X0 / X1
-    bwd_pass_front(d, C, L, smem, B, table, rowidx, d_output, PC, h, j0, lenS);
-    if (!(L.dbg & 4)) {
-      if (np0 < npairs) {
-        if (np0 * 2 + 1 < L.N1t) db1_accum<KB, true>(L, smem, h, np0, 0, acc0);
-        else db1_accum<KB, false>(L, smem, h, np0, 0, acc0);
-      }
-      if (np1 < npairs) {
-        if (np1 * 2 + 1 < L.N1t) db1_accum<KB, true>(L, smem, h, np1, 0, acc1);
-        else db1_accum<KB, false>(L, smem, h, np1, 0, acc1);
-      }
-    }
-    if (!(L.dbg & 8)) gemm_da(d, L, smem, j0, lenS, PC.pc[0]);
-  }
-  float* pc = PC.pc[1] + (size_t)chunk * d.slice[1];
-  if (np0 < npairs) db1_store<KB>(d, L, np0, 0, acc0, pc);
-  if (np1 < npairs) db1_store<KB>(d, L, np1, 0, acc1, pc);
-}
-
-__global__ __launch_bounds__(kThreads, 3) void bwd_kernel(Dims d, Plan P, CorePtrs C, int B,
-                                                         const int64_t* __restrict__ rowidx,
-                                                         const float* __restrict__ d_output,
-                                                         Partials PC, Lds L) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  zero_hot_counters(PC);
-  const int chunk = blockIdx.x;
-#define STAMP(i) do { if (L.stamps && threadIdx.x == 0) L.stamps[(size_t)chunk * 16 + (i)] = wall_clock64(); } while (0)
-  STAMP(0);
-  const int4 cr = P.chunk_rec[chunk];
-  const int s = cr.x, start = cr.y, len = cr.z;
-  if (len == 0) return;
-  STAMP(1);
-  const int tid = threadIdx.x;
-  const int D = d.D;
-  stage_chunk(d, P, C, L, smem, s, start, len);
-  STAMP(2);
-  if (L.dbg & 16) return;
-  const int4* I = (const int4*)(smem + L.oI);
-  if (tid < len) {  // partial gradients of the thin cores are stored in the cores' SORTED order (Plan::ipos)
-    const int n = I[tid].x;
-    ((int4*)(smem + L.oI))[L.MC + tid] = make_int4(P.ipos[0][n], 0, d.T > 2 ? P.ipos[2][n] : 0, d.T > 3 ? P.ipos[3][n] : 0);
-  }
-  const int table = PC.tableidx ? (int)PC.tableidx[I[0].x] : s / d.p[1];
-  if (d.T >= 3) {
-    // bag gradients of the chunk's lookups
-    float* Gb = smem + L.oG;
-    if ((D & 3) == 0) {
-      const int d4 = D / 4;
-      for (int e = tid; e < len * d4; e += kThreads) {
-        unsigned rem;
-        const unsigned j = fdivmod((unsigned)e, L.fdD4, rem);
-        float4 gq = ((const float4*)(d_output + ((size_t)table * B + rowidx[I[j].x]) * D))[rem];
-        if (PC.psw) { const float sw = PC.psw[I[j].x]; gq.x *= sw; gq.y *= sw; gq.z *= sw; gq.w *= sw; }
-        ((float4*)Gb)[e] = gq;
-      }
-    } else {
-      for (int e = tid; e < len * D; e += kThreads) {
-        unsigned rem;
-        const unsigned j = fdivmod((unsigned)e, L.fdD, rem);
-        Gb[e] = d_output[((size_t)table * B + rowidx[I[j].x]) * D + rem] * (PC.psw ? PC.psw[I[j].x] : 1.f);
-      }
-    }
-    // (visible to the tail after the barrier that follows the first GEMM)
-  }
-  STAMP(3);
-  if (L.persist) {
-    const int kb = L.K0t <= 1 ? 1 : (L.K0t <= 2 ? 2 : 4);
-    if (kb == 1) bwd_passes<1>(d, C, L, smem, B, table, rowidx, d_output, PC, cr.w, len);
-    else if (kb == 2) bwd_passes<2>(d, C, L, smem, B, table, rowidx, d_output, PC, cr.w, len);
-    else bwd_passes<4>(d, C, L, smem, B, table, rowidx, d_output, PC, cr.w, len);
-  } else {
-    // single pass (SC == MC); d core_1 tiles computed and stored group by group
-    bwd_pass_front(d, C, L, smem, B, table, rowidx, d_output, PC, 0, 0, len);
-    const int w = tid / kWave;
-    const int npairs = (L.N1t + 1) / 2;
-    float* pc = PC.pc[1] + (size_t)cr.w * d.slice[1];  // .w = the chunk's partial slot
-    for (int np = w; np < npairs; np += kWaves) {
-      const bool two = (np * 2 + 1) < L.N1t;
-      for (int k0t = 0; k0t < L.K0t; k0t += 4) {
-        f32x4 acc[2][4];
-        db1_zero<4>(acc);
-        if (two) db1_accum<4, true>(L, smem, 0, np, k0t, acc);
-        else db1_accum<4, false>(L, smem, 0, np, k0t, acc);
-        db1_store<4>(d, L, np, k0t, acc, pc);
-      }
-    }
-    gemm_da(d, L, smem, 0, len, PC.pc[0]);
-  }
-  STAMP(7);
-#undef STAMP
 }
 
 __device__ __forceinline__ float apply_one(int optim, float g, float w, float lr, float eps, float* st) {
@@ -1636,11 +837,15 @@ static int spec_mc(const Dims& d, long long nnz) {
 
 // ---------------------------------------------------------- host side ------
 
-static int check_lds(const Dims& d, const Lds& L) {
-  if (L.MC <= 0 || L.bytes > 160 * 1024)
+// the generic kernels' carve for the block walk choose_tiles() picked (the plan was cut into chunks of its MC)
+static int generic_lds(const Dims& d, const Plan& P, bool bwd, Lds* L) {
+  const TileCfg cfg = choose_tiles(d);
+  if (cfg.MC <= 0 || cfg.MC != P.MC)
     TTX_FAIL(TTX_EUNSUPPORTED,
-             "TT shape needs %d B of LDS per work-group (core-1 slice %d x %d floats); limit 163840",
-             L.bytes, d.k[0], d.n[0]);
+             "no tiling of this TT shape fits %d B of LDS (one q1 block of x_0: %d x %d floats per lookup; ranks %d, %d)",
+             g_lds_budget, d.q[0], d.T >= 3 ? d.k[1] : d.n[0], d.k[0], d.T >= 3 ? d.k[1] : 1);
+  *L = make_lds(d, cfg.MC, bwd, cfg.bpp, cfg.KB);
+  if (L->bytes > 160 * 1024) TTX_FAIL(TTX_EUNSUPPORTED, "internal: LDS carve of %d B", L->bytes);
   return TTX_OK;
 }
 
@@ -1678,8 +883,8 @@ static int run_rows(const Dims& d, long long nnz, const Plan& P, const float* co
     ProfScope ps(TTX_PROF_FWD, st);
     return run_rows_spec(id, P, C, rows, zout, nzero, st);
   }
-  Lds L = make_lds(d, P.MC, false);
-  int rc = check_lds(d, L);
+  Lds L;
+  int rc = generic_lds(d, P, false, &L);
   if (rc) return rc;
   rc = allow_lds(fwd_kernel, L.bytes);
   if (rc) return rc;
@@ -1711,6 +916,31 @@ int ttx_debug_skip(int32_t mask) {
   return TTX_OK;
 }
 
+// test knob: LDS budget of the generic kernels' tile search (0 = the hardware's 160 KiB).  A small budget sends small
+// shapes through the block walk (K blocks x column passes) that large ranks need.
+int ttx_debug_lds_budget(int32_t bytes) {
+  if (bytes < 0 || bytes > 160 * 1024) TTX_FAIL(TTX_EINVAL, "LDS budget %d out of range", bytes);
+  g_lds_budget = bytes ? bytes : 160 * 1024;
+  return TTX_OK;
+}
+
+// test helper: how the generic kernels would walk this geometry's core_1 slice
+// out = {lookups per chunk, q1 blocks per column pass, rows per K block, column passes, K blocks, LDS bytes (backward)};
+// all zero when a shape-specialised kernel takes the geometry
+int ttx_debug_tiles(const ttx_geom* g, int32_t* out) {
+  Dims d;
+  int rc = make_dims(g, &d);
+  if (rc) return rc;
+  if (!out) TTX_FAIL(TTX_EINVAL, "out is NULL");
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  if (spec_shape(d)) return TTX_OK;
+  const TileCfg cfg = choose_tiles(d);
+  if (cfg.MC <= 0) return TTX_OK;
+  const Lds L = make_lds(d, cfg.MC, true, cfg.bpp, cfg.KB);
+  out[0] = L.MC; out[1] = L.bpp; out[2] = L.KB; out[3] = L.ncp; out[4] = L.nkb; out[5] = L.bytes;
+  return TTX_OK;
+}
+
 int ttx_set_chunk(int32_t mc) {
   if (mc < 0 || mc > 64) TTX_FAIL(TTX_EINVAL, "chunk %d out of range 0..64", mc);
   g_chunk_override = mc;
@@ -1729,7 +959,8 @@ static int common_checks(const Dims& d, int32_t D, int64_t nnz) {
   if (D != d.D) TTX_FAIL(TTX_EINVAL, "D=%d does not match prod(q)=%d", D, d.D);
   if (nnz < 0 || nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz=%lld out of range", (long long)nnz);
   if (choose_chunk(d, nnz) <= 0)
-    TTX_FAIL(TTX_EUNSUPPORTED, "core-1 slice (%d x %d floats) does not fit the LDS tiling", d.k[0], d.n[0]);
+    TTX_FAIL(TTX_EUNSUPPORTED, "no tiling of this TT shape fits the LDS (one q1 block of x_0 is %d x %d floats per lookup)",
+             d.q[0], d.T >= 3 ? d.k[1] : d.n[0]);
   return TTX_OK;
 }
 
@@ -1929,8 +1160,8 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
     rc = run_bwd_spec(id, d, P, C, B, rowidx, d_output, PC, st);
     if (rc) return rc;
   } else {
-    Lds L = make_lds(d, P.MC, true);
-    rc = check_lds(d, L);
+    Lds L;
+    rc = generic_lds(d, P, true, &L);
     if (rc) return rc;
     rc = allow_lds(bwd_kernel, L.bytes);
     if (rc) return rc;

@@ -91,6 +91,8 @@ def lib():
     L.ttx_profile_enable.argtypes = [C.c_int]
     L.ttx_profile_read.argtypes = [C.c_int, C.POINTER(i64), C.POINTER(C.c_double)]
     L.ttx_set_chunk.argtypes = [i32]
+    L.ttx_debug_lds_budget.argtypes = [i32]
+    L.ttx_debug_tiles.argtypes = [G, C.POINTER(i32)]
     for name in ("ttx_dedup_bytes", "ttx_tt_forward_dd_workspace_bytes", "ttx_tt_backward_dd_workspace_bytes"):
         getattr(L, name).restype = C.c_size_t
     L.ttx_dedup_bytes.argtypes = [G, i64]
@@ -611,3 +613,16 @@ def profile_read(which: int) -> Tuple[int, float]:
 
 def set_chunk(mc: int) -> None:
     _check(lib().ttx_set_chunk(mc))
+
+
+def debug_lds_budget(nbytes: int) -> None:
+    """Test knob: LDS budget of the generic kernels' tile search (0 = the hardware's 160 KiB)."""
+    _check(lib().ttx_debug_lds_budget(int(nbytes)))
+
+
+def debug_tiles(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks) -> dict:
+    """Test helper: the block walk the generic kernels take for this geometry under the current budget."""
+    g = _geom(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks)
+    out = (C.c_int32 * 6)()
+    _check(lib().ttx_debug_tiles(C.byref(g), out))
+    return dict(zip(("MC", "bpp", "KB", "ncp", "nkb", "bytes"), [int(x) for x in out]))

@@ -429,6 +429,14 @@ int ttx_profile_read(int which, int64_t* launches, double* total_ms);
 
 /* tuning knob (bench / tests): indices per work-group chunk; 0 = heuristic */
 int ttx_set_chunk(int32_t indices_per_chunk);
+/* test knob: LDS budget in bytes (<= 163840; 0 = that) of the generic kernels' tile search.  The generic contraction
+ * kernels walk a core_1 slice in K blocks x column passes sized to the budget (csrc/ttx_tt_generic.inc), so a small
+ * budget drives small shapes through the walk that ranks >= 80 need.  Set it before sizing workspaces / plans. */
+int ttx_debug_lds_budget(int32_t bytes);
+/* test helper: the walk the generic kernels take for geometry g under the current budget:
+ * out[6] = {lookups per chunk, q1 blocks per column pass, rows per K block, column passes, K blocks, LDS bytes};
+ * all zero when a shape-specialised kernel takes the geometry (or nothing fits the budget). */
+int ttx_debug_tiles(const ttx_geom* g, int32_t* out);
 /* ablation knob (scripts/ablate.py only): bit mask of kernel phases to skip;
  * results are INVALID while it is non-zero.  0 = normal operation. */
 int ttx_debug_skip(int32_t mask);

@@ -2,7 +2,7 @@
 
 run_plan_cases: geometry (T, q, ranks, p up to 3000), table count, batch, ragged / empty bags and a
 70 %-on-three-indices skew drawn at random so that every plan route (tiny / single launch / wave units / wide
-digit / table groups / multi-pass), per-table row factors (ttx_geom::p_tables) and the module's route
+digit / table groups / multi-pass), the generic kernels' block walk of core 1 (small LDS budgets), per-table row factors (ttx_geom::p_tables) and the module's route
 (ttx_lookup_prologue) are hit; forward + dense gradients.
 run_cache_cases: the cache-live prologue (offsets -> bag rows, cache lookup, stable partition: bit-exact) and the
 cache gather / SGD scatter.
@@ -42,6 +42,11 @@ def run_plan_cases(seed=0, max_cases=None, budget=None):
         else:
             q = [int(rs.randint(1, 5)) for _ in range(T)]
             r = [1] + [int(rs.randint(1, 9)) for _ in range(T - 1)] + [1]
+            if rs.rand() < 0.3:  # larger ranks: K blocks of core 1 (r1 > 32) once the LDS budget below is small
+                r = [1] + [int(rs.randint(1, 72)) for _ in range(T - 1)] + [1]
+        # the generic kernels' block walk (K blocks x column passes of a core_1 slice, csrc/ttx_tt_generic.inc): a small
+        # LDS budget drives these small shapes through it
+        lds_kb = 0 if spec else int(rs.choice([0, 0, 12, 16, 24, 40]))
         pmax = int(rs.choice([6, 40, 300, 700, 3000]))
         p = [int(rs.randint(2, pmax + 1)) for _ in range(T)]
         if np.prod(np.array(p, dtype=np.float64)) * 1.0 > 2e12:
@@ -63,6 +68,13 @@ def run_plan_cases(seed=0, max_cases=None, budget=None):
             hot = rs.randint(0, E_, size=3)
             idx = np.where(rs.rand(nnz) < 0.7, hot[rs.randint(0, 3, size=nnz)], idx).astype(np.int64)
         d_out = G.make_grad(int(rs.randint(1 << 30)), tables, B, D)
+        E.debug_lds_budget(lds_kb * 1024)
+        walk = E.debug_tiles(tables, p, q, r)
+        if not spec and walk["MC"] == 0:  # (nothing fits that budget)
+            E.debug_lds_budget(0)
+            walk = E.debug_tiles(tables, p, q, r)
+        if walk["ncp"] * walk["nkb"] > 1:
+            routes["block-walk"] = routes.get("block-walk", 0) + 1
         if tables > 1 and rs.rand() < 0.35:
             # tables of different row factors (ttx_geom::p_tables): the oracle does every table on its own
             ps = [[int(rs.randint(2, pmax + 1)) for _ in range(T)] for _ in range(tables)]
@@ -96,6 +108,7 @@ def run_plan_cases(seed=0, max_cases=None, budget=None):
                     assert_close(gsplit[c_][k].cpu().numpy(), rg[c_][0], what + f" grad{c_} table {k}", **tol)
             routes["mixed"] = routes.get("mixed", 0) + 1
             n += 1
+            E.debug_lds_budget(0)
             continue
         cores = G.make_cores(int(rs.randint(1 << 30)), tables, p, q, r[1:-1], "signed")
         c = dict(tables=tables, T=T, p=p, q=q, r=r, B=B, D=D)
@@ -114,7 +127,7 @@ def run_plan_cases(seed=0, max_cases=None, budget=None):
             plan = E.make_plan(tables, p, q, r, nnz, t(idx), ti, ri)
         out = E.tt_forward(1000, tables, B, D, p, q, r, Lt, nnz, t(idx), ri, ti, gc, plan=plan)
         grads = E.tt_dense_backward(1000, D, p, q, r, Lt, nnz, t(idx), ri, ti, t(d_out), gc, plan=plan)
-        what = f"case {n}: T={T} tables={tables} p={p} q={q} r={r} B={B} nnz={nnz}"
+        what = f"case {n}: T={T} tables={tables} p={p} q={q} r={r} B={B} nnz={nnz} walk={walk}"
         tol = dict(rtol=1e-4, atol_scale=2e-5)  # (hot slices: thousands of terms in an order of their own)
         assert_close(out.cpu().numpy(), ref_out, what + " out", **tol)
         for k in range(T):
@@ -123,6 +136,7 @@ def run_plan_cases(seed=0, max_cases=None, budget=None):
         route = "tiny" if nnz <= 1024 and E_ <= 2**32 else ("single" if S <= 256 and nnz <= 16384 else ("units" if S <= 256 else ("wide" if S <= 2048 else "multi-pass")))
         routes[route] = routes.get(route, 0) + 1
         n += 1
+        E.debug_lds_budget(0)
     return n, routes
 
 

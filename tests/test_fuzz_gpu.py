@@ -11,9 +11,10 @@ pytestmark = pytest.mark.gpu
 def test_plan_and_contraction_fuzz_slice(seed):
     n, routes = fuzz_cases.run_plan_cases(seed=seed, max_cases=125)
     assert n == 125
-    if seed == 0:
-        for route in ("tiny", "single", "units", "wide", "multi-pass", "mixed", "prologue"):
-            assert routes.get(route, 0) > 0, f"plan route {route!r} not exercised: {routes}"
+    must = ("tiny", "single", "units", "wide", "multi-pass", "mixed", "prologue", "block-walk") if seed == 0 else \
+        ("tiny", "single", "mixed", "prologue", "block-walk")
+    for route in must:
+        assert routes.get(route, 0) > 0, f"plan route {route!r} not exercised: {routes}"
 
 
 @pytest.mark.parametrize("seed", [0, 1])
