@@ -199,7 +199,10 @@ def main():
         # RCCL brings up 128 channels per communicator by default on this GPU; in the sandboxed boxes of this
         # pool that alone took minutes (measured: > 120 s at world size 1, 3.6 s with 4 channels).  The two
         # exchanges of a step are < 1 MB per peer: a handful of channels carries them.
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
+        # That cap is a bring-up-time fix measured on ONE rank; with real peers the channel count is RCCL's to choose
+        # (8 ranks x 7 xGMI links: nobody measured 8 channels there), so it is only applied to the one-rank run.
+        if world == 1:
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         dist.init_process_group("nccl", device_id=dev)
 
     import gen_inputs as G
@@ -376,6 +379,7 @@ def main():
     # (ttx_sharded.DirectExchange: current stream, capturable; torch.distributed's own collectives are not).
     # Falls back to the eager timing if capture is unavailable.
     mode, regions, plain_regions = "eager", None, None
+    degraded = None  # set when the reported mode is a fallback: the line says so and a multi-GPU run exits non-zero
     can_graph = not args.no_graph and (not wl["populate"] or ops._native_node() is not None)
     if sharded:
         can_graph = can_graph and ops._native_node() is not None and not os.environ.get("TTX_NO_DIRECT_RCCL")
@@ -387,12 +391,15 @@ def main():
             if sharded:
                 import threading
 
-                def bail():  # a hung collective must not take the driver's slot with it
+                def bail():  # a hung collective must not take the driver's slot with it -- and must not look like success
                     if rank == 0:
-                        print(json.dumps(build_line("eager", eager_regions, {}, None,
-                                                    note="direct-RCCL graph region did not finish; eager torch.distributed result")),
-                              flush=True)
-                    os._exit(0)
+                        line = build_line("eager", eager_regions, {}, None,
+                                          note="direct-RCCL graph region did not finish; eager torch.distributed result")
+                        line["degraded"] = "watchdog: the captured direct-RCCL region hung; exit code 3"
+                        print(json.dumps(line), flush=True)
+                    print(f"[bench] rank {rank}: direct-RCCL graph region did not finish in time -- exiting with code 3",
+                          file=sys.stderr, flush=True)
+                    os._exit(3)
 
                 dog = threading.Timer(float(os.environ.get("TTX_DIRECT_TIMEOUT", "240")), bail)
                 dog.daemon = True
@@ -468,8 +475,11 @@ def main():
                 pass
         except Exception as ex:  # noqa: BLE001
             print(f"[bench] graph capture unavailable ({type(ex).__name__}: {ex}); reporting the eager path", file=sys.stderr)
+            degraded = f"graph capture failed ({type(ex).__name__}: {ex}); eager path reported"
             if sharded:
                 mod.direct = None
+                if hasattr(mod, "drop_planned"):
+                    mod.drop_planned()
             regions = None
             torch.cuda.synchronize()
         finally:
@@ -542,12 +552,37 @@ def main():
             line["cpu_baseline"] = cpu_baseline(reqs_np, cores_np, d_out_np, Q_SHAPES, RANKS, B_GLOBAL)
         if args.run_baseline and not sharded and ntab == 1:
             line["dense_embedding_bag"] = dense_baseline(E_, D, reqs, grad, args.steps, args.warmup)
+        if degraded:
+            line["degraded"] = degraded
         print(json.dumps(line), flush=True)
     if sharded:
         dist.barrier()
-        # (no destroy_process_group / communicator teardown: both were seen to hang on this stack; exit ends them)
         sys.stdout.flush()
-        os._exit(0)
+        # Tear the communicators down like a well-behaved job -- under a timeout: ncclCommDestroy / destroy_process_group
+        # were seen to hang on this stack (one rank, sandboxed box).  A teardown that hangs is reported on stderr; the
+        # measurement above is complete either way.  A degraded multi-GPU run (fallback mode) exits non-zero.
+        import threading
+
+        done = threading.Event()
+
+        def teardown():
+            try:
+                direct = getattr(mod, "direct", None)
+                if direct is not None and hasattr(direct, "close"):
+                    direct.close()
+                dist.destroy_process_group()
+            except Exception as ex:  # noqa: BLE001
+                print(f"[bench] rank {rank}: teardown raised {type(ex).__name__}: {ex}", file=sys.stderr, flush=True)
+            done.set()
+
+        th = threading.Thread(target=teardown, daemon=True)
+        th.start()
+        if not done.wait(float(os.environ.get("TTX_TEARDOWN_TIMEOUT", "10"))):
+            print(f"[bench] rank {rank}: communicator teardown did not finish in time; leaving it to process exit",
+                  file=sys.stderr, flush=True)
+        rc = 4 if (degraded and world > 1) else 0
+        sys.stderr.flush()
+        os._exit(rc)
 
 
 if __name__ == "__main__":

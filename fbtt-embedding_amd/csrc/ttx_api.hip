@@ -60,6 +60,19 @@ static const TabGeom* tab_geom_for(const ttx_geom* g) {
   return dptr;
 }
 
+int allow_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> done;  // (kernel, device) -> bytes granted
+  int dev = 0;
+  TTX_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  int& granted = done[std::make_pair(kernel, dev)];
+  if (granted >= bytes) return TTX_OK;
+  TTX_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  granted = bytes;
+  return TTX_OK;
+}
+
 int make_dims(const ttx_geom* g, Dims* d) {
   // every entry point starts here: whatever error an earlier, unrelated runtime call left behind on this thread
   // is not this call's (the launches below check hipGetLastError() after themselves)

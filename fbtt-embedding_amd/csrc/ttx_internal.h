@@ -27,6 +27,11 @@ void set_error(const char* fmt, ...);
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// Allow `kernel` to be launched with up to `bytes` of dynamic LDS on the CURRENT device (beyond 64 KiB a kernel needs
+// hipFuncAttributeMaxDynamicSharedMemorySize).  The attribute is per device: remembered per (kernel, device) under a
+// lock -- the forward and the autograd thread, and several devices of one process, all get here.  TTX_OK / TTX_EHIP.
+int allow_dynamic_lds(const void* kernel, int bytes);
+
 // ------------------------------------------------------------- geometry ----
 // Derived per-stage GEMM shapes of the TT chain:
 //   x_t[m_t x n_t] = x_{t-1}[m_t x k_t] * core_{t+1}[i_{t+1}][k_t x n_t]

@@ -1258,10 +1258,9 @@ template <int BITS, bool GRP>
 static int plan_build_wide(const Dims& d, int N, const int* n_dev, const int64_t* indices, const int64_t* tableidx,
                            const int64_t* rowidx, const Plan& P, hipStream_t stream, const GrpArgs& ga) {
   constexpr size_t lds = (size_t)(kWideWaves * (1 << BITS) + kWideWaves) * sizeof(int);
-  static bool attr_done = false;
-  if (!attr_done) {
-    TTX_HIP(hipFuncSetAttribute((const void*)mbw_scatter_kernel<BITS, GRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+  if (lds > 64 * 1024) {
+    const int rc_attr = allow_dynamic_lds((const void*)mbw_scatter_kernel<BITS, GRP>, (int)lds);
+    if (rc_attr) return rc_attr;
   }
   const dim3 grid((N + kWideSpan - 1) / kWideSpan + (GRP ? ga.ngroups : 0), d.T);
   hipLaunchKernelGGL((mbw_count_kernel<BITS, GRP>), grid, dim3(kWideThreads), 0, stream, d, N, n_dev, indices, tableidx, P.cnt, ga);
@@ -1425,12 +1424,8 @@ int plan_build(const Dims& d, long long nnz, const int64_t* indices,
     const int nb = per / kWave;
 #define TTX_PLAN_LAUNCH(BPW)                                                                          \
   do {                                                                                                \
-    static bool attr_done = false;                                                                    \
-    if (!attr_done) {                                                                                 \
-      TTX_HIP(hipFuncSetAttribute((const void*)plan_small_kernel<BPW>,                                \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
-      attr_done = true;                                                                               \
-    }                                                                                                 \
+    const int rc_attr = allow_dynamic_lds((const void*)plan_small_kernel<BPW>, 160 * 1024);          \
+    if (rc_attr) return rc_attr;                                                                      \
     hipLaunchKernelGGL(plan_small_kernel<BPW>, dim3(d.T), dim3(kPlanThreads), lds, stream, d,         \
                        (int)nnz, indices, tableidx, rowidx, P, debug_stamps());                               \
   } while (0)
@@ -1506,6 +1501,9 @@ static unsigned long long dedup_key_space(const Dims& d) {  // tables * prod(p),
 }
 
 bool dedup_supported(const Dims& d, long long nnz) {
+  // (the gradient pre-sum keeps 64 groups x D floats of part sums + 8 KB in LDS: gsum_kernel, ttx_tt.hip -- a wider
+  //  embedding takes the plain path, which gives the same results)
+  if ((size_t)64 * d.D * sizeof(float) + 8192 > (size_t)160 * 1024) return false;
   return nnz > 0 && nnz <= kDedupMaxN && dedup_key_space(d) != 0;
 }
 
@@ -1632,12 +1630,8 @@ int dedup_build(const Dims& d, long long nnz, const int64_t* indices, const int6
   ProfScope ps(TTX_PROF_PLAN, stream);
 #define TTX_DEDUP_LAUNCH(BPW)                                                                                 \
   do {                                                                                                        \
-    static bool attr_done = false;                                                                            \
-    if (!attr_done) {                                                                                         \
-      TTX_HIP(hipFuncSetAttribute((const void*)dedup_small_kernel<BPW>,                                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-      attr_done = true;                                                                                       \
-    }                                                                                                         \
+    const int rc_attr = allow_dynamic_lds((const void*)dedup_small_kernel<BPW>, 160 * 1024);                  \
+    if (rc_attr) return rc_attr;                                                                              \
     hipLaunchKernelGGL(dedup_small_kernel<BPW>, dim3(1), dim3(kPlanThreads), lds, stream, N, E, d.num_tables, \
                        passes, indices, tableidx, M);                                                         \
   } while (0)

@@ -320,6 +320,10 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
                         const c10::optional<Tensor>& cache_opt_state, const Tensor& cache_weight,
                         const c10::optional<Tensor>& psw, at::TensorList pre, at::TensorList state,
                         at::TensorList cores) {
+    // bit 8 of `optim`: this batch's frequency update has been issued already (a planned-ahead prologue that was then
+    // discarded, tt_embeddings_ops.py): look the indices up without counting them a second time
+    const bool count_freq = (optim & 256) == 0;
+    optim &= 255;
     Geom G;
     make_geom(G, 1, p, q, r);
     const ttx_geom& g = G.g;
@@ -375,8 +379,9 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
                                            hashtbl.data_ptr<int64_t>(), cache_state.data_ptr<int32_t>(),
                                            rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
                                            pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(), ploc.data_ptr<int32_t>(),
-                                           &n_host, &part, n_tt.data_ptr<int32_t>(), hashtbl.data_ptr<int64_t>(),
-                                           cache_freq.data_ptr<int64_t>(), weighted ? psw->data_ptr<float>() : nullptr,
+                                           &n_host, &part, n_tt.data_ptr<int32_t>(),
+                                           count_freq ? hashtbl.data_ptr<int64_t>() : nullptr,
+                                           count_freq ? cache_freq.data_ptr<int64_t>() : nullptr, weighted ? psw->data_ptr<float>() : nullptr,
                                            weighted ? ppsw.data_ptr<float>() : nullptr,
                                            psw_grad ? porig.data_ptr<int32_t>() : nullptr, pws.data_ptr(), pwb, stream));
       TORCH_CHECK(part == 1, "tt_embeddings: the cache-live preprocessing did not partition");
@@ -701,7 +706,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         "the cache-live prologues of several equal-sized batches: -> [tableidx, pcol, prow, ploc, n_tt, plans], row k for batch k");
   m.def("rccl_unique_id", &rccl_unique_id, "ncclGetUniqueId (rank 0; broadcast the bytes to the others)");
   m.def("rccl_comm_init", &rccl_comm_init, "ncclCommInitRank on the given device (collective; releases the GIL)");
-  m.def("rccl_comm_destroy", &rccl_comm_destroy);
+  m.def("rccl_comm_destroy", &rccl_comm_destroy, "ncclCommDestroy (collective; releases the GIL: callers run it under a timeout)",
+        pybind11::call_guard<pybind11::gil_scoped_release>());
   m.def("rccl_all_to_all", &rccl_all_to_all, "equal-split all-to-all on the current stream (capturable)");
   m.def("rccl_all_to_allv", &rccl_all_to_allv, "all-to-all with per-peer element counts (ncclSend/ncclRecv group) on the current stream (capturable)");
   m.def("abi_version", []() { return ttx_version(); });

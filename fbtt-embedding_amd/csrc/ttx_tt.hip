@@ -851,9 +851,7 @@ static int generic_lds(const Dims& d, const Plan& P, bool bwd, Lds* L) {
 
 template <typename K>
 static int allow_lds(K kernel, int bytes) {
-  if (bytes > 64 * 1024) {
-    TTX_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  }
+  if (bytes > 64 * 1024) return allow_dynamic_lds((const void*)kernel, bytes);
   return TTX_OK;
 }
 
@@ -1290,13 +1288,18 @@ int ttx_tt_backward_dd(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, f
   {
     ProfScope ps(TTX_PROF_POOL, st);
     const int blocks = ((int)nnz + kGsumGroups - 1) / kGsumGroups;  // (upper bound: a work-group without pairs only looks for hot ones)
-    const size_t lds = (size_t)kGsumGroups * d.D * sizeof(float);
-    if (d.D % 4 == 0 && (((uintptr_t)d_output) & 15) == 0)
+    const size_t lds = (size_t)kGsumGroups * d.D * sizeof(float);  // (dedup_supported bounds it by the LDS of a CU)
+    if (d.D % 4 == 0 && (((uintptr_t)d_output) & 15) == 0) {
+      rc = allow_lds(gsum_kernel<float4>, (int)lds + 8192);
+      if (rc) return rc;
       hipLaunchKernelGGL(gsum_kernel<float4>, dim3(blocks), dim3(kGsumThreads), lds, st, M, B, d.D / 4, rowidx, tableidx, psw,
                          (const float4*)d_output, (float4*)Gu);
-    else
+    } else {
+      rc = allow_lds(gsum_kernel<float>, (int)lds + 8192);
+      if (rc) return rc;
       hipLaunchKernelGGL(gsum_kernel<float>, dim3(blocks), dim3(kGsumThreads), lds, st, M, B, d.D, rowidx, tableidx, psw, d_output,
                          Gu);
+    }
     TTX_HIP(hipGetLastError());
   }
   // the distinct pairs as a batch of their own: bag row of pair u is u, its bag gradient Gu[u] (B = 0: no table term)

@@ -452,7 +452,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             self.cache_freq.fill_(0)
             self.cache_state.fill_(-1)
             self.warmup = True
-            self._drop_prefetched()
+            self._drop_prefetched(counted=False)  # (the frequency table is empty again)
 
     def cache_populate(self) -> None:
         if self.use_cache:
@@ -492,6 +492,9 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         side = self.prefetch_stream(indices.device)
         ready = torch.cuda.Event()
         ready.record(cur)  # the batch's tensors exist at this point of the caller's stream
+        if side != cur:  # made (perhaps cast / concatenated) on the caller's stream, read on the side stream
+            idx.record_stream(side)
+            off.record_stream(side)
         with torch.cuda.stream(side):
             side.wait_event(ready)
             rowidx, tableidx, plan = fast.prologue(idx, off, self.num_tables, getattr(self, "_p_flat", self.tt_p_shapes),
@@ -501,7 +504,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             done = torch.cuda.Event()
             done.record(side)
         if len(self._prefetched) >= 8:  # (batches that never came: drop the oldest)
-            self._prefetched.pop(next(iter(self._prefetched)))
+            self._evict_oldest_prefetched()
         self._prefetched[key] = (idx, off, (rowidx, tableidx, plan), done, indices, offsets, indices._version,
                                  offsets._version, False)
         return True
@@ -540,14 +543,39 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                                       self.cache_freq if self.use_cache else None)
         for k, key in enumerate(keys):
             while len(self._prefetched) >= 64:
-                self._prefetched.pop(next(iter(self._prefetched)))
+                self._evict_oldest_prefetched()
             self._prefetched[key] = (norm[k][0], norm[k][1], tuple(t[k] for t in res), None, batches[k][0], batches[k][1],
                                      batches[k][0]._version, batches[k][1]._version, live)
         return True
 
-    def _drop_prefetched(self) -> None:
+    def _evict_oldest_prefetched(self) -> None:
+        """drop the oldest planned-ahead batch; its frequency update has been issued, so should the batch come after
+        all, its in-line prologue must not count it again (forward looks it up in _pf_evicted)"""
+        k = next(iter(self._prefetched))
+        hit = self._prefetched.pop(k)
+        if self.use_cache:
+            ev = self.__dict__.setdefault("_pf_evicted", {})
+            while len(ev) >= 64:
+                ev.pop(next(iter(ev)))
+            ev[k] = (hit[4], hit[5], hit[6], hit[7])
+
+    def _drop_prefetched(self, counted: bool = True) -> None:
+        """forget what was planned ahead.  counted: the dropped batches' frequency updates stay in the table
+        (cache_populate), so their in-line prologues must not repeat them."""
+        while counted and getattr(self, "_prefetched", None):
+            self._evict_oldest_prefetched()
         if getattr(self, "_prefetched", None):
             self._prefetched.clear()
+        if not counted and getattr(self, "_pf_evicted", None):
+            self._pf_evicted.clear()
+
+    def __getstate__(self):
+        """copy.deepcopy / torch.save of the module: the prefetch side stream and the planned-ahead batches (device
+        buffers, HIP events) belong to this process and this point in time -- they are recreated at first use."""
+        state = self.__dict__.copy()
+        for k in ("_pf_stream", "_prefetched", "_pf_key", "_pf_counted", "_pf_evicted"):
+            state.pop(k, None)
+        return state
 
     def prefetch_stream(self, device: Optional[torch.device] = None) -> "torch.cuda.Stream":
         """the side stream of prefetch() (created at first use; call this before a hipGraph capture that prefetches)"""
@@ -565,7 +593,10 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             return None
         hit = pf.pop(getattr(self, "_pf_key", None), None)
         self._pf_key = None
-        if hit is None or hit[8] != live:  # (planned for the other state of the cache: run the prologue in line)
+        if hit is None:
+            return None
+        if hit[8] != live:  # planned for the other state of the cache: the prologue runs in line -- without counting
+            self._pf_counted = self.use_cache  # the batch into the frequency table a second time
             return None
         pre, done = hit[2], hit[3]
         if done is not None:  # (prefetch(): ran on the side stream; prefetch_many(): same stream, stream-ordered)
@@ -594,6 +625,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         if indices.dim() != 1 or offsets.dim() != 1:
             raise ValueError("indices and offsets must be 1-D (the 2-D fixed-length form of nn.EmbeddingBag is not supported)")
         self._pf_key = None
+        self._pf_counted = False  # this batch's frequency update was issued by a planned-ahead prologue that is not used
         if getattr(self, "_prefetched", None):  # a prefetch() for exactly these tensor objects, not written to since?
             k = (id(indices), id(offsets))
             hit = self._prefetched.get(k)
@@ -605,6 +637,11 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                 self._pf_key = k
                 indices, offsets = hit[0], hit[1]  # (already in the int64 / closing-offset form)
         if self._pf_key is None:
+            ev = getattr(self, "_pf_evicted", None)
+            if ev:
+                e = ev.pop((id(indices), id(offsets)), None)
+                if e is not None and e[0] is indices and e[1] is offsets and e[2] == indices._version and e[3] == offsets._version:
+                    self._pf_counted = True
             indices, offsets = self._normalise(indices, offsets)
         if (offsets.numel() - 1) % self.num_tables != 0:
             raise ValueError(f"offsets must describe num_tables * B bags, got {offsets.numel() - 1} bags for "
@@ -630,10 +667,11 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             use_state = self.sparse and self.optimizer not in _SGD_LIKE
             optim = 2 if not self.sparse else (1 if use_state else 0)
             pre = self._take_prefetched(indices, offsets)  # (rowidx, tableidx, plan) if prefetch() ran for this batch
+            count = self.use_cache and not self._pf_counted
             return fast.lookup(indices.contiguous(), offsets.contiguous(), self.num_tables,
                                getattr(self, "_p_flat", self.tt_p_shapes),  # (per-table factors: flattened)
                                self.tt_q_shapes, self.tt_ranks, optim, self.learning_rate, self.eps,
-                               self.hashtbl if self.use_cache else None, self.cache_freq if self.use_cache else None,
+                               self.hashtbl if count else None, self.cache_freq if count else None,
                                list(self.optimizer_state) if use_state else [], list(self.tt_cores), per_sample_weights,
                                *(pre if pre is not None else (None, None, None)))
         if (fast is not None and not self.warmup and self.use_cache and self.num_tables == 1 and indices.is_cuda
@@ -643,10 +681,12 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             use_state = self.sparse and self.optimizer not in _SGD_LIKE
             optim = 2 if not self.sparse else (1 if use_state else 0)
             pre = self._take_prefetched(indices, offsets, live=True)  # planned ahead by prefetch_many()?
-            if per_sample_weights is not None:
-                pre = None  # (the planned-ahead partition does not carry weights: this batch's prologue runs in line)
+            if per_sample_weights is not None and pre is not None:
+                pre = None  # (the planned-ahead partition does not carry weights: this batch's prologue runs in line,
+                self._pf_counted = True  # without counting the batch a second time)
             return fast.lookup_cached(indices.contiguous(), offsets.contiguous(), self.tt_p_shapes, self.tt_q_shapes,
-                                      self.tt_ranks, optim, self.learning_rate, self.eps, self.hashtbl, self.cache_freq,
+                                      self.tt_ranks, optim | (256 if self._pf_counted else 0), self.learning_rate, self.eps,
+                                      self.hashtbl, self.cache_freq,
                                       self.cache_state, self.cache_optimizer_state if use_state else None,
                                       self.cache_weight, list(self.optimizer_state) if use_state else [],
                                       list(self.tt_cores), list(pre) if pre is not None else [], per_sample_weights)

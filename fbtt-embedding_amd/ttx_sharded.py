@@ -49,8 +49,8 @@ class DirectExchange:
     collectives are not: its watchdog aborts on an event recorded in a capturing stream).  Equal splits go through
     ncclAllToAll, per-peer counts (tables not a multiple of the world size: 26 on 8 ranks) through one
     ncclSend/ncclRecv group.  One communicator per process group, bootstrapped through torch.distributed.
-    (The communicator is never destroyed explicitly: ncclCommDestroy was seen to hang on this stack; it dies with
-    the process.)"""
+    close() destroys the communicator (ncclCommDestroy was seen to hang on a one-rank communicator in this pool's boxes:
+    bench.py calls it under a timeout); otherwise it dies with the process."""
 
     def __init__(self, group, device: torch.device) -> None:
         import ttx_torch
@@ -63,6 +63,14 @@ class DirectExchange:
         dist.broadcast_object_list(box, src=src, group=group)
         index = device.index if device.index is not None else torch.cuda.current_device()
         self.comm = ttx_torch.rccl_comm_init(box[0], self.rank, self.world, index)
+
+    def close(self) -> None:
+        """ncclCommDestroy (collective).  Callers that must not hang run it under a timeout (bench.py): it was seen not
+        to return on a one-rank communicator in a sandboxed box."""
+        comm, self.comm = self.comm, None
+        if comm is not None:
+            torch.cuda.synchronize()
+            self._lib.rccl_comm_destroy(comm)
 
     def all_to_all(self, out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None) -> None:
         """block p of `inp` (in_splits[p] elements) -> rank p; block p of `out` (out_splits[p] elements) <- rank p.
@@ -215,14 +223,37 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
             self.local.prefetch_many([(x, loc_off) for x in loc_idx])  # (False on CPU tensors: prologues then run in line)
         if not hasattr(self, "_planned"):
             self._planned = {}
-        for j, (i, o) in enumerate(batches):
-            while len(self._planned) >= 64:
-                self._planned.pop(next(iter(self._planned)))
+        if len(self._planned) + K > 64:
+            raise RuntimeError(f"ShardedTableBatchedTTEmbeddingBag.prefetch_many: {len(self._planned)} planned batches are still "
+                               f"pending; consume them with forward() or call drop_planned() on every rank first")
+        for j, (i, o) in enumerate(batches):  # keyed by the caller's OWN tensor objects (forward looks them up before any cast)
             self._planned[(id(i), id(o))] = (i, o, i._version, o._version, Lp, loc_idx[j], loc_off)
         return True
 
+    def drop_planned(self) -> None:
+        """Forget the batches planned ahead and not yet consumed (every rank must do the same: whether a step's index
+        exchange runs is decided per rank from this table)."""
+        if getattr(self, "_planned", None):
+            self._planned.clear()
+        if self.local is not None and hasattr(self.local, "_prefetched"):
+            self.local._prefetched.clear()
+
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, fixed_pooling: Optional[int] = None) -> torch.Tensor:
         W, NT, D = self.world, self.num_tables, self.embedding_dim
+        # a batch planned ahead is found by the caller's own tensor objects -- before the casts below replace them
+        planned = getattr(self, "_planned", None)
+        hit = planned.pop((id(indices), id(offsets)), None) if planned else None
+        if planned is not None and hit is None and len(planned) > 0:
+            # Whether this step's index exchange runs is decided by every rank on its own: a rank that misses while its
+            # peers hit would issue a collective the others skip, and the round would hang.  So a miss is an error.
+            raise RuntimeError("ShardedTableBatchedTTEmbeddingBag.forward: batches planned ahead (prefetch_many) are pending "
+                               "and this batch is not one of them; pass the planned tensor objects, or call drop_planned() "
+                               "on every rank")
+        if hit is not None and not (hit[0] is indices and hit[1] is offsets and hit[2] == indices._version
+                                    and hit[3] == offsets._version and fixed_pooling is not None and hit[4] == int(fixed_pooling)):
+            raise RuntimeError("ShardedTableBatchedTTEmbeddingBag.forward: this batch was planned ahead (prefetch_many) and "
+                               "has been written to, or is used with another fixed_pooling, since; falling back to an in-line "
+                               "index exchange on this rank alone would hang the other ranks")
         indices, offsets = indices.long(), offsets.long()
         B = (offsets.numel() - 1) // NT
         if W == 1 and not _FORCE_EXCHANGE:
@@ -232,10 +263,6 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         n_me = n_own[self.rank]
         order = self._cached(("order", dev), lambda: torch.tensor(self._order, device=dev))
         # ---- 1. lookups in -------------------------------------------------
-        hit = getattr(self, "_planned", {}).pop((id(indices), id(offsets)), None) if getattr(self, "_planned", None) else None
-        if hit is not None and not (hit[0] is indices and hit[1] is offsets and hit[2] == indices._version
-                                    and hit[3] == offsets._version and fixed_pooling is not None and hit[4] == int(fixed_pooling)):
-            hit = None  # (another tensor, or written to since: exchange in line)
         if hit is not None:  # planned ahead (prefetch_many): the index exchange of this batch is done
             loc_idx, loc_off = hit[5], hit[6]
         elif fixed_pooling is not None:

@@ -93,6 +93,8 @@ CASES = [
     (1, [6, 5, 7, 4], [2, 3, 2, 2], [4, 5, 3], 200, 8, 0.9),  # T = 4, 840 rows: nearly every lookup is a duplicate
     (1, [20, 22, 25], [4, 4, 4], [16, 16], 40, 3, 0.0),       # no duplicates to speak of, tiny batch (nnz < 1024)
     (1, [40, 50, 60], [4, 4, 4], [16, 16], 1400, 11, 0.95),   # ~15k lookups (the map's limit is 16384), three rows hot
+    (1, [20, 22, 25], [4, 8, 8], [16, 16], 200, 8, 0.85),     # D = 256: the gradient pre-sum's part sums are 64 KB of LDS
+    (2, [9, 8, 7], [4, 8, 10], [5, 6], 100, 6, 0.8),          # D = 320, generic kernels: 80 KB of part sums
 ]
 
 
@@ -134,6 +136,8 @@ def test_batches_the_map_does_not_take_fall_back_to_the_plain_plan():
     tb = torch.zeros_like(idx)
     plan = E.make_plan(1, p, q, r, idx.numel(), idx, tb, None, dedup=True)  # > 16384 lookups
     assert plan is not None and not isinstance(plan, E.DedupPlan)
+    wide = E.make_plan(1, p, [8, 8, 10], r, 100, idx[:100], tb[:100], None, dedup=True)  # D = 640: the pre-sum's LDS
+    assert wide is not None and not isinstance(wide, E.DedupPlan)
     big = [70000, 70000, 70000]  # 3.4e14 rows: keys do not fit 32 bits
     plan = E.make_plan(1, big, q, r, 100, idx[:100], tb[:100], None, dedup=True)
     assert plan is not None and not isinstance(plan, E.DedupPlan)

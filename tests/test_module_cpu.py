@@ -24,6 +24,24 @@ def ops(monkeypatch):
     return m
 
 
+def test_every_rank_the_reference_accepts_gets_a_tiling():
+    """Host logic of the generic kernels' tile search (csrc/ttx_tt_generic.inc choose_tiles): the shapes round 2 refused
+    with TTX_EUNSUPPORTED (core_1 slice beyond the LDS) get a block walk inside 160 KiB; workspace sizes are defined."""
+    import tt_embeddings as E
+
+    for q, ranks in (([4, 4, 4], [128, 128]), ([4, 4, 4], [96, 96]), ([4, 4, 4], [80, 80]), ([2, 8, 8], [64, 64]),
+                     ([4, 4, 4, 4], [128, 128, 128]), ([4, 4, 4], [512, 512]), ([3, 4, 5, 7], [13, 12, 7]), ([4, 8], [200])):
+        T = len(q)
+        p = [200, 220, 250, 7][:T]
+        r = [1] + ranks + [1]
+        tiles = E.debug_tiles(1, p, q, r)
+        assert tiles["MC"] >= 1 and 0 < tiles["bytes"] <= 160 * 1024, (q, ranks, tiles)
+        g = E._geom(1, p, q, r)
+        assert E.lib().ttx_tt_backward_workspace_bytes(ctypes.byref(g), 512, int(np.prod(q)), 10240) > 0
+    # a specialised shape reports no walk
+    assert E.debug_tiles(1, [200, 220, 250], [4, 4, 4], [1, 32, 32, 1])["MC"] == 0
+
+
 def test_abi_exports_every_declared_symbol():
     """libttx.so loads (no GPU needed) and exports every entry point include/ttx.h declares."""
     hdr = open(os.path.join(ROOT, "include", "ttx.h")).read()

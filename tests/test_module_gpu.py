@@ -783,3 +783,62 @@ def test_per_sample_weights_with_a_live_cache(node, optim):
     # without a gradient for the weights, and an unweighted call afterwards, the module keeps working
     a(idx, off, per_sample_weights=psw).backward(d_out)
     a(idx, off).backward(d_out)
+
+
+def test_discarded_planned_batches_are_counted_once_and_the_module_copies(node):
+    """A batch whose lookup prologue was planned ahead (prefetch / prefetch_many) has been counted into the frequency
+    table at that point.  When the planned entry is then not used -- cache_populate() in between, more than eight single
+    prefetches pending, per_sample_weights over a live cache -- the in-line prologue looks the indices up WITHOUT counting
+    them a second time (the LFU ranking of the next populate stays what the plain sequence gives).  And a module that has
+    prefetched deep-copies and pickles (the side stream and the planned buffers stay behind)."""
+    import copy
+    import io
+
+    import tt_embeddings_ops as ops
+
+    if node == "python":
+        pytest.skip("prefetch needs the C++ node")
+    p, q, r = [20, 22, 25], [4, 4, 4], [16, 16]
+    E_, D, B, Lp = 11000, 64, 64, 5
+    kw = dict(num_embeddings=E_, embedding_dim=D, tt_ranks=r, tt_p_shapes=p, tt_q_shapes=q, weight_dist="uniform", device=DEV,
+              sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, use_cache=True, cache_size=256, hashtbl_size=1 << 16)
+    torch.manual_seed(7)
+    m = ops.TTEmbeddingBag(**kw)
+    reqs = [(t(i), t(o)) for i, o in G.make_requests(41, 12, B, 1, Lp, E_)]
+    nnz = B * Lp
+    # (1) planned, then cache_populate() drops the plan: the batch is not counted again when it comes
+    assert m.prefetch_many(reqs[:2]) is True
+    assert int(m.cache_freq.sum()) == 2 * nnz
+    m.cache_populate()  # (resets the counts of the rows it caches / evicts: compare against what it leaves)
+    s0 = int(m.cache_freq.sum())
+    for i, o in reqs[:2]:
+        m(i, o)
+    assert int(m.cache_freq.sum()) == s0, "a batch planned before cache_populate() was counted twice"
+    m(*reqs[4])
+    assert int(m.cache_freq.sum()) == s0 + nnz  # (a batch that was never planned is counted as ever)
+    # (2) live cache, planned, then used with per_sample_weights (the planned partition carries no weights)
+    assert m.prefetch_many(reqs[2:4]) is True
+    assert int(m.cache_freq.sum()) == s0 + 3 * nnz
+    w = torch.rand(nnz, device=DEV)
+    m(reqs[2][0], reqs[2][1], per_sample_weights=w)
+    m(reqs[3][0], reqs[3][1])
+    assert int(m.cache_freq.sum()) == s0 + 3 * nnz, "a weighted batch over a planned entry was counted twice"
+    # (3) nine single prefetches: the oldest is evicted, comes after all, and is counted once
+    m.reset_cache()
+    for i, o in reqs[:9]:
+        assert m.prefetch(i, o) is True
+    for i, o in reqs[:9]:
+        m(i, o)
+    torch.cuda.synchronize()
+    assert int(m.cache_freq.sum()) == 9 * nnz, "an evicted planned batch was counted twice"
+    # (4) the module copies and pickles after having prefetched
+    assert m.prefetch(*reqs[9]) is True
+    m2 = copy.deepcopy(m)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    out = m(*reqs[9])
+    for other in (m2, m3):
+        assert not getattr(other, "_prefetched", None)
+        assert torch.equal(other(*reqs[9]), out)

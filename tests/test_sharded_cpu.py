@@ -177,12 +177,27 @@ def _worker_round(rank, world, port, q, NT, direct):
         if a.local is not None:
             for x, y in zip(a.local.tt_cores, b.local.tt_cores):
                 same = same and torch.equal(x, y)
-        # a batch written to after the planning is exchanged in line again
-        b.prefetch_many(batches[:1], fixed_pooling=fixed)
+        # a batch written to after the planning is an ERROR (a silent in-line exchange on one rank would hang the others);
+        # so is a batch that was not planned while planned ones are pending; drop_planned() clears the round
+        b.prefetch_many(batches[:2], fixed_pooling=fixed)
         batches[0][0].add_(1).remainder_(int(np.prod(P)))
+        for bad in (batches[0], batches[2]):
+            try:
+                b(*bad, fixed_pooling=fixed)
+                same = False
+            except RuntimeError as ex:
+                same = same and "planned ahead" in str(ex)
+        b.drop_planned()
         out_b = b(*batches[0], fixed_pooling=fixed).detach()
         out_a = a(*batches[0], fixed_pooling=fixed).detach()
         same = same and torch.equal(out_a, out_b) and len(b._planned) == 0
+        # int32 batches are found by their own tensor objects (the lookup precedes the cast to int64)
+        i32 = [(i.int(), o.int()) for i, o in batches[:2]]
+        assert b.prefetch_many(i32, fixed_pooling=fixed) is True
+        for (i, o) in i32:
+            out_b = b(i, o, fixed_pooling=fixed).detach()
+            same = same and torch.equal(out_b, a(i, o, fixed_pooling=fixed).detach())
+        same = same and len(b._planned) == 0
         assert b.prefetch_many(batches, fixed_pooling=None) is False  # ragged bags: not planned ahead
         q.put((rank, bool(same), "", None))
         dist.barrier()
