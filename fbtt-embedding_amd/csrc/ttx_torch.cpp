@@ -16,8 +16,11 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "ttx.h"
@@ -74,6 +77,17 @@ void check_cores(const ttx_geom& g, at::TensorList cores, const char* what) {
 
 Tensor bytes_on(const Tensor& like, size_t n) {
   return at::empty({(int64_t)(n ? n : 1)}, like.options().dtype(at::kByte));
+}
+
+// The arrival counters of pooling fused into the forward kernel (ttx_tt_forward_o): one int per lookup, all zero before
+// and after every call -- so ONE zero-initialised array per (device, stream) serves every step (no memset per call).
+Tensor arrive_zeros(const Tensor& like, int64_t n, hipStream_t stream) {
+  static std::mutex mu;
+  static std::map<std::pair<int, void*>, Tensor> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  Tensor& t = cache[std::make_pair((int)like.get_device(), (void*)stream)];
+  if (!t.defined() || t.numel() < n) t = at::zeros({std::max<int64_t>(n, 1 << 16)}, like.options().dtype(at::kInt));
+  return t;
 }
 
 struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
@@ -140,10 +154,19 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
     const bool psw_grad = weighted && psw->requires_grad() && nnz > 0;
     Tensor rows_keep;
     if (psw_grad) rows_keep = at::empty({nnz, D}, cores[0].options());
-    check(ttx_tt_forward_wr(&g, (int32_t)B, (int32_t)D, nnz, indices.data_ptr<int64_t>(), rowidx.data_ptr<int64_t>(),
-                            tableidx.data_ptr<int64_t>(), weighted ? psw->data_ptr<float>() : nullptr, cp,
-                            out.data_ptr<float>(), psw_grad ? rows_keep.data_ptr<float>() : nullptr,
-                            nnz > 0 ? plan.data_ptr() : nullptr, ws.data_ptr(), wb, stream));
+    // bag pooling inside the contraction kernel where the shape allows it (the bags are named by `offsets`).  Opt-in
+    // (TTX_FUSED_POOL=1): measured at the benchmark batch it saves the pooling launch (-5.3 us) and pays it back in the
+    // forward kernel's tail (+5.7 us: the completing lookups' dependent reads of rows that have just been written
+    // through to memory, clustered in the last work-groups to finish) -- DESIGN.md section 4.5.
+    static const bool fuse_pool = std::getenv("TTX_FUSED_POOL") != nullptr && std::getenv("TTX_FUSED_POOL")[0] == '1';
+    const int64_t na = (nnz > 0 && fuse_pool) ? ttx_tt_forward_arrive_ints(&g, nnz) : 0;
+    Tensor arrive;
+    if (na > 0) arrive = arrive_zeros(indices, na, stream);
+    check(ttx_tt_forward_o(&g, (int32_t)B, (int32_t)D, nnz, indices.data_ptr<int64_t>(), rowidx.data_ptr<int64_t>(),
+                           tableidx.data_ptr<int64_t>(), weighted ? psw->data_ptr<float>() : nullptr, cp,
+                           out.data_ptr<float>(), psw_grad ? rows_keep.data_ptr<float>() : nullptr,
+                           na > 0 ? offsets.data_ptr<int64_t>() : nullptr, na > 0 ? arrive.data_ptr<int32_t>() : nullptr,
+                           nnz > 0 ? plan.data_ptr() : nullptr, ws.data_ptr(), wb, stream));
 
     if (weighted) ctx->saved_data["psw"] = psw->detach();
     if (psw_grad) ctx->saved_data["rows"] = rows_keep;

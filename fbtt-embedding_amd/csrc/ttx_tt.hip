@@ -636,6 +636,8 @@ __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply
   __shared__ int s_last, s_nhot, s_hot[kReduceThreads];
   const int nthreads = blockDim.x, tid = threadIdx.x;
   int b = blockIdx.x;
+  const bool skip_pivot = rows_max < 0;  // (ablation only)
+  if (rows_max < 0) rows_max = -rows_max;
   if (b >= nslices) {
     // ---------------- segment work-group (t, j): its share of the hot slice(s) it intersects ----------------
     b -= nslices;
@@ -766,6 +768,7 @@ __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply
   while (t < d.T - 1 && b >= d.S[t]) { b -= d.S[t]; ++t; }
   const int s = b;
   const int sl = d.slice[t];
+  if (skip_pivot && t == 1) return;
   int beg, end;
   const int* __restrict__ list;
   if (t == 1) { beg = P.chunk_off[s]; end = P.chunk_off[s + 1]; list = nullptr; }
@@ -857,9 +860,11 @@ static int allow_lds(K kernel, int bytes) {
 
 static size_t rows_bytes(const Dims& d, long long nnz) { return align_up((size_t)nnz * d.D * 4); }
 
+static int g_skip_launch = 0;  // ablation (ttx_debug_skip bits 9..11): results invalid when != 0
+
 static int run_rows_spec(SpecId id, const Plan& P, const CorePtrs& C, float* rows, float* zout,
-                         long long nzero, hipStream_t st) {
-#define CALLF(S) spec_launch_fwd<S>(P, C, rows, zout, nzero, st)
+                         long long nzero, const PoolFuse& F, bool* fused, hipStream_t st) {
+#define CALLF(S) spec_launch_fwd<S>(P, C, rows, zout, nzero, F, fused, st)
   TTX_SPEC_DISPATCH(id, CALLF)
 #undef CALLF
   TTX_FAIL(TTX_EUNSUPPORTED, "no specialised forward kernel");
@@ -873,13 +878,20 @@ static int run_bwd_spec(SpecId id, const Dims& d, const Plan& P, const CorePtrs&
   TTX_FAIL(TTX_EUNSUPPORTED, "no specialised backward kernel");
 }
 
+// fuse: NULL, or the arguments of pooling inside the contraction kernel; *fused says whether the kernel that ran did it
 static int run_rows(const Dims& d, long long nnz, const Plan& P, const float* const* cores,
-                    float* rows, float* zout, long long nzero, hipStream_t st) {
+                    float* rows, float* zout, long long nzero, hipStream_t st, const PoolFuse* fuse = nullptr,
+                    bool* fused = nullptr) {
+  if (fused) *fused = false;
   if (const SpecId id = spec_match(d)) {
     CorePtrs C;
     for (int t = 0; t < TTX_MAX_CORES; ++t) C.c[t] = t < d.T ? (float*)cores[t] : nullptr;
     ProfScope ps(TTX_PROF_FWD, st);
-    return run_rows_spec(id, P, C, rows, zout, nzero, st);
+    bool did = fuse != nullptr && fuse->arrive != nullptr;
+    const PoolFuse none{};
+    const int rc = run_rows_spec(id, P, C, rows, zout, nzero, fuse ? *fuse : none, &did, st);
+    if (fused) *fused = did;
+    return rc;
   }
   Lds L;
   int rc = generic_lds(d, P, false, &L);
@@ -909,6 +921,7 @@ int ttx_debug_stamps(void* device_buffer) {
 // ablation knob for scripts/ablate.py: skip kernel phases (results become invalid)
 int ttx_debug_skip(int32_t mask) {
   g_disable_spec = (mask & 256) ? 1 : 0;  // bit 8: force the generic kernels (A/B tests)
+  g_skip_launch = (mask >> 9) & 63;       // bits 9..11: leave out the pooling launch / reduce_apply / reduce_apply's pivot slices (upper bounds); bit 12: no fused pooling (A/B)
   mask &= 255;
   g_debug_skip = mask;
   return TTX_OK;
@@ -982,6 +995,20 @@ int ttx_tt_forward_wr(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, cons
                       const int64_t* rowidx, const int64_t* tableidx, const float* psw,
                       const float* const* tt_cores, float* output, float* rows_keep, const void* plan, void* workspace,
                       size_t workspace_bytes, ttx_stream_t stream) {
+  return ttx_tt_forward_o(g, B, D, nnz, indices, rowidx, tableidx, psw, tt_cores, output, rows_keep, nullptr, nullptr, plan,
+                          workspace, workspace_bytes, stream);
+}
+
+int64_t ttx_tt_forward_arrive_ints(const ttx_geom* g, int64_t nnz) {
+  Dims d;
+  if (make_dims(g, &d) != TTX_OK || nnz <= 0 || nnz > kPoolSpanMin || d.D % 4 != 0 || !spec_shape(d)) return 0;
+  return nnz;
+}
+
+int ttx_tt_forward_o(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const int64_t* indices,
+                     const int64_t* rowidx, const int64_t* tableidx, const float* psw,
+                     const float* const* tt_cores, float* output, float* rows_keep, const int64_t* offsets,
+                     int32_t* arrive, const void* plan, void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
   Dims d;
   int rc = make_dims(g, &d);
   if (rc) return rc;
@@ -1010,9 +1037,20 @@ int ttx_tt_forward_wr(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, cons
   }
   if (rows_keep && (((uintptr_t)rows_keep) & 15)) TTX_FAIL(TTX_EINVAL, "rows_keep must be 16-byte aligned");
   float* rows = rows_keep ? rows_keep : (float*)ws;
-  rc = run_rows(d, nnz, P, tt_cores, rows, output, nout, st);  // also zeroes `output`
+  // pooling inside the contraction kernel (spec_fwd_kernel<.., FUSE>): the caller names the bags (offsets) and lends a
+  // zeroed counter per lookup; small batches of the specialised shapes only -- everything else pools in a launch of its own
+  PoolFuse F{};
+  const bool offer = offsets && arrive && nnz <= kPoolSpanMin && d.D % 4 == 0 && (((uintptr_t)rows | (uintptr_t)output) & 15) == 0 &&
+                     (size_t)nnz * d.D * 4 < (1ull << 31) && (long long)d.num_tables * B < (1ll << 30) && !(g_skip_launch & 8);
+  if (offer) {
+    F.arrive = arrive; F.offsets = offsets; F.rowidx = rowidx; F.tableidx = d.tab ? tableidx : nullptr; F.psw = psw;
+    F.out = output; F.B = B; F.bags = d.num_tables * B; F.p1 = d.p[1]; F.rows_bytes = (unsigned)((size_t)nnz * d.D * 4);
+    F.dbg = (g_skip_launch >> 4) & 3;
+  }
+  bool fused = false;
+  rc = run_rows(d, nnz, P, tt_cores, rows, output, nout, st, offer ? &F : nullptr, &fused);  // also zeroes `output`
   if (rc) return rc;
-  {
+  if (!(g_skip_launch & 1) && !fused) {
     ProfScope ps(TTX_PROF_POOL, st);
     if (d.D % 4 == 0 && (((uintptr_t)rows | (uintptr_t)output) & 15) == 0) {
       if (nnz <= kPoolSpanMin)
@@ -1168,14 +1206,14 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
                        rowidx, d_output, PC, L);
     TTX_HIP(hipGetLastError());
   }
-  {
+  if (!(g_skip_launch & 2)) {
     const int blocks = nslices + nsegs;  // slice owners, then the segment work-groups of hot slices
     int smax = 0;
     for (int t = 0; t < d.T; ++t) smax = d.slice[t] > smax ? d.slice[t] : smax;
     const int rthreads = smax <= 4096 ? TTX_RTHREADS_SMALL : kReduceThreads;  // (measured: 512 is 1.7 us faster at r = 32, 1024 at r = 64)
     ProfScope ps(TTX_PROF_APPLY, st);
     hipLaunchKernelGGL(reduce_apply_kernel, dim3(blocks), dim3(rthreads), 0, st, d, P, PC, optim, lr,
-                       eps, C, S, DW, nslices, (int)nnz);
+                       eps, C, S, DW, nslices, (g_skip_launch & 4) ? -(int)nnz : (int)nnz);
     TTX_HIP(hipGetLastError());
   }
   return TTX_OK;

@@ -72,6 +72,9 @@ def lib():
     L.ttx_plan_build.argtypes = [G, i64, vp, vp, vp, vp, sz, vp]
     L.ttx_tt_forward_workspace_bytes.argtypes = [G, i32, i32, i64]
     L.ttx_tt_forward.argtypes = [G, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.ttx_tt_forward_o.argtypes = [G, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.ttx_tt_forward_arrive_ints.argtypes = [G, i64]
+    L.ttx_tt_forward_arrive_ints.restype = i64
     L.ttx_tt_rows.argtypes = [G, i32, i64, vp, vp, vp, vp, vp, sz, vp]
     L.ttx_tt_backward_workspace_bytes.argtypes = [G, i32, i32, i64]
     L.ttx_tt_backward.argtypes = [G, i32, i32, i32, f32, f32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
@@ -101,6 +104,8 @@ def lib():
     L.ttx_tt_forward_dd.argtypes = [G, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.ttx_tt_backward_dd_workspace_bytes.argtypes = [G, i32, i64]
     L.ttx_tt_backward_dd.argtypes = [G, i32, i32, i32, f32, f32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    if os.environ.get("TTX_DEBUG_SKIP"):  # ablation runs (scripts/upper_bounds.py): results INVALID while set
+        L.ttx_debug_skip(int(os.environ["TTX_DEBUG_SKIP"]))
     _lib = L
     return L
 
@@ -205,6 +210,19 @@ def _workspace(dev: torch.device, stream: int, nbytes: int) -> torch.Tensor:
         ws = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=dev)
         _ws_cache[key] = ws
     return ws
+
+
+_arrive_cache = {}
+
+
+def _arrive_zeros(dev: torch.device, stream: int, n: int) -> torch.Tensor:
+    """the arrival counters of fused pooling: zero before and after every call, so one array per (device, stream)"""
+    key = (dev.index, stream)
+    t = _arrive_cache.get(key)
+    if t is None or t.numel() < n:
+        t = torch.zeros(max(n, 1 << 16), dtype=torch.int32, device=dev)
+        _arrive_cache[key] = t
+    return t
 
 
 def _ptr_array(tensors: Sequence[torch.Tensor]):
@@ -331,7 +349,8 @@ def _plan_ptr(plan: Optional[Plan], nnz: int):
 
 def tt_forward(batch_count: int, num_tables: int, B: int, D: int, tt_p_shapes: List[int], tt_q_shapes: List[int],
                tt_ranks: List[int], L: torch.Tensor, nnz: int, indices: torch.Tensor, rowidx: torch.Tensor,
-               tableidx: torch.Tensor, tt_cores: List[torch.Tensor], plan: Optional[Plan] = None) -> torch.Tensor:
+               tableidx: torch.Tensor, tt_cores: List[torch.Tensor], plan: Optional[Plan] = None,
+               offsets: Optional[torch.Tensor] = None, per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
     """tt_embeddings.cpp:13-26.  `batch_count` (the reference's GEMM chunk size)
     is accepted and ignored: the HIP path has no chunk loop.  `L` is validated
     for length only; strides are derived from tt_p_shapes."""
@@ -357,6 +376,18 @@ def tt_forward(batch_count: int, num_tables: int, B: int, D: int, tt_p_shapes: L
         return out
     nb = lb.ttx_tt_forward_workspace_bytes(C.byref(g), B, D, nnz)
     ws = _workspace(dev, st, nb)
+    if offsets is not None or per_sample_weights is not None:
+        # beyond the reference's signature: the bags' offsets (the ones rowidx / tableidx were derived from) let the
+        # contraction kernel pool the bags itself (include/ttx.h ttx_tt_forward_o) -- same output bit for bit
+        na = lb.ttx_tt_forward_arrive_ints(C.byref(g), nnz) if (offsets is not None and nnz > 0) else 0
+        arrive = _arrive_zeros(dev, st, na) if na > 0 else None
+        psw = None if per_sample_weights is None else _f32(per_sample_weights, "per_sample_weights")
+        with _guard(dev):
+            _check(lb.ttx_tt_forward_o(C.byref(g), B, D, nnz, indices.data_ptr(), rowidx.data_ptr(), tableidx.data_ptr(),
+                                       None if psw is None else psw.data_ptr(), _ptr_array(cores), out.data_ptr(), None,
+                                       _i64(offsets, "offsets").data_ptr() if na > 0 else None,
+                                       arrive.data_ptr() if na > 0 else None, _plan_ptr(plan, nnz), ws.data_ptr(), ws.numel(), st))
+        return out
     with _guard(dev):
         _check(lb.ttx_tt_forward(C.byref(g), B, D, nnz, indices.data_ptr(), rowidx.data_ptr(), tableidx.data_ptr(),
                                  _ptr_array(cores), out.data_ptr(), _plan_ptr(plan, nnz), ws.data_ptr(), ws.numel(), st))

@@ -128,6 +128,19 @@ int ttx_tt_forward_wr(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz,
                       const float* per_sample_weights, const float* const* tt_cores,
                       float* output, float* rows_keep, const void* plan, void* workspace,
                       size_t workspace_bytes, ttx_stream_t stream);
+
+/* Not in the reference: ttx_tt_forward_wr with the bag pooling done INSIDE the contraction kernel (no pooling launch:
+ * the lookup that completes a bag sums its rows in index order, same result bit for bit) where the shape and the
+ * batch allow it -- the call falls back to the separate pooling launch otherwise, so it is always valid.
+ *   offsets  [num_tables * B + 1] int64: the bags' extents in the table-major, include_last_offset form the rowidx /
+ *            tableidx arrays were derived from (tt_embeddings_ops.py:851; every lookup of bag b at [offsets[b], offsets[b+1]))
+ *   arrive   device array of ttx_tt_forward_arrive_ints() int32, ALL ZERO on entry; all zero again when the call's
+ *            kernels have run (keep one per stream, zero it once).  NULL / 0 ints: pooling stays a launch of its own. */
+int64_t ttx_tt_forward_arrive_ints(const ttx_geom* g, int64_t nnz);
+int ttx_tt_forward_o(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const int64_t* indices,
+                     const int64_t* rowidx, const int64_t* tableidx, const float* per_sample_weights,
+                     const float* const* tt_cores, float* output, float* rows_keep, const int64_t* offsets,
+                     int32_t* arrive, const void* plan, void* workspace, size_t workspace_bytes, ttx_stream_t stream);
 int ttx_psw_backward(int32_t B, int32_t D, int64_t nnz, const float* rows, const int64_t* rowidx,
                      const int64_t* tableidx, const float* d_output, float* d_psw, ttx_stream_t stream);
 

@@ -436,3 +436,52 @@ def test_errors():
         E.tt_forward(1000, 1, 2, 60, p, q, r, Lt, 4, i.cpu(), i, i, [x.cpu() for x in cores])
     with pytest.raises(RuntimeError):  # int32 indices
         E.tt_forward(1000, 1, 2, 60, p, q, r, Lt, 4, i.int(), i, i, cores)
+
+
+@pytest.mark.parametrize("ranks,q", [([32, 32], [4, 4, 4]), ([16, 16], [4, 4, 4]), ([64, 64], [4, 4, 8]), ([32, 32], [2, 4, 4]),
+                                      ([32, 32], [4, 8, 8]), ([16, 16], [2, 2, 4]), ([16, 16], [4, 4, 8]), ([13, 12], [3, 4, 5])])
+def test_pooling_fused_into_the_forward_kernel_is_bit_identical(ranks, q):
+    """ttx_tt_forward_o: given the bags' offsets the contraction kernel pools the bags itself -- the lookup that completes
+    a bag sums its rows in index order, the order of reduce_output_kernel (tt_embeddings_cuda.cu:920-962) -- instead of a
+    pooling launch of its own.  Output identical BIT FOR BIT to the unfused path: ragged and empty bags, several tables,
+    one long bag next to many short ones (the work-groups finish at very different times), per_sample_weights, and again
+    on the same counters (they must be left zeroed).  Shapes without a fused variant take the launch and agree trivially."""
+    import tt_embeddings as E
+
+    p = [6, 5, 7]
+    r = [1] + ranks + [1]
+    E_, D = int(np.prod(p)), int(np.prod(q))
+    Lt = torch.zeros(3, dtype=torch.int64, device=dev())
+    e0 = torch.empty(0, dtype=torch.int64, device=dev())
+    e1 = torch.empty(0, dtype=torch.int32, device=dev())
+    rs = np.random.RandomState(5)
+    cases = []
+    for tables, B, pf, std in ((1, 90, 3, 2), (3, 40, 5, 4), (1, 7, 1, 0), (2, 300, 20, 0)):
+        cases.append((tables, B) + G.make_bags(41 + B, B, E_, pf, std, tables))
+    # one bag of 3000 lookups among 200 short ones; half of the bags empty
+    lens = np.where(rs.rand(201) < 0.5, 0, rs.randint(1, 6, size=201))
+    lens[77] = 3000
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cases.append((1, 201, rs.randint(0, E_, size=int(off[-1])).astype(np.int64), off))
+    for tables, B, idx, off in cases:
+        cores = [t(x) for x in G.make_cores(42 + B, tables, p, q, r, "signed")]
+        ti, to = t(idx), t(off)
+        _, rowidx, tableidx, _, _ = E.preprocess_indices_sync(ti, to, tables, True, e0, e1)
+        nnz = ti.numel()
+        plan = E.make_plan(tables, p, q, r, nnz, ti, tableidx, rowidx)
+        ref = E.tt_forward(1000, tables, B, D, p, q, r, Lt, nnz, ti, rowidx, tableidx, cores, plan=plan)
+        for rep in range(3):
+            got = E.tt_forward(1000, tables, B, D, p, q, r, Lt, nnz, ti, rowidx, tableidx, cores, plan=plan if rep else None, offsets=to)
+            assert torch.equal(got, ref), f"fused pooling differs (tables={tables} B={B} rep={rep})"
+        w = t(rs.rand(nnz).astype(np.float32))
+        ref_w = E.tt_forward(1000, tables, B, D, p, q, r, Lt, nnz, ti, rowidx, tableidx, cores, plan=plan, per_sample_weights=w)
+        got_w = E.tt_forward(1000, tables, B, D, p, q, r, Lt, nnz, ti, rowidx, tableidx, cores, plan=plan, offsets=to, per_sample_weights=w)
+        assert torch.equal(got_w, ref_w), "weighted fused pooling differs"
+        arr = E._arrive_cache[(0, E._stream(dev()))]
+        assert int(arr.abs().sum()) == 0, "arrival counters were not left zeroed"
+    c = dict(tables=1, T=3, p=p, q=q, r=r, B=cases[0][1], D=D, indices=cases[0][2], offsets=cases[0][3],
+             cores=G.make_cores(42 + cases[0][1], 1, p, q, r, "signed"), d_out=G.make_grad(43, 1, cases[0][1], D))
+    got = E.tt_forward(1000, 1, c["B"], D, p, q, r, Lt, c["indices"].size, t(c["indices"]),
+                       *E.preprocess_indices_sync(t(c["indices"]), t(c["offsets"]), 1, True, e0, e1)[1:3], [t(x) for x in c["cores"]],
+                       offsets=t(c["offsets"]))
+    assert_close(got.cpu().numpy(), oracle_case(c, "fwd")["out"], "fused pooling vs oracle")
