@@ -746,7 +746,7 @@ __global__ __launch_bounds__(1024) void max_key_kernel(int N, const int64_t* __r
 // mark_popular_colidx_kernel cu:1115-1139
 __global__ __launch_bounds__(kCT) void mark_popular_kernel(int32_t H, int64_t cache_size,
                                                           int64_t* sorted_keys, int64_t* hashtbl,
-                                                          int64_t* cache_freq, int32_t* cache_state) {
+                                                          int64_t* cache_freq, int32_t* cache_state, int keep_state) {
   const int64_t n = (int64_t)blockIdx.x * kCT + threadIdx.x;
   if (n >= H) return;
   const int64_t key = sorted_keys[n];
@@ -761,7 +761,8 @@ __global__ __launch_bounds__(kCT) void mark_popular_kernel(int32_t H, int64_t ca
       // Deliberate fix (the reference leaves cache_state[slot] as it was): after a SECOND populate an evicted slot
       // would keep its old cache row number, and the next key inserted into that slot would be served -- and would
       // update -- another index's cached row.  Identical to the reference on a first populate (state is all -1).
-      cache_state[slot] = -1;
+      // keep_state: ttx_set_reference_exact(1) -- the reference's behaviour, bit for bit, on demand.
+      if (!keep_state) cache_state[slot] = -1;
     }
   } else if (n < cache_size) {
     sorted_keys[n] = 0;  // "a hack to use batch gemm"
@@ -981,6 +982,15 @@ int ttx_lookup_prologue_cached_multi(const ttx_geom* g, int32_t nbatch, int64_t 
 }
 
 // (A/B knob of scripts/bench_cache.py: 1 = the 32-lane-group kernel for every D)
+// ttx_set_reference_exact: bit 0 = cache_populate leaves the cache_state of an evicted slot as it was, like the reference's
+// mark_popular_colidx_kernel (tt_embeddings_cuda.cu:1131-1133) -- the deliberate fix switched off.
+static int g_reference_exact = 0;
+int ttx_set_reference_exact(int32_t flags) {
+  if (flags < 0 || flags > 1) TTX_FAIL(TTX_EINVAL, "unknown reference-exact flags %d", flags);
+  g_reference_exact = flags;
+  return TTX_OK;
+}
+
 static int g_cache_fwd_lookup_groups = 0;
 int ttx_debug_cache_fwd(int32_t lookup_groups) { g_cache_fwd_lookup_groups = lookup_groups; return TTX_OK; }
 
@@ -1100,6 +1110,77 @@ int ttx_cache_backward_rowwise_adagrad_approx_n(int64_t nnz, const int32_t* skip
   return TTX_OK;
 }
 
+// The 64-bit stable DESCENDING radix sort of (frequency, key) pairs behind cache_populate -- what the reference asks of
+// cub::DeviceRadixSort::SortPairsDescending(cache_freq, hashtbl, bits [0, 64)) (tt_embeddings_cuda.cu:1280-1308): LSD, 8 bits
+// per pass, as many passes as the largest frequency has bytes (one 8-byte read-back sizes it; a pass over all-zero digits
+// would leave the order unchanged).  ws: 4 x align_up(8 H) + counts + 2 KB.  -> pointers to the sorted copies inside ws.
+static int sort_pairs_desc(int64_t H, const int64_t* keys_in, const int64_t* vals_in, char* ws, int64_t** keys_sorted,
+                           int64_t** vals_sorted, hipStream_t st) {
+  int WT, U;
+  unit_shape(H, &WT, &U);
+  const size_t hb = align_up((size_t)H * 8);
+  int64_t* kA = (int64_t*)ws;
+  int64_t* kB = (int64_t*)(ws + hb);
+  int64_t* vA = (int64_t*)(ws + 2 * hb);
+  int64_t* vB = (int64_t*)(ws + 3 * hb);
+  int* cnt = (int*)(ws + 4 * hb);
+  unsigned long long* dmax = (unsigned long long*)((char*)cnt + align_up((size_t)256 * U * 4));
+  int* tot = (int*)(dmax + 32);  // 256 digit totals (the 2 KB behind the counts: dmax, then tot)
+  const int N = (int)H;
+  // size the sort: highest set bit of the largest frequency (8-byte read-back)
+  TTX_HIP(hipMemsetAsync(dmax, 0, 8, st));
+  hipLaunchKernelGGL(max_key_kernel, dim3((unsigned)((H + 1023) / 1024 < 256 ? (H + 1023) / 1024 : 256)), dim3(1024), 0, st, N,
+                     keys_in, dmax);
+  unsigned long long hmax = 0;
+  TTX_HIP(hipMemcpyAsync(&hmax, dmax, 8, hipMemcpyDeviceToHost, st));
+  TTX_HIP(hipStreamSynchronize(st));
+  int bits = 0;
+  while (bits < 64 && (hmax >> bits)) ++bits;
+  const int passes = bits == 0 ? 1 : (bits + 7) / 8;  // >= 1: also produces the sorted copy
+  const unsigned blocks = (unsigned)((U + kCT / kWave - 1) / (kCT / kWave));
+  const int64_t* ik = keys_in;
+  const int64_t* iv = vals_in;
+  int64_t* ok = kA;
+  int64_t* ov = vA;
+  for (int ps = 0; ps < passes; ++ps) {
+    hipLaunchKernelGGL(radix_count_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, U, ps * 8, ik, cnt);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(1024), 0, st, U, cnt, tot);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, U, ps * 8, ik, iv, cnt, tot,
+                       ok, ov);
+    ik = ok;
+    iv = ov;
+    ok = (ok == kA) ? kB : kA;
+    ov = (ov == vA) ? vB : vA;
+  }
+  TTX_HIP(hipGetLastError());
+  if (keys_sorted) *keys_sorted = (int64_t*)ik;
+  if (vals_sorted) *vals_sorted = (int64_t*)iv;
+  return TTX_OK;
+}
+
+// test hook: that sort on its own (tests/test_primref_gpu.py checks it against hipCUB's SortPairsDescending, the
+// library call the reference makes).  keys / vals are copied to keys_out / vals_out.
+size_t ttx_debug_sort_workspace_bytes(int64_t n) {
+  if (n <= 0) return 0;
+  int WT, U;
+  unit_shape(n, &WT, &U);
+  return 4 * align_up((size_t)n * 8) + align_up((size_t)256 * U * 4) + 2048 + 256;
+}
+
+int ttx_debug_sort_pairs_desc(int64_t n, const int64_t* keys, const int64_t* vals, int64_t* keys_out, int64_t* vals_out,
+                              void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
+  (void)hipGetLastError();
+  if (n <= 0 || n >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "n=%lld out of range", (long long)n);
+  if (!keys || !vals || !keys_out || !vals_out) TTX_FAIL(TTX_EINVAL, "NULL input");
+  if (!workspace || workspace_bytes < ttx_debug_sort_workspace_bytes(n)) TTX_FAIL(TTX_EWORKSPACE, "sort workspace too small");
+  int64_t *sk = nullptr, *sv = nullptr;
+  const int rc = sort_pairs_desc(n, keys, vals, (char*)workspace, &sk, &sv, (hipStream_t)stream);
+  if (rc) return rc;
+  TTX_HIP(hipMemcpyAsync(keys_out, sk, (size_t)n * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  TTX_HIP(hipMemcpyAsync(vals_out, sv, (size_t)n * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return TTX_OK;
+}
+
 size_t ttx_cache_populate_workspace_bytes(const ttx_geom* g, int64_t H, int64_t cache_size, int32_t D) {
   (void)D;
   Dims d;
@@ -1124,48 +1205,15 @@ int ttx_cache_populate(const ttx_geom* g, const float* const* tt_cores, int64_t 
   if (!hashtbl || !cache_freq || !cache_state || !tt_cores) TTX_FAIL(TTX_EINVAL, "NULL input");
   if (!workspace || workspace_bytes < ttx_cache_populate_workspace_bytes(g, H, cache_size, D))
     TTX_FAIL(TTX_EWORKSPACE, "cache_populate workspace too small");
+  char* ws = (char*)workspace;
+  int64_t* sorted_keys = nullptr;
+  rc = sort_pairs_desc(H, cache_freq, hashtbl, ws, nullptr, &sorted_keys, st);
+  if (rc) return rc;
   int WT, U;
   unit_shape(H, &WT, &U);
-  char* ws = (char*)workspace;
-  const size_t hb = align_up((size_t)H * 8);
-  int64_t* kA = (int64_t*)ws;
-  int64_t* kB = (int64_t*)(ws + hb);
-  int64_t* vA = (int64_t*)(ws + 2 * hb);
-  int64_t* vB = (int64_t*)(ws + 3 * hb);
-  int* cnt = (int*)(ws + 4 * hb);
-  unsigned long long* dmax = (unsigned long long*)((char*)cnt + align_up((size_t)256 * U * 4));
-  int* tot = (int*)(dmax + 32);  // 256 digit totals (the 2 KB behind the counts: dmax, then tot)
-  char* rows_ws = ws + 4 * hb + align_up((size_t)256 * U * 4) + 2048;
-  const int N = (int)H;
-  // size the sort: highest set bit of the largest frequency (8-byte read-back)
-  TTX_HIP(hipMemsetAsync(dmax, 0, 8, st));
-  hipLaunchKernelGGL(max_key_kernel, dim3((unsigned)((H + 1023) / 1024 < 256 ? (H + 1023) / 1024 : 256)), dim3(1024), 0, st, N,
-                     cache_freq, dmax);
-  unsigned long long hmax = 0;
-  TTX_HIP(hipMemcpyAsync(&hmax, dmax, 8, hipMemcpyDeviceToHost, st));
-  TTX_HIP(hipStreamSynchronize(st));
-  int bits = 0;
-  while (bits < 64 && (hmax >> bits)) ++bits;
-  const int passes = bits == 0 ? 1 : (bits + 7) / 8;  // >= 1: also produces the sorted copy
-  const unsigned blocks = (unsigned)((U + kCT / kWave - 1) / (kCT / kWave));
-  const int64_t* ik = cache_freq;
-  const int64_t* iv = hashtbl;
-  int64_t* ok = kA;
-  int64_t* ov = vA;
-  for (int ps = 0; ps < passes; ++ps) {
-    hipLaunchKernelGGL(radix_count_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, U, ps * 8, ik, cnt);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(1024), 0, st, U, cnt, tot);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, U, ps * 8, ik, iv, cnt, tot,
-                       ok, ov);
-    ik = ok;
-    iv = ov;
-    ok = (ok == kA) ? kB : kA;
-    ov = (ov == vA) ? vB : vA;
-  }
-  TTX_HIP(hipGetLastError());
-  int64_t* sorted_keys = (int64_t*)iv;
+  char* rows_ws = ws + 4 * align_up((size_t)H * 8) + align_up((size_t)256 * U * 4) + 2048;
   hipLaunchKernelGGL(mark_popular_kernel, dim3((unsigned)((H + kCT - 1) / kCT)), dim3(kCT), 0, st, (int32_t)H,
-                     cache_size, sorted_keys, hashtbl, cache_freq, cache_state);
+                     cache_size, sorted_keys, hashtbl, cache_freq, cache_state, g_reference_exact & 1);
   TTX_HIP(hipGetLastError());
   if (cache_size == 0) return TTX_OK;
   if (!cache_weight) TTX_FAIL(TTX_EINVAL, "cache_weight is NULL");

@@ -642,6 +642,29 @@ def profile_read(which: int) -> Tuple[int, float]:
     return int(n.value), float(ms.value)
 
 
+def set_reference_exact(flags: int) -> None:
+    """bit 0: cache_populate leaves the cache_state of evicted slots untouched, like the reference (include/ttx.h)"""
+    _check(lib().ttx_set_reference_exact(int(flags)))
+
+
+def debug_sort_pairs_desc(keys: torch.Tensor, vals: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """test hook: cache_populate's stable descending 64-bit radix sort of (key, value) pairs on its own"""
+    keys, vals = _i64(keys, "keys"), _i64(vals, "vals")
+    dev = _dev(keys)
+    n = keys.numel()
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    lb = lib()
+    lb.ttx_debug_sort_workspace_bytes.restype = C.c_size_t
+    lb.ttx_debug_sort_workspace_bytes.argtypes = [C.c_int64]
+    lb.ttx_debug_sort_pairs_desc.argtypes = [C.c_int64] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]
+    nb = lb.ttx_debug_sort_workspace_bytes(n)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    with _guard(dev):
+        _check(lb.ttx_debug_sort_pairs_desc(n, keys.data_ptr(), vals.data_ptr(), ko.data_ptr(), vo.data_ptr(), ws.data_ptr(), nb,
+                                            _stream(dev)))
+    return ko, vo
+
+
 def set_chunk(mc: int) -> None:
     _check(lib().ttx_set_chunk(mc))
 

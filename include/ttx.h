@@ -440,6 +440,17 @@ int ttx_profile_mask(int mask);
 int ttx_profile_reset(void);
 int ttx_profile_read(int which, int64_t* launches, double* total_ms);
 
+/* Behaviour switch.  flags bit 0: ttx_cache_populate leaves cache_state[slot] of an EVICTED slot untouched, exactly as the
+ * reference's mark_popular_colidx_kernel does (tt_embeddings_cuda.cu:1131-1133).  Default 0: the slot's cache row is
+ * dropped (cache_state = -1) -- otherwise, after a second populate, the next key inserted into that slot is served, and
+ * trains, another index's cached row.  Identical on a first populate.  Process-wide. */
+int ttx_set_reference_exact(int32_t flags);
+/* test hooks: the stable descending 64-bit radix sort of (key, value) pairs behind ttx_cache_populate, on its own
+ * (what the reference asks of cub::DeviceRadixSort::SortPairsDescending, tt_embeddings_cuda.cu:1280-1308) */
+size_t ttx_debug_sort_workspace_bytes(int64_t n);
+int ttx_debug_sort_pairs_desc(int64_t n, const int64_t* keys, const int64_t* vals, int64_t* keys_out, int64_t* vals_out,
+                              void* workspace, size_t workspace_bytes, ttx_stream_t stream);
+
 /* tuning knob (bench / tests): indices per work-group chunk; 0 = heuristic */
 int ttx_set_chunk(int32_t indices_per_chunk);
 /* test knob: LDS budget in bytes (<= 163840; 0 = that) of the generic kernels' tile search.  The generic contraction

@@ -418,6 +418,10 @@ static int cmp_desc(const void* a, const void* b) {
  * Slots are visited in sorted order 0..H-1; a key that can no longer be found
  * (only possible after a second populate) is skipped where
  * the reference would write out of bounds. */
+/* 1: leave the cache_state of an evicted slot as the reference does (cu:1131-1133); pairs with ttx_set_reference_exact */
+int ttxo_reference_exact = 0;
+void ttxo_set_reference_exact(int v) { ttxo_reference_exact = v; }
+
 int ttxo_cache_populate(const ttx_geom* g, const float* const* cores, int64_t H,
                         int64_t* hashtbl, int64_t* cache_freq, int32_t* cache_state,
                         int64_t cache_size, int32_t D, float* cache_weight) {
@@ -438,7 +442,7 @@ int ttxo_cache_populate(const ttx_geom* g, const float* const* cores, int64_t H,
         /* NOT in the reference (cu:1131-1133 leaves cache_state[slot] stale): deliberate fix shared with the
          * product, see DESIGN.md section 5 "Deviations"; no effect on a first populate.  The -m gpu test
          * test_second_populate_differs_from_reference_only_on_evicted_slots pins the difference. */
-        cache_state[slot] = -1;
+        if (!ttxo_reference_exact) cache_state[slot] = -1;
       }
     } else if (n < cache_size) {
       sorted[n] = 0; /* "a hack to use batch gemm", cu:1135-1138 */

@@ -200,6 +200,11 @@ def preprocess_indices(colidx, offsets, num_tables, warmup, hashtbl, cache_state
     return colidx, rowidx, tableidx, num_tt.value, None
 
 
+def set_reference_exact(flag):
+    """1: the oracle's cache_populate leaves the cache_state of evicted slots as the reference does (cu:1131-1133)"""
+    lib().ttxo_set_reference_exact(C.c_int(int(flag)))
+
+
 def cache_populate(geom, cores, hashtbl, cache_freq, cache_state, cache_weight):
     cores = [_f32(c) for c in cores]
     assert cache_weight.dtype == np.float32 and cache_state.dtype == np.int32

@@ -305,3 +305,16 @@ def test_second_populate_differs_from_reference_only_on_evicted_slots():
     ok, of, ost = keys1.copy(), freq1.copy(), state1.copy()
     O.cache_populate(O.make_geom(1, p, q, r), [c.cpu().numpy() for c in cores], ok, of, ost, np.zeros((cs, 64), dtype=np.float32))
     assert np.array_equal(ost, got) and np.array_equal(ok, pk.cpu().numpy())
+    # ... and with the fix switched off (ttx_set_reference_exact) product, reference kernel and oracle agree on EVERY slot
+    E.set_reference_exact(1)
+    O.set_reference_exact(1)
+    try:
+        xk, xf, xstate = t(keys1), t(freq1), t(state1)
+        E.cache_populate(E_, p, q, r, cores, Lt, xk, xf, xstate, dw)
+        assert torch.equal(xk, rk) and torch.equal(xf, rf) and torch.equal(xstate, rstate), "reference-exact second populate"
+        ok, of, ost = keys1.copy(), freq1.copy(), state1.copy()
+        O.cache_populate(O.make_geom(1, p, q, r), [c.cpu().numpy() for c in cores], ok, of, ost, np.zeros((cs, 64), dtype=np.float32))
+        assert np.array_equal(ost, ref) and np.array_equal(ok, rk.cpu().numpy()) and np.array_equal(of, rf.cpu().numpy())
+    finally:
+        E.set_reference_exact(0)
+        O.set_reference_exact(0)
