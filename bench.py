@@ -74,6 +74,9 @@ WORKLOADS = {
     "d256": dict(q=[4, 8, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d32q4": dict(q=[4, 2, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d128r32": dict(q=[4, 4, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    # generic kernels: ranks beyond the LDS (core 1 walked in K blocks x column passes), and the reference tests' odd ranks
+    "r128": dict(q=[4, 4, 4], ranks=[128, 128], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    "r13": dict(q=[4, 4, 4], ranks=[13, 12], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "tb16": dict(q=[4, 4, 4], ranks=[32, 32], tables=16, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "tb8": dict(q=[4, 4, 4], ranks=[32, 32], tables=8, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "tb4": dict(q=[4, 4, 4], ranks=[32, 32], tables=4, B=512, optimizer="sgd", alpha=1.0, populate=False),
@@ -315,6 +318,16 @@ def main():
                     traffic_note = "profiles/pmc_bwd_bytes.json was measured on another build of the kernels (source hash differs): not reported"
             except Exception:  # noqa: BLE001
                 pass
+        rocprof_us, rocprof_note = None, "no rocprofv3 summary of this build under profiles/ (scripts/regen_profiles.sh)"
+        if os.path.exists(pmc) and args.workload == "cfg2" and not sharded:
+            try:
+                j = json.load(open(pmc))
+                if j.get("source_hash") == source_hash() and j.get("rocprof_avg_us"):
+                    rocprof_us, rocprof_note = float(j["rocprof_avg_us"]), j.get("rocprof_source", "")
+                elif j.get("source_hash") != source_hash():
+                    rocprof_note = "profiles/pmc_bwd_bytes.json belongs to another build of the kernels (source hash differs)"
+            except Exception:  # noqa: BLE001
+                pass
         if sharded:
             own_txt = f"; {tables_total} tables sharded t -> rank t % {world} (tables per rank {owned}), RCCL all-to-all; B_local={B_local}"
         else:
@@ -363,7 +376,15 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "spec_bwd_kernel / bwd_kernel (backward contraction)", "achieved": round(achieved, 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 5),
                          "traffic": traffic, "traffic_source": traffic_note, "launches": n_bwd, "avg_us": round(bwd_us, 2),
-                         "timed_by": bwd_src, "flop_per_launch": bwd_flop_per_launch, "kernel_build": source_hash()},
+                         "timed_by": bwd_src, "flop_per_launch": bwd_flop_per_launch, "kernel_build": source_hash(),
+                         # the same kernel's duration as rocprofv3 --kernel-trace --stats reports it for THIS build (no launch
+                         # gap inside the bracket): the figure profiles/ documents; `frac` above is the conservative one
+                         "rocprof_avg_us": rocprof_us,
+                         "frac_rocprof": (round(bwd_flop_per_launch / (rocprof_us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 5)
+                                          if rocprof_us else None),
+                         "rocprof_source": rocprof_note},
+            "kernel_us_note": ("HIP-event brackets around each launch in an eager pass: every bracket includes ~2 us of launch "
+                               "gap, so their sum exceeds the replayed step; rocprofv3 durations: profiles/"),
         }
         if a2a is not None:
             line["all_to_all"] = a2a

@@ -124,46 +124,63 @@ class VarTableTTEmbeddingBag(TableBatchedTTEmbeddingBag):
 
 
 class MixedTTEmbeddingBag(nn.Module):
-    """TT embedding bags for tables of different cardinality, same embedding dimension and TT ranks.
+    """TT embedding bags for tables of different cardinality -- and, table by table, different TT ranks and different
+    factorings q of the (common) embedding dimension.
 
-    tables with equal TT row shape (`tt_p_shapes`) share one `TableBatchedTTEmbeddingBag`;
-    `self.groups[k]` is the module of group k, `self.group_tables[k]` its table ids.
-    `fused=True`: a single group, a `VarTableTTEmbeddingBag` over all tables.
+    Tables that can share a launch set share one module: `self.groups[k]` is the module of group k,
+    `self.group_tables[k]` its table ids.
+      fused=False: a group = tables of equal (p, q, ranks), a `TableBatchedTTEmbeddingBag`;
+      fused=True : a group = tables of equal (q, ranks) whatever their row factors p, a `VarTableTTEmbeddingBag` --
+                   tables that differ in q or ranks have slices of different sizes and stay separate launch sets.
+    `streams=True` gives every group a HIP stream of its own: eagerly the step is host-bound and nothing is gained, but
+    captured into a hipGraph (ttx_graph.GraphedRound) the groups become parallel branches and their kernels -- each too
+    small to fill the chip at DLRM batch sizes -- run side by side (scripts/bench_mixed.py).
+    `tt_ranks` / `tt_q_shapes`: one list for all tables, or one list per table.
     forward(indices, offsets[, per_sample_weights]) takes one tensor per table (nn.EmbeddingBag call form,
     `include_last_offset` as given to the constructor) and returns one [B, D] tensor per table."""
 
-    def __init__(self, num_embeddings: Sequence[int], embedding_dim: int, tt_ranks: List[int],
-                 tt_p_shapes: Optional[Sequence[Optional[List[int]]]] = None, tt_q_shapes: Optional[List[int]] = None,
+    def __init__(self, num_embeddings: Sequence[int], embedding_dim: int, tt_ranks,
+                 tt_p_shapes: Optional[Sequence[Optional[List[int]]]] = None, tt_q_shapes=None,
                  optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
                  sparse: bool = True, weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
                  device: Optional[torch.device] = None, include_last_offset: bool = False,
                  streams: bool = False, fused: bool = False) -> None:
         super().__init__()
-        nd = len(tt_ranks) + 1
         self.num_embeddings = [int(e) for e in num_embeddings]
+        n = len(self.num_embeddings)
         self.embedding_dim = int(embedding_dim)
         self.include_last_offset = bool(include_last_offset)
         self._streams = None
-        if fused:  # ONE batched lookup for all tables, whatever their row factors (VarTableTTEmbeddingBag)
-            self.group_tables = [list(range(len(self.num_embeddings)))]
-            self.groups = nn.ModuleList([VarTableTTEmbeddingBag(
-                self.num_embeddings, self.embedding_dim, list(tt_ranks), tt_p_shapes, tt_q_shapes, optimizer,
-                learning_rate, eps, sparse, weight_dist, enforce_embedding_dim, device, True)])
-            return
+        per_table = lambda v: v is not None and len(v) > 0 and isinstance(v[0], (list, tuple))  # noqa: E731
+        ranks = [[int(x) for x in r] for r in tt_ranks] if per_table(tt_ranks) else [[int(x) for x in tt_ranks]] * n
+        assert len(ranks) == n, "tt_ranks: one list, or one list per table"
+        if per_table(tt_q_shapes):
+            qs = [[int(x) for x in q] for q in tt_q_shapes]
+        else:
+            qs = [None if tt_q_shapes is None else [int(x) for x in tt_q_shapes]] * n
+        assert len(qs) == n, "tt_q_shapes: one list, or one list per table"
         shapes: List[Tuple[int, ...]] = []
         for k, e in enumerate(self.num_embeddings):
+            nd = len(ranks[k]) + 1
             given = tt_p_shapes[k] if tt_p_shapes is not None else None
             shapes.append(tuple(int(x) for x in given) if given is not None else tuple(suggested_tt_shapes(e, nd)))
-        by_shape: Dict[Tuple[int, ...], List[int]] = {}
-        for k, s in enumerate(shapes):
-            by_shape.setdefault(s, []).append(k)
-        self.group_tables: List[List[int]] = list(by_shape.values())
+        groups: Dict[tuple, List[int]] = {}
+        for k in range(n):
+            key = (tuple(ranks[k]), None if qs[k] is None else tuple(qs[k])) + (() if fused else (shapes[k],))
+            groups.setdefault(key, []).append(k)
+        self.group_tables = list(groups.values())
         self.groups = nn.ModuleList()
-        for s, tables in by_shape.items():
-            self.groups.append(TableBatchedTTEmbeddingBag(
-                len(tables), max(self.num_embeddings[k] for k in tables), self.embedding_dim, list(tt_ranks), list(s),
-                tt_q_shapes, optimizer, learning_rate, eps, sparse, False, 0, 0, weight_dist, enforce_embedding_dim,
-                device, True))
+        for tables in self.group_tables:
+            k0 = tables[0]
+            if fused:  # ONE batched lookup for the group's tables, whatever their row factors (VarTableTTEmbeddingBag)
+                self.groups.append(VarTableTTEmbeddingBag(
+                    [self.num_embeddings[k] for k in tables], self.embedding_dim, list(ranks[k0]), [list(shapes[k]) for k in tables],
+                    qs[k0], optimizer, learning_rate, eps, sparse, weight_dist, enforce_embedding_dim, device, True))
+            else:
+                self.groups.append(TableBatchedTTEmbeddingBag(
+                    len(tables), max(self.num_embeddings[k] for k in tables), self.embedding_dim, list(ranks[k0]),
+                    list(shapes[k0]), qs[k0], optimizer, learning_rate, eps, sparse, False, 0, 0, weight_dist,
+                    enforce_embedding_dim, device, True))
         self._streams = [torch.cuda.Stream(device=self.groups[0].tt_cores[0].device) for _ in self.groups] \
             if streams and len(self.groups) > 1 else None
 
@@ -184,6 +201,12 @@ class MixedTTEmbeddingBag(nn.Module):
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
                     res = mod(idx, off, True, psw)  # [tables, B, D]
+                if res.grad_fn is not None:
+                    # autograd runs this group's backward (recompute + fused optimizer) on the group's stream as well, and
+                    # with a fused optimizer there is no leaf gradient whose stream the engine would join at the end: join
+                    # it here, after the node has enqueued its kernels (needed for hipGraph capture -- "unjoined work" --
+                    # and for whoever reads the cores on the caller's stream next)
+                    res.grad_fn.register_hook(lambda gi, go, s=s, cur=cur: cur.wait_stream(s))
                 for t in (idx, off) + ((psw,) if psw is not None else ()):
                     t.record_stream(s)   # allocated on the caller's stream, read on the group's
                 res.record_stream(cur)   # ... and the other way round

@@ -43,3 +43,25 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): rnd.replay()
 torch.cuda.synchronize()
 print(f"fused, hipGraph round        : {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step")
+
+# ---- f4, the rest of the row: tables that differ in TT ranks / factoring -> one launch set per (q, ranks) group.  Eagerly the
+# groups run one after the other (host-bound either way); captured into ONE hipGraph with a HIP stream per group they are
+# parallel branches.  8 tables: r = 32 (x3), r = 16 (x3), r = 64 q = [4,4,4] (x1), r = 13/12 (generic kernels, x1).
+ranks2 = [[32, 32], [16, 16], [32, 32], [16, 16], [64, 64], [32, 32], [16, 16], [13, 12]]
+def launches(fn):
+    import tt_embeddings as E
+    E.profile_reset(); E.profile_enable(0x3F); fn(); torch.cuda.synchronize(); E.profile_enable(0)
+    return sum(E.profile_read(w)[0] for w in range(6))
+for streams in (False, True):
+    m2 = ttx_mixed.MixedTTEmbeddingBag(Es, D, ranks2, ps, q, include_last_offset=False, streams=streams, fused=True, **kw)
+    def step2(idx, off):
+        torch.autograd.backward(m2(idx, off), grads)
+    ms = timeit(step2)
+    n_l = launches(lambda: step2(*reqs[0]))
+    r2 = ttx_graph.GraphedRound(step2, reqs, warmup=2)
+    for _ in range(3): r2.replay()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): r2.replay()
+    torch.cuda.synchronize()
+    print(f"mixed ranks ({len(m2.groups)} shape groups, {n_l} kernel launches per step), streams={streams!s:5}: eager {ms:.3f} ms/step, "
+          f"hipGraph round {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step")

@@ -315,6 +315,40 @@ def test_mixed_cardinality_tables(ops):
     assert int(o2[B]) == idx[0].numel() and int(o2[-1]) == i2.numel()
 
 
+def test_mixed_ranks_and_factorings(ops):
+    """SURVEY.md section 8(f4), the rest of the row: tables that differ in TT RANKS and in the factoring q of the embedding
+    dimension behind one MixedTTEmbeddingBag -- one group per (q, ranks[, p]) -- against one TTEmbeddingBag per table"""
+    import ttx_mixed
+
+    D, B = 12, 7
+    Es = [100, 700, 90, 5000]
+    ps = [[4, 5, 5], [8, 9, 10], [4, 5, 5], [20, 16, 16]]
+    ranks = [[4, 5], [3, 2], [4, 5], [3, 2]]
+    qs = [[2, 3, 2], [3, 2, 2], [2, 3, 2], [3, 2, 2]]
+    mm = ttx_mixed.MixedTTEmbeddingBag(Es, D, ranks, ps, qs, sparse=False, weight_dist="uniform", device="cpu")
+    assert mm.group_tables == [[0, 2], [1], [3]]
+    rs = np.random.RandomState(4)
+    idx, off = [], []
+    for e in Es:
+        lens = rs.randint(0, 5, size=B)
+        off.append(torch.from_numpy(np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)))
+        idx.append(torch.from_numpy(rs.randint(0, e, size=int(lens.sum())).astype(np.int64)))
+    outs = mm(idx, off)
+    sum((o * (k + 1)).sum() for k, o in enumerate(outs)).backward()
+    for g, tables in enumerate(mm.group_tables):
+        for j, k in enumerate(tables):
+            one = ops.TTEmbeddingBag(Es[k], D, ranks[k], ps[k], qs[k], sparse=False, use_cache=False, weight_dist="uniform",
+                                     device="cpu", include_last_offset=False)
+            with torch.no_grad():
+                for dst, src in zip(one.tt_cores, mm.groups[g].tt_cores):
+                    dst.copy_(src[j:j + 1])
+            ref = one(idx[k], off[k])
+            assert_close(outs[k].detach().numpy(), ref.detach().numpy(), f"table {k} forward")
+            (ref * (k + 1)).sum().backward()
+            for t in range(3):
+                assert_close(mm.groups[g].tt_cores[t].grad[j].numpy(), one.tt_cores[t].grad[0].numpy(), f"table {k} grad{t}")
+
+
 def test_geometry_struct_layout_matches_the_header(tmp_path):
     """the ctypes mirror of ttx_geom (tt_embeddings._Geom) has the size and field offsets the C compiler gives
     include/ttx.h's struct -- incl. the trailing p_tables pointer of the per-table-row-factor geometry"""

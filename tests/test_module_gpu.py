@@ -424,6 +424,58 @@ def test_mixed_cardinality_tables(node, streams):
                          f"table {k} core{c} after two SGD steps")
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_mixed_ranks_one_graph(node, fused):
+    """f4: tables of different TT ranks AND factorings behind one MixedTTEmbeddingBag -- specialised (r = 32, 16) and generic
+    (r = 13 / 12, q = [2, 4, 8]) launch sets, one per shape group, each on a HIP stream of its own and captured into ONE
+    hipGraph as parallel branches.  The replayed round leaves every table's cores where one TTEmbeddingBag per table, stepped
+    eagerly, leaves them; the eager forward agrees too."""
+    import tt_embeddings_ops as ops
+    import ttx_graph
+    import ttx_mixed
+
+    if node == "python":
+        pytest.skip("graph capture of the module needs the C++ node")
+    D, B, Lp = 64, 64, 6
+    Es = [9000, 60000, 8000, 900000, 50000, 64000]
+    ps = [[20, 22, 25], [40, 40, 40], [20, 22, 25], [100, 100, 100], [40, 40, 40], [40, 40, 40]]
+    ranks = [[32, 32], [16, 16], [32, 32], [13, 12], [16, 16], [16, 16]]
+    qs = [[4, 4, 4], [4, 4, 4], [4, 4, 4], [4, 4, 4], [4, 4, 4], [2, 4, 8]]
+    kw = dict(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, weight_dist="uniform", device=DEV)
+    mm = ttx_mixed.MixedTTEmbeddingBag(Es, D, ranks, ps, qs, include_last_offset=False, streams=True, fused=fused, **kw)
+    assert len(mm.groups) == 4 and sorted(sum(mm.group_tables, [])) == list(range(6))
+    ones = []
+    for k in range(len(Es)):
+        g = next(i for i, tb in enumerate(mm.group_tables) if k in tb)
+        j = mm.group_tables[g].index(k)
+        one = ops.TTEmbeddingBag(Es[k], D, ranks[k], ps[k], qs[k], use_cache=False, include_last_offset=False, **kw)
+        rows = [mm.groups[g].table_rows(c)[j] for c in range(3)] if fused else [mm.groups[g].tt_cores[c][j] for c in range(3)]
+        with torch.no_grad():
+            for dst, src in zip(one.tt_cores, rows):
+                dst.copy_(src.reshape(dst.shape))
+        ones.append((one, g, j))
+    rs = np.random.RandomState(12)
+    grads = [t((rs.rand(B, D) * 0.1).astype(np.float32)) for _ in Es]
+    reqs = []
+    for _ in range(3):
+        reqs.append(([t(rs.randint(0, e, size=B * Lp).astype(np.int64)) for e in Es],
+                     [t(np.arange(0, B * Lp, Lp, dtype=np.int64)) for _ in Es]))
+    outs = mm(*reqs[0])
+    for k, (one, g, j) in enumerate(ones):
+        assert_close(outs[k].detach().cpu().numpy(), one(*[x[k] for x in reqs[0]]).detach().cpu().numpy(), f"table {k} forward")
+    rnd = ttx_graph.GraphedRound(lambda idx, off: torch.autograd.backward(mm(idx, off), grads), reqs, warmup=0)
+    rnd.replay()
+    for idx, off in reqs:
+        for k, (one, g, j) in enumerate(ones):
+            one(idx[k], off[k]).backward(grads[k])
+    torch.cuda.synchronize()
+    for k, (one, g, j) in enumerate(ones):
+        for c in range(3):
+            got = mm.groups[g].table_rows(c)[j] if fused else mm.groups[g].tt_cores[c][j].detach()
+            assert_close(got.cpu().numpy().reshape(one.tt_cores[c].shape), one.tt_cores[c].detach().cpu().numpy(),
+                         f"table {k} core{c} after the captured round")
+
+
 def test_graphed_round_equals_eager_steps(node):
     """ttx_graph.GraphedRound: replaying a captured round of fused-SGD steps leaves the cores exactly where the
     same steps run eagerly leave them (the kernels are deterministic, so bit-identical)"""
