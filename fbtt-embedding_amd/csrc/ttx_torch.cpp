@@ -123,28 +123,37 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
     auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
 
     Tensor out = at::empty({num_tables, B, D}, cores[0].options());
-    Tensor rowidx, tableidx, plan;
+    // bag rows, table ids and the lookup plan of this batch: the planned-ahead tensors, or ONE buffer
+    // [rowidx | tableidx | plan] (the eager step is host-bound: every allocation saved is a microsecond)
+    Tensor rowidx_t, tableidx_t, plan_t, buf;
+    int64_t *rowidx_p = nullptr, *tableidx_p = nullptr;
+    void* plan_p = nullptr;
     if (pre) {
       TORCH_CHECK(pre_rowidx.has_value() && pre_tableidx.has_value() && pre_rowidx->numel() == nnz &&
                       pre_tableidx->numel() == nnz && (size_t)pre_plan->numel() >= ttx_plan_bytes(&g, nnz),
                   "tt_embeddings: the prefetched prologue does not belong to this batch");
-      rowidx = *pre_rowidx;
-      tableidx = *pre_tableidx;
-      plan = *pre_plan;
+      rowidx_t = *pre_rowidx;
+      tableidx_t = *pre_tableidx;
+      plan_t = *pre_plan;
+      rowidx_p = rowidx_t.data_ptr<int64_t>();
+      tableidx_p = tableidx_t.data_ptr<int64_t>();
+      plan_p = plan_t.data_ptr();
     } else {
-      rowidx = at::empty_like(indices);
-      tableidx = at::empty_like(indices);
-    }
-    if (nnz > 0 && !pre) {
-      const size_t pb = ttx_plan_bytes(&g, nnz);
-      plan = bytes_on(indices, pb);
-      const bool upd = hashtbl.has_value() && hashtbl->defined() && hashtbl->numel() > 0 && cache_freq.has_value() &&
-                       cache_freq->defined();
-      if (upd) TORCH_CHECK(hashtbl->numel() == cache_freq->numel(), "tt_embeddings: hashtbl must match cache_freq");
-      check(ttx_lookup_prologue(&g, nnz, indices.data_ptr<int64_t>(), nb, offsets.data_ptr<int64_t>(),
-                                upd ? hashtbl->numel() : 0, upd ? hashtbl->data_ptr<int64_t>() : nullptr,
-                                upd ? cache_freq->data_ptr<int64_t>() : nullptr, rowidx.data_ptr<int64_t>(),
-                                tableidx.data_ptr<int64_t>(), plan.data_ptr(), pb, stream));
+      const size_t pb = nnz > 0 ? ttx_plan_bytes(&g, nnz) : 0;
+      const size_t ib = ((size_t)nnz * 8 + 255) / 256 * 256;
+      buf = bytes_on(indices, 2 * ib + pb);
+      char* base = (char*)buf.data_ptr();
+      rowidx_p = (int64_t*)base;
+      tableidx_p = (int64_t*)(base + ib);
+      plan_p = nnz > 0 ? (void*)(base + 2 * ib) : nullptr;
+      if (nnz > 0) {
+        const bool upd = hashtbl.has_value() && hashtbl->defined() && hashtbl->numel() > 0 && cache_freq.has_value() &&
+                         cache_freq->defined();
+        if (upd) TORCH_CHECK(hashtbl->numel() == cache_freq->numel(), "tt_embeddings: hashtbl must match cache_freq");
+        check(ttx_lookup_prologue(&g, nnz, indices.data_ptr<int64_t>(), nb, offsets.data_ptr<int64_t>(),
+                                  upd ? hashtbl->numel() : 0, upd ? hashtbl->data_ptr<int64_t>() : nullptr,
+                                  upd ? cache_freq->data_ptr<int64_t>() : nullptr, rowidx_p, tableidx_p, plan_p, pb, stream));
+      }
     }
     const float* cp[TTX_MAX_CORES] = {};
     for (int t = 0; t < g.T; ++t) cp[t] = cores[t].data_ptr<float>();
@@ -162,54 +171,76 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
     const int64_t na = (nnz > 0 && fuse_pool) ? ttx_tt_forward_arrive_ints(&g, nnz) : 0;
     Tensor arrive;
     if (na > 0) arrive = arrive_zeros(indices, na, stream);
-    check(ttx_tt_forward_o(&g, (int32_t)B, (int32_t)D, nnz, indices.data_ptr<int64_t>(), rowidx.data_ptr<int64_t>(),
-                           tableidx.data_ptr<int64_t>(), weighted ? psw->data_ptr<float>() : nullptr, cp,
+    check(ttx_tt_forward_o(&g, (int32_t)B, (int32_t)D, nnz, indices.data_ptr<int64_t>(), rowidx_p, tableidx_p,
+                           weighted ? psw->data_ptr<float>() : nullptr, cp,
                            out.data_ptr<float>(), psw_grad ? rows_keep.data_ptr<float>() : nullptr,
                            na > 0 ? offsets.data_ptr<int64_t>() : nullptr, na > 0 ? arrive.data_ptr<int32_t>() : nullptr,
-                           nnz > 0 ? plan.data_ptr() : nullptr, ws.data_ptr(), wb, stream));
+                           nnz > 0 ? plan_p : nullptr, ws.data_ptr(), wb, stream));
 
-    if (weighted) ctx->saved_data["psw"] = psw->detach();
-    if (psw_grad) ctx->saved_data["rows"] = rows_keep;
-    ctx->saved_data["p"] = p;
-    ctx->saved_data["q"] = q;
-    ctx->saved_data["r"] = r;
-    ctx->saved_data["num_tables"] = num_tables;
-    ctx->saved_data["optim"] = optim;
-    ctx->saved_data["lr"] = lr;
-    ctx->saved_data["eps"] = eps;
-    ctx->saved_data["T"] = (int64_t)g.T;
-    ctx->saved_data["nstate"] = (int64_t)state.size();
-    // integer tensors and the in-place-updated cores / state are kept out of the version-counter
-    // check on purpose (the fused optimizer mutates the cores between forward and the next backward)
-    std::vector<Tensor> keep = {indices, rowidx, tableidx};
-    if (plan.defined()) keep.push_back(plan);
-    ctx->saved_data["keep"] = keep;
-    ctx->saved_data["cores"] = std::vector<Tensor>(cores.begin(), cores.end());
-    ctx->saved_data["state"] = std::vector<Tensor>(state.begin(), state.end());
+    // What backward needs, in THREE saved entries (every saved_data entry is a string-keyed map insertion plus an IValue):
+    //   "m": {num_tables, optim, T, nstate, prefetched, weighted, psw_grad, |p|, p.., q.., r..}   "d": {lr, eps}
+    //   "t": indices, then [rowidx, tableidx, plan] (prefetched) or [buf], then cores.., state.., then psw, rows if present
+    // (integer tensors and the in-place-updated cores / state are kept out of the version-counter check on purpose: the
+    //  fused optimizer mutates the cores between forward and the next backward)
+    std::vector<int64_t> meta = {num_tables, optim, (int64_t)g.T, (int64_t)state.size(), pre ? 1 : 0, weighted ? 1 : 0,
+                                 psw_grad ? 1 : 0, (int64_t)p.size()};
+    meta.insert(meta.end(), p.begin(), p.end());
+    meta.insert(meta.end(), q.begin(), q.end());
+    meta.insert(meta.end(), r.begin(), r.end());
+    std::vector<Tensor> keep;
+    keep.reserve(6 + cores.size() + state.size());
+    keep.push_back(indices);
+    if (pre) { keep.push_back(rowidx_t); keep.push_back(tableidx_t); keep.push_back(plan_t); }
+    else keep.push_back(buf);
+    keep.insert(keep.end(), cores.begin(), cores.end());
+    keep.insert(keep.end(), state.begin(), state.end());
+    if (weighted) keep.push_back(psw->detach());
+    if (psw_grad) keep.push_back(rows_keep);
+    ctx->saved_data["m"] = std::move(meta);
+    ctx->saved_data["d"] = std::vector<double>{lr, eps};
+    ctx->saved_data["t"] = std::move(keep);
     return out;
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grad_outputs) {
-    const auto p = ctx->saved_data["p"].toIntVector();
-    const auto q = ctx->saved_data["q"].toIntVector();
-    const auto r = ctx->saved_data["r"].toIntVector();
-    const int64_t num_tables = ctx->saved_data["num_tables"].toInt();
-    const int64_t optim = ctx->saved_data["optim"].toInt();
-    const double lr = ctx->saved_data["lr"].toDouble(), eps = ctx->saved_data["eps"].toDouble();
-    const int64_t T = ctx->saved_data["T"].toInt(), nstate = ctx->saved_data["nstate"].toInt();
-    auto keep = ctx->saved_data["keep"].toTensorVector();
-    auto cores = ctx->saved_data["cores"].toTensorVector();
-    auto state = ctx->saved_data["state"].toTensorVector();
+    const auto meta = ctx->saved_data["m"].toIntVector();
+    const auto lre = ctx->saved_data["d"].toDoubleVector();
+    const auto keep = ctx->saved_data["t"].toTensorVector();
+    const int64_t num_tables = meta[0], optim = meta[1], T = meta[2], nstate = meta[3];
+    const bool pre = meta[4] != 0, weighted = meta[5] != 0, psw_grad = meta[6] != 0;
+    const int64_t np_ = meta[7];
+    const std::vector<int64_t> p(meta.begin() + 8, meta.begin() + 8 + np_);
+    const std::vector<int64_t> q(meta.begin() + 8 + np_, meta.begin() + 8 + np_ + T);
+    const std::vector<int64_t> r(meta.begin() + 8 + np_ + T, meta.begin() + 8 + np_ + 2 * T + 1);
+    const double lr = lre[0], eps = lre[1];
     Geom G;
     make_geom(G, num_tables, p, q, r);
     const ttx_geom& g = G.g;
-    const Tensor &indices = keep[0], &rowidx = keep[1], &tableidx = keep[2];
+    const Tensor& indices = keep[0];
     const int64_t nnz = indices.numel();
+    const int64_t *rowidx_p, *tableidx_p;
+    const void* plan_p;
+    size_t at = 1;
+    if (pre) {
+      rowidx_p = keep[1].data_ptr<int64_t>();
+      tableidx_p = keep[2].data_ptr<int64_t>();
+      plan_p = nnz > 0 ? keep[3].data_ptr() : nullptr;
+      at = 4;
+    } else {
+      const size_t ib = ((size_t)nnz * 8 + 255) / 256 * 256;
+      const char* base = (const char*)keep[1].data_ptr();
+      rowidx_p = (const int64_t*)base;
+      tableidx_p = (const int64_t*)(base + ib);
+      plan_p = nnz > 0 ? (const void*)(base + 2 * ib) : nullptr;
+      at = 2;
+    }
+    const Tensor* cores = &keep[at];
+    const Tensor* state = &keep[at + T];
+    const Tensor psw = weighted ? keep[at + T + nstate] : Tensor();
 
     // one slot per forward argument (lists expanded): indices, offsets, num_tables, p, q, r, optim, lr, eps,
     // hashtbl, cache_freq, per_sample_weights, pre_rowidx, pre_tableidx, pre_plan, state.., cores..
     constexpr int64_t kHead = 15;
-    const Tensor psw = ctx->saved_data.count("psw") ? ctx->saved_data["psw"].toTensor() : Tensor();
     variable_list grads(kHead + nstate + T);
     Tensor go = grad_outputs[0];
     TORCH_CHECK(go.defined(), "tt_embeddings: backward needs the output gradient");
@@ -235,17 +266,17 @@ struct TTLookupOp : public torch::autograd::Function<TTLookupOp> {
     const size_t wb = ttx_tt_backward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
     Tensor ws = bytes_on(indices, wb);
     check(ttx_tt_backward_w(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz,
-                            indices.data_ptr<int64_t>(), rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
+                            indices.data_ptr<int64_t>(), rowidx_p, tableidx_p,
                             psw.defined() ? psw.data_ptr<float>() : nullptr, go.data_ptr<float>(), cp,
                             optim == TTX_OPTIM_ADAGRAD ? sp : nullptr, optim == TTX_OPTIM_DENSE ? gp : nullptr,
-                            keep.size() > 3 ? keep[3].data_ptr() : nullptr, ws.data_ptr(), wb, stream));
+                            plan_p, ws.data_ptr(), wb, stream));
     if (optim == TTX_OPTIM_DENSE)
       for (int t = 0; t < T; ++t) grads[kHead + nstate + t] = dense[t];
-    if (ctx->saved_data.count("rows")) {  // gradient of the per_sample_weights (argument slot 11)
-      const Tensor rows = ctx->saved_data["rows"].toTensor();
+    if (psw_grad) {  // gradient of the per_sample_weights (argument slot 11)
+      const Tensor& rows = keep[at + T + nstate + 1];
       Tensor d_psw = at::empty({nnz}, rows.options());
-      check(ttx_psw_backward((int32_t)B, (int32_t)D, nnz, rows.data_ptr<float>(), rowidx.data_ptr<int64_t>(),
-                             tableidx.data_ptr<int64_t>(), go.data_ptr<float>(), d_psw.data_ptr<float>(), stream));
+      check(ttx_psw_backward((int32_t)B, (int32_t)D, nnz, rows.data_ptr<float>(), rowidx_p, tableidx_p, go.data_ptr<float>(),
+                             d_psw.data_ptr<float>(), stream));
       grads[11] = d_psw;
     }
     return grads;

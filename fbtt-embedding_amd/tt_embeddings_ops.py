@@ -548,6 +548,11 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                                      batches[k][0]._version, batches[k][1]._version, live)
         return True
 
+    def _apply(self, fn, *a, **kw):
+        """module.to() / .cuda() / .float(): buffers are replaced by new tensors -- forget the cached argument lists"""
+        self.__dict__.pop("_fa", None)
+        return super()._apply(fn, *a, **kw)
+
     def _evict_oldest_prefetched(self) -> None:
         """drop the oldest planned-ahead batch; its frequency update has been issued, so should the batch come after
         all, its in-line prologue must not count it again (forward looks it up in _pf_evicted)"""
@@ -573,7 +578,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         """copy.deepcopy / torch.save of the module: the prefetch side stream and the planned-ahead batches (device
         buffers, HIP events) belong to this process and this point in time -- they are recreated at first use."""
         state = self.__dict__.copy()
-        for k in ("_pf_stream", "_prefetched", "_pf_key", "_pf_counted", "_pf_evicted"):
+        for k in ("_pf_stream", "_prefetched", "_pf_key", "_pf_counted", "_pf_evicted", "_fa"):
             state.pop(k, None)
         return state
 
@@ -668,11 +673,16 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             optim = 2 if not self.sparse else (1 if use_state else 0)
             pre = self._take_prefetched(indices, offsets)  # (rowidx, tableidx, plan) if prefetch() ran for this batch
             count = self.use_cache and not self._pf_counted
-            return fast.lookup(indices.contiguous(), offsets.contiguous(), self.num_tables,
-                               getattr(self, "_p_flat", self.tt_p_shapes),  # (per-table factors: flattened)
+            fa = self.__dict__.get("_fa")  # (cores, state, hashtbl, cache_freq, p): looked up once, not per step -- every
+            if fa is None:                 #  nn.Module attribute / ParameterList access is microseconds of a host-bound step
+                fa = self._fa = (list(self.tt_cores), list(self.optimizer_state), self.hashtbl if self.use_cache else None,
+                                 self.cache_freq if self.use_cache else None,
+                                 getattr(self, "_p_flat", self.tt_p_shapes))  # (per-table factors: flattened)
+            return fast.lookup(indices if indices.is_contiguous() else indices.contiguous(),
+                               offsets if offsets.is_contiguous() else offsets.contiguous(), self.num_tables, fa[4],
                                self.tt_q_shapes, self.tt_ranks, optim, self.learning_rate, self.eps,
-                               self.hashtbl if count else None, self.cache_freq if count else None,
-                               list(self.optimizer_state) if use_state else [], list(self.tt_cores), per_sample_weights,
+                               fa[2] if count else None, fa[3] if count else None,
+                               fa[1] if use_state else [], fa[0], per_sample_weights,
                                *(pre if pre is not None else (None, None, None)))
         if (fast is not None and not self.warmup and self.use_cache and self.num_tables == 1 and indices.is_cuda
                 and indices.numel() > 0):
