@@ -74,6 +74,11 @@ WORKLOADS = {
     "d256": dict(q=[4, 8, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d32q4": dict(q=[4, 2, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d128r32": dict(q=[4, 4, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    # duplicate sharing where it can pay: a cfg5-size batch of a skewed stream (26 tables x 4096 bags x 20 lookups, Zipf 1.2)
+    "cfg5z": dict(q=[4, 4, 4], ranks=[32, 32], tables=26, B=4096, optimizer="sgd", alpha=1.2, populate=False),
+    "cfg5z-dedup": dict(q=[4, 4, 4], ranks=[32, 32], tables=26, B=4096, optimizer="sgd", alpha=1.2, populate=False, dedup=True),
+    "tb4z": dict(q=[4, 4, 4], ranks=[32, 32], tables=4, B=4096, optimizer="sgd", alpha=1.2, populate=False),
+    "tb4z-dedup": dict(q=[4, 4, 4], ranks=[32, 32], tables=4, B=4096, optimizer="sgd", alpha=1.2, populate=False, dedup=True),
     # generic kernels: ranks beyond the LDS (core 1 walked in K blocks x column passes), and the reference tests' odd ranks
     "r128": dict(q=[4, 4, 4], ranks=[128, 128], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "r13": dict(q=[4, 4, 4], ranks=[13, 12], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),

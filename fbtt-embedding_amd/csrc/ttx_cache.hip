@@ -790,6 +790,69 @@ static void unit_shape(long long n, int* WT, int* U) {  // wave units of the pop
 constexpr int kScanUnits = 1024;  // beyond this many units the counts are scanned by their own launch
 static int num_units(long long n) { return n > 0 ? (int)((n + kCT - 1) / kCT) : 1; }
 
+// The 64-bit stable DESCENDING radix sort of (frequency, key) pairs behind cache_populate -- what the reference asks of
+// cub::DeviceRadixSort::SortPairsDescending(cache_freq, hashtbl, bits [0, 64)) (tt_embeddings_cuda.cu:1280-1308): LSD, 8 bits
+// per pass, as many passes as the largest frequency has bytes (one 8-byte read-back sizes it; a pass over all-zero digits
+// would leave the order unchanged).  ws: 4 x align_up(8 H) + counts + 2 KB.  -> pointers to the sorted copies inside ws.
+// passes: 8-bit passes to run (the caller knows how many bytes its keys have), or -1: one 8-byte read-back of the largest key
+// sizes the sort (cache_populate; not capturable).
+size_t sort_pairs_ws_bytes(int64_t n) {
+  if (n <= 0) return 0;
+  int WT, U;
+  unit_shape(n, &WT, &U);
+  return 4 * align_up((size_t)n * 8) + align_up((size_t)256 * U * 4) + 2048 + 256;
+}
+
+int sort_pairs_desc(int64_t H, const int64_t* keys_in, const int64_t* vals_in, char* ws, int64_t** keys_sorted,
+                    int64_t** vals_sorted, hipStream_t st, int passes_known) {
+  int WT, U;
+  unit_shape(H, &WT, &U);
+  const size_t hb = align_up((size_t)H * 8);
+  int64_t* kA = (int64_t*)ws;
+  int64_t* kB = (int64_t*)(ws + hb);
+  int64_t* vA = (int64_t*)(ws + 2 * hb);
+  int64_t* vB = (int64_t*)(ws + 3 * hb);
+  int* cnt = (int*)(ws + 4 * hb);
+  unsigned long long* dmax = (unsigned long long*)((char*)cnt + align_up((size_t)256 * U * 4));
+  int* tot = (int*)(dmax + 32);  // 256 digit totals (the 2 KB behind the counts: dmax, then tot)
+  const int N = (int)H;
+  int passes = passes_known;
+  if (passes < 0) {
+    // size the sort: highest set bit of the largest frequency (8-byte read-back)
+    TTX_HIP(hipMemsetAsync(dmax, 0, 8, st));
+    hipLaunchKernelGGL(max_key_kernel, dim3((unsigned)((H + 1023) / 1024 < 256 ? (H + 1023) / 1024 : 256)), dim3(1024), 0, st, N,
+                       keys_in, dmax);
+    unsigned long long hmax = 0;
+    TTX_HIP(hipMemcpyAsync(&hmax, dmax, 8, hipMemcpyDeviceToHost, st));
+    TTX_HIP(hipStreamSynchronize(st));
+    int bits = 0;
+    while (bits < 64 && (hmax >> bits)) ++bits;
+    passes = (bits + 7) / 8;
+  }
+  if (passes < 1) passes = 1;  // (>= 1: also produces the sorted copy)
+  if (passes > 8) passes = 8;
+  const unsigned blocks = (unsigned)((U + kCT / kWave - 1) / (kCT / kWave));
+  const int64_t* ik = keys_in;
+  const int64_t* iv = vals_in;
+  int64_t* ok = kA;
+  int64_t* ov = vA;
+  for (int ps = 0; ps < passes; ++ps) {
+    hipLaunchKernelGGL(radix_count_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, U, ps * 8, ik, cnt);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(1024), 0, st, U, cnt, tot);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, U, ps * 8, ik, iv, cnt, tot,
+                       ok, ov);
+    ik = ok;
+    iv = ov;
+    ok = (ok == kA) ? kB : kA;
+    ov = (ov == vA) ? vB : vA;
+  }
+  TTX_HIP(hipGetLastError());
+  if (keys_sorted) *keys_sorted = (int64_t*)ik;
+  if (vals_sorted) *vals_sorted = (int64_t*)iv;
+  return TTX_OK;
+}
+
+
 }  // namespace ttx
 
 using namespace ttx;
@@ -1110,62 +1173,9 @@ int ttx_cache_backward_rowwise_adagrad_approx_n(int64_t nnz, const int32_t* skip
   return TTX_OK;
 }
 
-// The 64-bit stable DESCENDING radix sort of (frequency, key) pairs behind cache_populate -- what the reference asks of
-// cub::DeviceRadixSort::SortPairsDescending(cache_freq, hashtbl, bits [0, 64)) (tt_embeddings_cuda.cu:1280-1308): LSD, 8 bits
-// per pass, as many passes as the largest frequency has bytes (one 8-byte read-back sizes it; a pass over all-zero digits
-// would leave the order unchanged).  ws: 4 x align_up(8 H) + counts + 2 KB.  -> pointers to the sorted copies inside ws.
-static int sort_pairs_desc(int64_t H, const int64_t* keys_in, const int64_t* vals_in, char* ws, int64_t** keys_sorted,
-                           int64_t** vals_sorted, hipStream_t st) {
-  int WT, U;
-  unit_shape(H, &WT, &U);
-  const size_t hb = align_up((size_t)H * 8);
-  int64_t* kA = (int64_t*)ws;
-  int64_t* kB = (int64_t*)(ws + hb);
-  int64_t* vA = (int64_t*)(ws + 2 * hb);
-  int64_t* vB = (int64_t*)(ws + 3 * hb);
-  int* cnt = (int*)(ws + 4 * hb);
-  unsigned long long* dmax = (unsigned long long*)((char*)cnt + align_up((size_t)256 * U * 4));
-  int* tot = (int*)(dmax + 32);  // 256 digit totals (the 2 KB behind the counts: dmax, then tot)
-  const int N = (int)H;
-  // size the sort: highest set bit of the largest frequency (8-byte read-back)
-  TTX_HIP(hipMemsetAsync(dmax, 0, 8, st));
-  hipLaunchKernelGGL(max_key_kernel, dim3((unsigned)((H + 1023) / 1024 < 256 ? (H + 1023) / 1024 : 256)), dim3(1024), 0, st, N,
-                     keys_in, dmax);
-  unsigned long long hmax = 0;
-  TTX_HIP(hipMemcpyAsync(&hmax, dmax, 8, hipMemcpyDeviceToHost, st));
-  TTX_HIP(hipStreamSynchronize(st));
-  int bits = 0;
-  while (bits < 64 && (hmax >> bits)) ++bits;
-  const int passes = bits == 0 ? 1 : (bits + 7) / 8;  // >= 1: also produces the sorted copy
-  const unsigned blocks = (unsigned)((U + kCT / kWave - 1) / (kCT / kWave));
-  const int64_t* ik = keys_in;
-  const int64_t* iv = vals_in;
-  int64_t* ok = kA;
-  int64_t* ov = vA;
-  for (int ps = 0; ps < passes; ++ps) {
-    hipLaunchKernelGGL(radix_count_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, U, ps * 8, ik, cnt);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(1024), 0, st, U, cnt, tot);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(blocks), dim3(kCT), 0, st, N, WT, U, ps * 8, ik, iv, cnt, tot,
-                       ok, ov);
-    ik = ok;
-    iv = ov;
-    ok = (ok == kA) ? kB : kA;
-    ov = (ov == vA) ? vB : vA;
-  }
-  TTX_HIP(hipGetLastError());
-  if (keys_sorted) *keys_sorted = (int64_t*)ik;
-  if (vals_sorted) *vals_sorted = (int64_t*)iv;
-  return TTX_OK;
-}
-
 // test hook: that sort on its own (tests/test_primref_gpu.py checks it against hipCUB's SortPairsDescending, the
 // library call the reference makes).  keys / vals are copied to keys_out / vals_out.
-size_t ttx_debug_sort_workspace_bytes(int64_t n) {
-  if (n <= 0) return 0;
-  int WT, U;
-  unit_shape(n, &WT, &U);
-  return 4 * align_up((size_t)n * 8) + align_up((size_t)256 * U * 4) + 2048 + 256;
-}
+size_t ttx_debug_sort_workspace_bytes(int64_t n) { return sort_pairs_ws_bytes(n); }
 
 int ttx_debug_sort_pairs_desc(int64_t n, const int64_t* keys, const int64_t* vals, int64_t* keys_out, int64_t* vals_out,
                               void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
@@ -1174,7 +1184,7 @@ int ttx_debug_sort_pairs_desc(int64_t n, const int64_t* keys, const int64_t* val
   if (!keys || !vals || !keys_out || !vals_out) TTX_FAIL(TTX_EINVAL, "NULL input");
   if (!workspace || workspace_bytes < ttx_debug_sort_workspace_bytes(n)) TTX_FAIL(TTX_EWORKSPACE, "sort workspace too small");
   int64_t *sk = nullptr, *sv = nullptr;
-  const int rc = sort_pairs_desc(n, keys, vals, (char*)workspace, &sk, &sv, (hipStream_t)stream);
+  const int rc = sort_pairs_desc(n, keys, vals, (char*)workspace, &sk, &sv, (hipStream_t)stream, -1);
   if (rc) return rc;
   TTX_HIP(hipMemcpyAsync(keys_out, sk, (size_t)n * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   TTX_HIP(hipMemcpyAsync(vals_out, sv, (size_t)n * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -1207,7 +1217,7 @@ int ttx_cache_populate(const ttx_geom* g, const float* const* tt_cores, int64_t 
     TTX_FAIL(TTX_EWORKSPACE, "cache_populate workspace too small");
   char* ws = (char*)workspace;
   int64_t* sorted_keys = nullptr;
-  rc = sort_pairs_desc(H, cache_freq, hashtbl, ws, nullptr, &sorted_keys, st);
+  rc = sort_pairs_desc(H, cache_freq, hashtbl, ws, nullptr, &sorted_keys, st, -1);
   if (rc) return rc;
   int WT, U;
   unit_shape(H, &WT, &U);

@@ -177,6 +177,13 @@ DedupMap carve_dedup(long long nnz, void* base);
 int dedup_build(const Dims& d, long long nnz, const int64_t* indices, const int64_t* tableidx, const DedupMap& M,
                 hipStream_t stream);
 
+// stable DESCENDING LSD radix sort of (int64 key, int64 value) pairs, 8 bits per pass, multi-work-group (ttx_cache.hip):
+// cache_populate's sort of (frequency, key) and the key sort of the duplicate map.  ws: sort_pairs_ws_bytes(n);
+// passes: number of 8-bit passes, or -1 to size the sort by one read-back of the largest key (not capturable).
+size_t sort_pairs_ws_bytes(int64_t n);
+int sort_pairs_desc(int64_t n, const int64_t* keys_in, const int64_t* vals_in, char* ws, int64_t** keys_sorted,
+                    int64_t** vals_sorted, hipStream_t st, int passes);
+
 // ------------------------------------------------------------ profiling ----
 void prof_begin(int which, hipStream_t s);
 void prof_end(int which, hipStream_t s);

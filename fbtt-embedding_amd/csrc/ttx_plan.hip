@@ -1472,9 +1472,16 @@ int plan_build_batches(const Dims& d, int nbatch, long long nnz, const int* n_de
 // run heads are the distinct pairs.  Deterministic (no ordering-dependent atomics), one launch, <= 16384 lookups
 // (144 KB of LDS); larger batches and key spaces beyond 2^32 are not deduplicated (same results either way:
 // sharing the contraction of duplicates never changes a value, only how often it is computed).
-size_t dedup_bytes(long long nnz) {
+// (batches beyond the single-work-group map also keep the key sort's buffers here: keys, values, the sort's workspace,
+//  run heads per block of 1024 sorted positions)
+static size_t dedup_map_bytes(long long nnz) {
   const size_t n = r64((size_t)nnz + 1);
   return align_up(64 * sizeof(int)) + 3 * align_up(n * sizeof(int64_t)) + 3 * align_up(n * sizeof(int));
+}
+static size_t dedup_blocks(long long nnz) { return ((size_t)nnz + 1023) / 1024; }
+size_t dedup_bytes(long long nnz) {
+  return dedup_map_bytes(nnz) + 2 * align_up((size_t)nnz * 8) + align_up(sort_pairs_ws_bytes(nnz)) +
+         align_up((dedup_blocks(nnz) + 1) * sizeof(int));
 }
 
 DedupMap carve_dedup(long long nnz, void* base) {
@@ -1500,11 +1507,25 @@ static unsigned long long dedup_key_space(const Dims& d) {  // tables * prod(p),
   return (e <= (1ull << 32) && all <= (1ull << 32)) ? all : 0;
 }
 
+// tables * prod(p) as a 64-bit key space (batches beyond the single-work-group map sort 64-bit keys), or 0
+static unsigned long long dedup_key_space64(const Dims& d) {
+  if (d.tab) return 0;
+  unsigned long long e = 1;
+  for (int t = 0; t < d.T; ++t) {
+    if (e > (1ull << 61) / (unsigned long long)d.p[t]) return 0;
+    e *= (unsigned long long)d.p[t];
+  }
+  if (e > (1ull << 61) / (unsigned long long)d.num_tables) return 0;
+  return e * (unsigned long long)d.num_tables;
+}
+
 bool dedup_supported(const Dims& d, long long nnz) {
   // (the gradient pre-sum keeps 64 groups x D floats of part sums + 8 KB in LDS: gsum_kernel, ttx_tt.hip -- a wider
   //  embedding takes the plain path, which gives the same results)
   if ((size_t)64 * d.D * sizeof(float) + 8192 > (size_t)160 * 1024) return false;
-  return nnz > 0 && nnz <= kDedupMaxN && dedup_key_space(d) != 0;
+  if (nnz <= 0 || nnz >= (1ll << 31)) return false;
+  if (nnz <= kDedupMaxN && dedup_key_space(d) != 0) return true;   // one work-group sorts the batch in LDS
+  return dedup_key_space64(d) != 0;                                // multi-work-group 64-bit key sort
 }
 
 template <int kBPW>
@@ -1615,9 +1636,134 @@ __global__ __launch_bounds__(kPlanThreads) void dedup_small_kernel(int N, unsign
   }
 }
 
+// ---- the same map for ANY batch size (round 3): the batch's 64-bit keys table * prod(p) + index go through the
+// multi-work-group stable radix sort that cache_populate uses (ttx_cache.hip sort_pairs_desc: descending, so the
+// distinct pairs come out in descending key order -- the order does not matter to anybody --, occurrences of a pair in
+// index order because the sort is stable); run heads are counted per block of 1024 sorted positions, scanned by one
+// work-group, and a last launch writes the map.  No ordering-dependent atomics: deterministic.  The number of 8-bit passes
+// follows from the geometry (bytes of tables * prod(p)), so nothing is read back and the build captures into a hipGraph.
+constexpr int kDdThreads = 1024;
+__global__ __launch_bounds__(kDdThreads) void dd_keys_kernel(int N, unsigned long long E, int num_tables,
+                                                            const int64_t* __restrict__ indices,
+                                                            const int64_t* __restrict__ tableidx, int64_t* __restrict__ keys,
+                                                            int64_t* __restrict__ vals) {
+  const int i = blockIdx.x * kDdThreads + threadIdx.x;
+  if (i >= N) return;
+  // out-of-range inputs are clamped into the table's key range (the plan's decode clamps them likewise)
+  const unsigned long long e = (unsigned long long)max(indices[i], (int64_t)0);
+  const int tbv = (tableidx && num_tables > 1) ? (int)tableidx[i] : 0;
+  const unsigned long long tb = (unsigned long long)min(max(tbv, 0), num_tables - 1);
+  keys[i] = (int64_t)(tb * E + (e < E ? e : E - 1));
+  vals[i] = i;
+}
+
+// run heads among this block's 1024 sorted positions -> *total; returns this thread's inclusive count
+__device__ __forceinline__ int dd_block_heads(bool head, int* wt, int* total) {
+  const int lane = lane_id(), w = threadIdx.x / kWave;
+  const unsigned long long hm = __ballot(head);
+  const int inc_w = __popcll(hm & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull)));
+  if (lane == 0) wt[w] = __popcll(hm);
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int k = 0; k < kDdThreads / kWave; ++k) {
+    const int c = wt[k];
+    if (k < w) base += c;
+    tot += c;
+  }
+  *total = tot;
+  __syncthreads();
+  return base + inc_w;
+}
+
+__global__ __launch_bounds__(kDdThreads) void dd_count_kernel(int N, const int64_t* __restrict__ sk, int* __restrict__ blk_cnt) {
+  __shared__ int wt[kDdThreads / kWave];
+  const int i = blockIdx.x * kDdThreads + threadIdx.x;
+  const bool head = i < N && (i == 0 || sk[i] != sk[i - 1]);
+  int total;
+  dd_block_heads(head, wt, &total);
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = total;
+}
+
+// exclusive scan of the per-block head counts (one work-group); the total is the number of distinct pairs
+__global__ __launch_bounds__(kDdThreads) void dd_scan_kernel(int nblk, int N, int* __restrict__ blk_cnt, DedupMap M) {
+  __shared__ int wt[kDdThreads / kWave + 1];
+  int carry = 0;
+  for (int b0 = 0; b0 < nblk; b0 += kDdThreads) {
+    const int i = b0 + threadIdx.x;
+    const int v = i < nblk ? blk_cnt[i] : 0;
+    const int inc = wave_incl_scan(v);
+    const int w = threadIdx.x / kWave;
+    if (lane_id() == kWave - 1) wt[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int run = 0;
+      for (int k = 0; k < kDdThreads / kWave; ++k) { const int c = wt[k]; wt[k] = run; run += c; }
+      wt[kDdThreads / kWave] = run;
+    }
+    __syncthreads();
+    if (i < nblk) blk_cnt[i] = carry + wt[w] + inc - v;
+    carry += wt[kDdThreads / kWave];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    M.nu[0] = carry;
+    M.occ_off[carry] = N;
+  }
+}
+
+__global__ __launch_bounds__(kDdThreads) void dd_emit_kernel(int N, unsigned long long E, const int64_t* __restrict__ sk,
+                                                            const int64_t* __restrict__ sv, const int* __restrict__ blk_base,
+                                                            DedupMap M) {
+  __shared__ int wt[kDdThreads / kWave];
+  const int i = blockIdx.x * kDdThreads + threadIdx.x;
+  const int64_t key = i < N ? sk[i] : 0;
+  const bool head = i < N && (i == 0 || key != sk[i - 1]);
+  int total;
+  const int inc = dd_block_heads(head, wt, &total);
+  if (i >= N) return;
+  const int u = blk_base[blockIdx.x] + inc - 1;  // the pair of position i: heads at or before it, minus one
+  const int n = (int)sv[i];
+  M.uid[n] = u;
+  M.occ[i] = n;
+  M.iota[i] = i;
+  if (head) {
+    const unsigned long long tb = (unsigned long long)key / E;
+    M.occ_off[u] = i;
+    M.uidx[u] = (int64_t)((unsigned long long)key - tb * E);
+    M.utab[u] = (int64_t)tb;
+  }
+}
+
+static int dedup_build_large(const Dims& d, long long nnz, const int64_t* indices, const int64_t* tableidx, const DedupMap& M,
+                             hipStream_t stream) {
+  const unsigned long long all = dedup_key_space64(d);
+  const unsigned long long E = all / (unsigned long long)d.num_tables;
+  int bits = 1;
+  while (bits < 62 && (1ull << bits) < all) ++bits;
+  const int passes = (bits + 7) / 8;
+  const int N = (int)nnz;
+  char* extra = (char*)M.nu + dedup_map_bytes(nnz);
+  int64_t* keys = (int64_t*)extra;
+  int64_t* vals = (int64_t*)(extra + align_up((size_t)nnz * 8));
+  char* sws = extra + 2 * align_up((size_t)nnz * 8);
+  int* blk = (int*)(sws + align_up(sort_pairs_ws_bytes(nnz)));
+  const int nblk = (int)dedup_blocks(nnz);
+  ProfScope ps(TTX_PROF_PLAN, stream);
+  hipLaunchKernelGGL(dd_keys_kernel, dim3(nblk), dim3(kDdThreads), 0, stream, N, E, d.num_tables, indices, tableidx, keys, vals);
+  int64_t *sk = nullptr, *sv = nullptr;
+  const int rc = sort_pairs_desc(nnz, keys, vals, sws, &sk, &sv, stream, passes);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dd_count_kernel, dim3(nblk), dim3(kDdThreads), 0, stream, N, sk, blk);
+  hipLaunchKernelGGL(dd_scan_kernel, dim3(1), dim3(kDdThreads), 0, stream, nblk, N, blk, M);
+  hipLaunchKernelGGL(dd_emit_kernel, dim3(nblk), dim3(kDdThreads), 0, stream, N, E, sk, sv, blk, M);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
 int dedup_build(const Dims& d, long long nnz, const int64_t* indices, const int64_t* tableidx, const DedupMap& M,
                 hipStream_t stream) {
   if (!dedup_supported(d, nnz)) TTX_FAIL(TTX_EUNSUPPORTED, "batch of %lld lookups / this key space is not deduplicated", nnz);
+  if (nnz > kDedupMaxN || dedup_key_space(d) == 0) return dedup_build_large(d, nnz, indices, tableidx, M, stream);
   const unsigned long long all = dedup_key_space(d);
   const unsigned long long E = all / (unsigned long long)d.num_tables;
   int bits = 1;

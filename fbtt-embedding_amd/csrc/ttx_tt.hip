@@ -1244,7 +1244,7 @@ int ttx_dedup_build(const ttx_geom* g, int64_t nnz, const int64_t* indices, cons
   int rc = make_dims(g, &d);
   if (rc) return rc;
   if (!dedup_supported(d, nnz))
-    TTX_FAIL(TTX_EUNSUPPORTED, "duplicate sharing needs 1..%d lookups and tables * prod(p) <= 2^32", kDedupMaxN);
+    TTX_FAIL(TTX_EUNSUPPORTED, "duplicate sharing: tables of one row shape, tables * prod(p) < 2^61, D <= %d", (160 * 1024 - 8192) / 256);
   if (!indices || (d.num_tables > 1 && !tableidx)) TTX_FAIL(TTX_EINVAL, "NULL input");
   if (!dedup || dedup_bytes_ < dedup_bytes(nnz)) TTX_FAIL(TTX_EWORKSPACE, "dedup buffer too small: %zu < %zu", dedup_bytes_, dedup_bytes(nnz));
   if (!plan || plan_bytes_ < plan_bytes(d, nnz)) TTX_FAIL(TTX_EWORKSPACE, "plan buffer too small: %zu < %zu", plan_bytes_, plan_bytes(d, nnz));

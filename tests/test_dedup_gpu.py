@@ -103,7 +103,6 @@ def test_dedup_vs_oracle_and_plain_path(case):
     tables, p, q, r, B, pf, frac = CASES[case]
     c = make_case(100 + case, tables, p, q, r, B, pf, frac)
     nnz = c["indices"].size
-    assert nnz <= 16384
     distinct = np.unique(c["indices"] + np.repeat(np.arange(tables), np.diff(c["offsets"][::B])) * int(np.prod(np.array(p, dtype=np.int64)))).size
     for mode in ("dense", "sgd", "adagrad"):
         got, again, plain, orc = run(c, mode, True), run(c, mode, True), run(c, mode, False), oracle(c, mode)
@@ -134,13 +133,45 @@ def test_batches_the_map_does_not_take_fall_back_to_the_plain_plan():
     p, q, r = [20, 22, 25], [4, 4, 4], [1, 16, 16, 1]
     idx = t(np.random.RandomState(0).randint(0, 11000, size=20000).astype(np.int64))
     tb = torch.zeros_like(idx)
-    plan = E.make_plan(1, p, q, r, idx.numel(), idx, tb, None, dedup=True)  # > 16384 lookups
-    assert plan is not None and not isinstance(plan, E.DedupPlan)
     wide = E.make_plan(1, p, [8, 8, 10], r, 100, idx[:100], tb[:100], None, dedup=True)  # D = 640: the pre-sum's LDS
     assert wide is not None and not isinstance(wide, E.DedupPlan)
-    big = [70000, 70000, 70000]  # 3.4e14 rows: keys do not fit 32 bits
-    plan = E.make_plan(1, big, q, r, 100, idx[:100], tb[:100], None, dedup=True)
-    assert plan is not None and not isinstance(plan, E.DedupPlan)
+    # (round 3: batches of any size and key spaces beyond 2^32 ARE mapped -- the multi-work-group key sort)
+    assert isinstance(E.make_plan(1, p, q, r, idx.numel(), idx, tb, None, dedup=True), E.DedupPlan)
+    big = [70000, 70000, 70000]  # 3.4e14 rows: 64-bit keys
+    assert isinstance(E.make_plan(1, big, q, r, 100, idx[:100], tb[:100], None, dedup=True), E.DedupPlan)
+
+
+LARGE = [
+    # (tables, p, q, ranks, B, pooling, duplicate fraction): beyond the single-work-group map's 16384 lookups / 32-bit keys
+    (1, [40, 50, 60], [4, 4, 4], [16, 16], 2500, 11, 0.9),      # ~27k lookups, three sort passes
+    (5, [20, 22, 25], [4, 4, 4], [16, 16], 900, 10, 0.6),       # five tables, ~45k lookups
+    (2, [3000, 4000, 5000], [4, 4, 4], [16, 16], 300, 6, 0.7),  # 1.2e11 rows per table: five sort passes of the 64-bit keys
+    (1, [7, 9, 11], [3, 4, 5], [13, 12], 4000, 8, 0.5),         # generic kernels, 693 rows: nearly everything a duplicate
+]
+
+
+@pytest.mark.parametrize("case", range(len(LARGE)))
+def test_dedup_of_large_batches_vs_oracle_and_plain_path(case):
+    """the duplicate map for ANY batch size (multi-work-group stable radix sort of 64-bit keys, run heads, scan): forward
+    bit-identical to the plain path, gradients / fused SGD against the oracle, deterministic"""
+    tables, p, q, r, B, pf, frac = LARGE[case]
+    c = make_case(300 + case, tables, p, q, r, B, pf, frac)
+    nnz = c["indices"].size
+    assert nnz > 16384 or np.prod(np.array(p, dtype=np.float64)) * tables > 2.0**32
+    distinct = np.unique(c["indices"] + np.repeat(np.arange(tables), np.diff(c["offsets"][::B])) * int(np.prod(np.array(p, dtype=np.int64)))).size
+    for mode in ("dense", "sgd"):
+        got, again, plain, orc = run(c, mode, True), run(c, mode, True), run(c, mode, False), oracle(c, mode)
+        assert got["nu"] == distinct, "number of distinct (table, index) pairs"
+        assert np.array_equal(got["out"], plain["out"]), "forward must be bit-identical to the plain path"
+        assert_close(got["out"], orc["out"], f"large case {case} out")
+        tol = dict(rtol=1e-4, atol_scale=2e-5)  # (hot rows: sums over thousands of occurrences in an order of their own)
+        for k in range(len(p)):
+            if mode == "dense":
+                assert_close(got["grads"][k], orc["grads"][k], f"large case {case} grad{k}", **tol)
+                assert np.array_equal(got["grads"][k], again["grads"][k]), "not deterministic"
+            else:
+                assert_close(got["cores"][k], orc["cores"][k], f"large case {case} sgd core{k}", **tol)
+                assert np.array_equal(got["cores"][k], again["cores"][k]), "not deterministic"
 
 
 @pytest.mark.parametrize("route", ["native-present", "python-only"])
