@@ -346,6 +346,74 @@ __global__ __launch_bounds__(kThreads) void pool_gather_kernel(int N, int B, int
   }
 }
 
+// the same for large batches (D % 4 == 0), the wave-span form of pool4_kernel: a wave owns 64 consecutive lookups, finds
+// the run heads among them with one ballot, its four 16-lane groups take the heads round-robin; a group fetches 16 map
+// entries at once and keeps 16 row loads in flight.  (One group per lookup with only the heads working keeps one group in
+// twenty busy at 20 lookups per bag: 2.13 M lookups 416 -> see profiles.)  Same sums in the same (index) order.
+__global__ __launch_bounds__(kThreads) void pool_gather4_kernel(int N, int B, int D4, const int64_t* __restrict__ rowidx,
+                                                               const int64_t* __restrict__ tableidx,
+                                                               const int* __restrict__ uid, const float4* __restrict__ rows,
+                                                               const float* __restrict__ psw, float4* __restrict__ out) {
+  __shared__ unsigned char hpos[kThreads / kWave][kWave];
+  const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  const int n0 = (blockIdx.x * (kThreads / kWave) + w) * kWave;
+  if (n0 >= N) return;  // (wave-uniform)
+  const int n = n0 + lane;
+  bool head = false;
+  if (n < N) head = n == 0 || rowidx[n - 1] != rowidx[n] || tableidx[n - 1] != tableidx[n];
+  const unsigned long long heads = __ballot(head);
+  if (head) hpos[w][__popcll(heads & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+  const int nheads = __popcll(heads);
+  const int g = lane >> 4, l = lane & 15, sh = lane & 48;
+  for (int k = g; k < nheads; k += 4) {
+    const int pos = hpos[w][k];
+    const int hn = n0 + pos;
+    const int64_t r = rowidx[hn], tb = tableidx[hn];
+    int sl;
+    if (k + 1 < nheads) {
+      sl = hpos[w][k + 1] - pos;
+    } else {  // the span's last run may go on behind it: 16 candidates per ballot (one group gets here)
+      sl = min(N, n0 + kWave) - hn;
+      if (hn + sl < N)
+        for (;;) {
+          const int c = hn + sl + l;
+          const bool same = c < N && rowidx[c] == r && tableidx[c] == tb;
+          const unsigned m = (unsigned)(__ballot(!same) >> sh) & 0xffffu;
+          if (m) { sl += __builtin_ctz(m); break; }
+          sl += 16;
+        }
+    }
+    float4* o = out + ((size_t)tb * B + r) * D4;
+    for (int e0 = 0; e0 < D4; e0 += 16) {
+      const int e = e0 + l;
+      const bool ev = e < D4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ev) acc = o[e];
+      for (int base = 0; base < sl; base += 16) {
+        const int j = base + l;
+        const int u = j < sl ? uid[hn + j] : 0;
+        const float wv = (psw && j < sl) ? psw[hn + j] : 1.f;
+        const int cnt = min(16, sl - base);
+        float4 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int uq = __shfl(u, q, 16);
+          if (q < cnt && ev) v[q] = rows[(size_t)uq * D4 + e];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {  // added in index order
+          const float wq = __shfl(wv, q, 16);
+          if (q < cnt && ev) {
+            if (psw) vfma(acc, wq, v[q]);
+            else vadd(acc, v[q]);
+          }
+        }
+      }
+      if (ev) o[e] = acc;
+    }
+  }
+}
+
 // Gu[u, :] = sum over the occurrences n of distinct pair u, in index order, of (psw[n] *) d_output[table(n), row(n), :].
 // A 1024-thread work-group = 64 groups of 16 lanes.  Pairs with fewer than kGsumCoop occurrences are summed by one
 // group each (work-group b takes pairs [64 b, 64 b + 64)); a pair hit more often -- a hot row of a skewed stream takes
@@ -1288,7 +1356,10 @@ int ttx_tt_forward_dd(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, cons
   if (rc) return rc;
   ProfScope ps(TTX_PROF_POOL, st);
   const int blocks = ((int)nnz + kThreads / 16 - 1) / (kThreads / 16);
-  if (d.D % 4 == 0 && (((uintptr_t)rows | (uintptr_t)output) & 15) == 0)
+  if (d.D % 4 == 0 && (((uintptr_t)rows | (uintptr_t)output) & 15) == 0 && nnz > kPoolSpanMin)
+    hipLaunchKernelGGL(pool_gather4_kernel, dim3(((int)nnz + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (int)nnz, B, d.D / 4,
+                       rowidx, tableidx, M.uid, (const float4*)rows, psw, (float4*)output);
+  else if (d.D % 4 == 0 && (((uintptr_t)rows | (uintptr_t)output) & 15) == 0)
     hipLaunchKernelGGL(pool_gather_kernel<float4>, dim3(blocks), dim3(kThreads), 0, st, (int)nnz, B, d.D / 4, rowidx, tableidx,
                        M.uid, (const float4*)rows, psw, (float4*)output);
   else

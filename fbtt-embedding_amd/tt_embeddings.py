@@ -104,6 +104,8 @@ def lib():
     L.ttx_tt_forward_dd.argtypes = [G, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.ttx_tt_backward_dd_workspace_bytes.argtypes = [G, i32, i64]
     L.ttx_tt_backward_dd.argtypes = [G, i32, i32, i32, f32, f32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    if os.environ.get("TTX_LDS_BUDGET"):  # experiments: LDS budget of the generic kernels' tile search (bytes)
+        L.ttx_debug_lds_budget(int(os.environ["TTX_LDS_BUDGET"]))
     if os.environ.get("TTX_DEBUG_SKIP"):  # ablation runs (scripts/upper_bounds.py): results INVALID while set
         L.ttx_debug_skip(int(os.environ["TTX_DEBUG_SKIP"]))
     _lib = L

@@ -147,6 +147,7 @@ LARGE = [
     (5, [20, 22, 25], [4, 4, 4], [16, 16], 900, 10, 0.6),       # five tables, ~45k lookups
     (2, [3000, 4000, 5000], [4, 4, 4], [16, 16], 300, 6, 0.7),  # 1.2e11 rows per table: five sort passes of the 64-bit keys
     (1, [7, 9, 11], [3, 4, 5], [13, 12], 4000, 8, 0.5),         # generic kernels, 693 rows: nearly everything a duplicate
+    (2, [20, 22, 25], [4, 4, 4], [16, 16], 4200, 10, 0.7),      # ~84k lookups: the wave-span gather pooling (> 65536 lookups)
 ]
 
 
