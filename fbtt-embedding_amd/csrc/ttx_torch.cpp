@@ -404,26 +404,36 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
                   "tt_embeddings: per_sample_weights must be a contiguous float32 GPU tensor, one weight per index "
                   "(and the batch's prologue runs in line)");
     const bool psw_grad = weighted && psw->requires_grad();
-    Tensor tableidx, pcol, prow, ploc, n_tt, plan, ppsw, porig;
+    Tensor ppsw, porig, buf;
+    std::vector<Tensor> pre_t;
+    // the partitioned arrays, the split point and the plan of the misses: the six planned-ahead tensors, or ONE buffer
+    // [tableidx | pcol | prow | ploc | n_tt | plan | rowidx, preprocessing scratch] (host-bound step: one allocation, not eight)
+    int64_t *tableidx_p, *pcol_p, *prow_p;
+    int32_t *ploc_p, *ntt_p;
+    void* plan_p;
     const size_t pb = ttx_plan_bytes(&g, nnz);
+    const size_t ib = ((size_t)nnz * 8 + 255) / 256 * 256, lb = ((size_t)nnz * 4 + 255) / 256 * 256;
     if (pre.size() == 6) {  // planned ahead (prologue_cached_multi): frequency update, lookup, partition and plan are done
-      tableidx = pre[0]; pcol = pre[1]; prow = pre[2]; ploc = pre[3]; n_tt = pre[4]; plan = pre[5];
+      const Tensor &tableidx = pre[0], &pcol = pre[1], &prow = pre[2], &ploc = pre[3], &n_tt = pre[4], &plan = pre[5];
       TORCH_CHECK(tableidx.numel() == nnz && pcol.numel() == nnz && prow.numel() == nnz && ploc.numel() == nnz &&
                       n_tt.numel() == 1 && (size_t)plan.numel() >= pb && pcol.scalar_type() == at::kLong &&
                       ploc.scalar_type() == at::kInt && n_tt.scalar_type() == at::kInt && plan.is_contiguous(),
                   "tt_embeddings: the planned-ahead prologue does not match this batch");
+      pre_t.assign(pre.begin(), pre.end());
+      tableidx_p = tableidx.data_ptr<int64_t>(); pcol_p = pcol.data_ptr<int64_t>(); prow_p = prow.data_ptr<int64_t>();
+      ploc_p = ploc.data_ptr<int32_t>(); ntt_p = n_tt.data_ptr<int32_t>(); plan_p = plan.data_ptr();
     } else {
       TORCH_CHECK(pre.size() == 0, "tt_embeddings: pre must be prologue_cached_multi's six tensors of the batch, or empty");
-      Tensor rowidx = at::empty_like(indices);
-      tableidx = at::empty_like(indices);
-      pcol = at::empty_like(indices);
-      prow = at::empty_like(indices);
-      ploc = at::empty({nnz}, indices.options().dtype(at::kInt));
       const size_t pwb = ttx_preprocess_workspace_bytes(nnz);
-      Tensor pws = bytes_on(indices, pwb);
+      const size_t pbA = (pb + 255) / 256 * 256;
+      buf = bytes_on(indices, 3 * ib + lb + 256 + pbA + ib + pwb);
+      char* base = (char*)buf.data_ptr();
+      tableidx_p = (int64_t*)base; pcol_p = (int64_t*)(base + ib); prow_p = (int64_t*)(base + 2 * ib);
+      ploc_p = (int32_t*)(base + 3 * ib); ntt_p = (int32_t*)(base + 3 * ib + lb); plan_p = base + 3 * ib + lb + 256;
+      int64_t* rowidx_p = (int64_t*)(base + 3 * ib + lb + 256 + pbA);  // (scratch: only the partitioned rows are used later)
+      void* pws_p = base + 3 * ib + lb + 256 + pbA + ib;
       // the split point (number of TT entries) stays on the device: the kernels below read it there,
       // nnz only sizes grids and workspaces -- no host synchronisation, the step can be graph-captured
-      n_tt = at::empty({1}, indices.options().dtype(at::kInt));
       int32_t n_host = 0, part = 0;
       if (weighted) {  // the weights follow their lookups through the partition; the origins bring their gradient back
         ppsw = at::empty({nnz}, cores[0].options());
@@ -431,17 +441,14 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
       }
       check(ttx_preprocess_indices_async_w(nnz, indices.data_ptr<int64_t>(), B, offsets.data_ptr<int64_t>(), 1, 0, H,
                                            hashtbl.data_ptr<int64_t>(), cache_state.data_ptr<int32_t>(),
-                                           rowidx.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
-                                           pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(), ploc.data_ptr<int32_t>(),
-                                           &n_host, &part, n_tt.data_ptr<int32_t>(),
+                                           rowidx_p, tableidx_p, pcol_p, prow_p, ploc_p,
+                                           &n_host, &part, ntt_p,
                                            count_freq ? hashtbl.data_ptr<int64_t>() : nullptr,
                                            count_freq ? cache_freq.data_ptr<int64_t>() : nullptr, weighted ? psw->data_ptr<float>() : nullptr,
                                            weighted ? ppsw.data_ptr<float>() : nullptr,
-                                           psw_grad ? porig.data_ptr<int32_t>() : nullptr, pws.data_ptr(), pwb, stream));
+                                           psw_grad ? porig.data_ptr<int32_t>() : nullptr, pws_p, pwb, stream));
       TORCH_CHECK(part == 1, "tt_embeddings: the cache-live preprocessing did not partition");
-      plan = bytes_on(indices, pb);
-      check(ttx_plan_build_n(&g, nnz, n_tt.data_ptr<int32_t>(), pcol.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
-                             prow.data_ptr<int64_t>(), plan.data_ptr(), pb, stream));
+      check(ttx_plan_build_n(&g, nnz, ntt_p, pcol_p, tableidx_p, prow_p, plan_p, pb, stream));
     }
 
     Tensor out = at::empty({1, B, D}, cores[0].options());
@@ -452,58 +459,74 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     // (a gradient for the weights needs every lookup's forward row: the contraction's for the misses, the cache's for the hits)
     Tensor rows_keep;
     if (psw_grad) rows_keep = at::empty({nnz, D}, cores[0].options());
-    check(ttx_tt_forward_wr(&g, (int32_t)B, (int32_t)D, nnz, pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(),
-                            tableidx.data_ptr<int64_t>(), weighted ? ppsw.data_ptr<float>() : nullptr, cp,
-                            out.data_ptr<float>(), psw_grad ? rows_keep.data_ptr<float>() : nullptr, plan.data_ptr(),
+    check(ttx_tt_forward_wr(&g, (int32_t)B, (int32_t)D, nnz, pcol_p, prow_p, tableidx_p,
+                            weighted ? ppsw.data_ptr<float>() : nullptr, cp,
+                            out.data_ptr<float>(), psw_grad ? rows_keep.data_ptr<float>() : nullptr, plan_p,
                             ws.data_ptr(), wb, stream));
-    check(ttx_cache_forward_nw((int32_t)B, nnz, n_tt.data_ptr<int32_t>(), ploc.data_ptr<int32_t>(),
-                               prow.data_ptr<int64_t>(), weighted ? ppsw.data_ptr<float>() : nullptr, (int32_t)D,
+    check(ttx_cache_forward_nw((int32_t)B, nnz, ntt_p, ploc_p, prow_p, weighted ? ppsw.data_ptr<float>() : nullptr, (int32_t)D,
                                cache_weight.data_ptr<float>(), out.data_ptr<float>(), stream));
     if (psw_grad)
-      check(ttx_cache_rows_n(nnz, n_tt.data_ptr<int32_t>(), ploc.data_ptr<int32_t>(), (int32_t)D,
-                             cache_weight.data_ptr<float>(), rows_keep.data_ptr<float>(), stream));
+      check(ttx_cache_rows_n(nnz, ntt_p, ploc_p, (int32_t)D, cache_weight.data_ptr<float>(), rows_keep.data_ptr<float>(), stream));
 
-    ctx->saved_data["p"] = p;
-    ctx->saved_data["q"] = q;
-    ctx->saved_data["r"] = r;
-    ctx->saved_data["optim"] = optim;
-    ctx->saved_data["lr"] = lr;
-    ctx->saved_data["eps"] = eps;
-    ctx->saved_data["T"] = (int64_t)g.T;
-    ctx->saved_data["nstate"] = (int64_t)state.size();
-    ctx->saved_data["npre"] = (int64_t)pre.size();
-    if (weighted) ctx->saved_data["ppsw"] = ppsw;
-    if (psw_grad) {
-      ctx->saved_data["rows"] = rows_keep;
-      ctx->saved_data["porig"] = porig;
-    }
-    std::vector<Tensor> keep = {pcol, prow, tableidx, ploc, cache_weight, n_tt};
-    ctx->saved_data["keep"] = keep;
-    if (cache_opt_state.has_value() && cache_opt_state->defined()) ctx->saved_data["copt"] = *cache_opt_state;
-    if (plan.defined()) ctx->saved_data["plan"] = plan;
-    ctx->saved_data["cores"] = std::vector<Tensor>(cores.begin(), cores.end());
-    ctx->saved_data["state"] = std::vector<Tensor>(state.begin(), state.end());
+    // three saved entries (see TTLookupOp::forward): "m" = {optim, T, nstate, npre, weighted, psw_grad, has_copt, has_plan, p.., q.., r..},
+    // "d" = {lr, eps}, "t" = cache_weight, then the six planned-ahead tensors or [buf], [copt], cores.., state.., [ppsw], [rows, porig]
+    const bool has_copt = cache_opt_state.has_value() && cache_opt_state->defined();
+    std::vector<int64_t> meta = {optim, (int64_t)g.T, (int64_t)state.size(), (int64_t)pre.size(), weighted ? 1 : 0, psw_grad ? 1 : 0,
+                                 has_copt ? 1 : 0, nnz};
+    meta.insert(meta.end(), p.begin(), p.end());
+    meta.insert(meta.end(), q.begin(), q.end());
+    meta.insert(meta.end(), r.begin(), r.end());
+    std::vector<Tensor> keep = {cache_weight};
+    keep.reserve(14 + cores.size() + state.size());
+    if (pre.size() == 6) keep.insert(keep.end(), pre_t.begin(), pre_t.end());
+    else keep.push_back(buf);
+    if (has_copt) keep.push_back(*cache_opt_state);
+    keep.insert(keep.end(), cores.begin(), cores.end());
+    keep.insert(keep.end(), state.begin(), state.end());
+    if (weighted) keep.push_back(ppsw);
+    if (psw_grad) { keep.push_back(rows_keep); keep.push_back(porig); }
+    ctx->saved_data["m"] = std::move(meta);
+    ctx->saved_data["d"] = std::vector<double>{lr, eps};
+    ctx->saved_data["t"] = std::move(keep);
     return out;
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grad_outputs) {
-    const auto p = ctx->saved_data["p"].toIntVector();
-    const auto q = ctx->saved_data["q"].toIntVector();
-    const auto r = ctx->saved_data["r"].toIntVector();
-    const int64_t optim = ctx->saved_data["optim"].toInt();
-    const double lr = ctx->saved_data["lr"].toDouble(), eps = ctx->saved_data["eps"].toDouble();
-    const int64_t T = ctx->saved_data["T"].toInt(), nstate = ctx->saved_data["nstate"].toInt() + ctx->saved_data["npre"].toInt();
-    auto keep = ctx->saved_data["keep"].toTensorVector();
-    auto cores = ctx->saved_data["cores"].toTensorVector();
-    auto state = ctx->saved_data["state"].toTensorVector();
+    const auto meta = ctx->saved_data["m"].toIntVector();
+    const auto lre = ctx->saved_data["d"].toDoubleVector();
+    const auto keep = ctx->saved_data["t"].toTensorVector();
+    const int64_t optim = meta[0], T = meta[1], nstate_own = meta[2], nstate = meta[2] + meta[3];
+    const bool weighted = meta[4] != 0, psw_grad = meta[5] != 0, has_copt = meta[6] != 0, planned = meta[3] == 6;
+    const int64_t nnz = meta[7];
+    const std::vector<int64_t> p(meta.begin() + 8, meta.begin() + 8 + T);
+    const std::vector<int64_t> q(meta.begin() + 8 + T, meta.begin() + 8 + 2 * T);
+    const std::vector<int64_t> r(meta.begin() + 8 + 2 * T, meta.begin() + 8 + 3 * T + 1);
+    const double lr = lre[0], eps = lre[1];
     Geom G;
     make_geom(G, 1, p, q, r);
     const ttx_geom& g = G.g;
-    const Tensor &pcol = keep[0], &prow = keep[1], &tableidx = keep[2], &ploc = keep[3], &cache_weight = keep[4];
-    const int32_t* n_tt = keep[5].data_ptr<int32_t>();  // device-side split point
-    const Tensor cache_opt_state = ctx->saved_data.count("copt") ? ctx->saved_data["copt"].toTensor() : Tensor();
-    const Tensor plan = ctx->saved_data.count("plan") ? ctx->saved_data["plan"].toTensor() : Tensor();
-    const int64_t nnz = pcol.numel();
+    const Tensor& cache_weight = keep[0];
+    const int64_t *tableidx_p, *pcol_p, *prow_p;
+    const int32_t *ploc_p, *n_tt;  // n_tt: the device-side split point
+    const void* plan_p;
+    size_t at = 1;
+    if (planned) {  // {tableidx, pcol, prow, ploc, n_tt, plan}
+      tableidx_p = keep[1].data_ptr<int64_t>(); pcol_p = keep[2].data_ptr<int64_t>(); prow_p = keep[3].data_ptr<int64_t>();
+      ploc_p = keep[4].data_ptr<int32_t>(); n_tt = keep[5].data_ptr<int32_t>(); plan_p = keep[6].data_ptr();
+      at = 7;
+    } else {
+      const size_t ib = ((size_t)nnz * 8 + 255) / 256 * 256, lb = ((size_t)nnz * 4 + 255) / 256 * 256;
+      const char* base = (const char*)keep[1].data_ptr();
+      tableidx_p = (const int64_t*)base; pcol_p = (const int64_t*)(base + ib); prow_p = (const int64_t*)(base + 2 * ib);
+      ploc_p = (const int32_t*)(base + 3 * ib); n_tt = (const int32_t*)(base + 3 * ib + lb); plan_p = base + 3 * ib + lb + 256;
+      at = 2;
+    }
+    const Tensor cache_opt_state = has_copt ? keep[at++] : Tensor();
+    const Tensor* cores = &keep[at];
+    const Tensor* state = &keep[at + T];
+    at += T + nstate_own;
+    const Tensor ppsw = weighted ? keep[at++] : Tensor();
+    const Tensor rows_keep_s = psw_grad ? keep[at] : Tensor(), porig_s = psw_grad ? keep[at + 1] : Tensor();
 
     variable_list grads(kHead + nstate + T);
     Tensor go = grad_outputs[0];
@@ -528,29 +551,28 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
       }
     }
     const size_t wb = ttx_tt_backward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
-    Tensor ws = bytes_on(pcol, wb);
-    const Tensor ppsw = ctx->saved_data.count("ppsw") ? ctx->saved_data["ppsw"].toTensor() : Tensor();
+    Tensor ws = bytes_on(cache_weight, wb);
     check(ttx_tt_backward_w(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz,
-                            pcol.data_ptr<int64_t>(), prow.data_ptr<int64_t>(), tableidx.data_ptr<int64_t>(),
+                            pcol_p, prow_p, tableidx_p,
                             ppsw.defined() ? ppsw.data_ptr<float>() : nullptr, go.data_ptr<float>(), cp,
                             optim == TTX_OPTIM_ADAGRAD ? sp : nullptr, optim == TTX_OPTIM_DENSE ? gp : nullptr,
-                            plan.defined() ? plan.data_ptr() : nullptr, ws.data_ptr(), wb, stream));
-    if (ctx->saved_data.count("rows")) {  // gradient of the per_sample_weights (argument slot 13), in the caller's order
-      const Tensor rows_keep = ctx->saved_data["rows"].toTensor(), porig = ctx->saved_data["porig"].toTensor();
+                            plan_p, ws.data_ptr(), wb, stream));
+    if (psw_grad) {  // gradient of the per_sample_weights (argument slot 13), in the caller's order
+      const Tensor &rows_keep = rows_keep_s, &porig = porig_s;
       Tensor d_part = at::empty({nnz}, rows_keep.options());
-      check(ttx_psw_backward((int32_t)B, (int32_t)D, nnz, rows_keep.data_ptr<float>(), prow.data_ptr<int64_t>(),
-                             tableidx.data_ptr<int64_t>(), go.data_ptr<float>(), d_part.data_ptr<float>(), stream));
+      check(ttx_psw_backward((int32_t)B, (int32_t)D, nnz, rows_keep.data_ptr<float>(), prow_p, tableidx_p, go.data_ptr<float>(),
+                             d_part.data_ptr<float>(), stream));
       Tensor d_psw = at::empty({nnz}, rows_keep.options());
       d_psw.index_copy_(0, porig.to(at::kLong), d_part);
       grads[13] = d_psw;
     }
-    const int32_t* loc = ploc.data_ptr<int32_t>();
-    const int64_t* rows = prow.data_ptr<int64_t>();
+    const int32_t* loc = ploc_p;
+    const int64_t* rows = prow_p;
     const float* gcache = go.data_ptr<float>();  // (weighted: every cached lookup's own scaled gradient row)
     Tensor scaled, iota;
     if (ppsw.defined()) {
       scaled = at::empty({nnz, D}, go.options());
-      iota = at::empty({nnz}, prow.options());
+      iota = at::empty({nnz}, go.options().dtype(at::kLong));
       check(ttx_cache_weighted_grad_n(nnz, n_tt, (int32_t)D, go.data_ptr<float>(), rows, ppsw.data_ptr<float>(),
                                       scaled.data_ptr<float>(), iota.data_ptr<int64_t>(), stream));
       gcache = scaled.data_ptr<float>();

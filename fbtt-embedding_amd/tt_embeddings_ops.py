@@ -551,6 +551,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
     def _apply(self, fn, *a, **kw):
         """module.to() / .cuda() / .float(): buffers are replaced by new tensors -- forget the cached argument lists"""
         self.__dict__.pop("_fa", None)
+        self.__dict__.pop("_fc", None)
         return super()._apply(fn, *a, **kw)
 
     def _evict_oldest_prefetched(self) -> None:
@@ -578,7 +579,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         """copy.deepcopy / torch.save of the module: the prefetch side stream and the planned-ahead batches (device
         buffers, HIP events) belong to this process and this point in time -- they are recreated at first use."""
         state = self.__dict__.copy()
-        for k in ("_pf_stream", "_prefetched", "_pf_key", "_pf_counted", "_pf_evicted", "_fa"):
+        for k in ("_pf_stream", "_prefetched", "_pf_key", "_pf_counted", "_pf_evicted", "_fa", "_fc"):
             state.pop(k, None)
         return state
 
@@ -694,12 +695,16 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             if per_sample_weights is not None and pre is not None:
                 pre = None  # (the planned-ahead partition does not carry weights: this batch's prologue runs in line,
                 self._pf_counted = True  # without counting the batch a second time)
-            return fast.lookup_cached(indices.contiguous(), offsets.contiguous(), self.tt_p_shapes, self.tt_q_shapes,
+            fc = self.__dict__.get("_fc")  # (the module's tensors, looked up once: see _fa above)
+            if fc is None:
+                fc = self._fc = (list(self.tt_cores), list(self.optimizer_state), self.hashtbl, self.cache_freq, self.cache_state,
+                                 self.cache_optimizer_state, self.cache_weight)
+            return fast.lookup_cached(indices if indices.is_contiguous() else indices.contiguous(),
+                                      offsets if offsets.is_contiguous() else offsets.contiguous(), self.tt_p_shapes, self.tt_q_shapes,
                                       self.tt_ranks, optim | (256 if self._pf_counted else 0), self.learning_rate, self.eps,
-                                      self.hashtbl, self.cache_freq,
-                                      self.cache_state, self.cache_optimizer_state if use_state else None,
-                                      self.cache_weight, list(self.optimizer_state) if use_state else [],
-                                      list(self.tt_cores), list(pre) if pre is not None else [], per_sample_weights)
+                                      fc[2], fc[3], fc[4], fc[5] if use_state else None,
+                                      fc[6], fc[1] if use_state else [],
+                                      fc[0], list(pre) if pre is not None else [], per_sample_weights)
         prologue = getattr(_engine, "lookup_prologue", None)
         if prologue is not None and self.warmup and indices.numel() > 0:
             # cache not live: frequency update, offsets -> bag rows and the lookup plan in one native call
