@@ -645,7 +645,31 @@ def _cache_live_pair(ops, p, q, r, E_, D, B, Lp, optimizer, n_req=5, cache_size=
     #  order -- as in the reference -- and then break frequency ties at the cache's edge differently)
     b.load_state_dict(a.state_dict())
     b.warmup = False
-    reqs = [(t(i), t(o)) for i, o in G.make_requests(71, n_req, B, 1, Lp, E_, alpha=1.2)]
+    # Keys the comparison "planned ahead == in line" cannot be made on: a CACHED key that sits behind its home slot with an
+    # empty slot in front of it (its home's first tenant was evicted by the populate).  The reference's insert claims the
+    # first empty-or-matching slot of the probe sequence (hashtbl_cuda_utils.cuh:102-133), so the next time such a key is
+    # counted it gets a SECOND seat in front of its cached one and is a miss from then on -- unless another key has taken
+    # that empty slot first.  Which of the two happens depends on the order in which the batches are counted: one after the
+    # other in line, all of a planned round at once (prefetch_many).  Either outcome is a legal reference behaviour (there the
+    # order of two racing inserts is the hardware's); the requests simply leave those few keys out.
+    keys, state = a.hashtbl.cpu().numpy(), a.cache_state.cpu().numpy()
+    H = keys.size
+    prone = set()
+    for s_ in np.nonzero(state >= 0)[0]:
+        k = int(keys[s_])
+        h = O.hash64(k, H)
+        c = h
+        while c != s_:
+            if keys[c] == -1:
+                prone.add(k)
+                break
+            c = (c + 1) % H
+    reqs = []
+    for i, o in G.make_requests(71, n_req, B, 1, Lp, E_, alpha=1.2):
+        if prone:
+            safe = next(v for v in range(E_) if v not in prone)
+            i = np.where(np.isin(i, list(prone)), safe, i)
+        reqs.append((t(i), t(o)))
     return a, b, reqs
 
 
