@@ -454,7 +454,36 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             self.warmup = True
             self._drop_prefetched(counted=False)  # (the frequency table is empty again)
 
-    def cache_populate(self) -> None:
+    def _write_back(self, lr: float, steps: int = 1) -> None:
+        """`steps` SGD steps of size `lr` on the cores toward every CACHED row (see cache_populate)."""
+        slots = torch.nonzero(self.cache_state >= 0).flatten()
+        n = int(slots.numel())
+        if n == 0:
+            return
+        keys = self.hashtbl[slots].contiguous()
+        target = self.cache_weight.detach()[self.cache_state[slots].long()]           # what the cached rows have learnt
+        offsets = torch.arange(0, n + 1, dtype=torch.int64, device=keys.device)     # one lookup per bag
+        no_tbl = torch.empty(0, dtype=torch.int64, device=keys.device)
+        colidx, rowidx, tableidx, _, _ = _engine.preprocess_indices_sync(keys, offsets, 1, True, no_tbl,
+                                                                          torch.empty(0, dtype=torch.int32, device=keys.device))
+        cores = [c.detach() for c in self.tt_cores]
+        for _ in range(max(1, int(steps))):
+            rows = _engine.tt_forward(1000, 1, n, self.embedding_dim, self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks, self.L, n,
+                                      colidx, rowidx, tableidx, cores)                  # the rows as the cores hold them
+            diff = (rows - target.unsqueeze(0)).contiguous()  # d/d row of 1/2 ||TT row - cached row||^2
+            _engine.tt_sgd_backward(1000, self.embedding_dim, float(lr), self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks, self.L,
+                                    n, colidx, rowidx, tableidx, diff, cores)
+
+    def cache_populate(self, write_back: float = 0.0, write_back_steps: int = 1) -> None:
+        """tt_embeddings_ops.py:800-814.  `write_back` (NOT in the reference; default 0 = its behaviour): cached rows are trained
+        directly, and a populate decompresses every cache row anew from the cores -- what the cached copies learnt since the last
+        populate is dropped.  A dense row has no exact TT representation, so there is no inverse; with write_back = lr > 0 the
+        cores first take `write_back_steps` fused SGD steps of that size toward the cached rows (gradient of 1/2 ||TT row - cached row||^2
+        for every cached key, through the ordinary forward / backward contraction), which moves the TT rows toward what the cache
+        learnt -- an approximation (the cached keys share core slices: a few steps recover part of the difference, measured in
+        tests/test_module_cpu.py), off by default."""
+        if self.use_cache and write_back > 0.0 and not self.warmup:
+            self._write_back(write_back, write_back_steps)
         if self.use_cache:
             _engine.cache_populate(self.num_embeddings, self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks,
                                    list(self.tt_cores), self.L, self.hashtbl, self.cache_freq, self.cache_state,

@@ -276,6 +276,50 @@ def test_cache_life_cycle(ops):
     assert m.warmup and int((m.hashtbl >= 0).sum()) == 0
 
 
+def test_cache_write_back_moves_the_cores_toward_the_cached_rows(ops):
+    """SURVEY section 8(f3), last item: cache_populate(write_back=lr) (not in the reference; off by default) -- before the cache
+    rows are decompressed anew, the cores take one SGD step toward what the cached rows learnt.  The TT rows of the cached keys
+    must end up closer to the trained cache rows than they were; write_back=0 leaves the cores untouched (the reference)."""
+    p, q, r = [4, 5, 5], [2, 3, 2], [4, 5]
+    E_, D, B, Lp = 100, 12, 16, 4
+    torch.manual_seed(2)
+    m = ops.TTEmbeddingBag(E_, D, r, p, q, sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, use_cache=True, cache_size=20,
+                           hashtbl_size=256, weight_dist="uniform", device="cpu")
+    with torch.no_grad():
+        for c, src in zip(m.tt_cores, G.make_cores(7, 1, p, q, r, "signed")):
+            c.copy_(torch.from_numpy(src))
+    rs = np.random.RandomState(3)
+    off = torch.arange(0, B * Lp + 1, Lp)
+
+    def batch():
+        return torch.from_numpy((rs.zipf(1.3, size=B * Lp) % E_).astype(np.int64))
+
+    for _ in range(3):
+        m(batch(), off)
+    m.cache_populate()
+    for _ in range(4):  # steady state: hits train their cache rows
+        m(batch(), off).backward(torch.from_numpy((rs.rand(B, D) * 0.1).astype(np.float32)))
+    slots = torch.nonzero(m.cache_state >= 0).flatten()
+    keys = m.hashtbl[slots]
+    target = m.cache_weight.detach()[m.cache_state[slots].long()].clone()
+
+    def tt_rows():
+        full = ops.tt_matrix_to_full(m.tt_p_shapes, m.tt_q_shapes, m.tt_ranks, [c.detach() for c in m.tt_cores], [1, 0, 2, 3])
+        return full[keys]
+
+    before = float((tt_rows() - target).norm())
+    assert before > 1e-3, "the cached rows must have moved away from the cores (otherwise the case shows nothing)"
+    cores0 = [c.detach().clone() for c in m.tt_cores]
+    m.cache_populate()  # the reference's behaviour: cores untouched
+    assert all(torch.equal(a, b) for a, b in zip(cores0, m.tt_cores))
+    # (populate reset the cache rows to the TT rows: restore what they had learnt, then populate with the write-back)
+    with torch.no_grad():
+        m.cache_weight[m.cache_state[slots].long()] = target
+    m.cache_populate(write_back=2.0, write_back_steps=10)
+    after = float((tt_rows() - target).norm())
+    assert after < 0.8 * before, (before, after)  # (ten steps recover > 20 % of the distance here; one step 2 %)
+
+
 def test_mixed_cardinality_tables(ops):
     """tables of different cardinality behind one module (ttx_mixed): grouped by TT
     row shape, one table-batched lookup per group, DLRM call form (a tensor pair per table in, [B, D] per
