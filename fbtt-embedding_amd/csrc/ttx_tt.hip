@@ -931,16 +931,17 @@ static size_t rows_bytes(const Dims& d, long long nnz) { return align_up((size_t
 static int g_skip_launch = 0;  // ablation (ttx_debug_skip bits 9..11): results invalid when != 0
 
 static int run_rows_spec(SpecId id, const Plan& P, const CorePtrs& C, float* rows, float* zout,
-                         long long nzero, const PoolFuse& F, bool* fused, hipStream_t st) {
-#define CALLF(S) spec_launch_fwd<S>(P, C, rows, zout, nzero, F, fused, st)
+                         long long nzero, const PoolFuse& F, bool* fused, bool pad, const RealDims& R, hipStream_t st) {
+#define CALLF(S) spec_launch_fwd<S>(P, C, rows, zout, nzero, F, fused, pad, R, st)
   TTX_SPEC_DISPATCH(id, CALLF)
 #undef CALLF
   TTX_FAIL(TTX_EUNSUPPORTED, "no specialised forward kernel");
 }
 
 static int run_bwd_spec(SpecId id, const Dims& d, const Plan& P, const CorePtrs& C, int B,
-                        const int64_t* rowidx, const float* d_output, const Partials& PC, hipStream_t st) {
-#define CALLB(S) spec_launch_bwd<S>(d, P, C, B, rowidx, d_output, PC, st)
+                        const int64_t* rowidx, const float* d_output, const Partials& PC, bool pad, const RealDims& R,
+                        hipStream_t st) {
+#define CALLB(S) spec_launch_bwd<S>(d, P, C, B, rowidx, d_output, PC, pad, R, st)
   TTX_SPEC_DISPATCH(id, CALLB)
 #undef CALLB
   TTX_FAIL(TTX_EUNSUPPORTED, "no specialised backward kernel");
@@ -951,13 +952,14 @@ static int run_rows(const Dims& d, long long nnz, const Plan& P, const float* co
                     float* rows, float* zout, long long nzero, hipStream_t st, const PoolFuse* fuse = nullptr,
                     bool* fused = nullptr) {
   if (fused) *fused = false;
-  if (const SpecId id = spec_match(d)) {
+  bool pad = false;
+  if (const SpecId id = spec_match(d, &pad)) {
     CorePtrs C;
     for (int t = 0; t < TTX_MAX_CORES; ++t) C.c[t] = t < d.T ? (float*)cores[t] : nullptr;
     ProfScope ps(TTX_PROF_FWD, st);
-    bool did = fuse != nullptr && fuse->arrive != nullptr;
+    bool did = fuse != nullptr && fuse->arrive != nullptr && !pad;
     const PoolFuse none{};
-    const int rc = run_rows_spec(id, P, C, rows, zout, nzero, fuse ? *fuse : none, &did, st);
+    const int rc = run_rows_spec(id, P, C, rows, zout, nzero, fuse ? *fuse : none, &did, pad, real_dims(d), st);
     if (fused) *fused = did;
     return rc;
   }
@@ -989,6 +991,7 @@ int ttx_debug_stamps(void* device_buffer) {
 // ablation knob for scripts/ablate.py: skip kernel phases (results become invalid)
 int ttx_debug_skip(int32_t mask) {
   g_disable_spec = (mask & 256) ? 1 : 0;  // bit 8: force the generic kernels (A/B tests)
+  g_disable_pad = (mask & 32768) ? 1 : 0;  // bit 15: shape-specialised kernels for exact shapes only (A/B tests)
   g_skip_launch = (mask >> 9) & 63;       // bits 9..11: leave out the pooling launch / reduce_apply / reduce_apply's pivot slices (upper bounds); bit 12: no fused pooling (A/B)
   mask &= 255;
   g_debug_skip = mask;
@@ -1069,7 +1072,8 @@ int ttx_tt_forward_wr(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, cons
 
 int64_t ttx_tt_forward_arrive_ints(const ttx_geom* g, int64_t nnz) {
   Dims d;
-  if (make_dims(g, &d) != TTX_OK || nnz <= 0 || nnz > kPoolSpanMin || d.D % 4 != 0 || !spec_shape(d)) return 0;
+  bool pad = false;
+  if (make_dims(g, &d) != TTX_OK || nnz <= 0 || nnz > kPoolSpanMin || d.D % 4 != 0 || !spec_match(d, &pad) || pad) return 0;
   return nnz;
 }
 
@@ -1259,9 +1263,10 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
     S.c[t] = (t < d.T && optim == TTX_OPTIM_ADAGRAD) ? optimizer_state[t] : nullptr;
     DW.c[t] = (t < d.T && optim == TTX_OPTIM_DENSE) ? d_tt_cores[t] : nullptr;
   }
-  if (const SpecId id = spec_match(d)) {
+  bool pad = false;
+  if (const SpecId id = spec_match(d, &pad)) {
     ProfScope ps(TTX_PROF_BWD, st);
-    rc = run_bwd_spec(id, d, P, C, B, rowidx, d_output, PC, st);
+    rc = run_bwd_spec(id, d, P, C, B, rowidx, d_output, PC, pad, real_dims(d), st);
     if (rc) return rc;
   } else {
     Lds L;

@@ -34,12 +34,18 @@ def test_every_rank_the_reference_accepts_gets_a_tiling():
         T = len(q)
         p = [200, 220, 250, 7][:T]
         r = [1] + ranks + [1]
-        tiles = E.debug_tiles(1, p, q, r)
+        E.lib().ttx_debug_skip(256)  # (the generic kernels: r = 64 with q = [2,8,8] would also take a padded specialised one)
+        try:
+            tiles = E.debug_tiles(1, p, q, r)
+        finally:
+            E.lib().ttx_debug_skip(0)
         assert tiles["MC"] >= 1 and 0 < tiles["bytes"] <= 160 * 1024, (q, ranks, tiles)
         g = E._geom(1, p, q, r)
         assert E.lib().ttx_tt_backward_workspace_bytes(ctypes.byref(g), 512, int(np.prod(q)), 10240) > 0
-    # a specialised shape reports no walk
+    # a specialised shape reports no walk -- nor does one that a specialised kernel holds padded (ranks 13 / 12)
     assert E.debug_tiles(1, [200, 220, 250], [4, 4, 4], [1, 32, 32, 1])["MC"] == 0
+    assert E.debug_tiles(1, [7, 9, 11], [3, 4, 5], [1, 13, 12, 1])["MC"] == 0
+    assert E.debug_tiles(1, [7, 9, 11], [3, 4, 5], [1, 2, 2, 1])["MC"] > 0  # (less than an eighth of the template's work: generic)
 
 
 def test_abi_exports_every_declared_symbol():

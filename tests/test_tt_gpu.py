@@ -351,6 +351,7 @@ def test_block_walk_under_a_small_lds_budget(q, ranks, budget):
     r = [1] + ranks + [1]
     E_, D = int(np.prod(p)), int(np.prod(q))
     E.debug_lds_budget(budget * 1024)
+    E.lib().ttx_debug_skip(256)  # (some of these shapes would take a padded shape-specialised kernel: this is about the generic ones)
     try:
         tiles = E.debug_tiles(1, p, q, r)
         assert tiles["MC"] > 0 and tiles["ncp"] * tiles["nkb"] > 1 and tiles["bytes"] <= budget * 1024, tiles
@@ -361,6 +362,7 @@ def test_block_walk_under_a_small_lds_budget(q, ranks, budget):
             _check_modes(c, f"walk q={q} r={ranks} {tiles} tables={tables}")
     finally:
         E.debug_lds_budget(0)
+        E.lib().ttx_debug_skip(0)
 
 
 @pytest.mark.parametrize("q,ranks", [([4, 4, 4], [128, 128]), ([4, 4, 4], [96, 96]), ([4, 4, 4], [80, 80]), ([2, 8, 8], [64, 64]),
@@ -376,8 +378,16 @@ def test_large_rank_shapes(q, ranks):
     p = [6, 5, 7, 3][:T]
     r = [1] + ranks + [1]
     E_, D = int(np.prod(p)), int(np.prod(q))
-    tiles = E.debug_tiles(1, p, q, r)
-    assert tiles["MC"] > 0 and tiles["bytes"] <= 160 * 1024, tiles
+    E.lib().ttx_debug_skip(256)  # (r = 64 with q = [2,8,8] also fits a padded specialised kernel: the generic walk is meant here)
+    try:
+        tiles = E.debug_tiles(1, p, q, r)
+        assert tiles["MC"] > 0 and tiles["bytes"] <= 160 * 1024, tiles
+        _large_rank_cases(E, T, p, q, r, ranks, E_, D, tiles)
+    finally:
+        E.lib().ttx_debug_skip(0)
+
+
+def _large_rank_cases(E, T, p, q, r, ranks, E_, D, tiles):
     for tables, B, pf, std in ((1, 60, 4, 3), (2, 20, 3, 2)):
         idx, off = G.make_bags(31 + B, B, E_, pf, std, tables)
         c = dict(tables=tables, T=T, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
@@ -485,3 +495,44 @@ def test_pooling_fused_into_the_forward_kernel_is_bit_identical(ranks, q):
                        *E.preprocess_indices_sync(t(c["indices"]), t(c["offsets"]), 1, True, e0, e1)[1:3], [t(x) for x in c["cores"]],
                        offsets=t(c["offsets"]))
     assert_close(got.cpu().numpy(), oracle_case(c, "fwd")["out"], "fused pooling vs oracle")
+
+
+@pytest.mark.parametrize("q,ranks", [([3, 4, 5], [13, 12]), ([4, 4, 4], [13, 12]), ([4, 4, 4], [24, 24]), ([4, 4, 8], [48, 40]),
+                                      ([4, 4, 4], [8, 8]), ([1, 3, 4], [16, 16]), ([2, 3, 3], [20, 32]), ([4, 5, 7], [60, 40]),
+                                      ([3, 8, 8], [64, 50]), ([2, 2, 4], [12, 12]), ([4, 4, 4], [16, 32]), ([2, 8, 8], [64, 64])])
+def test_padded_shapes_run_on_the_specialised_kernels(q, ranks):
+    """Round 3: a T = 3 geometry with q0 <= 4, q1 <= 8, q2 <= 8 and ranks <= 64 that is NOT one of the fifteen exact shapes --
+    ranks that are not multiples of 16 (the reference tests' 13 / 12, tt_embeddings_test.py:65-70), factorings like [3, 4, 5] --
+    runs on the smallest shape-specialised kernel that holds it (PAD variants, csrc/ttx_tt_spec.inc: the global loads read zeros
+    outside the real extents, the stores skip them).  Against the oracle and against the generic kernels; forward, dense / SGD /
+    Adagrad; one and three tables, ragged bags, partial groups."""
+    import tt_embeddings as E
+
+    p = [6, 5, 7]
+    r = [1] + ranks + [1]
+    E_, D = int(np.prod(p)), int(np.prod(q))
+    assert E.debug_tiles(1, p, q, r)["MC"] == 0, "the geometry is expected to take a (padded) specialised kernel"
+    for tables, B, pf, std in ((1, 90, 3, 2), (3, 40, 5, 4), (1, 7, 1, 0)):
+        idx, off = G.make_bags(51 + B, B, E_, pf, std, tables)
+        c = dict(tables=tables, T=3, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+                 cores=G.make_cores(52 + B, tables, p, q, r, "signed"), d_out=G.make_grad(53, tables, B, D))
+        for mode in ("dense", "sgd", "adagrad"):
+            got = run_case(c, mode, plan_shared=True)
+            orc = oracle_case(c, mode)
+            E.lib().ttx_debug_skip(256)  # generic kernels
+            try:
+                gen = run_case(c, mode, plan_shared=False)
+            finally:
+                E.lib().ttx_debug_skip(0)
+            assert_close(got["out"], orc["out"], f"padded {ranks}{q} out vs oracle")
+            assert_close(got["out"], gen["out"], f"padded {ranks}{q} out vs generic")
+            gref = oracle_case(c, "dense")["grads"] if mode == "adagrad" else None
+            for k in range(3):
+                if mode == "dense":
+                    assert_close(got["grads"][k], orc["grads"][k], f"padded {ranks}{q} grad{k} vs oracle")
+                    assert_close(got["grads"][k], gen["grads"][k], f"padded {ranks}{q} grad{k} vs generic")
+                elif mode == "sgd":
+                    assert_close(got["cores"][k], orc["cores"][k], f"padded {ranks}{q} sgd core{k}")
+                else:
+                    assert_close(got["state"][k], orc["state"][k], f"padded {ranks}{q} state{k}")
+                    assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"padded {ranks}{q} adagrad core{k}")
