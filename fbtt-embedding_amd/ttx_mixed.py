@@ -60,7 +60,12 @@ class VarTableTTEmbeddingBag(TableBatchedTTEmbeddingBag):
                  tt_p_shapes: Optional[Sequence[Optional[List[int]]]] = None, tt_q_shapes: Optional[List[int]] = None,
                  optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
                  sparse: bool = True, weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
-                 device: Optional[torch.device] = None, include_last_offset: bool = True) -> None:
+                 device: Optional[torch.device] = None, include_last_offset: bool = True,
+                 table_ranks: Optional[Sequence[List[int]]] = None) -> None:
+        """`table_ranks` (one list per table, every entry <= the matching `tt_ranks` entry): tables of SMALLER TT ranks ride in the
+        same batched lookup -- table k is initialised as a table of its own ranks and its slices are stored zero-padded to the
+        common ranks.  The padding stays zero under the fused optimizers (every gradient term of a padded entry has a zero factor),
+        so table k keeps behaving as a rank-`table_ranks[k]` table; what it costs is the multiply-adds on the zeros."""
         nn.Module.__init__(self)
         self.include_last_offset = bool(include_last_offset)
         if device is None:
@@ -96,16 +101,21 @@ class VarTableTTEmbeddingBag(TableBatchedTTEmbeddingBag):
             self.tt_cores.append(nn.Parameter(torch.empty(shape, device=device, dtype=torch.float32)))
             self.optimizer_state.append(torch.zeros(shape if stateful else 0, device=device, dtype=torch.float32))
         # every table is initialised as a table of its own cardinality would be
+        self.table_ranks = None if table_ranks is None else [[1] + [int(x) for x in rk] + [1] for rk in table_ranks]
+        if self.table_ranks is not None:
+            assert len(self.table_ranks) == len(Es) and all(len(rk) == nd + 1 and all(a <= b for a, b in zip(rk, self.tt_ranks))
+                                                             for rk in self.table_ranks), "table_ranks: per table, <= tt_ranks"
         for k, e in enumerate(Es):
+            rk = self.tt_ranks if self.table_ranks is None else self.table_ranks[k]
             one = TableBatchedTTEmbeddingBag.__new__(TableBatchedTTEmbeddingBag)
             nn.Module.__init__(one)
             one.num_tables, one.tt_ndim, one.num_embeddings, one.embedding_dim = 1, nd, e, self.embedding_dim
-            one.tt_ranks, one.tt_p_shapes, one.tt_q_shapes = self.tt_ranks, ps[k], self.tt_q_shapes
-            one.tt_cores = [torch.empty((1, ps[k][t], self.tt_cores[t].shape[2]), device=device) for t in range(nd)]
+            one.tt_ranks, one.tt_p_shapes, one.tt_q_shapes = rk, ps[k], self.tt_q_shapes
+            one.tt_cores = [torch.empty((1, ps[k][t], rk[t] * self.tt_q_shapes[t] * rk[t + 1]), device=device) for t in range(nd)]
             TableBatchedTTEmbeddingBag.reset_parameters(one, weight_dist)
             with torch.no_grad():
                 for t in range(nd):
-                    self.table_rows(t)[k].copy_(one.tt_cores[t][0])
+                    self.set_table_core(k, t, one.tt_cores[t][0])
         self.use_cache = False
         self.register_buffer("hashtbl", torch.empty(0, device=device, dtype=torch.int64))
         self.register_buffer("cache_freq", torch.empty(0, device=device, dtype=torch.int64))
@@ -113,6 +123,26 @@ class VarTableTTEmbeddingBag(TableBatchedTTEmbeddingBag):
         self.cache_optimizer_state = None
         self.cache_weight = None
         self.warmup = True
+
+    def set_table_core(self, k: int, t: int, core: torch.Tensor) -> None:
+        """core t of table k from its natural shape [p_k_t, r_t q_t r_{t+1}] (the table's own ranks), zero-padded to the common ranks"""
+        rows = self.table_rows(t)[k]
+        if self.table_ranks is None:
+            rows.copy_(core.reshape(rows.shape))
+            return
+        R0, q, R1 = self.tt_ranks[t], self.tt_q_shapes[t], self.tt_ranks[t + 1]
+        r0, r1 = self.table_ranks[k][t], self.table_ranks[k][t + 1]
+        rows.zero_()
+        rows.view(-1, R0, q, R1)[:, :r0, :, :r1] = core.reshape(-1, r0, q, r1)
+
+    def table_core(self, k: int, t: int) -> torch.Tensor:
+        """core t of table k in its natural shape [p_k_t, r_t q_t r_{t+1}] (a copy when the table's ranks are padded)"""
+        rows = self.table_rows(t)[k]
+        if self.table_ranks is None:
+            return rows
+        R0, q, R1 = self.tt_ranks[t], self.tt_q_shapes[t], self.tt_ranks[t + 1]
+        r0, r1 = self.table_ranks[k][t], self.table_ranks[k][t + 1]
+        return rows.view(-1, R0, q, R1)[:, :r0, :, :r1].reshape(rows.shape[0], -1)
 
     def table_rows(self, t: int) -> List[torch.Tensor]:
         """views [p_k_t, slice] of core t, one per table"""
@@ -130,8 +160,10 @@ class MixedTTEmbeddingBag(nn.Module):
     Tables that can share a launch set share one module: `self.groups[k]` is the module of group k,
     `self.group_tables[k]` its table ids.
       fused=False: a group = tables of equal (p, q, ranks), a `TableBatchedTTEmbeddingBag`;
-      fused=True : a group = tables of equal (q, ranks) whatever their row factors p, a `VarTableTTEmbeddingBag` --
-                   tables that differ in q or ranks have slices of different sizes and stay separate launch sets.
+      fused=True : a group = tables of equal factoring q whatever their row factors p AND their ranks, a `VarTableTTEmbeddingBag`:
+                   ONE launch set per q -- tables of smaller ranks are stored zero-padded to the group's largest (exact: the padding
+                   stays zero under the fused optimizers; costs the multiply-adds on the zeros: done by default when that is at most
+                   twice the tables' own work, `pad_ranks=True / False` forces it / keeps one group per (q, ranks)).  Tables that differ in q produce output rows of different layouts: separate launch sets.
     `streams=True` gives every group a HIP stream of its own: eagerly the step is host-bound and nothing is gained, but
     captured into a hipGraph (ttx_graph.GraphedRound) the groups become parallel branches and their kernels -- each too
     small to fill the chip at DLRM batch sizes -- run side by side (scripts/bench_mixed.py).
@@ -144,7 +176,7 @@ class MixedTTEmbeddingBag(nn.Module):
                  optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
                  sparse: bool = True, weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
                  device: Optional[torch.device] = None, include_last_offset: bool = False,
-                 streams: bool = False, fused: bool = False) -> None:
+                 streams: bool = False, fused: bool = False, pad_ranks: Optional[bool] = None) -> None:
         super().__init__()
         self.num_embeddings = [int(e) for e in num_embeddings]
         n = len(self.num_embeddings)
@@ -164,18 +196,40 @@ class MixedTTEmbeddingBag(nn.Module):
             nd = len(ranks[k]) + 1
             given = tt_p_shapes[k] if tt_p_shapes is not None else None
             shapes.append(tuple(int(x) for x in given) if given is not None else tuple(suggested_tt_shapes(e, nd)))
+        if pad_ranks is None and fused:
+            # auto: one launch set per factoring when the zero padding costs at most twice the tables' own multiply-adds
+            # (measured, scripts/bench_mixed.py: ranks 32 / 16 in one set 0.278 vs 0.297 ms/step in two; ranks 64 / 32 / 16 /
+            # [13,12] in one set 0.72 vs 0.43 in four)
+            def madds(rk, q):
+                return sum(rk[i] * q[i] * rk[i + 1] for i in range(len(q)))
+            pad_ranks = True
+            by_q: Dict[tuple, List[int]] = {}
+            for k in range(n):
+                by_q.setdefault((len(ranks[k]), None if qs[k] is None else tuple(qs[k])), []).append(k)
+            for tabs in by_q.values():
+                qq = qs[tabs[0]] or suggested_tt_shapes(self.embedding_dim, len(ranks[tabs[0]]) + 1, allow_round_up=not enforce_embedding_dim)
+                rmax = [max(ranks[k][i] for k in tabs) for i in range(len(ranks[tabs[0]]))]
+                real = sum(madds([1] + ranks[k] + [1], qq) for k in tabs)
+                if madds([1] + rmax + [1], qq) * len(tabs) > 2 * real:
+                    pad_ranks = False
         groups: Dict[tuple, List[int]] = {}
         for k in range(n):
-            key = (tuple(ranks[k]), None if qs[k] is None else tuple(qs[k])) + (() if fused else (shapes[k],))
+            # fused: tables of one factoring q share a batched lookup whatever their ranks (smaller ranks are zero-padded to the
+            # group's largest, VarTableTTEmbeddingBag(table_ranks=)); pad_ranks=False keeps one group per (q, ranks)
+            key = ((len(ranks[k]),) if fused and pad_ranks else (tuple(ranks[k]),)) + (None if qs[k] is None else tuple(qs[k]),) + \
+                  (() if fused else (shapes[k],))
             groups.setdefault(key, []).append(k)
         self.group_tables = list(groups.values())
         self.groups = nn.ModuleList()
         for tables in self.group_tables:
             k0 = tables[0]
             if fused:  # ONE batched lookup for the group's tables, whatever their row factors (VarTableTTEmbeddingBag)
+                rmax = [max(ranks[k][i] for k in tables) for i in range(len(ranks[k0]))]
+                mixed_ranks = any(ranks[k] != rmax for k in tables)
                 self.groups.append(VarTableTTEmbeddingBag(
-                    [self.num_embeddings[k] for k in tables], self.embedding_dim, list(ranks[k0]), [list(shapes[k]) for k in tables],
-                    qs[k0], optimizer, learning_rate, eps, sparse, weight_dist, enforce_embedding_dim, device, True))
+                    [self.num_embeddings[k] for k in tables], self.embedding_dim, rmax, [list(shapes[k]) for k in tables],
+                    qs[k0], optimizer, learning_rate, eps, sparse, weight_dist, enforce_embedding_dim, device, True,
+                    [ranks[k] for k in tables] if mixed_ranks else None))
             else:
                 self.groups.append(TableBatchedTTEmbeddingBag(
                     len(tables), max(self.num_embeddings[k] for k in tables), self.embedding_dim, list(ranks[k0]),

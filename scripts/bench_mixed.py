@@ -52,8 +52,8 @@ def launches(fn):
     import tt_embeddings as E
     E.profile_reset(); E.profile_enable(0x3F); fn(); torch.cuda.synchronize(); E.profile_enable(0)
     return sum(E.profile_read(w)[0] for w in range(6))
-for streams in (False, True):
-    m2 = ttx_mixed.MixedTTEmbeddingBag(Es, D, ranks2, ps, q, include_last_offset=False, streams=streams, fused=True, **kw)
+for streams, pad in ((False, False), (True, False), (False, True)):
+    m2 = ttx_mixed.MixedTTEmbeddingBag(Es, D, ranks2, ps, q, include_last_offset=False, streams=streams, fused=True, pad_ranks=pad, **kw)
     def step2(idx, off):
         torch.autograd.backward(m2(idx, off), grads)
     ms = timeit(step2)
@@ -63,5 +63,20 @@ for streams in (False, True):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): r2.replay()
     torch.cuda.synchronize()
-    print(f"mixed ranks ({len(m2.groups)} shape groups, {n_l} kernel launches per step), streams={streams!s:5}: eager {ms:.3f} ms/step, "
+    print(f"mixed ranks ({len(m2.groups)} launch sets, {n_l} kernel launches per step), streams={streams!s:5} pad_ranks={pad!s:5}: eager {ms:.3f} ms/step, "
+          f"hipGraph round {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step")
+# the same with ranks 32 / 16 only (padding 16 -> 32 costs 4x the multiply-adds of the small tables, not 16x)
+ranks3 = [[32, 32], [16, 16]] * 4
+for pad in (False, True):
+    m3 = ttx_mixed.MixedTTEmbeddingBag(Es, D, ranks3, ps, q, include_last_offset=False, fused=True, pad_ranks=pad, **kw)
+    def step3(idx, off):
+        torch.autograd.backward(m3(idx, off), grads)
+    ms = timeit(step3)
+    n_l = launches(lambda: step3(*reqs[0]))
+    r3 = ttx_graph.GraphedRound(step3, reqs, warmup=2)
+    for _ in range(3): r3.replay()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): r3.replay()
+    torch.cuda.synchronize()
+    print(f"ranks 32 / 16 ({len(m3.groups)} launch sets, {n_l} kernel launches per step), pad_ranks={pad!s:5}: eager {ms:.3f} ms/step, "
           f"hipGraph round {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step")

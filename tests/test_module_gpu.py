@@ -442,14 +442,16 @@ def test_mixed_ranks_one_graph(node, fused):
     ranks = [[32, 32], [16, 16], [32, 32], [13, 12], [16, 16], [16, 16]]
     qs = [[4, 4, 4], [4, 4, 4], [4, 4, 4], [4, 4, 4], [4, 4, 4], [2, 4, 8]]
     kw = dict(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, weight_dist="uniform", device=DEV)
-    mm = ttx_mixed.MixedTTEmbeddingBag(Es, D, ranks, ps, qs, include_last_offset=False, streams=True, fused=fused, **kw)
-    assert len(mm.groups) == 4 and sorted(sum(mm.group_tables, [])) == list(range(6))
+    mm = ttx_mixed.MixedTTEmbeddingBag(Es, D, ranks, ps, qs, include_last_offset=False, streams=True, fused=fused, pad_ranks=True, **kw)
+    # fused: ONE batched lookup per factoring q -- the five q = [4,4,4] tables of ranks 32 / 16 / [13,12] ride together, the smaller
+    # ranks zero-padded to 32 -- and one for q = [2,4,8]; not fused: a group per (p, q, ranks)
+    assert len(mm.groups) == (2 if fused else 4) and sorted(sum(mm.group_tables, [])) == list(range(6))
     ones = []
     for k in range(len(Es)):
         g = next(i for i, tb in enumerate(mm.group_tables) if k in tb)
         j = mm.group_tables[g].index(k)
         one = ops.TTEmbeddingBag(Es[k], D, ranks[k], ps[k], qs[k], use_cache=False, include_last_offset=False, **kw)
-        rows = [mm.groups[g].table_rows(c)[j] for c in range(3)] if fused else [mm.groups[g].tt_cores[c][j] for c in range(3)]
+        rows = [mm.groups[g].table_core(j, c) for c in range(3)] if fused else [mm.groups[g].tt_cores[c][j] for c in range(3)]
         with torch.no_grad():
             for dst, src in zip(one.tt_cores, rows):
                 dst.copy_(src.reshape(dst.shape))
@@ -471,7 +473,7 @@ def test_mixed_ranks_one_graph(node, fused):
     torch.cuda.synchronize()
     for k, (one, g, j) in enumerate(ones):
         for c in range(3):
-            got = mm.groups[g].table_rows(c)[j] if fused else mm.groups[g].tt_cores[c][j].detach()
+            got = mm.groups[g].table_core(j, c) if fused else mm.groups[g].tt_cores[c][j].detach()
             assert_close(got.cpu().numpy().reshape(one.tt_cores[c].shape), one.tt_cores[c].detach().cpu().numpy(),
                          f"table {k} core{c} after the captured round")
 
