@@ -574,6 +574,20 @@ def main():
                                              "frac": round(gbs / (PEAK_HBM_TBS * 1e3), 4), "cached_lookups_per_launch": round(cached),
                                              "bytes_per_launch": round(bytes_), "avg_us": breakdown["cache_gather_us"],
                                              "timed_by": "HIP events around each launch (includes launch gap); rocprof figures: profiles/"}
+            # the same kernel as rocprofv3 --kernel-trace --stats timed it on THIS build (scripts/kprof.sh -> profiles/rocprof_kernels.json)
+            rk = os.path.join(ROOT, "profiles", "rocprof_kernels.json")
+            try:
+                j = json.load(open(rk))
+                ks = j["workloads"].get(args.workload, {}) if j.get("source_hash") == source_hash() else {}
+                us = next((v["avg_us"] for k, v in ks.items() if k.startswith("cache_forward")), None)
+            except Exception:  # noqa: BLE001
+                us = None
+            if us:
+                g2 = bytes_ / (us * 1e-6) / 1e9
+                line["cache_gather_roofline"].update({"rocprof_avg_us": us, "achieved_rocprof": round(g2, 1),
+                                                      "frac_rocprof": round(g2 / (PEAK_HBM_TBS * 1e3), 4)})
+            else:
+                line["cache_gather_roofline"]["rocprof_avg_us"] = None
         if not sharded and not args.no_cpu_baseline and ntab == 1:
             line["cpu_baseline"] = cpu_baseline(reqs_np, cores_np, d_out_np, Q_SHAPES, RANKS, B_GLOBAL)
         if args.run_baseline and not sharded and ntab == 1:

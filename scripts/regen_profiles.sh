@@ -7,6 +7,7 @@
 #   pmc_bwd_bytes.json          backward contraction: HBM bytes per launch + rocprof duration, stamped with the source hash
 #   <tag>_sq_pmc.md             SQ counters (MFMA busy, waits, LDS) of the cfg2 kernels
 #   <tag>_other_workloads.md    rocprofv3 per-kernel durations of the other workloads (cfg3, cfg3warm, cfg4, cfg5shard, dims, generic)
+#   rocprof_kernels.json        the same durations as data, stamped with the source hash (bench.py --workload cfg3 reads it)
 #   <tag>_cache_bandwidth.md    cache-path kernels: durations and GB/s on the algorithmic bytes
 set -u
 TAG=${1:-r03}
@@ -18,6 +19,7 @@ cp gpurun_out/prof_$TAG/${TAG}_kernel_stats.md gpurun_out/prof_$TAG/pmc_bwd_byte
   echo '```'; scripts/pmc_sq.sh "$TAG" 2>&1 | tail -60; echo '```'; } > "$OUT/${TAG}_sq_pmc.md"
 { echo "# $TAG: rocprofv3 --kernel-trace --stats per-kernel durations of the other workloads (eager launches, 30 steps; MI355X)"; echo;
   scripts/kprof.sh "$TAG" cfg3 cfg3warm cfg4 cfg5shard tb4 d32 d16 d256 r128 r13 2>&1; } > "$OUT/${TAG}_other_workloads.md"
+cp gpurun_out/kprof_$TAG/rocprof_kernels.json "$OUT/" 2>/dev/null
 for W in cfg3 cfg3warm cfg4 cfg5shard r128 r13; do
   python bench.py --workload $W --steps 100 --repeats 3 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_$W.json"
 done
