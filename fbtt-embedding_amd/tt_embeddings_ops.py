@@ -81,6 +81,11 @@ class OptimType(Enum):
 
 
 _SGD_LIKE = (OptimType.SGD, OptimType.EXACT_SGD)  # everything else -> Adagrad kernel (:221,:248)
+# dedup="auto" policy (measured crossover): the map + pre-sum + gather pooling cost about a quarter of the plain
+# step at 327k lookups, so sharing pays below ~0.7 distinct pairs per lookup; 0.6 leaves a margin
+_DEDUP_AUTO_MIN_NNZ = int(os.environ.get("TTX_DEDUP_AUTO_MIN_NNZ", 65536))
+_DEDUP_AUTO_MAX_DISTINCT = 0.6
+_DEDUP_AUTO_PERIOD = 256
 
 
 class BufferList(nn.Module):
@@ -300,9 +305,14 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         super().__init__()
         # dedup (not in the reference): lookups of a batch that repeat a (table, row) pair share ONE contraction,
         # forward and backward (include/ttx.h "duplicate lookups").  Same results; pays on skewed index streams
-        # while the row cache is not live, costs two extra launches on uniform ones.  Batches the map does not
-        # take (> 16384 lookups, key space > 2^32) run the plain path.
-        self.dedup = bool(dedup)
+        # while the row cache is not live, costs the key sort and two extra launches on uniform ones.
+        # dedup="auto": the module decides per batch -- sharing runs only at batches of >= _DEDUP_AUTO_MIN_NNZ lookups
+        # (below that every kernel of the plain step sits at its launch floor: sharing cannot pay) and only
+        # while the stream's last sampled batch had <= _DEDUP_AUTO_MAX_DISTINCT distinct pairs per lookup; the sample is
+        # the shared path itself (its map holds the distinct count; one read-back every _DEDUP_AUTO_PERIOD batches, never
+        # under stream capture).
+        self.dedup = "auto" if dedup == "auto" else bool(dedup)
+        self._dd_auto = [False, 0]  # [sharing on, batches until the next sample]
         # nn.EmbeddingBag call form: False = offsets hold only the bag starts (PyTorch's default,
         # what DLRM passes); True = the reference's form, num_tables*B + 1 entries (:851)
         self.include_last_offset = bool(include_last_offset)
@@ -511,7 +521,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         and events only; captures into a hipGraph as a forked branch.  Returns False (and does nothing) whenever the
         overlap does not apply: cache live, no C++ node, CPU tensors, empty batch, duplicate sharing."""
         fast = _native_node()
-        if (fast is None or not self.warmup or not indices.is_cuda or indices.numel() == 0 or getattr(self, "dedup", False)
+        if (fast is None or not self.warmup or not indices.is_cuda or indices.numel() == 0 or self._dedup_may_share(indices.numel())
                 or indices.dim() != 1 or offsets.dim() != 1):
             return False
         key = (id(indices), id(offsets))  # (identity: the entry keeps both objects alive, so neither id nor memory is reused)
@@ -550,7 +560,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         fast = _native_node()
         batches = list(batches)
         live = not self.warmup
-        if fast is None or not batches or getattr(self, "dedup", False) or (live and not (self.use_cache and self.num_tables == 1)):
+        if fast is None or not batches or self._dedup_may_share(batches[0][0].numel()) or (live and not (self.use_cache and self.num_tables == 1)):
             return False
         norm, keys = [], []
         for indices, offsets in batches:
@@ -642,6 +652,20 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         return pre
 
     # --------------------------------------------------------------- forward
+    def _dedup_may_share(self, nnz: int) -> bool:
+        d = getattr(self, "dedup", False)
+        return bool(d) and (d != "auto" or nnz >= _DEDUP_AUTO_MIN_NNZ)
+
+    def _dedup_auto(self, nnz: int):
+        """dedup="auto": (share this batch?, sample its distinct fraction?)."""
+        if nnz < _DEDUP_AUTO_MIN_NNZ:
+            return False, False
+        st = self.__dict__.setdefault("_dd_auto", [False, 0])
+        if st[1] <= 0 and not torch.cuda.is_current_stream_capturing():
+            return True, True
+        st[1] -= 1
+        return st[0], False
+
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True,
                 per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
         """-> [num_tables, B, D].  (`warmup` is ignored like in the reference,
@@ -682,8 +706,12 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             raise ValueError(f"offsets must describe num_tables * B bags, got {offsets.numel() - 1} bags for "
                              f"{self.num_tables} tables")
         fast = _native_node()
-        if getattr(self, "dedup", False) and self.warmup and indices.is_cuda and indices.numel() > 0 and per_sample_weights is None \
-                and getattr(_engine, "DedupPlan", None) is not None:
+        share = getattr(self, "dedup", False) and self.warmup and indices.is_cuda and indices.numel() > 0 \
+            and per_sample_weights is None and getattr(_engine, "DedupPlan", None) is not None
+        sample = False
+        if share and self.dedup == "auto":
+            share, sample = self._dedup_auto(indices.numel())
+        if share:
             # duplicate lookups share their contraction: frequency update + bag rows as usual, then the map and the
             # plan of the distinct pairs (one work-group sorts the batch's keys), through the reference-shaped route
             indices, rowidx, tableidx, n_tt, cache_locations = _engine.preprocess_indices_sync(
@@ -691,6 +719,11 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                 *((self.cache_freq,) if self.use_cache else ()))
             rowidx._ttx_plan = _engine.make_plan(self.num_tables, self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks,
                                                  n_tt, indices, tableidx, rowidx, dedup=True)
+            if sample:  # the map's header holds the number of distinct pairs (one read-back per sampling period)
+                dd = getattr(rowidx._ttx_plan, "dd", None)
+                frac = float(dd[:4].view(torch.int32).item()) / max(n_tt, 1) if dd is not None else 1.0
+                self._dd_auto = [frac <= _DEDUP_AUTO_MAX_DISTINCT, _DEDUP_AUTO_PERIOD]
+                self._dd_auto_last = frac
             return TTLookupFunction.apply(
                 (offsets.numel() - 1) // self.num_tables, self.embedding_dim, self.tt_p_shapes, self.tt_q_shapes,
                 self.tt_ranks, self.L, n_tt, 0, indices, rowidx, tableidx, self.optimizer, self.learning_rate,

@@ -210,3 +210,54 @@ def test_module_with_dedup_tracks_the_plain_module(route, monkeypatch):
                      rtol=1e-4, atol_scale=2e-5)
     fa, fb = a.cache_freq.cpu().numpy(), b.cache_freq.cpu().numpy()
     assert int(fa.sum()) == int(fb.sum()) == 4 * B * Lp or abs(int(fa.sum()) - int(fb.sum())) < 8
+
+
+def test_dedup_auto_follows_the_streams_duplicate_share(monkeypatch):
+    """dedup="auto": small batches never share; at large batches the module samples the distinct fraction from the
+    shared path's own map and keeps sharing on a skewed stream, drops it on a uniform one -- the outputs equal the plain
+    module's bit for bit either way (identical cores: no backward in between)."""
+    import tt_embeddings_ops as ops
+
+    monkeypatch.setattr(ops, "_DEDUP_AUTO_MIN_NNZ", 20000)
+    monkeypatch.setattr(ops, "_DEDUP_AUTO_PERIOD", 3)
+    p, q, r = [200, 220, 250], [4, 4, 4], [16, 16]
+    E_, D = 11_000_000, 64
+    kw = dict(num_embeddings=E_, embedding_dim=D, tt_ranks=r, tt_p_shapes=p, tt_q_shapes=q, weight_dist="uniform", device=DEV,
+              sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05)
+    torch.manual_seed(5)
+    a = ops.TTEmbeddingBag(dedup="auto", **kw)
+    b = ops.TTEmbeddingBag(**kw)
+    with torch.no_grad():
+        for x, y in zip(b.tt_cores, a.tt_cores):
+            x.copy_(y)
+    rs = np.random.RandomState(6)
+
+    def batch(B, Lp, zipf):
+        off = t(np.arange(0, B * Lp + 1, Lp, dtype=np.int64))
+        raw = rs.zipf(1.2, size=B * Lp) if zipf else rs.randint(0, E_, size=B * Lp)
+        return t(raw.astype(np.int64) % E_), off
+
+    with torch.no_grad():
+        idx, off = batch(256, 20, True)  # 5120 lookups: below the threshold
+        assert torch.equal(a(idx, off), b(idx, off)) and a._dd_auto == [False, 0]
+        idx, off = batch(1536, 20, True)  # 30720 lookups, skewed: sampled, sharing stays on
+        assert torch.equal(a(idx, off), b(idx, off))
+        assert a._dd_auto == [True, 3] and a._dd_auto_last < 0.6
+        for _ in range(3):
+            idx, off = batch(1536, 20, True)
+            assert torch.equal(a(idx, off), b(idx, off))
+        assert a._dd_auto == [True, 0]
+        idx, off = batch(1536, 20, False)  # uniform stream: the next sample turns sharing off
+        assert torch.equal(a(idx, off), b(idx, off))
+        assert a._dd_auto == [False, 3] and a._dd_auto_last > 0.95
+        idx, off = batch(1536, 20, False)
+        assert torch.equal(a(idx, off), b(idx, off)) and a._dd_auto == [False, 2]
+    # and a training step through the shared path of an auto module
+    a._dd_auto = [False, 0]
+    idx, off = batch(1536, 20, True)
+    oa, ob = a(idx, off), b(idx, off)
+    g = t((rs.rand(1536, D) * 0.1).astype(np.float32))
+    oa.backward(g)
+    ob.backward(g)
+    for k in range(3):
+        assert_close(a.tt_cores[k].detach().cpu().numpy(), b.tt_cores[k].detach().cpu().numpy(), f"core{k}", rtol=1e-4, atol_scale=2e-5)

@@ -55,13 +55,16 @@ def test_plan_kernel_keeps_its_arguments_out_of_scratch(plan_res):
 
 def test_contraction_and_reduce_kernels_budget(tt_res):
     cfg2 = "Shape3ILi32ELi4ELi32ELi4ELi2ELi16ELi4EEELb0"  # (.., passes 2, chunk 16, q0 4), one sub-chunk
-    fwd, bwd = pick(tt_res, "spec_fwd_kernel", cfg2 + "ELb0E"), pick(tt_res, "spec_bwd_kernel", cfg2)  # (ELb0E: pooling not fused)
-    fused = pick(tt_res, "spec_fwd_kernel", cfg2 + "ELb1E")  # ... the variant that pools the bags itself (ttx_tt_forward_o)
+    # template flags after the shape: forward <MULTI, FUSE (pooling fused), PAD (padded shape)>, backward <MULTI, PAD>
+    fwd, bwd = pick(tt_res, "spec_fwd_kernel", cfg2 + "ELb0ELb0E"), pick(tt_res, "spec_bwd_kernel", cfg2 + "ELb0E")
+    fused = pick(tt_res, "spec_fwd_kernel", cfg2 + "ELb1ELb0E")  # ... the variant that pools the bags itself (ttx_tt_forward_o)
+    padf, padb = pick(tt_res, "spec_fwd_kernel", cfg2 + "ELb0ELb1E"), pick(tt_res, "spec_bwd_kernel", cfg2 + "ELb1E")
+    assert padf["ScratchSize"] == 0 and padb["ScratchSize"] == 0 and padb["VGPRs"] <= 128, (padf, padb)
     assert fwd["ScratchSize"] == 0 and bwd["ScratchSize"] == 0 and fused["ScratchSize"] == 0, (fwd, bwd, fused)
     assert fused["VGPRs"] <= 128, fused
     assert bwd["VGPRs"] <= 104, bwd  # four 256-thread work-groups per CU need <= 128; round 2 shipped 98
     d32 = "Shape3ILi32ELi4ELi32ELi4ELi2ELi32ELi2EEELb0"   # q0 = 2 (a select between a lane's two lookups once went to scratch)
-    for k, d32k in (("spec_fwd_kernel", d32 + "ELb0E"), ("spec_bwd_kernel", d32)):
+    for k, d32k in (("spec_fwd_kernel", d32 + "ELb0ELb0E"), ("spec_bwd_kernel", d32 + "ELb0E")):
         r = pick(tt_res, k, d32k)
         assert r["ScratchSize"] == 0 and r["VGPRs"] <= 128, (k, r)
     red = pick(tt_res, "reduce_apply_kernel")
