@@ -1520,9 +1520,6 @@ static unsigned long long dedup_key_space64(const Dims& d) {
 }
 
 bool dedup_supported(const Dims& d, long long nnz) {
-  // (the gradient pre-sum keeps 64 groups x D floats of part sums + 8 KB in LDS: gsum_kernel, ttx_tt.hip -- a wider
-  //  embedding takes the plain path, which gives the same results)
-  if ((size_t)64 * d.D * sizeof(float) + 8192 > (size_t)160 * 1024) return false;
   if (nnz <= 0 || nnz >= (1ll << 31)) return false;
   if (nnz <= kDedupMaxN && dedup_key_space(d) != 0) return true;   // one work-group sorts the batch in LDS
   return dedup_key_space64(d) != 0;                                // multi-work-group 64-bit key sort

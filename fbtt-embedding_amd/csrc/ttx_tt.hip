@@ -414,94 +414,184 @@ __global__ __launch_bounds__(kThreads) void pool_gather4_kernel(int N, int B, in
   }
 }
 
-// Gu[u, :] = sum over the occurrences n of distinct pair u, in index order, of (psw[n] *) d_output[table(n), row(n), :].
-// A 1024-thread work-group = 64 groups of 16 lanes.  Pairs with fewer than kGsumCoop occurrences are summed by one
-// group each (work-group b takes pairs [64 b, 64 b + 64)); a pair hit more often -- a hot row of a skewed stream takes
-// a sixth of the batch -- is summed by ALL 64 groups of one work-group, group g taking the g-th part of its occurrence
-// list, the part sums folded in group order through LDS: a fixed order either way, deterministic.  Hot pairs are
-// dealt round-robin over the work-groups (the map orders pairs by key, so a Zipf stream's hot rows 1, 2, 3, .. are
-// neighbours: pair u goes to work-group u % gridDim).  A group's lanes fetch 16 occurrences' bag rows at once and
-// keep 16 gradient-row loads in flight.
-constexpr int kGsumCoop = 16;
-constexpr int kGsumThreads = 1024;
-constexpr int kGsumGroups = kGsumThreads / 16;
+// Gu[u, :] = sum over the occurrences n of distinct pair u of (psw[n] *) d_output[table(n), row(n), :], in a fixed order.
+// The map lists the occurrences sorted by pair (occ[], a pair's in index order).  That list is cut into SLICES of
+// kGsSlice positions, whatever pairs they belong to: gsum_slice_kernel gives every slice to one 16-lane group, which
+// fetches its gradient rows (16 in flight, the index chain occ -> bag row paid once per slice) and adds them in
+// order; a pair whose run lies inside the slice is finished and stored, the part of a run that began in an earlier slice
+// goes to P[slice][0], the part of a run that continues into the next one to P[slice][1].  gsum_fold_kernel then
+// finishes the pairs that span slices: the group of the slice a run ENDS in adds P[first][1], .., P[last - 1][1], P[last][0]
+// in slice order.  Every group does the same amount of work whatever the skew -- on a Zipf stream 70 % of the
+// occurrences belong to pairs hit 16+ times, which the former one-owner-per-pair kernel summed with a work-group each,
+// one after the other -- and the order of addition is fixed by the sort: deterministic.  Slice length measured at 2.1 M /
+// 327k lookups (Zipf 1.2): 128 -> 208 / 73 us, 64 -> 152 / 46, 32 -> 127 / 28 (the fold grows the other way: 13 / 29 / 57 us
+// before long runs were folded by the whole work-group, 17 / 7 us with it); the one-owner kernel took 427 / 115 us.
+constexpr int kGsSlice = 32;
+constexpr int kGsRounds = kGsSlice / 16;
+constexpr int kGsThreads = 256;
+__device__ __forceinline__ long long shfl64(long long v, int j) {
+  return ((long long)__shfl((int)(v >> 32), j, 16) << 32) | (unsigned)__shfl((int)v, j, 16);
+}
 template <typename V>
-__device__ __forceinline__ void gsum_group(int lo, int hi, int B, int DV, const int* __restrict__ occ,
-                                           const int64_t* __restrict__ rowidx, const int64_t* __restrict__ tableidx,
-                                           const float* __restrict__ psw, const V* __restrict__ dout, V* dst) {
+__global__ __launch_bounds__(kGsThreads) void gsum_slice_kernel(DedupMap M, int N, int B, int DV, const int64_t* __restrict__ rowidx,
+                                                               const int64_t* __restrict__ tableidx,
+                                                               const float* __restrict__ psw, const V* __restrict__ dout,
+                                                               V* __restrict__ Gu, V* __restrict__ P) {
   const int l = threadIdx.x & 15;
+  const int s = blockIdx.x * (kGsThreads / 16) + threadIdx.x / 16;
+  const int k0 = s * kGsSlice;
+  if (k0 >= N) return;  // (no barrier below)
+  const int kend = min(N, k0 + kGsSlice);
+  int n[kGsRounds];
+#pragma unroll
+  for (int r = 0; r < kGsRounds; ++r) {
+    const int k = k0 + 16 * r + l;
+    n[r] = k < kend ? M.occ[k] : -1;
+  }
+  const int nprev = k0 > 0 ? M.occ[k0 - 1] : -1, nnext = kend < N ? M.occ[kend] : -1;
+  long long off[kGsRounds];
+  float w[kGsRounds];
+  int up[kGsRounds];
+#pragma unroll
+  for (int r = 0; r < kGsRounds; ++r) {
+    off[r] = 0, w[r] = 1.f, up[r] = -1;
+    if (n[r] >= 0) {
+      off[r] = (long long)tableidx[n[r]] * B + rowidx[n[r]];  // (64-bit: tables * B may exceed 2^31)
+      up[r] = M.uid[n[r]];
+      if (psw) w[r] = psw[n[r]];
+    }
+  }
+  const int uprev = nprev >= 0 ? M.uid[nprev] : -1, unext = nnext >= 0 ? M.uid[nnext] : -2;
+  unsigned last = 0;  // bit r: position (r, l) is the last of its pair's run
+#pragma unroll
+  for (int r = 0; r < kGsRounds; ++r) {
+    int nx = __shfl_down(up[r], 1, 16);
+    const int first_of_next = r + 1 < kGsRounds ? __shfl(up[r + 1 < kGsRounds ? r + 1 : r], 0, 16) : unext;
+    if (l == 15) nx = first_of_next;
+    if (k0 + 16 * r + l + 1 >= kend) nx = unext;
+    if (nx != up[r]) last |= 1u << r;
+  }
+  const bool began_before = __shfl(up[0], 0, 16) == uprev;
+  V* Ps = P + (size_t)s * 2 * DV;
   for (int eb = 0; eb < DV; eb += 16) {
     const int e = eb + l;
     const bool ev = e < DV;
     V acc;
     vzero(acc);
-    for (int base = lo; base < hi; base += 16) {
-      const int k = base + l;
-      long long off = 0;  // bag of the occurrence: table * B + row (64-bit: tables * B may exceed 2^31)
-      float w = 1.f;
-      if (k < hi) {
-        const int n = occ[k];
-        off = (long long)tableidx[n] * B + rowidx[n];
-        if (psw) w = psw[n];
-      }
-      const int cnt = min(16, hi - base);
+    bool head = began_before, open = false;
+#pragma unroll
+    for (int r = 0; r < kGsRounds; ++r) {
+      const int cnt = min(16, kend - (k0 + 16 * r));
+      if (cnt <= 0) break;
       V v[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const long long oq = ((long long)__shfl((int)(off >> 32), q, 16) << 32) | (unsigned)__shfl((int)off, q, 16);
-        if (q < cnt && ev) v[q] = dout[(size_t)oq * DV + e];
+      for (int j = 0; j < 16; ++j) {
+        const long long oj = shfl64(off[r], j);
+        if (j < cnt && ev) v[j] = dout[(size_t)oj * DV + e];
       }
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float wq = __shfl(w, q, 16);
-        if (q < cnt && ev) {
-          if (psw) vfma(acc, wq, v[q]);
-          else vadd(acc, v[q]);
+      for (int j = 0; j < 16; ++j) {
+        const float wj = __shfl(w[r], j, 16);
+        const int uj = __shfl(up[r], j, 16);
+        const bool lj = (__shfl((int)last, j, 16) >> r) & 1;
+        if (j < cnt) {
+          if (ev) {
+            if (psw) vfma(acc, wj, v[j]);
+            else vadd(acc, v[j]);
+          }
+          open = true;
+          if (lj) {
+            if (ev) {
+              if (head) Ps[e] = acc;
+              else Gu[(size_t)uj * DV + e] = acc;
+            }
+            vzero(acc);
+            head = false, open = false;
+          }
         }
       }
     }
-    if (ev) dst[e] = acc;
+    if (open && ev) Ps[DV + e] = acc;
   }
 }
 
+// partials [a, b) of the run that began in slice sf and ends in slice s (partial i: P[sf + i][1], the last one P[s][0]),
+// column e, added in order, 16 loads in flight
 template <typename V>
-__global__ __launch_bounds__(kGsumThreads) void gsum_kernel(DedupMap M, int B, int DV, const int64_t* __restrict__ rowidx,
-                                                           const int64_t* __restrict__ tableidx,
-                                                           const float* __restrict__ psw, const V* __restrict__ dout,
-                                                           V* __restrict__ Gu) {
-  extern __shared__ __attribute__((aligned(16))) float gs_lds[];
-  __shared__ int hot[kDedupMaxN / kGsumCoop], nhot;
-  V* part = (V*)gs_lds;  // [kGsumGroups][DV]
-  const int nu = M.nu[0];
-  const int g = threadIdx.x / 16;
-  if (threadIdx.x == 0) nhot = 0;
-  __syncthreads();
-  {  // this work-group's hot pairs: u = b, b + G, b + 2G, .. (one test per thread)
-    for (int u = blockIdx.x + threadIdx.x * gridDim.x; u < nu; u += kGsumThreads * gridDim.x)
-      if (M.occ_off[u + 1] - M.occ_off[u] >= kGsumCoop) hot[atomicAdd(&nhot, 1)] = u;
+__device__ __forceinline__ V fold_partials(const V* __restrict__ P, int sf, int s, int a, int b, int DV, int e, bool ev) {
+  V acc;
+  vzero(acc);
+  for (int base = a; base < b; base += 16) {
+    const int c = min(16, b - base);
+    V v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int t = sf + base + j;
+      if (j < c && ev) v[j] = P[((size_t)t * 2 + (t == s ? 0 : 1)) * DV + e];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < c && ev) vadd(acc, v[j]);
   }
-  {  // pairs [64 b, 64 b + 64), one group each
-    const int u = blockIdx.x * kGsumGroups + g;
-    if (u < nu) {
+  return acc;
+}
+
+// One 16-lane group per slice: the group of the slice a run ENDS in folds that run's partials.  A run of more than
+// kGsFoldCoop partials (a hot row of a skewed stream: thousands of occurrences) is folded by the 16 groups of the
+// work-group together -- group g sums the g-th part, the part sums are added in group order through LDS -- instead of
+// one group walking hundreds of rows 16 at a time while the launch waits for it.  Fixed partition, fixed order.
+constexpr int kGsFoldCoop = 64;
+template <typename V>
+__global__ __launch_bounds__(kGsThreads) void gsum_fold_kernel(DedupMap M, int N, int DV, const V* __restrict__ P, V* __restrict__ Gu) {
+  constexpr int kG = kGsThreads / 16;
+  __shared__ V part[kG][16];
+  __shared__ int longs[kG][3];
+  __shared__ int nlong;
+  const int l = threadIdx.x & 15, g = threadIdx.x / 16;
+  const int s = blockIdx.x * kG + g;
+  const int k0 = s * kGsSlice;
+  if (threadIdx.x == 0) nlong = 0;
+  __syncthreads();
+  int u = -1, sf = 0;
+  if (k0 < N && k0 > 0) {
+    u = M.uid[M.occ[k0]];
+    if (M.uid[M.occ[k0 - 1]] != u) u = -1;  // no run crosses into this slice
+    else {
       const int lo = M.occ_off[u], hi = M.occ_off[u + 1];
-      if (hi - lo < kGsumCoop) gsum_group<V>(lo, hi, B, DV, M.occ, rowidx, tableidx, psw, dout, Gu + (size_t)u * DV);
+      if ((hi - 1) / kGsSlice != s) u = -1;  // it ends in a later slice, whose group folds it
+      else sf = lo / kGsSlice;
     }
   }
-  __syncthreads();
-  const int nh = nhot;
-  for (int hh = 0; hh < nh; ++hh) {  // (work-group-uniform; which of its hot pairs a work-group takes first does not matter)
-    const int u = hot[hh];
-    const int lo = M.occ_off[u], hi = M.occ_off[u + 1];
-    const int per = (hi - lo + kGsumGroups - 1) / kGsumGroups;
-    const int a = min(hi, lo + g * per), b = min(hi, a + per);
-    gsum_group<V>(a, b, B, DV, M.occ, rowidx, tableidx, psw, dout, part + (size_t)g * DV);
-    __syncthreads();
-    for (int e = threadIdx.x; e < DV; e += kGsumThreads) {
-      V acc = part[e];
-      for (int q = 1; q < kGsumGroups; ++q) vadd(acc, part[(size_t)q * DV + e]);
-      Gu[(size_t)u * DV + e] = acc;
+  if (u >= 0 && s - sf + 1 > kGsFoldCoop) {
+    if (l == 0) {
+      const int i = atomicAdd(&nlong, 1);
+      longs[i][0] = u, longs[i][1] = sf, longs[i][2] = s;
     }
-    __syncthreads();
+    u = -1;
+  }
+  if (u >= 0)
+    for (int eb = 0; eb < DV; eb += 16) {
+      const int e = eb + l;
+      const V acc = fold_partials<V>(P, sf, s, 0, s - sf + 1, DV, e, e < DV);
+      if (e < DV) Gu[(size_t)u * DV + e] = acc;
+    }
+  __syncthreads();
+  const int nl = nlong;
+  for (int h = 0; h < nl; ++h) {  // (work-group-uniform; the order of the list does not touch any value)
+    const int uu = longs[h][0], f = longs[h][1], se = longs[h][2];
+    const int cnt = se - f + 1, per = (cnt + kG - 1) / kG;
+    const int a = min(cnt, g * per), b = min(cnt, a + per);
+    for (int eb = 0; eb < DV; eb += 16) {
+      const int e = eb + l;
+      part[g][l] = fold_partials<V>(P, f, se, a, b, DV, e, e < DV);
+      __syncthreads();
+      if (g == 0 && e < DV) {
+        V acc = part[0][l];
+        for (int q = 1; q < kG; ++q) vadd(acc, part[q][l]);
+        Gu[(size_t)uu * DV + e] = acc;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -1374,7 +1464,12 @@ int ttx_tt_forward_dd(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, cons
   return TTX_OK;
 }
 
-static size_t gu_bytes(const Dims& d, long long nnz) { return align_up((size_t)nnz * d.D * sizeof(float)); }
+// summed bag gradients of the distinct pairs [nnz][D] + the slice partials of the pre-sum [slices][2][D]
+static size_t gu_rows_bytes(const Dims& d, long long nnz) { return align_up((size_t)nnz * d.D * sizeof(float)); }
+static size_t gu_bytes(const Dims& d, long long nnz) {
+  const size_t slices = ((size_t)nnz + kGsSlice - 1) / kGsSlice;
+  return gu_rows_bytes(d, nnz) + align_up(slices * 2 * d.D * sizeof(float));
+}
 
 size_t ttx_tt_backward_dd_workspace_bytes(const ttx_geom* g, int32_t D, int64_t nnz) {
   Dims d;
@@ -1401,18 +1496,17 @@ int ttx_tt_backward_dd(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, f
   float* Gu = (float*)workspace;
   {
     ProfScope ps(TTX_PROF_POOL, st);
-    const int blocks = ((int)nnz + kGsumGroups - 1) / kGsumGroups;  // (upper bound: a work-group without pairs only looks for hot ones)
-    const size_t lds = (size_t)kGsumGroups * d.D * sizeof(float);  // (dedup_supported bounds it by the LDS of a CU)
+    const int N = (int)nnz;
+    const int blocks = ((N + kGsSlice - 1) / kGsSlice + kGsThreads / 16 - 1) / (kGsThreads / 16);
+    float* Pp = (float*)((char*)workspace + gu_rows_bytes(d, nnz));
     if (d.D % 4 == 0 && (((uintptr_t)d_output) & 15) == 0) {
-      rc = allow_lds(gsum_kernel<float4>, (int)lds + 8192);
-      if (rc) return rc;
-      hipLaunchKernelGGL(gsum_kernel<float4>, dim3(blocks), dim3(kGsumThreads), lds, st, M, B, d.D / 4, rowidx, tableidx, psw,
-                         (const float4*)d_output, (float4*)Gu);
+      hipLaunchKernelGGL(gsum_slice_kernel<float4>, dim3(blocks), dim3(kGsThreads), 0, st, M, N, B, d.D / 4, rowidx, tableidx, psw,
+                         (const float4*)d_output, (float4*)Gu, (float4*)Pp);
+      hipLaunchKernelGGL(gsum_fold_kernel<float4>, dim3(blocks), dim3(kGsThreads), 0, st, M, N, d.D / 4, (const float4*)Pp, (float4*)Gu);
     } else {
-      rc = allow_lds(gsum_kernel<float>, (int)lds + 8192);
-      if (rc) return rc;
-      hipLaunchKernelGGL(gsum_kernel<float>, dim3(blocks), dim3(kGsumThreads), lds, st, M, B, d.D, rowidx, tableidx, psw, d_output,
-                         Gu);
+      hipLaunchKernelGGL(gsum_slice_kernel<float>, dim3(blocks), dim3(kGsThreads), 0, st, M, N, B, d.D, rowidx, tableidx, psw, d_output,
+                         Gu, Pp);
+      hipLaunchKernelGGL(gsum_fold_kernel<float>, dim3(blocks), dim3(kGsThreads), 0, st, M, N, d.D, (const float*)Pp, Gu);
     }
     TTX_HIP(hipGetLastError());
   }

@@ -94,7 +94,9 @@ CASES = [
     (1, [20, 22, 25], [4, 4, 4], [16, 16], 40, 3, 0.0),       # no duplicates to speak of, tiny batch (nnz < 1024)
     (1, [40, 50, 60], [4, 4, 4], [16, 16], 1400, 11, 0.95),   # ~15k lookups (the map's limit is 16384), three rows hot
     (1, [20, 22, 25], [4, 8, 8], [16, 16], 200, 8, 0.85),     # D = 256: the gradient pre-sum's part sums are 64 KB of LDS
-    (2, [9, 8, 7], [4, 8, 10], [5, 6], 100, 6, 0.8),          # D = 320, generic kernels: 80 KB of part sums
+    (2, [9, 8, 7], [4, 8, 10], [5, 6], 100, 6, 0.8),          # D = 320, generic kernels
+    (1, [9, 8, 7], [8, 8, 10], [4, 4], 60, 5, 0.8),           # D = 640: ten column blocks per gradient row in the pre-sum
+    (1, [20, 22, 25], [4, 4, 4], [16, 16], 64, 130, 0.97),    # three rows take nearly all of ~8k lookups: runs over many slices
 ]
 
 
@@ -127,14 +129,15 @@ def test_dedup_vs_oracle_and_plain_path(case):
                 assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"case {case} adagrad core{k}")
 
 
-def test_batches_the_map_does_not_take_fall_back_to_the_plain_plan():
+def test_which_batches_the_map_takes():
     import tt_embeddings as E
 
     p, q, r = [20, 22, 25], [4, 4, 4], [1, 16, 16, 1]
     idx = t(np.random.RandomState(0).randint(0, 11000, size=20000).astype(np.int64))
     tb = torch.zeros_like(idx)
-    wide = E.make_plan(1, p, [8, 8, 10], r, 100, idx[:100], tb[:100], None, dedup=True)  # D = 640: the pre-sum's LDS
-    assert wide is not None and not isinstance(wide, E.DedupPlan)
+    # (the slice-wise gradient pre-sum keeps nothing in LDS: any embedding dimension is mapped -- D = 640 was refused before)
+    assert isinstance(E.make_plan(1, p, [8, 8, 10], r, 100, idx[:100], tb[:100], None, dedup=True), E.DedupPlan)
+    assert E.make_plan(1, p, q, r, 0, idx[:0], tb[:0], None, dedup=True) is None  # empty batch: no plan at all
     # (round 3: batches of any size and key spaces beyond 2^32 ARE mapped -- the multi-work-group key sort)
     assert isinstance(E.make_plan(1, p, q, r, idx.numel(), idx, tb, None, dedup=True), E.DedupPlan)
     big = [70000, 70000, 70000]  # 3.4e14 rows: 64-bit keys
