@@ -187,14 +187,16 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D,
  * Not in the reference (which contracts every lookup on its own): a batch's lookups are mapped onto their
  * DISTINCT (table, index) pairs, the contraction runs once per pair, bag pooling gathers each lookup's row
  * through the map (same sums in the same order: the output is bit-identical to ttx_tt_forward's), and the
- * backward first adds up, in index order, the bag gradients of a pair's occurrences -- one contraction, one
- * set of partial gradients per pair.  Pays when a batch repeats rows (a Zipf stream before its cache is
- * populated: 28 % of the lookups distinct); on a uniform stream it only adds the launches of the map.
+ * backward first adds up, in a fixed order, the bag gradients of a pair's occurrences -- one contraction, one
+ * set of partial gradients per pair.  Pays on large batches that repeat rows (Zipf 1.2, 327k lookups: 0.79 ->
+ * 0.35 ms/step); on a uniform stream it only adds the key sort and the launches of the map.
  *
- *   ttx_dedup_bytes     size of the map buffer; 0 = this batch is not deduplicated (more than 16384 lookups,
- *                       per-table row factors, or num_tables * prod(p) > 2^32): use the plain entry points.
- *   ttx_dedup_build     builds the map (one work-group sorts the batch's keys in LDS: deterministic) AND the
- *                       lookup plan of the distinct pairs into `plan` (ttx_plan_bytes(g, nnz) bytes).
+ *   ttx_dedup_bytes     size of the map buffer; 0 = this batch is not deduplicated (per-table row factors, a
+ *                       key space num_tables * prod(p) beyond 2^61, nnz >= 2^31): use the plain entry points.
+ *   ttx_dedup_build     builds the map (<= 16384 lookups with 32-bit keys: one work-group sorts the keys in LDS;
+ *                       otherwise a multi-work-group stable radix sort of 64-bit keys -- deterministic either
+ *                       way, nothing read back: capturable) AND the lookup plan of the distinct pairs into
+ *                       `plan` (ttx_plan_bytes(g, nnz) bytes).
  *   ttx_tt_forward_dd / ttx_tt_backward_dd   as ttx_tt_forward_w / ttx_tt_backward_w (psw may be NULL), driven
  *                       by a map + plan built for the same (indices, tableidx). */
 size_t ttx_dedup_bytes(const ttx_geom* g, int64_t nnz);
