@@ -258,8 +258,13 @@ __device__ __forceinline__ void hashtbl_count(int64_t key, int32_t H, int64_t* h
                                               unsigned long long times = 1ull) {
   int32_t idx = (int32_t)hash64(key, H);
   for (int c = 0; c < kMaxProbes; ++c) {
-    const unsigned long long old = atomicCAS((unsigned long long*)&hashtbl[idx],
-                                             (unsigned long long)(-1ll), (unsigned long long)key);
+    // A slot only ever goes from empty to a key while inserts run (eviction is cache_populate's, another launch), so a
+    // plain load that shows a key is final: the CAS is issued only where the slot looks empty -- in steady state, where
+    // nearly every key is already seated, that leaves ONE atomic per key (the count) instead of two.  (A stale "empty"
+    // just takes the CAS.)
+    unsigned long long old = (unsigned long long)hashtbl[idx];
+    if ((int64_t)old == -1)
+      old = atomicCAS((unsigned long long*)&hashtbl[idx], (unsigned long long)(-1ll), (unsigned long long)key);
     if ((int64_t)old == -1 || (int64_t)old == key) {
       atomicAdd((unsigned long long*)&cache_freq[idx], times);
       return;
