@@ -171,6 +171,11 @@ struct DedupMap {
   int* occ_off;
 };
 constexpr int kDedupMaxN = 16384;  // one work-group sorts the batch in LDS
+// header of the map: int [0] = distinct pairs; from byte 64 on, int64 tstart[tables + 1] = first pair of every table (the pairs
+// are table-major; written for 1 < tables <= dedup_max_tables(), the "offsets" the plan of the pairs groups its tables by)
+__host__ __device__ inline int64_t* dedup_tstart(const DedupMap& M) { return (int64_t*)((char*)M.nu + 64); }
+int dedup_max_tables();
+bool plan_groups_tables(const Dims& d, long long N);  // would plan_build use table groups, given table-major offsets?
 bool dedup_supported(const Dims& d, long long nnz);
 size_t dedup_bytes(long long nnz);
 DedupMap carve_dedup(long long nnz, void* base);

@@ -1331,6 +1331,16 @@ static void launch_finish(const Dims& d, int N, const int* n_dev, bool has_row, 
   hipLaunchKernelGGL(mb_chunks_kernel, dim3(1), dim3(1024), 0, stream, d, N, n_dev, has_row ? 1 : 0, P);
 }
 
+// would the plan of N lookups use table groups if it were given table-major offsets?  (plan_build_mb's own order of choices)
+bool plan_groups_tables(const Dims& d, long long N) {
+  if (d.num_tables <= 1 || d.tab) return false;
+  int smax = 1;
+  for (int t = 0; t < d.T; ++t) if (d.S[t] > smax) smax = d.S[t];
+  if (smax <= 256) return false;                                                    // one 8-bit pass
+  if (smax <= 2048 && (N + kWideSpan - 1) / kWideSpan <= kWideMaxG) return false;   // one wide digit, no groups
+  return true;
+}
+
 static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* indices, const int64_t* tableidx,
                          const int64_t* rowidx, const Plan& P, hipStream_t stream, const int64_t* offsets,
                          int bags_per_table) {
@@ -1474,9 +1484,12 @@ int plan_build_batches(const Dims& d, int nbatch, long long nnz, const int* n_de
 // sharing the contraction of duplicates never changes a value, only how often it is computed).
 // (batches beyond the single-work-group map also keep the key sort's buffers here: keys, values, the sort's workspace,
 //  run heads per block of 1024 sorted positions)
+// header: [0] distinct pairs, then (8-byte aligned, from int 16 on) tstart[kDedupMaxTables + 1]: first pair of every table
+constexpr int kDedupMaxTables = 1023;
+constexpr size_t kDedupHdrBytes = 64 + (kDedupMaxTables + 1) * sizeof(int64_t);
 static size_t dedup_map_bytes(long long nnz) {
   const size_t n = r64((size_t)nnz + 1);
-  return align_up(64 * sizeof(int)) + 3 * align_up(n * sizeof(int64_t)) + 3 * align_up(n * sizeof(int));
+  return align_up(kDedupHdrBytes) + 3 * align_up(n * sizeof(int64_t)) + 3 * align_up(n * sizeof(int));
 }
 static size_t dedup_blocks(long long nnz) { return ((size_t)nnz + 1023) / 1024; }
 size_t dedup_bytes(long long nnz) {
@@ -1489,7 +1502,7 @@ DedupMap carve_dedup(long long nnz, void* base) {
   char* cur = (char*)base;
   auto take = [&](size_t bytes) { char* r = cur; cur += align_up(bytes); return r; };
   DedupMap M;
-  M.nu = (int*)take(64 * sizeof(int));
+  M.nu = (int*)take(kDedupHdrBytes);
   M.uidx = (int64_t*)take(n * sizeof(int64_t));
   M.utab = (int64_t*)take(n * sizeof(int64_t));
   M.iota = (int64_t*)take(n * sizeof(int64_t));
@@ -1650,7 +1663,9 @@ __global__ __launch_bounds__(kDdThreads) void dd_keys_kernel(int N, unsigned lon
   const unsigned long long e = (unsigned long long)max(indices[i], (int64_t)0);
   const int tbv = (tableidx && num_tables > 1) ? (int)tableidx[i] : 0;
   const unsigned long long tb = (unsigned long long)min(max(tbv, 0), num_tables - 1);
-  keys[i] = (int64_t)(tb * E + (e < E ? e : E - 1));
+  // complemented: the (descending, stable) pair sort then leaves the pairs ASCENDING by (table, index) -- table-major like
+  // the module's bags, which is what lets the plan of the pairs sort each table group by itself (dedup_tstart_kernel)
+  keys[i] = (int64_t)((unsigned long long)num_tables * E - 1ull - (tb * E + (e < E ? e : E - 1)));
   vals[i] = i;
 }
 
@@ -1708,7 +1723,7 @@ __global__ __launch_bounds__(kDdThreads) void dd_scan_kernel(int nblk, int N, in
   }
 }
 
-__global__ __launch_bounds__(kDdThreads) void dd_emit_kernel(int N, unsigned long long E, const int64_t* __restrict__ sk,
+__global__ __launch_bounds__(kDdThreads) void dd_emit_kernel(int N, unsigned long long E, unsigned long long all, const int64_t* __restrict__ sk,
                                                             const int64_t* __restrict__ sv, const int* __restrict__ blk_base,
                                                             DedupMap M) {
   __shared__ int wt[kDdThreads / kWave];
@@ -1724,11 +1739,25 @@ __global__ __launch_bounds__(kDdThreads) void dd_emit_kernel(int N, unsigned lon
   M.occ[i] = n;
   M.iota[i] = i;
   if (head) {
-    const unsigned long long tb = (unsigned long long)key / E;
+    const unsigned long long real = all - 1ull - (unsigned long long)key;  // (dd_keys_kernel stores the complement)
+    const unsigned long long tb = real / E;
     M.occ_off[u] = i;
-    M.uidx[u] = (int64_t)((unsigned long long)key - tb * E);
+    M.uidx[u] = (int64_t)(real - tb * E);
     M.utab[u] = (int64_t)tb;
   }
+}
+
+// first pair of every table in the (ascending, table-major) pair list: tstart[t] = lower bound of t in utab[0, nu)
+__global__ __launch_bounds__(256) void dedup_tstart_kernel(int num_tables, DedupMap M) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t > num_tables) return;
+  const int nu = M.nu[0];
+  int lo = 0, hi = nu;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (M.utab[mid] < (int64_t)t) lo = mid + 1; else hi = mid;
+  }
+  dedup_tstart(M)[t] = lo;
 }
 
 static int dedup_build_large(const Dims& d, long long nnz, const int64_t* indices, const int64_t* tableidx, const DedupMap& M,
@@ -1752,13 +1781,29 @@ static int dedup_build_large(const Dims& d, long long nnz, const int64_t* indice
   if (rc) return rc;
   hipLaunchKernelGGL(dd_count_kernel, dim3(nblk), dim3(kDdThreads), 0, stream, N, sk, blk);
   hipLaunchKernelGGL(dd_scan_kernel, dim3(1), dim3(kDdThreads), 0, stream, nblk, N, blk, M);
-  hipLaunchKernelGGL(dd_emit_kernel, dim3(nblk), dim3(kDdThreads), 0, stream, N, E, sk, sv, blk, M);
+  hipLaunchKernelGGL(dd_emit_kernel, dim3(nblk), dim3(kDdThreads), 0, stream, N, E, all, sk, sv, blk, M);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }
 
+int dedup_max_tables() { return kDedupMaxTables; }
+
+static int dedup_build_map(const Dims& d, long long nnz, const int64_t* indices, const int64_t* tableidx, const DedupMap& M,
+                           hipStream_t stream);
 int dedup_build(const Dims& d, long long nnz, const int64_t* indices, const int64_t* tableidx, const DedupMap& M,
                 hipStream_t stream) {
+  const int rc = dedup_build_map(d, nnz, indices, tableidx, M, stream);
+  if (rc) return rc;
+  if (d.num_tables <= kDedupMaxTables && plan_groups_tables(d, nnz)) {
+    ProfScope ps(TTX_PROF_PLAN, stream);
+    hipLaunchKernelGGL(dedup_tstart_kernel, dim3((d.num_tables + 256) / 256), dim3(256), 0, stream, d.num_tables, M);
+    TTX_HIP(hipGetLastError());
+  }
+  return TTX_OK;
+}
+
+static int dedup_build_map(const Dims& d, long long nnz, const int64_t* indices, const int64_t* tableidx, const DedupMap& M,
+                           hipStream_t stream) {
   if (!dedup_supported(d, nnz)) TTX_FAIL(TTX_EUNSUPPORTED, "batch of %lld lookups / this key space is not deduplicated", nnz);
   if (nnz > kDedupMaxN || dedup_key_space(d) == 0) return dedup_build_large(d, nnz, indices, tableidx, M, stream);
   const unsigned long long all = dedup_key_space(d);

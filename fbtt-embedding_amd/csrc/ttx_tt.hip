@@ -1407,7 +1407,7 @@ int ttx_dedup_build(const ttx_geom* g, int64_t nnz, const int64_t* indices, cons
   int rc = make_dims(g, &d);
   if (rc) return rc;
   if (!dedup_supported(d, nnz))
-    TTX_FAIL(TTX_EUNSUPPORTED, "duplicate sharing: tables of one row shape, tables * prod(p) < 2^61, D <= %d", (160 * 1024 - 8192) / 256);
+    TTX_FAIL(TTX_EUNSUPPORTED, "duplicate sharing: tables of one row shape, tables * prod(p) < 2^61, nnz < 2^31");
   if (!indices || (d.num_tables > 1 && !tableidx)) TTX_FAIL(TTX_EINVAL, "NULL input");
   if (!dedup || dedup_bytes_ < dedup_bytes(nnz)) TTX_FAIL(TTX_EWORKSPACE, "dedup buffer too small: %zu < %zu", dedup_bytes_, dedup_bytes(nnz));
   if (!plan || plan_bytes_ < plan_bytes(d, nnz)) TTX_FAIL(TTX_EWORKSPACE, "plan buffer too small: %zu < %zu", plan_bytes_, plan_bytes(d, nnz));
@@ -1418,7 +1418,10 @@ int ttx_dedup_build(const ttx_geom* g, int64_t nnz, const int64_t* indices, cons
   if (rc) return rc;
   // the plan of the DISTINCT pairs: their count lives on the device, "bag row" of pair u is u
   Plan P = carve_plan(d, nnz, plan);
-  return plan_build(d, nnz, M.uidx, M.utab, M.iota, P, (hipStream_t)stream, M.nu);
+  // (the pairs are table-major: with several tables the plan may sort each table group by itself, as it does for the
+  //  module's table-major bags -- "offsets" = first pair of every table, one "bag" per table)
+  const bool grouped = d.num_tables <= dedup_max_tables() && plan_groups_tables(d, nnz);
+  return plan_build(d, nnz, M.uidx, M.utab, M.iota, P, (hipStream_t)stream, M.nu, grouped ? dedup_tstart(M) : nullptr, 1);
 }
 
 size_t ttx_tt_forward_dd_workspace_bytes(const ttx_geom* g, int32_t D, int64_t nnz) {

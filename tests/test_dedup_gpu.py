@@ -151,6 +151,9 @@ LARGE = [
     (2, [3000, 4000, 5000], [4, 4, 4], [16, 16], 300, 6, 0.7),  # 1.2e11 rows per table: five sort passes of the 64-bit keys
     (1, [7, 9, 11], [3, 4, 5], [13, 12], 4000, 8, 0.5),         # generic kernels, 693 rows: nearly everything a duplicate
     (2, [20, 22, 25], [4, 4, 4], [16, 16], 4200, 10, 0.7),      # ~84k lookups: the wave-span gather pooling (> 65536 lookups)
+    (12, [200, 220, 250], [4, 4, 4], [16, 16], 250, 10, 0.7),   # 3000 slice ids in core 2: the plan of the pairs sorts table
+                                                                # groups by themselves (first pair of every table = its offsets)
+    (12, [200, 220, 250], [4, 4, 4], [16, 16], 250, 10, 0.0),   # ... the same with hardly any duplicates, some tables' groups thin
 ]
 
 
