@@ -57,6 +57,8 @@ XGMI_GBS = 153.0          # per link, per direction
 WORKLOADS = {
     "cfg2": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "cfg3": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.2, populate=True),
+    # SURVEY.md 8(d) names two exponents for cfg3's Zipf stream (the reference never sets one): 1.2 above, 1.05 here
+    "cfg3a105": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.05, populate=True),
     # cfg3's index stream before the cache is populated: every hot row goes through the contraction
     "cfg3warm": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.2, populate=False),
     # ... with duplicate lookups sharing their contraction (TTEmbeddingBag(dedup=True))

@@ -78,6 +78,7 @@ def lib():
     L.ttx_tt_rows.argtypes = [G, i32, i64, vp, vp, vp, vp, vp, sz, vp]
     L.ttx_tt_backward_workspace_bytes.argtypes = [G, i32, i32, i64]
     L.ttx_tt_backward.argtypes = [G, i32, i32, i32, f32, f32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.ttx_tt_backward_w.argtypes = [G, i32, i32, i32, f32, f32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.ttx_update_cache_state.argtypes = [i64, vp, i64, vp, vp, vp]
     L.ttx_preprocess_workspace_bytes.argtypes = [i64]
     L.ttx_preprocess_indices_sync.argtypes = [i64, vp, i64, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp,
@@ -373,7 +374,9 @@ def tt_forward(batch_count: int, num_tables: int, B: int, D: int, tt_p_shapes: L
         nb = lb.ttx_tt_forward_dd_workspace_bytes(C.byref(g), D, nnz)
         ws = _workspace(dev, st, nb)
         with _guard(dev):
-            _check(lb.ttx_tt_forward_dd(C.byref(g), B, D, nnz, rowidx.data_ptr(), tableidx.data_ptr(), None, plan.dd.data_ptr(),
+            psw = None if per_sample_weights is None else _f32(per_sample_weights, "per_sample_weights")
+            _check(lb.ttx_tt_forward_dd(C.byref(g), B, D, nnz, rowidx.data_ptr(), tableidx.data_ptr(),
+                                        None if psw is None else psw.data_ptr(), plan.dd.data_ptr(),
                                         _plan_ptr(plan, nnz), _ptr_array(cores), out.data_ptr(), ws.data_ptr(), ws.numel(), st))
         return out
     nb = lb.ttx_tt_forward_workspace_bytes(C.byref(g), B, D, nnz)
@@ -396,7 +399,8 @@ def tt_forward(batch_count: int, num_tables: int, B: int, D: int, tt_p_shapes: L
     return out
 
 
-def _backward(optim, D, lr, eps, p, q, ranks, nnz, indices, rowidx, tableidx, d_output, tt_cores, state, plan):
+def _backward(optim, D, lr, eps, p, q, ranks, nnz, indices, rowidx, tableidx, d_output, tt_cores, state, plan,
+              per_sample_weights=None):
     g = _geom(tt_cores[0].size(0), p, q, ranks)
     num_tables = g.num_tables  # (tables of different row factors: len(p), the cores are [1, sum p, slice])
     dev = _dev(d_output)
@@ -415,42 +419,52 @@ def _backward(optim, D, lr, eps, p, q, ranks, nnz, indices, rowidx, tableidx, d_
         sptr = _ptr_array(_cores(state, g, "optimizer_state"))
     lb = lib()
     st = _stream(dev)
+    # (beyond the reference's signature: nn.EmbeddingBag's per_sample_weights scale each lookup's share of its bag gradient)
+    psw = None if per_sample_weights is None else _f32(per_sample_weights, "per_sample_weights")
+    pswp = None if psw is None else psw.data_ptr()
     if isinstance(plan, DedupPlan) and nnz > 0:
         nb = lb.ttx_tt_backward_dd_workspace_bytes(C.byref(g), D, nnz)
         ws = _workspace(dev, st, nb)
         with _guard(dev):
-            _check(lb.ttx_tt_backward_dd(C.byref(g), optim, B, D, lr, eps, nnz, rowidx.data_ptr(), tableidx.data_ptr(), None,
+            _check(lb.ttx_tt_backward_dd(C.byref(g), optim, B, D, lr, eps, nnz, rowidx.data_ptr(), tableidx.data_ptr(), pswp,
                                          d_output.data_ptr(), plan.dd.data_ptr(), _plan_ptr(plan, nnz), _ptr_array(cores), sptr,
                                          gptr, ws.data_ptr(), ws.numel(), st))
         return grads
     nb = lb.ttx_tt_backward_workspace_bytes(C.byref(g), B, D, nnz)
     ws = _workspace(dev, st, nb)
     with _guard(dev):
-        _check(lb.ttx_tt_backward(C.byref(g), optim, B, D, lr, eps, nnz, indices.data_ptr(), rowidx.data_ptr(),
-                                  tableidx.data_ptr(), d_output.data_ptr(), _ptr_array(cores), sptr, gptr,
-                                  _plan_ptr(plan, nnz), ws.data_ptr(), ws.numel(), st))
+        if psw is not None:
+            _check(lb.ttx_tt_backward_w(C.byref(g), optim, B, D, lr, eps, nnz, indices.data_ptr(), rowidx.data_ptr(),
+                                        tableidx.data_ptr(), pswp, d_output.data_ptr(), _ptr_array(cores), sptr, gptr,
+                                        _plan_ptr(plan, nnz), ws.data_ptr(), ws.numel(), st))
+        else:
+            _check(lb.ttx_tt_backward(C.byref(g), optim, B, D, lr, eps, nnz, indices.data_ptr(), rowidx.data_ptr(),
+                                      tableidx.data_ptr(), d_output.data_ptr(), _ptr_array(cores), sptr, gptr,
+                                      _plan_ptr(plan, nnz), ws.data_ptr(), ws.numel(), st))
     return grads
 
 
 def tt_dense_backward(batch_count, D, tt_p_shapes, tt_q_shapes, tt_ranks, L, nnz, indices, rowidx, tableidx, d_output,
-                      tt_cores, plan: Optional[Plan] = None) -> List[torch.Tensor]:
+                      tt_cores, plan: Optional[Plan] = None, per_sample_weights: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """tt_embeddings.cpp:28-40: returns the list of dense core gradients."""
     return _backward(OPTIM_DENSE, D, 0.0, 0.0, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, rowidx, tableidx,
-                     d_output, tt_cores, None, plan)
+                     d_output, tt_cores, None, plan, per_sample_weights)
 
 
 def tt_sgd_backward(batch_count, D, learning_rate, tt_p_shapes, tt_q_shapes, tt_ranks, L, nnz, indices, rowidx,
-                    tableidx, d_output, tt_cores, plan: Optional[Plan] = None) -> None:
+                    tableidx, d_output, tt_cores, plan: Optional[Plan] = None,
+                    per_sample_weights: Optional[torch.Tensor] = None) -> None:
     """tt_embeddings.cpp:42-55: fused gradient + SGD, cores updated in place."""
     _backward(OPTIM_SGD, D, learning_rate, 0.0, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, rowidx, tableidx,
-              d_output, tt_cores, None, plan)
+              d_output, tt_cores, None, plan, per_sample_weights)
 
 
 def tt_adagrad_backward(batch_count, D, learning_rate, eps, tt_p_shapes, tt_q_shapes, tt_ranks, L, nnz, indices,
-                        rowidx, tableidx, d_output, optimizer_state, tt_cores, plan: Optional[Plan] = None) -> None:
+                        rowidx, tableidx, d_output, optimizer_state, tt_cores, plan: Optional[Plan] = None,
+                        per_sample_weights: Optional[torch.Tensor] = None) -> None:
     """tt_embeddings.cpp:57-72: fused gradient + Adagrad, cores and state in place."""
     _backward(OPTIM_ADAGRAD, D, learning_rate, eps, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, rowidx,
-              tableidx, d_output, tt_cores, list(optimizer_state), plan)
+              tableidx, d_output, tt_cores, list(optimizer_state), plan, per_sample_weights)
 
 
 def update_cache_state(indices: torch.Tensor, hashtbl: torch.Tensor, cache_freq: torch.Tensor) -> None:

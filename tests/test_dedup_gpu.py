@@ -267,3 +267,49 @@ def test_dedup_auto_follows_the_streams_duplicate_share(monkeypatch):
     ob.backward(g)
     for k in range(3):
         assert_close(a.tt_cores[k].detach().cpu().numpy(), b.tt_cores[k].detach().cpu().numpy(), f"core{k}", rtol=1e-4, atol_scale=2e-5)
+
+
+@pytest.mark.parametrize("case", [0, 2, 6])
+def test_dedup_with_per_sample_weights(case):
+    """nn.EmbeddingBag's per_sample_weights through the shared path (C ABI: ttx_tt_forward_dd / ttx_tt_backward_dd with
+    weights): forward bit-identical to the weighted plain path, dense gradients and fused SGD within the fp32 tolerance of it
+    -- and of the oracle run on the weighted bag gradient of every lookup (a weight scales a lookup's row going in and its
+    share of the bag gradient coming back)."""
+    import tt_embeddings as E
+
+    tables, p, q, r, B, pf, frac = CASES[case]
+    c = make_case(700 + case, tables, p, q, r, B, pf, frac)
+    rs = np.random.RandomState(9)
+    nnz = c["indices"].size
+    w = t((rs.rand(nnz) * 1.5 + 0.25).astype(np.float32))
+    idx, off = t(c["indices"]), t(c["offsets"])
+    Lt = torch.zeros(len(p), dtype=torch.int64, device=DEV)
+    _, rowidx, tableidx, _, _ = E.preprocess_indices_sync(idx, off, tables, True, torch.empty(0, dtype=torch.int64, device=DEV),
+                                                          torch.empty(0, dtype=torch.int32, device=DEV))
+    D, rp = c["D"], c["r"]
+    d_out = t(c["d_out"])
+    res = {}
+    for dedup in (True, False):
+        plan = E.make_plan(tables, p, q, rp, nnz, idx, tableidx, rowidx, dedup=dedup)
+        assert isinstance(plan, E.DedupPlan) == dedup
+        cores = [t(x) for x in c["cores"]]
+        out = E.tt_forward(1000, tables, B, D, p, q, rp, Lt, nnz, idx, rowidx, tableidx, cores, plan=plan, per_sample_weights=w)
+        grads = E.tt_dense_backward(1000, D, p, q, rp, Lt, nnz, idx, rowidx, tableidx, d_out, cores, plan=plan, per_sample_weights=w)
+        E.tt_sgd_backward(1000, D, LR, p, q, rp, Lt, nnz, idx, rowidx, tableidx, d_out, cores, plan=plan, per_sample_weights=w)
+        res[dedup] = (out.cpu().numpy(), [g.cpu().numpy() for g in grads], [x.cpu().numpy() for x in cores])
+    assert np.array_equal(res[True][0], res[False][0]), "weighted forward must be bit-identical to the plain weighted path"
+    tol = dict(rtol=1e-4, atol_scale=2e-5)
+    for k in range(len(p)):
+        assert_close(res[True][1][k], res[False][1][k], f"weighted grad{k}", **tol)
+        assert_close(res[True][2][k], res[False][2][k], f"weighted sgd core{k}", **tol)
+    # oracle: every lookup a bag of its own (B' = nnz, row n), bag gradient w[n] * d_out[bag(n)]
+    g = O.make_geom(tables, p, q, rp)
+    ro, tb = O.rowidx_from_offsets(c["offsets"], tables)
+    wn = w.cpu().numpy()
+    per_lookup = (c["d_out"].reshape(tables, B, D)[tb, ro] * wn[:, None]).astype(np.float32)
+    own_rows = np.arange(nnz, dtype=np.int64)
+    gref = O.tt_backward(g, O.OPTIM_DENSE, nnz, D, 0, 0, c["indices"], own_rows, np.zeros(nnz, dtype=np.int64) if tables == 1 else tb,
+                         per_lookup[None] if tables == 1 else None, [x.copy() for x in c["cores"]]) if tables == 1 else None
+    if gref is not None:
+        for k in range(len(p)):
+            assert_close(res[True][1][k], gref[k], f"weighted grad{k} vs oracle", **tol)
