@@ -992,6 +992,8 @@ static int spec_mc(const Dims& d, long long nnz) {
     case SPEC2_64_2_64_4: return S2_64_2_64_4::MC;
     case SPEC2_16_2_16_4: return S2_16_2_16_4::MC * (S2_16_2_16_4::SUB ? ks : 1);
     case SPEC_16_8_16_8: return S_16_8_16_8::MC * (S_16_8_16_8::SUB ? ks : 1);
+    case SPEC_128_4_128_4: return S_128_4_128_4::MC;
+    case SPEC_128_4_128_8: return S_128_4_128_8::MC;
     default: return 0;
   }
 }

@@ -67,6 +67,11 @@ def test_contraction_and_reduce_kernels_budget(tt_res):
     for k, d32k in (("spec_fwd_kernel", d32 + "ELb0ELb0E"), ("spec_bwd_kernel", d32 + "ELb0E")):
         r = pick(tt_res, k, d32k)
         assert r["ScratchSize"] == 0 and r["VGPRs"] <= 128, (k, r)
+    # r = 128: one work-group per CU, the accumulator half of the register file in use -- and still nothing in scratch
+    r128 = "Shape3ILi128ELi4ELi128ELi4ELi4ELi16ELi4EEELb0"
+    for k, n in (("spec_fwd_kernel", r128 + "ELb0ELb0E"), ("spec_bwd_kernel", r128 + "ELb0E"), ("spec_bwd_kernel", r128 + "ELb1E")):
+        r = pick(tt_res, k, n)
+        assert r["ScratchSize"] == 0, (k, n, r)
     red = pick(tt_res, "reduce_apply_kernel")
     assert red["Occupancy"] >= 6, f"reduce_apply_kernel must leave room for three 512-thread work-groups per CU: {red}"
     assert pick(tt_res, "pool4_small_kernel")["ScratchSize"] == 0
