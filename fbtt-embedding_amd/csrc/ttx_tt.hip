@@ -994,6 +994,7 @@ static int spec_mc(const Dims& d, long long nnz) {
     case SPEC_16_8_16_8: return S_16_8_16_8::MC * (S_16_8_16_8::SUB ? ks : 1);
     case SPEC_128_4_128_4: return S_128_4_128_4::MC;
     case SPEC_128_4_128_8: return S_128_4_128_8::MC;
+    case SPEC_128_8_128_8: return S_128_8_128_8::MC;
     default: return 0;
   }
 }

@@ -282,7 +282,7 @@ def test_benchmark_shape_large_batch_variant(q):
 @pytest.mark.parametrize("ranks,q", [([32, 32], [4, 4, 4]), ([16, 16], [4, 4, 4]), ([32, 32], [4, 4, 8]), ([16, 16], [4, 4, 8]),
                                       ([64, 64], [4, 4, 8]), ([64, 64], [4, 4, 4]), ([32, 32], [2, 4, 4]), ([16, 16], [2, 4, 4]), ([64, 64], [2, 4, 4]),
                                       ([32, 32], [4, 8, 8]), ([64, 64], [4, 8, 8]), ([32, 32], [2, 2, 4]), ([64, 64], [2, 2, 4]), ([16, 16], [2, 2, 4]),
-                                      ([16, 16], [4, 8, 8]), ([128, 128], [4, 4, 4]), ([128, 128], [4, 4, 8])])
+                                      ([16, 16], [4, 8, 8]), ([128, 128], [4, 4, 4]), ([128, 128], [4, 4, 8]), ([128, 128], [4, 8, 8])])
 def test_specialised_shapes_vs_oracle_and_generic(ranks, q):
     """the shape-specialised wave-independent kernels (ttx_tt_spec.inc): against the oracle,
     and against the generic kernels (forced with the debug knob) on the same inputs;
@@ -500,9 +500,9 @@ def test_pooling_fused_into_the_forward_kernel_is_bit_identical(ranks, q):
 @pytest.mark.parametrize("q,ranks", [([3, 4, 5], [13, 12]), ([4, 4, 4], [13, 12]), ([4, 4, 4], [24, 24]), ([4, 4, 8], [48, 40]),
                                       ([4, 4, 4], [8, 8]), ([1, 3, 4], [16, 16]), ([2, 3, 3], [20, 32]), ([4, 5, 7], [60, 40]),
                                       ([3, 8, 8], [64, 50]), ([2, 2, 4], [12, 12]), ([4, 4, 4], [16, 32]), ([2, 8, 8], [64, 64]),
-                                      ([4, 4, 4], [96, 96]), ([4, 4, 4], [80, 100]), ([3, 4, 7], [72, 128]), ([2, 4, 4], [128, 128])])
+                                      ([4, 4, 4], [96, 96]), ([4, 4, 4], [80, 100]), ([3, 4, 7], [72, 128]), ([2, 4, 4], [128, 128]), ([4, 6, 8], [100, 90])])
 def test_padded_shapes_run_on_the_specialised_kernels(q, ranks):
-    """Round 3: a T = 3 geometry with q0 <= 4, q1 <= 8, q2 <= 8 and ranks <= 64 (<= 128 for q <= [4,4,8]) that is NOT one of the exact shapes --
+    """Round 3: a T = 3 geometry with q0 <= 4, q1 <= 8, q2 <= 8 and ranks <= 128 that is NOT one of the exact shapes --
     ranks that are not multiples of 16 (the reference tests' 13 / 12, tt_embeddings_test.py:65-70), factorings like [3, 4, 5] --
     runs on the smallest shape-specialised kernel that holds it (PAD variants, csrc/ttx_tt_spec.inc: the global loads read zeros
     outside the real extents, the stores skip them).  Against the oracle and against the generic kernels; forward, dense / SGD /
