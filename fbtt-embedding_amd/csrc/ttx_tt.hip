@@ -25,67 +25,9 @@
 //   X0  = A  * B1   k-step {k, k+8, k+16, k+24}  (B rows 8 apart: 8*ld == 16 mod 32)
 //   dB1 = A^T* dX0  k-step {m, m+8, m+16, m+24}  (both operands row-strided)
 //   dA  = dX0* B1^T k-step {c, c+1, c+2, c+3}    (both operands column-adjacent)
-#include "ttx_internal.h"
+#include "ttx_tt_common.h"
 
 namespace ttx {
-
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / kWave;
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct CorePtrs {
-  float* c[TTX_MAX_CORES];
-};
-
-// n / d and n % d for small operands via one fp32 multiply and a fix-up
-struct FastDiv {
-  unsigned d;
-  float rcp;
-};
-__host__ __device__ __forceinline__ FastDiv make_fd(int d) {
-  FastDiv f;
-  f.d = (unsigned)(d > 0 ? d : 1);
-  f.rcp = 1.0f / (float)f.d;
-  return f;
-}
-#define make_fd_dev make_fd
-__device__ __forceinline__ unsigned fdivmod(unsigned n, const FastDiv f, unsigned& rem) {
-  if (n >> 22) {
-    rem = n % f.d;
-    return n / f.d;
-  }
-  unsigned q = (unsigned)((float)n * f.rcp);
-  int r = (int)n - (int)(q * f.d);
-  if (r < 0) { q -= 1; r += (int)f.d; }
-  else if (r >= (int)f.d) { q += 1; r -= (int)f.d; }
-  rem = (unsigned)r;
-  return q;
-}
-
-struct Partials {
-  float* pc[TTX_MAX_CORES];  // pc[1] is per CHUNK, the others per lookup
-  const float* psw;          // per_sample_weights by lookup (nn.EmbeddingBag), or NULL: the bag gradient of
-                             // lookup n enters the backward scaled by psw[n]
-  const int64_t* tableidx;   // tables of different row factors (Dims::tab): the table of a pivot slice is read
-                             // from one of its lookups; NULL otherwise (table = slice / p_1)
-  // hot slices (reduce_apply_kernel): arrival counters, one per core slice (zeroed by the backward
-  // contraction kernel), and the segment partial sums, two slots per segment
-  int* hot_cnt;
-  int n_hot_cnt;
-  float* seg[TTX_MAX_CORES];
-};
-
-// zero the hot-slice arrival counters (called by work-group 0 of the backward contraction kernels,
-// which always run right before reduce_apply_kernel on the same stream)
-__device__ __forceinline__ void zero_hot_counters(const Partials& PC) {
-  if (blockIdx.x == 0 && PC.hot_cnt)
-    for (int i = threadIdx.x; i < PC.n_hot_cnt; i += blockDim.x) PC.hot_cnt[i] = 0;
-}
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
 
 #include "ttx_tt_generic.inc"
 
@@ -1023,21 +965,27 @@ static size_t rows_bytes(const Dims& d, long long nnz) { return align_up((size_t
 
 static int g_skip_launch = 0;  // ablation (ttx_debug_skip bits 9..11): results invalid when != 0
 
-static int run_rows_spec(SpecId id, const Plan& P, const CorePtrs& C, float* rows, float* zout,
-                         long long nzero, const PoolFuse& F, bool* fused, bool pad, const RealDims& R, hipStream_t st) {
-#define CALLF(S) spec_launch_fwd<S>(P, C, rows, zout, nzero, F, fused, pad, R, st)
-  TTX_SPEC_DISPATCH(id, CALLF)
-#undef CALLF
-  TTX_FAIL(TTX_EUNSUPPORTED, "no specialised forward kernel");
+// the family's translation unit takes it (ttx_tt_spec{16,32,64,128a,128b,128c}.hip)
+static int run_rows_spec(TTX_SPEC_FWD_ARGS) {
+  int rc = spec_fwd_32(id, P, C, rows, zout, nzero, F, fused, pad, R, st);
+  if (rc == kSpecNotMine) rc = spec_fwd_64(id, P, C, rows, zout, nzero, F, fused, pad, R, st);
+  if (rc == kSpecNotMine) rc = spec_fwd_16(id, P, C, rows, zout, nzero, F, fused, pad, R, st);
+  if (rc == kSpecNotMine) rc = spec_fwd_128a(id, P, C, rows, zout, nzero, F, fused, pad, R, st);
+  if (rc == kSpecNotMine) rc = spec_fwd_128b(id, P, C, rows, zout, nzero, F, fused, pad, R, st);
+  if (rc == kSpecNotMine) rc = spec_fwd_128c(id, P, C, rows, zout, nzero, F, fused, pad, R, st);
+  if (rc == kSpecNotMine) TTX_FAIL(TTX_EUNSUPPORTED, "no specialised forward kernel");
+  return rc;
 }
 
-static int run_bwd_spec(SpecId id, const Dims& d, const Plan& P, const CorePtrs& C, int B,
-                        const int64_t* rowidx, const float* d_output, const Partials& PC, bool pad, const RealDims& R,
-                        hipStream_t st) {
-#define CALLB(S) spec_launch_bwd<S>(d, P, C, B, rowidx, d_output, PC, pad, R, st)
-  TTX_SPEC_DISPATCH(id, CALLB)
-#undef CALLB
-  TTX_FAIL(TTX_EUNSUPPORTED, "no specialised backward kernel");
+static int run_bwd_spec(TTX_SPEC_BWD_ARGS) {
+  int rc = spec_bwd_32(id, d, P, C, B, rowidx, d_output, PC, pad, R, st);
+  if (rc == kSpecNotMine) rc = spec_bwd_64(id, d, P, C, B, rowidx, d_output, PC, pad, R, st);
+  if (rc == kSpecNotMine) rc = spec_bwd_16(id, d, P, C, B, rowidx, d_output, PC, pad, R, st);
+  if (rc == kSpecNotMine) rc = spec_bwd_128a(id, d, P, C, B, rowidx, d_output, PC, pad, R, st);
+  if (rc == kSpecNotMine) rc = spec_bwd_128b(id, d, P, C, B, rowidx, d_output, PC, pad, R, st);
+  if (rc == kSpecNotMine) rc = spec_bwd_128c(id, d, P, C, B, rowidx, d_output, PC, pad, R, st);
+  if (rc == kSpecNotMine) TTX_FAIL(TTX_EUNSUPPORTED, "no specialised backward kernel");
+  return rc;
 }
 
 // fuse: NULL, or the arguments of pooling inside the contraction kernel; *fused says whether the kernel that ran did it

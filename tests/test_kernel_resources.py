@@ -43,7 +43,11 @@ def plan_res():
 
 @pytest.fixture(scope="module")
 def tt_res():
-    return resources("ttx_tt.hip")
+    # (the shape-specialised kernels are a translation unit per rank family)
+    res = {}
+    for src in ("ttx_tt.hip", "ttx_tt_spec32.hip", "ttx_tt_spec128a.hip"):
+        res.update(resources(src))
+    return res
 
 
 def test_plan_kernel_keeps_its_arguments_out_of_scratch(plan_res):
