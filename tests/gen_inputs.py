@@ -90,6 +90,8 @@ def test_shape(T):
 CFG1 = dict(p=[1, 2, 5], q=[1, 1, 3], ranks=[2, 2])                  # README toy example
 CFG2 = dict(p=[200, 220, 250], q=[4, 4, 4], ranks=[32, 32], B=512, L=20)  # benchmark default
 CFG4 = dict(p=[200, 220, 250], q=[4, 4, 8], ranks=[64, 64], B=512, L=20)
+# ranks 128 (the r = 128 shape-specialised kernels; not a BASELINE config): a table small enough to expand with the reference
+R128 = dict(p=[20, 22, 25], q=[4, 4, 4], ranks=[128, 128], B=96, L=8)
 CFG5 = dict(p=[200, 220, 250], q=[4, 4, 4], ranks=[32, 32], tables=26, L=20)  # 26-table batched lookup, global B = 4096
 CFG5_SEED = 5150
 CFG5_GOLDEN_TABLES = (0, 13, 25)  # tables whose reference results are stored in tests/golden/cfg5.npz (B = 512)

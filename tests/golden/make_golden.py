@@ -105,7 +105,7 @@ def write_small():
     np.savez_compressed(os.path.join(HERE, "small_cases.npz"), **blob)
 
 
-def write_big(tag, cfg, seed):
+def write_big(tag, cfg, seed, nrows=16):
     p, q, r, B, L = cfg["p"], cfg["q"], cfg["ranks"], cfg["B"], cfg["L"]
     E, D = int(np.prod(p)), int(np.prod(q))
     cores = G.make_cores(seed, 1, p, q, r, "uniform")
@@ -116,7 +116,7 @@ def write_big(tag, cfg, seed):
     blob = {"seed": np.array([seed]), "out": out}
     for t in range(3):
         g = grads[t].reshape(-1, grads[t].shape[-1])  # [p_t, slice]
-        rows = np.sort(rs.choice(g.shape[0], size=min(16, g.shape[0]), replace=False))
+        rows = np.sort(rs.choice(g.shape[0], size=min(nrows, g.shape[0]), replace=False))
         blob[f"grad{t}_rows"] = rows
         blob[f"grad{t}_sub"] = g[rows]
         blob[f"sgd{t}_sub"] = sgd[t].reshape(g.shape)[rows]
@@ -156,3 +156,4 @@ if __name__ == "__main__":
         write_big("cfg2", G.CFG2, 1234)
         write_big("cfg4", G.CFG4, 4321)
         write_cfg5()
+        write_big("r128", G.R128, 2468, nrows=2)  # (a core_1 slice is 256 KB at r = 128: two sampled slices per core)

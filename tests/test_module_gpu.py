@@ -100,12 +100,13 @@ def _run_big(tag, mode):
     return res
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg4"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg4", "r128"])
 def test_benchmark_configs_full_size(tag):
     """BASELINE configs[1] (cfg2, SGD) and configs[3] (cfg4: ranks 64, D=128,
-    Adagrad) at full size against the golden sub-samples / per-slice sums"""
-    check_big(tag, _run_big(tag, "dense"), _run_big(tag, "sgd") if tag == "cfg2" else None,
-              _run_big(tag, "adagrad") if tag == "cfg4" else None)
+    Adagrad) at full size against the golden sub-samples / per-slice sums; and ranks [128,128] (the r = 128
+    shape-specialised kernels) against what the reference's Python gives for it (SGD and Adagrad)"""
+    check_big(tag, _run_big(tag, "dense"), _run_big(tag, "sgd") if tag != "cfg4" else None,
+              _run_big(tag, "adagrad") if tag != "cfg2" else None)
 
 
 def test_full_size_linearity_and_determinism():

@@ -51,7 +51,7 @@ def test_small_cases_sgd_adagrad(small_cases):
 
 
 def big_case(tag):
-    cfg, seed = (G.CFG2, 1234) if tag == "cfg2" else (G.CFG4, 4321)
+    cfg, seed = {"cfg2": (G.CFG2, 1234), "cfg4": (G.CFG4, 4321), "r128": (G.R128, 2468)}[tag]
     z = np.load(os.path.join(HERE, "golden", f"{tag}.npz"))
     assert int(z["seed"][0]) == seed
     p, q, r = cfg["p"], cfg["q"], G.pad_ranks(cfg["ranks"], 3)
@@ -80,10 +80,10 @@ def check_big(tag, res_dense, res_sgd=None, res_ada=None):
             assert_adagrad_close(res_ada["cores"][k].reshape(g.shape)[rows], z[f"ada{k}_sub"], z[f"grad{k}_sub"], f"{tag} ada{k} rows")
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg4"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg4", "r128"])
 def test_benchmark_configs(tag):
     c, _ = big_case(tag)
-    check_big(tag, _run(c, "dense"), _run(c, "sgd") if tag == "cfg2" else None, _run(c, "adagrad") if tag == "cfg4" else None)
+    check_big(tag, _run(c, "dense"), _run(c, "sgd") if tag != "cfg4" else None, _run(c, "adagrad") if tag != "cfg2" else None)
 
 
 def test_hash_known_answers():
