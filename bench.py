@@ -84,6 +84,8 @@ WORKLOADS = {
     # generic kernels: ranks beyond the LDS (core 1 walked in K blocks x column passes), and the reference tests' odd ranks
     "r128": dict(q=[4, 4, 4], ranks=[128, 128], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "r13": dict(q=[4, 4, 4], ranks=[13, 12], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    "d512": dict(q=[8, 8, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    "d256b1024": dict(q=[4, 8, 8], ranks=[32, 32], tables=1, B=1024, optimizer="sgd", alpha=1.0, populate=False),
     "r96": dict(q=[4, 4, 4], ranks=[96, 96], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "r256": dict(q=[4, 4, 4], ranks=[256, 256], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "tb16": dict(q=[4, 4, 4], ranks=[32, 32], tables=16, B=512, optimizer="sgd", alpha=1.0, populate=False),

@@ -104,6 +104,29 @@ __global__ __launch_bounds__(kCT) void compute_rowidx_kernel(int64_t nb, int32_t
   }
 }
 
+// ---- core-0 row split (ttx_split0_expand, include/ttx.h): a table whose first factor q0 = k q0' is looked up as k
+// "part lookups" per index in a table with p0' = k p0 rows of q0' -- core 0 [p0, q0, r1] IS [k p0, q0', r1] -- part h of bag b
+// becoming bag k b + h of a batch with k times the bags and D / k columns: [B, D] row-major is [k B, D / k].
+// One 8-lane group per bag (compute_rowidx_kernel's shape): virtual offsets, and the bag's indices copied k times.
+__global__ __launch_bounds__(kCT) void split0_expand_kernel(int64_t nb, int32_t k, int64_t p_rest,
+                                                           const int64_t* __restrict__ indices,
+                                                           const int64_t* __restrict__ offsets, int64_t* out_idx,
+                                                           int64_t* out_off) {
+  const int64_t b = (int64_t)blockIdx.x * (kCT / 8) + threadIdx.x / 8;
+  if (b >= nb) return;
+  const int64_t beg = offsets[b], end = offsets[b + 1], len = end - beg;
+  const int l8 = threadIdx.x & 7;
+  if (l8 < k || k > 8)
+    for (int h = l8; h < k; h += 8) out_off[b * k + h] = beg * k + h * len;
+  if (b == nb - 1 && l8 == 0) out_off[nb * k] = end * k;
+  for (int64_t l = beg + l8; l < end; l += 8) {
+    const int64_t idx = indices[l];
+    const int64_t i0 = idx / p_rest;                  // (i0 p_rest + rem  ->  (k i0 + h) p_rest + rem)
+    const int64_t v0 = idx + i0 * (k - 1) * p_rest;
+    for (int h = 0; h < k; ++h) out_idx[beg * k + h * len + (l - beg)] = v0 + h * p_rest;
+  }
+}
+
 // ---- stable partition (cache_lookup_kernel cu:1356-1375 + Flagged) ---------
 // rowidx_update_kernel looked every index up (loc, -1 <=> TT entry) and counted the TT entries of
 // every unit = work-group of kCT positions.  Few units: the scatter launch sums the counts before
@@ -866,6 +889,16 @@ int ttx_update_cache_state(int64_t nnz, const int64_t* indices, int64_t H, int64
   if (!indices || !hashtbl || !cache_freq) TTX_FAIL(TTX_EINVAL, "NULL input");
   hipLaunchKernelGGL(update_cache_state_kernel, dim3((unsigned)((nnz + kCT - 1) / kCT)), dim3(kCT), 0,
                      (hipStream_t)stream, nnz, indices, (int32_t)H, hashtbl, cache_freq);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
+int ttx_split0_expand(int64_t nnz, int64_t nb, int32_t k, int64_t p_rest, const int64_t* indices, const int64_t* offsets,
+                      int64_t* out_indices, int64_t* out_offsets, ttx_stream_t stream) {
+  if (nnz < 0 || nb <= 0 || k < 2 || k > 64 || p_rest <= 0) TTX_FAIL(TTX_EINVAL, "split0: nnz=%lld nb=%lld k=%d", (long long)nnz, (long long)nb, k);
+  if (!offsets || !out_offsets || (nnz > 0 && (!indices || !out_indices))) TTX_FAIL(TTX_EINVAL, "NULL input");
+  hipLaunchKernelGGL(split0_expand_kernel, dim3((unsigned)((nb + kCT / 8 - 1) / (kCT / 8))), dim3(kCT), 0, (hipStream_t)stream, nb,
+                     k, p_rest, indices, offsets, out_indices, out_offsets);
   TTX_HIP(hipGetLastError());
   return TTX_OK;
 }

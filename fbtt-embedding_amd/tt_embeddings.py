@@ -78,6 +78,7 @@ def lib():
     L.ttx_tt_rows.argtypes = [G, i32, i64, vp, vp, vp, vp, vp, sz, vp]
     L.ttx_tt_backward_workspace_bytes.argtypes = [G, i32, i32, i64]
     L.ttx_tt_backward.argtypes = [G, i32, i32, i32, f32, f32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.ttx_split0_expand.argtypes = [i64, i64, i32, i64, vp, vp, vp, vp, vp]
     L.ttx_tt_backward_w.argtypes = [G, i32, i32, i32, f32, f32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.ttx_update_cache_state.argtypes = [i64, vp, i64, vp, vp, vp]
     L.ttx_preprocess_workspace_bytes.argtypes = [i64]
@@ -308,6 +309,20 @@ def make_plan(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz, indices, tabl
         _check(L.ttx_plan_build(C.byref(g), nnz, indices.data_ptr(), tableidx.data_ptr(),
                                 None if rowidx is None else _i64(rowidx, "rowidx").data_ptr(), buf.data_ptr(), nb, _stream(dev)))
     return Plan(buf, nnz, (num_tables, tuple(tt_p_shapes), tuple(tt_q_shapes), tuple(tt_ranks)))
+
+
+def split0_expand(indices: torch.Tensor, offsets: torch.Tensor, k: int, p_rest: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Not in the reference: the part lookups of a table whose first factor is split k ways (include/ttx.h, "core-0 row
+    split").  offsets: nb + 1 entries.  -> (indices [k nnz], offsets [k nb + 1])."""
+    dev = _dev(indices)
+    indices, offsets = _i64(indices, "indices"), _i64(offsets, "offsets")
+    nnz, nb = indices.numel(), offsets.numel() - 1
+    out_i = torch.empty(k * nnz, dtype=torch.int64, device=dev)
+    out_o = torch.empty(k * nb + 1, dtype=torch.int64, device=dev)
+    with _guard(dev):
+        _check(lib().ttx_split0_expand(nnz, nb, k, p_rest, indices.data_ptr(), offsets.data_ptr(), out_i.data_ptr(),
+                                       out_o.data_ptr(), _stream(dev)))
+    return out_i, out_o
 
 
 def lookup_prologue(colidx: torch.Tensor, offsets: torch.Tensor, num_tables: int, tt_p_shapes, tt_q_shapes, tt_ranks,

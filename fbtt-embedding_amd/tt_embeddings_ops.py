@@ -88,6 +88,19 @@ _DEDUP_AUTO_MAX_DISTINCT = 0.6
 _DEDUP_AUTO_PERIOD = 256
 
 
+def _split0_factor(q: Sequence[int], ranks: Sequence[int]) -> int:
+    """k > 1: a T = 3 table with q0 = k q0' (2 <= q0' <= 4, k <= 4), q1, q2 <= 8 and ranks <= 128 is contracted as k part
+    lookups per index in the table [k p0, p1, p2] x [q0', q1, q2] -- core 0 [p0, q0, r1] IS [k p0, q0', r1] -- which the
+    shape-specialised kernels take (include/ttx.h "core-0 row split"; the reference's default factoring of D = 512 is
+    [8, 8, 8]).  0: no split."""
+    if len(q) != 3 or q[0] <= 4 or q[1] > 8 or q[2] > 8 or max(ranks) > 128 or os.environ.get("TTX_NO_SPLIT0"):
+        return 0
+    for k in (2, 3, 4):
+        if q[0] % k == 0 and 2 <= q[0] // k <= 4:
+            return k
+    return 0
+
+
 class BufferList(nn.Module):
     """An indexable list of registered buffers named `<name><i>` (state_dict
     keys `optimizer_state.optimizer_state0`, ...)."""
@@ -338,6 +351,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         self.num_tables, self.tt_ndim = num_tables, nd
         self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
         self.tt_ranks = [1] + tt_ranks + [1]
+        self._split0 = _split0_factor(self.tt_q_shapes, tt_ranks)  # (q0 > 4: part lookups on the q0 <= 4 kernels)
         self.sparse, self.optimizer, self.learning_rate, self.eps = sparse, optimizer, learning_rate, eps
         logging.info("Creating TTEmbeddingBag tt_p_shapes: %s, tt_q_shapes: %s, tt_ranks: %s, sparse: %s, "
                      "optimizer: %s, learning_rate: %s, eps: %s, use_cache: %s, cache_size: %s, hashtbl_size: %s",
@@ -522,7 +536,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         overlap does not apply: cache live, no C++ node, CPU tensors, empty batch, duplicate sharing."""
         fast = _native_node()
         if (fast is None or not self.warmup or not indices.is_cuda or indices.numel() == 0 or self._dedup_may_share(indices.numel())
-                or indices.dim() != 1 or offsets.dim() != 1):
+                or indices.dim() != 1 or offsets.dim() != 1 or self.__dict__.get("_split0", 0) > 1):
             return False
         key = (id(indices), id(offsets))  # (identity: the entry keeps both objects alive, so neither id nor memory is reused)
         idx, off = self._normalise(indices, offsets)
@@ -560,7 +574,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         fast = _native_node()
         batches = list(batches)
         live = not self.warmup
-        if fast is None or not batches or self._dedup_may_share(batches[0][0].numel()) or (live and not (self.use_cache and self.num_tables == 1)):
+        if fast is None or not batches or self.__dict__.get("_split0", 0) > 1 or self._dedup_may_share(batches[0][0].numel()) or (live and not (self.use_cache and self.num_tables == 1)):
             return False
         norm, keys = [], []
         for indices, offsets in batches:
@@ -652,6 +666,25 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         return pre
 
     # --------------------------------------------------------------- forward
+    def _forward_split0(self, fast, indices: torch.Tensor, offsets: torch.Tensor, k: int) -> torch.Tensor:
+        """q0 = k q0': k part lookups per index through the C++ node on the table [k p0, p1, p2] x [q0', q1, q2] (views of
+        core 0 and its optimizer state: the same memory); the output [tables, k B, D / k] IS [tables, B, D]."""
+        use_state = self.sparse and self.optimizer not in _SGD_LIKE
+        optim = 2 if not self.sparse else (1 if use_state else 0)
+        if self.use_cache:  # (the frequency table counts the caller's indices, not the part lookups)
+            _engine.update_cache_state(indices, self.hashtbl, self.cache_freq)
+        p, q, nt = self.tt_p_shapes, self.tt_q_shapes, self.num_tables
+        vi, vo = _engine.split0_expand(indices, offsets, k, p[1] * p[2])
+        c0 = self.tt_cores[0]
+        cores = [c0.view(nt, k * p[0], c0.size(2) // k), self.tt_cores[1], self.tt_cores[2]]
+        state = []
+        if use_state:
+            s0 = self.optimizer_state[0]
+            state = [s0.view(nt, k * p[0], s0.size(2) // k), self.optimizer_state[1], self.optimizer_state[2]]
+        out = fast.lookup(vi, vo, nt, [k * p[0], p[1], p[2]], [q[0] // k, q[1], q[2]], self.tt_ranks, optim,
+                          self.learning_rate, self.eps, None, None, state, cores, None, None, None, None)
+        return out.view(nt, (offsets.numel() - 1) // nt, self.embedding_dim)
+
     def _dedup_may_share(self, nnz: int) -> bool:
         d = getattr(self, "dedup", False)
         return bool(d) and (d != "auto" or nnz >= _DEDUP_AUTO_MIN_NNZ)
@@ -729,6 +762,9 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                 self.tt_ranks, self.L, n_tt, 0, indices, rowidx, tableidx, self.optimizer, self.learning_rate,
                 self.eps, self.sparse, None, self.cache_optimizer_state, self.cache_weight,
                 list(self.optimizer_state), *self.tt_cores)
+        if (self.__dict__.get("_split0", 0) > 1 and fast is not None and self.warmup and indices.is_cuda and indices.numel() > 0
+                and per_sample_weights is None and not hasattr(self, "_p_flat")):
+            return self._forward_split0(fast, indices, offsets, self._split0)
         if fast is not None and self.warmup and indices.is_cuda and indices.numel() > 0:
             # cache not live: the whole lookup (prologue, forward, and the backward / fused optimizer node)
             # is the C++ autograd node of csrc/ttx_torch.cpp -- same C ABI calls, no interpreter in between

@@ -214,6 +214,17 @@ int ttx_tt_backward_dd(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, f
                        const void* plan, float* const* tt_cores, float* const* optimizer_state,
                        float* const* d_tt_cores, void* workspace, size_t workspace_bytes, ttx_stream_t stream);
 
+/* ------------------------------------------- core-0 row split (not in the reference) -----
+ * A T = 3 table whose first factor is q0 = k q0' (q0 = 8: k = 2, q0' = 4) is contracted as k PART lookups per index
+ * in the table p' = [k p0, p1, p2], q' = [q0', q1, q2]: core 0 [p0, q0, r1] is, element for element, [k p0, q0', r1]; index
+ * (i0, i1, i2) becomes (k i0 + h, i1, i2), h = 0..k-1, and part h of bag b is bag k b + h of a batch with k nb bags and
+ * D / k columns -- an output [nb, D] row-major IS [k nb, D / k], so nothing is copied back.  This is how factorings with
+ * q0 > 4 (the reference's default for D = 512, [8,8,8]) reach the shape-specialised kernels (q0 <= 4): same sums, the
+ * core-1 / core-2 gradients of the parts add up in the ordinary reduction.  `offsets` holds nb + 1 entries (closing entry
+ * included), bags table-major as everywhere; out_indices [k nnz], out_offsets [k nb + 1].  p_rest = p1 * p2. */
+int ttx_split0_expand(int64_t nnz, int64_t nb, int32_t k, int64_t p_rest, const int64_t* indices, const int64_t* offsets,
+                      int64_t* out_indices, int64_t* out_offsets, ttx_stream_t stream);
+
 /* ------------------------------------------------------ software cache -----
  * replaces update_cache_state_cuda (tt_embeddings.cpp:74,
  * tt_embeddings_cuda.cu:1077-1113): cache_freq[slot(idx)] += 1 with at most 3

@@ -921,3 +921,54 @@ def test_discarded_planned_batches_are_counted_once_and_the_module_copies(node):
     for other in (m2, m3):
         assert not getattr(other, "_prefetched", None)
         assert torch.equal(other(*reqs[9]), out)
+
+
+@pytest.mark.parametrize("q,ranks,tables", [([8, 8, 8], [16, 16], 1), ([8, 4, 4], [32, 32], 3), ([6, 4, 8], [16, 24], 2),
+                                             ([12, 4, 4], [16, 16], 1), ([16, 2, 4], [13, 12], 1)])
+def test_first_factor_beyond_four_runs_as_part_lookups(q, ranks, tables):
+    """q0 > 4 (the reference's default factoring of D = 512 is [8, 8, 8]): core 0 [p0, q0, r1] IS [k p0, q0 / k, r1], every
+    index becomes k part lookups whose rows are the k parts of the bag's output row (include/ttx.h "core-0 row split"), and the
+    shape-specialised kernels (q0 <= 4) take the table.  Against the oracle on the ORIGINAL geometry and against the same
+    module with the split switched off (generic kernels); dense gradients, fused SGD and Adagrad; ragged and empty bags."""
+    import tt_embeddings_ops as ops
+
+    p = [5, 6, 7]
+    r = [1] + ranks + [1]
+    E_, D, B = int(np.prod(p)), int(np.prod(q)), 50
+    idx, off = G.make_bags(71, B, E_, 4, 3, tables)
+    c = dict(tables=tables, T=3, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+             cores=G.make_cores(72, tables, p, q, r, "signed"), d_out=G.make_grad(73, tables, B, D))
+    g = O.make_geom(tables, p, q, r)
+    rowidx, tableidx = O.rowidx_from_offsets(off, tables)
+
+    def run(split, **kw):
+        m = module_for(c, **kw)
+        assert m._split0 > 1, "the geometry is expected to split"
+        if not split:
+            m._split0 = 0
+        out = m(t(idx), t(off))
+        out.backward(t(c["d_out"]))
+        return m, out.detach().cpu().numpy()
+
+    # dense
+    ms, outs = run(True, sparse=False)
+    mg, outg = run(False, sparse=False)
+    ref_out = O.tt_forward(g, B, D, idx, rowidx, tableidx, [x.copy() for x in c["cores"]])
+    ref_g = O.tt_backward(g, O.OPTIM_DENSE, B, D, 0, 0, idx, rowidx, tableidx, c["d_out"], [x.copy() for x in c["cores"]])
+    assert_close(outs, ref_out, f"split q={q} out vs oracle")
+    assert_close(outs, outg, f"split q={q} out vs generic")
+    for k in range(3):
+        assert_close(ms.tt_cores[k].grad.cpu().numpy(), ref_g[k], f"split q={q} grad{k} vs oracle")
+        assert_close(ms.tt_cores[k].grad.cpu().numpy(), mg.tt_cores[k].grad.cpu().numpy(), f"split q={q} grad{k} vs generic")
+    # fused SGD / Adagrad
+    ms, _ = run(True, sparse=True, optimizer=ops.OptimType.SGD, learning_rate=LR)
+    cores = [x.copy() for x in c["cores"]]
+    O.tt_backward(g, O.OPTIM_SGD, B, D, LR, 0, idx, rowidx, tableidx, c["d_out"], cores)
+    for k in range(3):
+        assert_close(ms.tt_cores[k].detach().cpu().numpy(), cores[k], f"split q={q} sgd core{k}")
+    ms, _ = run(True, sparse=True, optimizer=ops.OptimType.EXACT_ADAGRAD, learning_rate=LR, eps=EPS)
+    cores, state = [x.copy() for x in c["cores"]], [np.zeros_like(x) for x in c["cores"]]
+    O.tt_backward(g, O.OPTIM_ADAGRAD, B, D, LR, EPS, idx, rowidx, tableidx, c["d_out"], cores, state)
+    for k in range(3):
+        assert_close(ms.optimizer_state[k].cpu().numpy(), state[k], f"split q={q} adagrad state{k}")
+        assert_adagrad_close(ms.tt_cores[k].detach().cpu().numpy(), cores[k], ref_g[k], f"split q={q} adagrad core{k}")
