@@ -18,9 +18,9 @@ cp gpurun_out/prof_$TAG/${TAG}_kernel_stats.md gpurun_out/prof_$TAG/pmc_bwd_byte
 { echo "# $TAG: SQ counters of the cfg2 step's kernels (rocprofv3 --pmc, two passes of 8 counters; eager launches)"; echo;
   echo '```'; scripts/pmc_sq.sh "$TAG" 2>&1 | tail -60; echo '```'; } > "$OUT/${TAG}_sq_pmc.md"
 { echo "# $TAG: rocprofv3 --kernel-trace --stats per-kernel durations of the other workloads (eager launches, 30 steps; MI355X)"; echo;
-  scripts/kprof.sh "$TAG" cfg3 cfg3warm cfg4 cfg5shard tb4 d32 d16 d256 r128 r13 2>&1; } > "$OUT/${TAG}_other_workloads.md"
+  scripts/kprof.sh "$TAG" cfg3 cfg3warm cfg4 cfg5shard tb4 d32 d16 d256 r128 r13 d512 r256 2>&1; } > "$OUT/${TAG}_other_workloads.md"
 cp gpurun_out/kprof_$TAG/rocprof_kernels.json "$OUT/" 2>/dev/null
-for W in cfg3 cfg3a105 cfg3warm cfg4 cfg5shard r128 r13; do
+for W in cfg3 cfg3a105 cfg3warm cfg4 cfg5shard r128 r13 d512; do
   python bench.py --workload $W --steps 100 --repeats 3 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_$W.json"
 done
 scripts/cache_rocprof.sh "$TAG" > /dev/null 2>&1
