@@ -64,6 +64,11 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// sixteen independent 4 x 4 outer products (a block = four consecutive lanes): D[lane 4b+j][reg i] += a[lane 4b+i] * b[lane 4b+j]
+__device__ __forceinline__ f32x4 mfma1(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
 // the grid also zeroes the pooled output (the bag-pooling kernel that follows accumulates
 // onto it): saves a memset launch
 __device__ __forceinline__ void zero_output(float* __restrict__ out, long long n) {

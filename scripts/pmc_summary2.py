@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Per-kernel averages of rocprofv3 PMC counters (*_counter_collection.csv) WITH the dispatch duration and the figures
+derived from them (MI355X_MICROARCH.md, "rocprofv3 PMC slots"):
+  clock      = GRBM_GUI_ACTIVE / duration                      (effective shader clock while the kernel ran)
+  mfma_busy  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE)      (share of the run the matrix pipes were busy)
+  parked / issue-stall / active = SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES
+usage: pmc_summary2.py <csv> [<csv> ...]      (markdown on stdout, ttx kernels only)"""
+import collections
+import csv
+import sys
+
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+seen = set()
+for f in sys.argv[1:]:
+    for r in csv.DictReader(open(f)):
+        if "ttx::" not in r["Kernel_Name"]:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ttx::", "")
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        key = (f, r["Dispatch_Id"])
+        if key not in seen:
+            seen.add(key)
+            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, cs in acc.items():
+    d = sum(dur[k]) / len(dur[k])
+    m = {c: sum(v) / len(v) for c, v in cs.items()}
+    print(f"### `{k}`  ({len(dur[k])} dispatches, avg {d:.1f} us under the counters)")
+    print("| counter | avg per dispatch |\n|---|---|")
+    for c in sorted(m):
+        print(f"| {c} | {m[c]:.0f} |")
+    der = []
+    gui = m.get("GRBM_GUI_ACTIVE")
+    if gui:
+        der.append(f"clock {gui / 8 / d / 1e3:.2f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration)")
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+            der.append(f"MFMA pipes busy {m["SQ_VALU_MFMA_BUSY_CYCLES"] / (128 * gui):.3f} of the run (busy cycles / (1024 SIMDs x GUI_ACTIVE / 8 XCDs))")
+    if "SQ_WAVE_CYCLES" in m:
+        w = m["SQ_WAVE_CYCLES"]
+        for c, nm in (("SQ_WAIT_ANY", "parked (waitcnt / barrier)"), ("SQ_WAIT_INST_ANY", "issue-stalled"), ("SQ_ACTIVE_INST_ANY", "issuing")):
+            if c in m:
+                der.append(f"{nm} {m[c] / w:.3f} of wave time")
+    if "SQ_INSTS_VALU_MFMA_MOPS_F32" in m and "SQ_INSTS_VALU" in m:
+        der.append(f"VALU instructions per 512 MFMA MOPS {m['SQ_INSTS_VALU'] / max(m['SQ_INSTS_VALU_MFMA_MOPS_F32'] / 512, 1):.2f}")
+    if der:
+        print("\nderived: " + "; ".join(der))
+    print()
