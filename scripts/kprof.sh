@@ -7,7 +7,7 @@ REPO=$(pwd); OUT=$REPO/gpurun_out/kprof_$TAG; mkdir -p "$OUT"; export TMPDIR=/tm
 for W in "$@"; do
   cd /tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$W" -- python "$REPO/bench.py" --workload "$W" --steps 30 --warmup 5 \
-      --repeats 1 --no-cpu-baseline --no-graph ${KPROF_ARGS:-} > "$OUT/$W.log" 2>&1
+      --repeats 1 --no-cpu-baseline --no-secondary --no-graph ${KPROF_ARGS:-} > "$OUT/$W.log" 2>&1
   cd "$REPO"
   F=$(find "$OUT/$W" -name "*kernel_stats.csv" | head -1)
   { echo "## $W"; python scripts/stats_csv_to_md.py "$F" "$W" | grep -E "ttx::|^\| kernel|^\|---"; grep "^{\"metric" "$OUT/$W.log" | tail -1 | python -c "

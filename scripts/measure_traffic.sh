@@ -12,7 +12,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 50 --warmup 10 --repeats 1 --no-cpu-baseline $*"
+ARGS="--steps 50 --warmup 10 --repeats 1 --no-cpu-baseline --no-secondary $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$REPO/bench.py" $ARGS > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_rd" -- python "$REPO/bench.py" $ARGS --no-graph > "$OUT/pmc_rd.log" 2>&1

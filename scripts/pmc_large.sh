@@ -4,7 +4,7 @@
 set -u
 TAG=$1; W=$2; shift 2
 REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_${TAG}_$W; mkdir -p "$OUT"; export TMPDIR=/tmp
-ARGS="--workload $W --steps 12 --warmup 3 --repeats 1 --no-cpu-baseline --no-graph $*"
+ARGS="--workload $W --steps 12 --warmup 3 --repeats 1 --no-cpu-baseline --no-secondary --no-graph $*"
 cd /tmp
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS \
   --output-format csv -d "$OUT/p1" -- python "$REPO/bench.py" $ARGS > "$OUT/p1.log" 2>&1

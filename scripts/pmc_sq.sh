@@ -3,7 +3,7 @@
 set -u
 TAG=${1:-sq}; shift || true
 REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-graph $*"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-graph $*"
 cd /tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT \
   --output-format csv -d "$OUT/p1" -- python "$REPO/bench.py" $ARGS > "$OUT/p1.log" 2>&1
