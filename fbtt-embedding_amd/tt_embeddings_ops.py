@@ -601,6 +601,18 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                                      batches[k][0]._version, batches[k][1]._version, live)
         return True
 
+    def _cached_args_stale(self, cores, state, buffers) -> bool:
+        """the cached argument lists (_fa / _fc) hold the Parameter / buffer OBJECTS; anything that re-binds one --
+        load_state_dict(assign=True), m.tt_cores[i] = nn.Parameter(..), register_buffer over an old name -- must not leave the
+        native node training the orphaned tensors.  Identity checks against the module's own dicts: no attribute protocol, ~1 us."""
+        pc, ps = self.tt_cores._parameters, self.optimizer_state._buffers  # (BufferList: registered buffers, in order)
+        if len(pc) != len(cores) or any(a is not b for a, b in zip(cores, pc.values())):
+            return True
+        if len(ps) != len(state) or any(a is not b for a, b in zip(state, ps.values())):
+            return True
+        bufs = self._buffers
+        return any(t is not None and bufs.get(name) is not t for name, t in buffers)
+
     def _apply(self, fn, *a, **kw):
         """module.to() / .cuda() / .float(): buffers are replaced by new tensors -- forget the cached argument lists"""
         self.__dict__.pop("_fa", None)
@@ -773,6 +785,8 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             pre = self._take_prefetched(indices, offsets)  # (rowidx, tableidx, plan) if prefetch() ran for this batch
             count = self.use_cache and not self._pf_counted
             fa = self.__dict__.get("_fa")  # (cores, state, hashtbl, cache_freq, p): looked up once, not per step -- every
+            if fa is not None and self._cached_args_stale(fa[0], fa[1], (("hashtbl", fa[2]), ("cache_freq", fa[3]))):
+                fa = None                  #  (a Parameter / buffer was re-bound: load_state_dict(assign=True), tt_cores[i] = ..)
             if fa is None:                 #  nn.Module attribute / ParameterList access is microseconds of a host-bound step
                 fa = self._fa = (list(self.tt_cores), list(self.optimizer_state), self.hashtbl if self.use_cache else None,
                                  self.cache_freq if self.use_cache else None,
@@ -794,6 +808,9 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                 pre = None  # (the planned-ahead partition does not carry weights: this batch's prologue runs in line,
                 self._pf_counted = True  # without counting the batch a second time)
             fc = self.__dict__.get("_fc")  # (the module's tensors, looked up once: see _fa above)
+            if fc is not None and self._cached_args_stale(fc[0], fc[1], (("hashtbl", fc[2]), ("cache_freq", fc[3]), ("cache_state", fc[4]),
+                                                                         ("cache_optimizer_state", fc[5]), ("cache_weight", fc[6]))):
+                fc = None
             if fc is None:
                 fc = self._fc = (list(self.tt_cores), list(self.optimizer_state), self.hashtbl, self.cache_freq, self.cache_state,
                                  self.cache_optimizer_state, self.cache_weight)

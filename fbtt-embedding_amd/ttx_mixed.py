@@ -153,6 +153,21 @@ class VarTableTTEmbeddingBag(TableBatchedTTEmbeddingBag):
         raise NotImplementedError("full_weight() is per table: build a TTEmbeddingBag from table_rows()")
 
 
+def _lookup_node(fn):
+    """the autograd node that runs a group's backward kernels: `fn` itself, or the first node behind the view / reshape nodes
+    the module put on top of it (a node with more than one differentiable input, or none behind it, ends the walk)"""
+    seen = 0
+    while fn is not None and seen < 8:
+        name = type(fn).__name__
+        if not any(v in name for v in ("View", "Reshape", "Alias", "Unsqueeze", "Squeeze", "Permute", "Transpose", "Clone", "Contiguous")):
+            return fn
+        nxt = [f for f, _ in fn.next_functions if f is not None]
+        if len(nxt) != 1:
+            return fn
+        fn, seen = nxt[0], seen + 1
+    return fn
+
+
 class MixedTTEmbeddingBag(nn.Module):
     """TT embedding bags for tables of different cardinality -- and, table by table, different TT ranks and different
     factorings q of the (common) embedding dimension.
@@ -255,12 +270,15 @@ class MixedTTEmbeddingBag(nn.Module):
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
                     res = mod(idx, off, True, psw)  # [tables, B, D]
-                if res.grad_fn is not None:
+                node = _lookup_node(res.grad_fn)
+                if node is not None:
                     # autograd runs this group's backward (recompute + fused optimizer) on the group's stream as well, and
                     # with a fused optimizer there is no leaf gradient whose stream the engine would join at the end: join
                     # it here, after the node has enqueued its kernels (needed for hipGraph capture -- "unjoined work" --
-                    # and for whoever reads the cores on the caller's stream next)
-                    res.grad_fn.register_hook(lambda gi, go, s=s, cur=cur: cur.wait_stream(s))
+                    # and for whoever reads the cores on the caller's stream next).  The hook goes on the LOOKUP node, not on
+                    # whatever reshapes its result (q0 > 4 returns a view: a ViewBackward hook would fire before the lookup's
+                    # backward has enqueued anything -- round 3 advisor finding)
+                    node.register_hook(lambda gi, go, s=s, cur=cur: cur.wait_stream(s))
                 for t in (idx, off) + ((psw,) if psw is not None else ()):
                     t.record_stream(s)   # allocated on the caller's stream, read on the group's
                 res.record_stream(cur)   # ... and the other way round

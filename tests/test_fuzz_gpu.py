@@ -7,16 +7,17 @@ import fuzz_cases
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_plan_and_contraction_fuzz_slice(seed):
-    n, routes = fuzz_cases.run_plan_cases(seed=seed, max_cases=125)
-    assert n == 125
+    n, routes = fuzz_cases.run_plan_cases(seed=seed, max_cases=125 if seed < 2 else 60)
+    assert n == (125 if seed < 2 else 60)
     must = ("tiny", "single", "units", "wide", "multi-pass", "mixed", "prologue", "block-walk") if seed == 0 else \
-        ("tiny", "single", "mixed", "prologue", "block-walk")
+        (("tiny", "single", "mixed", "prologue", "block-walk") if seed == 1 else ("tiny", "single"))
     for route in must:
         assert routes.get(route, 0) > 0, f"plan route {route!r} not exercised: {routes}"
 
 
-@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_cache_prologue_gather_scatter_fuzz_slice(seed):
-    assert fuzz_cases.run_cache_cases(seed=seed, max_cases=125) == 125
+    n = 125 if seed < 2 else 60
+    assert fuzz_cases.run_cache_cases(seed=seed, max_cases=n) == n

@@ -972,3 +972,125 @@ def test_first_factor_beyond_four_runs_as_part_lookups(q, ranks, tables):
     for k in range(3):
         assert_close(ms.optimizer_state[k].cpu().numpy(), state[k], f"split q={q} adagrad state{k}")
         assert_adagrad_close(ms.tt_cores[k].detach().cpu().numpy(), cores[k], ref_g[k], f"split q={q} adagrad core{k}")
+
+
+def test_rebinding_parameters_and_buffers_reaches_the_native_node(node):
+    """Round 3 advisor finding: the module caches the argument lists it hands the C++ node (Parameter / buffer OBJECTS).  Anything
+    that re-binds one -- load_state_dict(assign=True), tt_cores[i] = nn.Parameter(..) -- must be seen by the next call: forward
+    over the new tensors, the fused optimizer on the new tensors, nothing on the orphaned ones."""
+    import tt_embeddings_ops as ops
+
+    p, q, r = [20, 22, 25], [4, 4, 4], [16, 16]
+    E_, D, B = 20 * 22 * 25, 64, 64
+    kw = dict(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, use_cache=False, weight_dist="uniform", device=DEV)
+    m, other = ops.TTEmbeddingBag(E_, D, r, p, q, **kw), ops.TTEmbeddingBag(E_, D, r, p, q, **kw)
+    with torch.no_grad():
+        for dst, src in zip(other.tt_cores, G.make_cores(77, 1, p, q, r, "signed")):
+            dst.copy_(t(src))
+    idx, off = (t(a) for a in G.make_bags(78, B, E_, 6, 2, 1))
+    grad = t(G.make_grad(79, 1, B, D)[0])
+    m(idx, off).backward(grad)  # (first call: the argument lists are cached now)
+    old = [c for c in m.tt_cores]
+    old_vals = [c.detach().clone() for c in old]
+    m.load_state_dict({k: v.clone() for k, v in other.state_dict().items()}, assign=True)
+    assert all(a is not b for a, b in zip(old, m.tt_cores)), "assign=True re-binds the parameters"
+    want = other(idx, off)
+    got = m(idx, off)
+    assert torch.equal(got.detach(), want.detach()), "forward must read the re-bound cores"
+    got.backward(grad)
+    want.backward(grad)
+    torch.cuda.synchronize()
+    for a, b in zip(m.tt_cores, other.tt_cores):
+        assert torch.equal(a.detach(), b.detach()), "the fused optimizer must train the re-bound cores"
+    for a, b in zip(old, old_vals):
+        assert torch.equal(a.detach(), b), "... and leave the orphaned ones alone"
+    # a single core replaced in place
+    with torch.no_grad():
+        m.tt_cores[1] = torch.nn.Parameter(other.tt_cores[1].detach().clone() * 0.5)
+        other.tt_cores[1].mul_(0.5)
+    assert torch.equal(m(idx, off).detach(), other(idx, off).detach())
+
+
+def test_cache_write_back_on_the_hip_path(node):
+    """SURVEY section 8(f3), last clause, on the GPU: cache_populate(write_back=lr) (off by default, not in the reference) takes
+    SGD steps on the cores toward what the cached rows learnt before the rows are decompressed anew.  The TT rows of the cached
+    keys end up closer to the trained cache rows; write_back=0 -- the reference's behaviour -- leaves the cores bit-identical."""
+    import tt_embeddings_ops as ops
+
+    p, q, r = [4, 5, 5], [2, 3, 2], [4, 5]
+    E_, D, B, Lp = 100, 12, 16, 4
+    m = ops.TTEmbeddingBag(E_, D, r, p, q, sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, use_cache=True, cache_size=20,
+                           hashtbl_size=256, weight_dist="uniform", device=DEV)
+    with torch.no_grad():
+        for c, src in zip(m.tt_cores, G.make_cores(7, 1, p, q, r, "signed")):
+            c.copy_(t(src))
+    rs = np.random.RandomState(3)
+    off = torch.arange(0, B * Lp + 1, Lp, device=DEV)
+
+    def batch():
+        return t((rs.zipf(1.3, size=B * Lp) % E_).astype(np.int64))
+
+    for _ in range(3):
+        m(batch(), off)
+    m.cache_populate()
+    for _ in range(4):  # steady state: hits train their cache rows
+        m(batch(), off).backward(t((rs.rand(B, D) * 0.1).astype(np.float32)))
+    slots = torch.nonzero(m.cache_state >= 0).flatten()
+    keys = m.hashtbl[slots]
+    target = m.cache_weight.detach()[m.cache_state[slots].long()].clone()
+
+    def tt_rows():
+        full = ops.tt_matrix_to_full(m.tt_p_shapes, m.tt_q_shapes, m.tt_ranks, [c.detach().cpu() for c in m.tt_cores], [1, 0, 2, 3])
+        return full[keys.cpu()]
+
+    before = float((tt_rows() - target.cpu()).norm())
+    assert before > 1e-3, "the cached rows must have moved away from the cores (otherwise the case shows nothing)"
+    cores0 = [c.detach().clone() for c in m.tt_cores]
+    m.cache_populate()  # the reference's behaviour: cores untouched
+    assert all(torch.equal(a, b) for a, b in zip(cores0, m.tt_cores))
+    with torch.no_grad():  # (populate reset the cache rows to the TT rows: restore what they had learnt)
+        m.cache_weight[m.cache_state[slots].long()] = target
+    m.cache_populate(write_back=2.0, write_back_steps=10)
+    torch.cuda.synchronize()
+    after = float((tt_rows() - target.cpu()).norm())
+    assert after < 0.8 * before, (before, after)
+
+
+def test_streamed_group_with_a_view_on_top_joins_after_the_lookup_node(node):
+    """Round 3 advisor finding: MixedTTEmbeddingBag(streams=True) joins a group's stream from a hook on the group's autograd
+    node; a q0 > 4 table (part lookups) returns a VIEW of the lookup's result, and a hook on the ViewBackward node fires before
+    the lookup's backward has enqueued its kernels.  The hook must sit on the lookup node: after backward() returns, the caller's
+    stream has to be ordered after the group streams' fused-optimizer kernels -- checked by reading the cores on the caller's
+    stream right away, against the same steps without streams."""
+    import tt_embeddings_ops as ops
+    import ttx_mixed
+
+    if node == "python":
+        pytest.skip("part lookups (q0 > 4) run through the C++ node")
+    D, q, r, B = 512, [8, 8, 8], [16, 16]
+    Es, ps = [9000, 60000], [[20, 22, 25], [40, 40, 40]]
+    kw = dict(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, weight_dist="uniform", device=DEV)
+    torch.manual_seed(5)
+    ms = ttx_mixed.MixedTTEmbeddingBag(Es, D, r, ps, q, include_last_offset=False, streams=True, fused=False, **kw)
+    mp = ttx_mixed.MixedTTEmbeddingBag(Es, D, r, ps, q, include_last_offset=False, streams=False, fused=False, **kw)
+    assert len(ms.groups) == 2 and ms._streams is not None
+    with torch.no_grad():
+        for a, b in zip(ms.groups, mp.groups):
+            for dst, src in zip(b.tt_cores, a.tt_cores):
+                dst.copy_(src)
+    rs = np.random.RandomState(13)
+    grads = [t((rs.rand(B, D) * 0.1).astype(np.float32)) for _ in Es]
+    for step in range(3):
+        idx, off = [], []
+        for e in Es:
+            lens = rs.randint(1, 8, size=B)
+            off.append(t(np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)))
+            idx.append(t(rs.randint(0, e, size=int(lens.sum())).astype(np.int64)))
+        outs = ms(idx, off)
+        assert any("View" in type(o.grad_fn).__name__ or "Select" in type(o.grad_fn).__name__ for o in outs)
+        torch.autograd.backward(outs, grads)
+        snap = [c.detach().clone() for g in ms.groups for c in g.tt_cores]  # read on the caller's stream, no synchronize
+        torch.autograd.backward(mp(idx, off), grads)
+        want = [c.detach().clone() for g in mp.groups for c in g.tt_cores]
+        for a, b in zip(snap, want):
+            assert torch.equal(a, b), f"step {step}: the caller's stream read the cores before the group stream's update"
