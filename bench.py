@@ -91,11 +91,20 @@ WORKLOADS = {
     "tb16": dict(q=[4, 4, 4], ranks=[32, 32], tables=16, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "tb8": dict(q=[4, 4, 4], ranks=[32, 32], tables=8, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "tb4": dict(q=[4, 4, 4], ranks=[32, 32], tables=4, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    # two and four cores (the reference contracts 2, 3 and 4: tt_embeddings_cuda.cu:754-776, tt_embeddings_test.py:65-70), the same
+    # 11M-row table: p = [3317, 3317] / [58, 58, 58, 58]
+    "t2": dict(q=[8, 8], ranks=[32], p=[3317, 3317], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    "t4": dict(q=[2, 4, 4, 2], ranks=[32, 32, 32], p=[58, 58, 58, 58], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    "t2big": dict(q=[8, 8], ranks=[32], p=[3317, 3317], tables=4, B=4096, optimizer="sgd", alpha=1.0, populate=False),
+    "t4big": dict(q=[2, 4, 4, 2], ranks=[32, 32, 32], p=[58, 58, 58, 58], tables=4, B=4096, optimizer="sgd", alpha=1.0, populate=False),
 }
 
 
 def flop_per_nnz_fwd(q, r):
-    return 2.0 * (q[0] * r[0] * q[1] * r[1] + q[0] * q[1] * r[1] * q[2])
+    """the reference benchmark's count (tt_embeddings_benchmark.py:154-158: q0 r1 q1 r2 + q0 q1 r2 q2 multiply-adds for three
+    cores), stated for any number of cores: contraction step t multiplies [q_0 .. q_{t-1} x r_t] by core t's [r_t x q_t r_{t+1}]"""
+    rr = list(r) + [1]
+    return 2.0 * sum(float(np.prod(q[:t])) * rr[t - 1] * q[t] * rr[t] for t in range(1, len(q)))
 
 
 def source_hash():
@@ -215,6 +224,8 @@ def main():
                     help="(test) take the N > 1 code path -- process group, sharded module, all-to-all -- with one rank")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
+    global P_SHAPES
+    P_SHAPES = wl.get("p", P_SHAPES)
     Q_SHAPES, RANKS, B_GLOBAL = wl["q"], wl["ranks"], wl["B"]
     if args.optimizer is None:
         args.optimizer = wl["optimizer"]
@@ -394,7 +405,7 @@ def main():
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if cfg5 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"{args.workload}: {what} E=11000000 D={D} p=[200,220,250] q={Q_SHAPES} ranks={RANKS} "
+            "config": {"workload": (f"{args.workload}: {what} E={E_} D={D} p={P_SHAPES} q={Q_SHAPES} ranks={RANKS} "
                                     f"B={B_GLOBAL} L=20 nnz/step={nnz_step_total} sparse {args.optimizer.upper()}, use_cache={cache_txt}{own_txt}"),
                        "nnz_per_step_total": nnz_step_total, "flop_per_nnz_fwd_bwd": 3.0 * fl_fwd,
                        "path": "Python module -> C++ autograd node (or ctypes) -> C ABI -> HIP" + (graph_txt or "; eager")},

@@ -101,9 +101,16 @@ struct Plan {
   int* scratch[TTX_MAX_CORES][3];  // rank / ping / pong per core, [nnz] each
   int max_chunks;
   int MC;
+  // four cores through the three-core kernels (t4_scratch_floats > 0): per lookup, in pivot order, the last two cores'
+  // product M [r2][q2 q3] and, backward, its gradient
+  float* t4m;   // [position][r2 q2 q3]
+  float* t4g;   // [lookup n][r2 q2 q3]
+  int4* t4o;    // [position in core 2's sorted order] = {lookup n, sid_2, sid_3, row of its core-3 partial (ipos[3][n])}
 };
 
 int choose_chunk(const Dims& d, long long nnz);  // lookups per chunk (kernel variant / LDS-budget heuristic)
+// floats of per-lookup scratch a four-core geometry needs in its plan to run on the three-core kernels (0: it does not)
+size_t t4_scratch_floats(const Dims& d);
 int max_chunks(const Dims& d, long long nnz, int MC);
 size_t plan_bytes(const Dims& d, long long nnz);
 // carve `base` into the plan arrays (same function for builder and consumers)

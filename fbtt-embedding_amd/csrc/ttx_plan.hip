@@ -58,6 +58,7 @@ static size_t plan_ints(const Dims& d, long long nnz, int MC) {
   n += r64((size_t)nnz * 4);                                        // lrec
   n += r64((size_t)nnz);                                            // lrow
   n += r64(cnt_ints(d, nnz));                                       // multi-block digit counts
+  if (const size_t tf = t4_scratch_floats(d)) n += 2 * r64((size_t)nnz * tf) + r64((size_t)nnz * 4);  // four cores on the three-core kernels: M, d M, the lookups in core 2's order
   return n;
 }
 
@@ -85,6 +86,11 @@ Plan carve_plan(const Dims& d, long long nnz, void* base) {
     for (int i = 0; i < 3; ++i) P.scratch[t][i] = take(nnz);
   }
   P.chunk_off = take((size_t)d.S[1] + 1);
+  if (const size_t tf = t4_scratch_floats(d)) {
+    P.t4m = (float*)take((size_t)nnz * tf);
+    P.t4g = (float*)take((size_t)nnz * tf);
+    P.t4o = (int4*)take((size_t)nnz * 4);
+  }
   return P;
 }
 

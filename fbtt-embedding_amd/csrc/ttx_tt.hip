@@ -941,6 +941,298 @@ static int spec_mc(const Dims& d, long long nnz) {
   }
 }
 
+// ---- four cores through the three-core kernels (round 4) -------------------------------------------------------------------
+// The reference contracts a lookup's cores left to right whatever their number (tt_embeddings_cuda.cu:754-918, 993-1054); for four
+// cores that is x_0 [q0 q1 x r2] times core 2's [r2 x q2 r3] -- two thirds of the lookup's multiply-adds -- on a slice that is the
+// lookup's own (8 KB at r = 32: the generic kernels stream it from L2 per lookup, 362 us forward / 1265 us backward at the
+// benchmark's batch).  Matrix-chain order says otherwise: contract the LAST TWO cores of the lookup first,
+//     M_n [r2 x q2 q3] = core_2[i_2] [r2 q2 x r3] * core_3[i_3] [r3 x q3]          (2 r2 q2 r3 q3 multiply-adds: 8 K at r = 32),
+// and the lookup is a THREE-core lookup (core_0[i_0], core_1[i_1], M_n) with last factor q2 q3: the shape-specialised kernels
+// take it as it is -- same plan (pivot = core 1), M_n read per lookup where they read core_2's slice (RealDims::c2n).  Backward:
+// the three-core kernel leaves d M_n where it leaves d core_2's partial rows, and
+//     d core_2[i_2] += d M_n * core_3[i_3]^T,      d core_3[i_3] += core_2[i_2]^T * d M_n
+// are the per-lookup partial rows reduce_apply sums like any other core's.  Sums are re-associated, results agree with the
+// left-to-right order to rounding (tested against the oracle at the default tolerance).  Taken when q2 q3 <= 8 and the
+// three-core geometry has a specialised kernel (exact or padded); everything else stays on the generic kernels.
+// Limits of the route: q3 <= 8 (follows from q2 q3 <= 8), a core-2 slice of at most kT4Slice floats (staged in LDS by the
+// gradient kernel: r = 32 with q2 = 4, r = 64 with q2 = 2).
+constexpr int kT4Slice = 8192;
+constexpr int kT4Stage = 1024;  // floats of a lookup's d M row + core-3 slice the gradient kernel stages per step
+static bool t4_merge_dims(const Dims& d, Dims* d3) {
+  if (d.T != 4 || g_disable_spec || (long long)d.q[2] * d.q[3] > 8 || (long long)d.r[2] * d.q[2] * d.r[3] > kT4Slice || d.r[3] > 128 ||
+      (long long)d.r[2] * d.q[2] * d.q[3] + (long long)d.r[3] * d.q[3] > kT4Stage)
+    return false;
+  Dims e = d;
+  e.T = 3;
+  e.q[2] = d.q[2] * d.q[3];
+  e.r[3] = 1;
+  e.r[4] = 0;
+  e.p[2] = 1; e.p[3] = 0; e.q[3] = 0;
+  e.slice[2] = d.r[2] * e.q[2];
+  e.slice[3] = 0;
+  e.S[2] = 0; e.S[3] = 0;
+  if (!spec_match(e)) return false;
+  if (d3) *d3 = e;
+  return true;
+}
+size_t t4_scratch_floats(const Dims& d) { return t4_merge_dims(d, nullptr) ? (size_t)d.r[2] * d.q[2] * d.q[3] : 0; }
+
+
+// M[i][rq][x3] = sum_k core_2[sid_2][rq][k] * core_3[sid_3][k][x3] for the lookup at pivot position i (rq = (kk, x2) of r2 q2):
+// one thread per (i, rq) row -- float4 loads of its r3 values when r3 % 4 == 0 --, k ascending.  Also leaves the lookup's
+// {n, sid_2, sid_3, row of its core-3 partial} at its place in core 2's SORTED order (Plan::t4o): the backward's gradient
+// kernel walks that order and reaches a lookup's operands in two dependent loads instead of four.
+template <int Q3>
+__global__ __launch_bounds__(256) void t4_merge_kernel(Plan P, const float* __restrict__ c2, const float* __restrict__ c3,
+                                                       float* __restrict__ M, int r2q2, int r3) {
+  const long long total = (long long)P.hdr[2] * r2q2;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(e / r2q2), rq = (int)(e % r2q2);
+    const int4 rec = P.lrec[i];
+    if (rq == 0) P.t4o[P.ipos[2][rec.x]] = make_int4(rec.x, rec.z, rec.w, P.ipos[3][rec.x]);
+    const float* a = c2 + ((size_t)rec.z * r2q2 + rq) * r3;
+    const float* b = c3 + (size_t)rec.w * r3 * Q3;
+    float acc[Q3];
+#pragma unroll
+    for (int x = 0; x < Q3; ++x) acc[x] = 0.f;
+    if ((r3 & 3) == 0) {
+#pragma unroll 4
+      for (int k = 0; k < r3; k += 4) {
+        const float4 av = *(const float4*)(a + k);
+        float bv[4 * Q3];  // core_3[k .. k+3][0 .. Q3): 4 Q3 consecutive floats, the same for every row of the lookup
+#pragma unroll
+        for (int v = 0; v < Q3; ++v) *(float4*)(bv + 4 * v) = *(const float4*)(b + k * Q3 + 4 * v);
+#pragma unroll
+        for (int x = 0; x < Q3; ++x) {
+          acc[x] = fmaf(av.x, bv[0 * Q3 + x], acc[x]);
+          acc[x] = fmaf(av.y, bv[1 * Q3 + x], acc[x]);
+          acc[x] = fmaf(av.z, bv[2 * Q3 + x], acc[x]);
+          acc[x] = fmaf(av.w, bv[3 * Q3 + x], acc[x]);
+        }
+      }
+    } else {
+      for (int k = 0; k < r3; ++k) {
+        const float av = a[k];
+#pragma unroll
+        for (int x = 0; x < Q3; ++x) acc[x] = fmaf(av, b[k * Q3 + x], acc[x]);
+      }
+    }
+    float* o = M + (size_t)e * Q3;
+#pragma unroll
+    for (int x = 0; x < Q3; ++x) o[x] = acc[x];
+  }
+}
+
+// Gradients of cores 2 and 3 from d M (by lookup).  Work-group g takes positions [g SEG, (g + 1) SEG) of core 2's SORTED order
+// (Plan::perm[2]: lookups of one slice are consecutive), stages the slice once per run, and per lookup n of the run
+//   (a) adds  d M_n [rq][x3] * core_3[sid_3][k][x3]  to the run's sum of d core_2[slice][rq][k]            (registers),
+//   (b) writes core_2[slice]^T d M_n = the lookup's partial row of core 3 at its place in core 3's order  (Plan::ipos[3]).
+// A run's sum is stored as ONE partial row at the run's first position: a slice's partial rows are then at off[2][s] and at the
+// multiples of SEG inside its range -- no list, and SEG times fewer 16 KB rows than one per lookup (168 MB at 10k lookups).
+// The next lookup's d M row and core-3 slice are fetched into registers while the current one is multiplied.
+constexpr int kT4Threads = 256;
+constexpr int kT4Batch = 4;  // lookups staged per step of the gradient kernel (their loads are in flight together)
+template <int Q3, int NO>    // NO: outputs of (a) per thread (n2 <= NO * 256)
+__global__ __launch_bounds__(kT4Threads) void t4_grad23_kernel(Plan P, const float* __restrict__ c2, const float* __restrict__ c3,
+                                                              const float* __restrict__ dM, float* __restrict__ pc2,
+                                                              float* __restrict__ pc3, int r2q2, int r3, int SEG) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int n2 = r2q2 * r3, n3 = r3 * Q3, pm = r2q2 * Q3;
+  float* c2s = sm;                       // [r2q2][r3]         the run's core-2 slice
+  float* gms = c2s + n2;                 // [LB][r2q2][Q3]     d M of the step's lookups
+  float* c3s = gms + kT4Batch * pm;      // [LB][r3][Q3]       their core-3 slices
+  float* red = c3s + kT4Batch * n3;      // [parts][n3]        partial sums of (b)
+  const int tid = threadIdx.x, nnz = P.hdr[2];
+  const int beg = blockIdx.x * SEG, end = min(nnz, beg + SEG);
+  if (beg >= end) return;
+  float acc[NO];
+  int ork[NO];  // (rq << 16 | k) of output tid + 256 u: the division happens once, not per lookup
+#pragma unroll
+  for (int u = 0; u < NO; ++u) {
+    const int o = tid + u * kT4Threads, rq = o / r3;
+    ork[u] = (rq << 16) | (o - rq * r3);
+    acc[u] = 0.f;
+  }
+  const int parts = n3 >= kT4Threads ? 1 : kT4Threads / n3;   // (b): the rq range is cut into `parts`
+  const int rqper = (r2q2 + parts - 1) / parts;
+  int run0 = beg, cur_sid = -1;
+  for (int j0 = beg; j0 < end; j0 += kT4Batch) {
+    const int nb = min(kT4Batch, end - j0);
+    int4 rc[kT4Batch];
+#pragma unroll
+    for (int b = 0; b < kT4Batch; ++b) rc[b] = P.t4o[min(j0 + b, end - 1)];
+    __syncthreads();  // (the previous step's staged rows are free)
+#pragma unroll
+    for (int b = 0; b < kT4Batch; ++b) {
+      if (b < nb) {
+        for (int e = tid; e < pm; e += kT4Threads) gms[b * pm + e] = dM[(size_t)rc[b].x * pm + e];
+        for (int e = tid; e < n3; e += kT4Threads) c3s[b * n3 + e] = c3[(size_t)rc[b].z * n3 + e];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < kT4Batch; ++b) {
+      if (b >= nb) break;
+      if (rc[b].y != cur_sid) {  // a new run: flush the previous sum, stage this slice (work-group-uniform)
+        if (cur_sid >= 0) {
+#pragma unroll
+          for (int u = 0; u < NO; ++u) {
+            const int o = tid + u * kT4Threads;
+            if (o < n2) pc2[(size_t)run0 * n2 + o] = acc[u];
+            acc[u] = 0.f;
+          }
+        }
+        __syncthreads();  // (everyone is done with the previous slice)
+        for (int e = tid; e < n2; e += kT4Threads) c2s[e] = c2[(size_t)rc[b].y * n2 + e];
+        cur_sid = rc[b].y;
+        run0 = j0 + b;
+      }
+      __syncthreads();  // (the step's rows -- and a new slice -- are staged)
+      const float* gm = gms + b * pm;
+      const float* c3l = c3s + b * n3;
+      // (a) d core_2[rq][k] += sum_x3 dM[rq][x3] * core_3[k][x3]
+#pragma unroll
+      for (int u = 0; u < NO; ++u) {
+        const int o = tid + u * kT4Threads;
+        if (o < n2) {
+          const int rq = ork[u] >> 16, k = ork[u] & 0xffff;
+          float v = acc[u];
+#pragma unroll
+          for (int x = 0; x < Q3; ++x) v = fmaf(gm[rq * Q3 + x], c3l[k * Q3 + x], v);
+          acc[u] = v;
+        }
+      }
+      // (b) the lookup's row of d core_3: [k][x3] = sum_rq core_2[rq][k] * dM[rq][x3], rq ascending inside a part, parts in order
+      const int row3 = rc[b].w;
+      for (int o0 = 0; o0 < n3; o0 += kT4Threads) {
+        const int part = n3 >= kT4Threads ? 0 : tid / n3, o3 = n3 >= kT4Threads ? o0 + tid : tid - part * n3;
+        float v = 0.f;
+        if (part < parts && o3 < n3) {
+          const int k = o3 / Q3, x = o3 - k * Q3;
+          const int q0 = part * rqper, q1 = min(r2q2, q0 + rqper);
+#pragma unroll 8
+          for (int rq = q0; rq < q1; ++rq) v = fmaf(c2s[rq * r3 + k], gm[rq * Q3 + x], v);
+          if (parts > 1) red[part * n3 + o3] = v;
+        }
+        if (parts > 1) {
+          __syncthreads();
+          if (tid < n3) {
+            float t = red[tid];
+            for (int pp = 1; pp < parts; ++pp) t += red[pp * n3 + tid];
+            pc3[(size_t)row3 * n3 + tid] = t;
+          }
+          __syncthreads();  // (red is free for the next lookup)
+        } else if (part < parts && o3 < n3) {
+          pc3[(size_t)row3 * n3 + o3] = v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NO; ++u) {
+    const int o = tid + u * kT4Threads;
+    if (o < n2) pc2[(size_t)run0 * n2 + o] = acc[u];
+  }
+}
+
+// ... and their reduction + optimizer: one work-group per slice of core 2 (partial rows at off[2][s] and at the multiples of SEG
+// inside the slice's range, in that order) and of core 3 (one row per lookup, rows [off[3][s], off[3][s+1]), in order).
+// DENSE writes the gradient (zeros for an untouched slice); SGD / Adagrad touch every element of every touched slice.
+__global__ __launch_bounds__(kT4Threads) void t4_apply23_kernel(Plan P, const float* __restrict__ pc2, const float* __restrict__ pc3,
+                                                               int S2, int n2, int n3, int SEG, int optim, float lr, float eps,
+                                                               float* w2, float* w3, float* st2, float* st3, float* dw2,
+                                                               float* dw3) {
+  __shared__ float red[kT4Threads];
+  const bool is2 = (int)blockIdx.x < S2;
+  const int s = is2 ? blockIdx.x : blockIdx.x - S2;
+  const int* off = is2 ? P.off[2] : P.off[3];
+  const int beg = off[s], end = off[s + 1], sl = is2 ? n2 : n3;
+  const float* pc = is2 ? pc2 : pc3;
+  float* w = (is2 ? w2 : w3) + (size_t)s * sl;
+  float* st = (is2 ? st2 : st3);
+  float* dw = (is2 ? dw2 : dw3);
+  const int tid = threadIdx.x;
+  auto emit = [&](int e, float g) {
+    if (optim == TTX_OPTIM_DENSE) {
+      dw[(size_t)s * sl + e] = g;
+    } else {
+      float sv = optim == TTX_OPTIM_ADAGRAD ? st[(size_t)s * sl + e] : 0.f;
+      w[e] = apply_one(optim, g, w[e], lr, eps, &sv);
+      if (optim == TTX_OPTIM_ADAGRAD) st[(size_t)s * sl + e] = sv;
+    }
+  };
+  if (beg >= end) {
+    if (optim == TTX_OPTIM_DENSE)
+      for (int e = tid; e < sl; e += kT4Threads) dw[(size_t)s * sl + e] = 0.f;
+    return;
+  }
+  if (is2) {  // few rows (the run sums), long: four elements of four rows in flight per thread
+    const int r1 = (beg / SEG + 1) * SEG;  // rows: beg, then r1, r1 + SEG, .. below end
+    for (int e0 = 0; e0 < sl; e0 += 4 * kT4Threads) {
+      float g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + tid + u * kT4Threads;
+        g[u] = e < sl ? pc[(size_t)beg * sl + e] : 0.f;
+      }
+      for (int r = r1; r < end; r += SEG)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + tid + u * kT4Threads;
+          if (e < sl) g[u] += pc[(size_t)r * sl + e];
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + tid + u * kT4Threads;
+        if (e < sl) emit(e, g[u]);
+      }
+    }
+    return;
+  }
+  // core 3: many rows (one per lookup), short: G = 256 / V row groups of V = min(sl, 256) lanes, group g sums rows beg + g,
+  // beg + g + G, .. with four in flight; the group sums are added in group order
+  for (int e0 = 0; e0 < sl; e0 += kT4Threads) {
+    const int V = min(sl - e0, kT4Threads), G = kT4Threads / V;
+    const int g = tid / V, v = tid - g * V;
+    float acc = 0.f;
+    if (g < G) {
+      int r = beg + g;
+      for (; r + 3 * G < end; r += 4 * G) {
+        const float x0 = pc[(size_t)r * sl + e0 + v], x1 = pc[(size_t)(r + G) * sl + e0 + v];
+        const float x2 = pc[(size_t)(r + 2 * G) * sl + e0 + v], x3 = pc[(size_t)(r + 3 * G) * sl + e0 + v];
+        acc += x0; acc += x1; acc += x2; acc += x3;
+      }
+      for (; r < end; r += G) acc += pc[(size_t)r * sl + e0 + v];
+    }
+    __syncthreads();
+    red[tid] = acc;
+    __syncthreads();
+    if (g == 0) {
+      for (int k = 1; k < G; ++k) acc += red[k * V + v];
+      emit(e0 + v, acc);
+    }
+  }
+}
+static int t4_grid(long long work) {
+  const long long b = (work + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+// positions of core 2's sorted order per work-group of the gradient kernel: few enough rows per slice at large batches, enough
+// work-groups at small ones
+static int t4_seg(long long nnz) { return nnz >= (1 << 18) ? 128 : (nnz >= (1 << 16) ? 64 : 32); }
+#define TTX_T4_Q3(Q3, CALL)                                  \
+  switch (Q3) {                                              \
+    case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
+    case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; default: CALL(8); break; \
+  }
+static int t4_merge(const Dims& d, long long nnz, const Plan& P, const float* c2, const float* c3, hipStream_t st) {
+  const int r2q2 = d.r[2] * d.q[2];
+#define TTX_T4_CALL(Q) hipLaunchKernelGGL(t4_merge_kernel<Q>, dim3(t4_grid(nnz * r2q2)), dim3(256), 0, st, P, c2, c3, P.t4m, r2q2, d.r[3])
+  TTX_T4_Q3(d.q[3], TTX_T4_CALL)
+#undef TTX_T4_CALL
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
 // ---------------------------------------------------------- host side ------
 
 // the generic kernels' carve for the block walk choose_tiles() picked (the plan was cut into chunks of its MC)
@@ -994,6 +1286,22 @@ static int run_rows(const Dims& d, long long nnz, const Plan& P, const float* co
                     bool* fused = nullptr) {
   if (fused) *fused = false;
   bool pad = false;
+  Dims d3;
+  if (t4_merge_dims(d, &d3)) {  // four cores: the last two contracted per lookup, then the three-core kernel (see t4_merge_kernel)
+    if (!P.t4m) TTX_FAIL(TTX_EINVAL, "internal: the plan carries no scratch for the four-core route");
+    const SpecId id = spec_match(d3, &pad);
+    ProfScope ps(TTX_PROF_FWD, st);
+    const int rcm = t4_merge(d, nnz, P, cores[2], cores[3], st);
+    if (rcm) return rcm;
+    CorePtrs C;
+    for (int t = 0; t < TTX_MAX_CORES; ++t) C.c[t] = nullptr;
+    C.c[0] = (float*)cores[0]; C.c[1] = (float*)cores[1]; C.c[2] = P.t4m;
+    RealDims R = real_dims(d3);
+    R.c2n = 1;
+    bool did = false;  // (no fused pooling on this route)
+    const PoolFuse none{};
+    return run_rows_spec(id, P, C, rows, zout, nzero, none, &did, pad, R, st);
+  }
   if (const SpecId id = spec_match(d, &pad)) {
     CorePtrs C;
     for (int t = 0; t < TTX_MAX_CORES; ++t) C.c[t] = t < d.T ? (float*)cores[t] : nullptr;
@@ -1056,7 +1364,7 @@ int ttx_debug_tiles(const ttx_geom* g, int32_t* out) {
   if (rc) return rc;
   if (!out) TTX_FAIL(TTX_EINVAL, "out is NULL");
   for (int i = 0; i < 6; ++i) out[i] = 0;
-  if (spec_shape(d)) return TTX_OK;
+  if (spec_shape(d) || t4_merge_dims(d, nullptr)) return TTX_OK;
   const TileCfg cfg = choose_tiles(d);
   if (cfg.MC <= 0) return TTX_OK;
   const Lds L = make_lds(d, cfg.MC, true, cfg.bpp, cfg.KB);
@@ -1305,7 +1613,46 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
     DW.c[t] = (t < d.T && optim == TTX_OPTIM_DENSE) ? d_tt_cores[t] : nullptr;
   }
   bool pad = false;
-  if (const SpecId id = spec_match(d, &pad)) {
+  bool t4_route = false;
+  Dims d3;
+  if (t4_merge_dims(d, &d3)) {  // four cores on the three-core kernel: M, the backward with d M where core 2's partials go, d M -> cores 2, 3
+    if (!P.t4m || !P.t4g) TTX_FAIL(TTX_EINVAL, "internal: the plan carries no scratch for the four-core route");
+    const SpecId id = spec_match(d3, &pad);
+    const int r2q2 = d.r[2] * d.q[2], n2 = r2q2 * d.r[3], n3 = d.r[3] * d.q[3], pm = r2q2 * d.q[3];
+    ProfScope ps(TTX_PROF_BWD, st);
+    rc = t4_merge(d, nnz, P, tt_cores[2], tt_cores[3], st);
+    if (rc) return rc;
+    CorePtrs C3;
+    for (int t = 0; t < TTX_MAX_CORES; ++t) C3.c[t] = nullptr;
+    C3.c[0] = tt_cores[0]; C3.c[1] = tt_cores[1]; C3.c[2] = P.t4m;
+    Partials PC3 = PC;
+    PC3.pc[2] = P.t4g;
+    PC3.pc[3] = nullptr;
+    RealDims R = real_dims(d3);
+    R.c2n = 1;
+    rc = run_bwd_spec(id, d3, P, C3, B, rowidx, d_output, PC3, pad, R, st);
+    if (rc) return rc;
+    const int SEG = t4_seg(nnz);
+    const int parts = n3 >= kT4Threads ? 1 : kT4Threads / n3;
+    const size_t lds = (size_t)(n2 + kT4Batch * (pm + n3) + (parts > 1 ? parts * n3 : 0)) * sizeof(float);
+    const int gblocks = (int)((nnz + SEG - 1) / SEG);
+#define TTX_T4_CALL(Q)                                                                                                          \
+    do {                                                                                                                         \
+      if (n2 <= 8 * kT4Threads)                                                                                                   \
+        hipLaunchKernelGGL((t4_grad23_kernel<Q, 8>), dim3(gblocks), dim3(kT4Threads), lds, st, P, tt_cores[2], tt_cores[3], P.t4g, \
+                           PC.pc[2], PC.pc[3], r2q2, d.r[3], SEG);                                                               \
+      else if (n2 <= 16 * kT4Threads)                                                                                             \
+        hipLaunchKernelGGL((t4_grad23_kernel<Q, 16>), dim3(gblocks), dim3(kT4Threads), lds, st, P, tt_cores[2], tt_cores[3], P.t4g, \
+                           PC.pc[2], PC.pc[3], r2q2, d.r[3], SEG);                                                               \
+      else                                                                                                                        \
+        hipLaunchKernelGGL((t4_grad23_kernel<Q, 32>), dim3(gblocks), dim3(kT4Threads), lds, st, P, tt_cores[2], tt_cores[3], P.t4g, \
+                           PC.pc[2], PC.pc[3], r2q2, d.r[3], SEG);                                                               \
+    } while (0)
+    TTX_T4_Q3(d.q[3], TTX_T4_CALL)
+#undef TTX_T4_CALL
+    TTX_HIP(hipGetLastError());
+    t4_route = true;
+  } else if (const SpecId id = spec_match(d, &pad)) {
     ProfScope ps(TTX_PROF_BWD, st);
     rc = run_bwd_spec(id, d, P, C, B, rowidx, d_output, PC, pad, real_dims(d), st);
     if (rc) return rc;
@@ -1319,6 +1666,23 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
     hipLaunchKernelGGL(bwd_kernel, dim3(P.max_chunks), dim3(kThreads), L.bytes, st, d, P, C, B,
                        rowidx, d_output, PC, L);
     TTX_HIP(hipGetLastError());
+  }
+  if (t4_route && !(g_skip_launch & 2)) {
+    // four-core route: cores 0 and 1 through reduce_apply as a two-core geometry (the pivot is core 1 either way), cores 2 and 3
+    // from the run sums / per-lookup rows the gradient kernel left (t4_apply23_kernel)
+    Dims d2 = d;
+    d2.T = 2;
+    int ns2 = d.S[0] + d.S[1], nsg2 = num_segments(d, nnz, MC, 0) + hot_wgs(P.max_chunks, d.slice[1], 1);
+    const int smax = d.slice[0] > d.slice[1] ? d.slice[0] : d.slice[1];
+    const int rthreads = smax <= 4096 ? TTX_RTHREADS_SMALL : kReduceThreads;
+    ProfScope ps(TTX_PROF_APPLY, st);
+    hipLaunchKernelGGL(reduce_apply_kernel, dim3(ns2 + nsg2), dim3(rthreads), 0, st, d2, P, PC, optim, lr, eps, C, S, DW, ns2,
+                       (int)nnz);
+    TTX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(t4_apply23_kernel, dim3(d.S[2] + d.S[3]), dim3(kT4Threads), 0, st, P, PC.pc[2], PC.pc[3], d.S[2],
+                       d.slice[2], d.slice[3], t4_seg(nnz), optim, lr, eps, C.c[2], C.c[3], S.c[2], S.c[3], DW.c[2], DW.c[3]);
+    TTX_HIP(hipGetLastError());
+    return TTX_OK;
   }
   if (!(g_skip_launch & 2)) {
     const int blocks = nslices + nsegs;  // slice owners, then the segment work-groups of hot slices

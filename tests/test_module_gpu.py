@@ -1067,7 +1067,7 @@ def test_streamed_group_with_a_view_on_top_joins_after_the_lookup_node(node):
 
     if node == "python":
         pytest.skip("part lookups (q0 > 4) run through the C++ node")
-    D, q, r, B = 512, [8, 8, 8], [16, 16]
+    D, q, r, B = 512, [8, 8, 8], [16, 16], 64
     Es, ps = [9000, 60000], [[20, 22, 25], [40, 40, 40]]
     kw = dict(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, weight_dist="uniform", device=DEV)
     torch.manual_seed(5)

@@ -537,3 +537,45 @@ def test_padded_shapes_run_on_the_specialised_kernels(q, ranks):
                 else:
                     assert_close(got["state"][k], orc["state"][k], f"padded {ranks}{q} state{k}")
                     assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"padded {ranks}{q} adagrad core{k}")
+
+
+@pytest.mark.parametrize("q,ranks", [([2, 4, 4, 2], [32, 32, 32]), ([4, 4, 2, 2], [16, 32, 16]), ([3, 4, 2, 3], [13, 12, 7]),
+                                      ([2, 2, 4, 2], [16, 16, 8]), ([4, 4, 4, 2], [32, 32, 8]), ([2, 8, 2, 4], [64, 40, 20]),
+                                      ([2, 3, 1, 5], [20, 30, 33])])
+def test_four_cores_run_on_the_three_core_kernels(q, ranks):
+    """Round 4: a T = 4 geometry with q2 q3 <= 8 runs on the shape-specialised three-core kernels -- the last two cores of a
+    lookup are contracted first (per lookup, M = core_2[i2] * core_3[i3]: matrix-chain order, a tenth of the multiply-adds the
+    reference's left-to-right order spends on core 2), the three-core kernel reads M where it reads core 2's slice, and the
+    backward's d M is turned into the partial rows of cores 2 and 3 (csrc/ttx_tt.hip t4_merge_kernel / t4_unmerge_kernel).
+    Against the oracle (left to right, as the reference) and against the generic kernels; forward, dense / SGD / Adagrad; one and
+    three tables, ragged bags, partial groups."""
+    import tt_embeddings as E
+
+    p = [4, 5, 3, 4]
+    r = [1] + ranks + [1]
+    E_, D = int(np.prod(p)), int(np.prod(q))
+    assert E.debug_tiles(1, p, q, r)["MC"] == 0, "the geometry is expected to take the three-core kernels"
+    for tables, B, pf, std in ((1, 90, 3, 2), (3, 40, 5, 4), (1, 7, 1, 0)):
+        idx, off = G.make_bags(61 + B, B, E_, pf, std, tables)
+        c = dict(tables=tables, T=4, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+                 cores=G.make_cores(62 + B, tables, p, q, r, "signed"), d_out=G.make_grad(63, tables, B, D))
+        for mode in ("dense", "sgd", "adagrad"):
+            got = run_case(c, mode, plan_shared=True)
+            orc = oracle_case(c, mode)
+            E.lib().ttx_debug_skip(256)  # generic kernels
+            try:
+                gen = run_case(c, mode, plan_shared=False)
+            finally:
+                E.lib().ttx_debug_skip(0)
+            assert_close(got["out"], orc["out"], f"T=4 {ranks}{q} out vs oracle")
+            assert_close(got["out"], gen["out"], f"T=4 {ranks}{q} out vs generic")
+            gref = oracle_case(c, "dense")["grads"] if mode == "adagrad" else None
+            for k in range(4):
+                if mode == "dense":
+                    assert_close(got["grads"][k], orc["grads"][k], f"T=4 {ranks}{q} grad{k} vs oracle")
+                    assert_close(got["grads"][k], gen["grads"][k], f"T=4 {ranks}{q} grad{k} vs generic")
+                elif mode == "sgd":
+                    assert_close(got["cores"][k], orc["cores"][k], f"T=4 {ranks}{q} sgd core{k}")
+                else:
+                    assert_close(got["state"][k], orc["state"][k], f"T=4 {ranks}{q} state{k}")
+                    assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"T=4 {ranks}{q} adagrad core{k}")
