@@ -941,6 +941,144 @@ static int spec_mc(const Dims& d, long long nnz) {
   }
 }
 
+// ---- two cores (round 4) ---------------------------------------------------------------------------------------------------
+// A two-core lookup is ONE small product, row = core_0[i_0] [q0 x r1] * core_1[i_1] [r1 x q1]: 2 q0 r1 q1 multiply-adds on two
+// slices of q0 r1 and r1 q1 floats -- 2 FLOP per byte fetched, nothing for a matrix pipe to win (cdna_hip_programming.md: byte
+// work stays byte work).  What the generic kernels lose there (29 / 55 us forward / backward at the benchmark's batch, D = 64 =
+// [8, 8], r = 32) is instructions: MFMA tiles padded from 8 to 16 columns, the block-walk bookkeeping.  These kernels do the
+// least: a work-group per plan chunk (lookups of one core-1 slice) stages that slice once, TRANSPOSED, a wave stages one lookup's
+// core-0 slice (and gradient row) with one coalesced load each and every lane produces its outputs from float4 LDS reads.
+// Backward: d core_0 of the lookup goes out as its partial row, d core_1 accumulates in registers over the wave's lookups and
+// the four waves' sums leave as the chunk's partial -- the layouts reduce_apply expects from any backward kernel.
+// Shapes: r1 % 4 == 0, r1 <= 128, q0, q1 <= 16 (everything else stays on the generic kernels).
+constexpr int kT2Threads = 256;
+static bool t2_shape(const Dims& d) {
+  return d.T == 2 && !g_disable_spec && d.r[1] % 4 == 0 && d.r[1] <= 128 && d.q[0] <= 16 && d.q[1] <= 16;
+}
+struct T2Lds { int ldk, oBt, oA, oG, oR, floats; };  // ldk: row stride of the k-major tiles (r1 + 4: float4 rows, spread over the banks)
+static T2Lds t2_lds(const Dims& d, bool bwd) {
+  T2Lds L;
+  L.ldk = d.r[1] + 4;
+  L.oBt = 0;
+  L.oA = L.oBt + d.q[1] * L.ldk;
+  L.oG = L.oA + kWaves * d.q[0] * L.ldk;
+  L.oR = L.oG + (bwd ? kWaves * (d.D + 4) : 0);
+  L.floats = L.oR + (bwd ? kWaves * d.r[1] * d.q[1] : 0);
+  return L;
+}
+
+__global__ __launch_bounds__(kT2Threads) void t2_fwd_kernel(Dims d, Plan P, CorePtrs C, float* __restrict__ rows,
+                                                           float* __restrict__ zout, long long nzero, T2Lds L) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  zero_output(zout, nzero);
+  const int4 cr = P.chunk_rec[blockIdx.x];
+  const int s = cr.x, start = cr.y, len = cr.z;
+  if (len == 0) return;
+  const int tid = threadIdx.x, lane = lane_id(), w = tid / kWave;
+  const int q0 = d.q[0], q1 = d.q[1], r1 = d.r[1], D = d.D, ldk = L.ldk;
+  float* Bt = sm + L.oBt;                 // [q1][ldk]: core_1[s][k][b] at Bt[b][k]
+  float* As = sm + L.oA + w * q0 * ldk;   // [q0][ldk]: this wave's lookup
+  const float* B1 = C.c[1] + (size_t)s * d.slice[1];
+  for (int e = tid; e < r1 * q1; e += kT2Threads) Bt[(e % q1) * ldk + e / q1] = B1[e];
+  __syncthreads();
+  const int nA4 = q0 * r1 / 4;
+  for (int j = w; j < len; j += kWaves) {
+    const int4 rec = P.lrec[start + j];
+    const float4* A4 = (const float4*)(C.c[0] + (size_t)rec.y * d.slice[0]);
+    for (int e = lane; e < nA4; e += kWave) {  // (one coalesced round for q0 r1 <= 256)
+      const float4 v = A4[e];
+      const int a = (4 * e) / r1, k = (4 * e) % r1;
+      *(float4*)(As + a * ldk + k) = v;
+    }
+    // (wave-private region: LDS operations of a wave complete in order, no barrier)
+    for (int o = lane; o < D; o += kWave) {
+      const int a = o / q1, b = o - a * q1;
+      const float4* ar = (const float4*)(As + a * ldk);
+      const float4* br = (const float4*)(Bt + b * ldk);
+      float acc = 0.f;
+      for (int k4 = 0; k4 < r1 / 4; ++k4) {  // k ascending: the reference's order of additions
+        const float4 x = ar[k4], y = br[k4];
+        acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+      }
+      rows[(size_t)rec.x * D + o] = acc;
+    }
+  }
+}
+
+template <int NB>  // d core_1 outputs per lane: r1 q1 <= 64 NB
+__global__ __launch_bounds__(kT2Threads) void t2_bwd_kernel(Dims d, Plan P, CorePtrs C, int B, const int64_t* __restrict__ rowidx,
+                                                           const float* __restrict__ d_output, Partials PC, T2Lds L) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  zero_hot_counters(PC);
+  const int4 cr = P.chunk_rec[blockIdx.x];
+  const int s = cr.x, start = cr.y, len = cr.z;
+  if (len == 0) return;
+  const int tid = threadIdx.x, lane = lane_id(), w = tid / kWave;
+  const int q0 = d.q[0], q1 = d.q[1], r1 = d.r[1], D = d.D, ldk = L.ldk, ldg = D + 4;
+  float* Bt = sm + L.oBt;
+  float* As = sm + L.oA + w * q0 * ldk;
+  float* Gs = sm + L.oG + w * ldg;        // [q0][q1] gradient row of the lookup's bag
+  float* Rd = sm + L.oR;                  // [waves][r1 q1] the waves' d core_1 sums
+  const float* B1 = C.c[1] + (size_t)s * d.slice[1];
+  for (int e = tid; e < r1 * q1; e += kT2Threads) Bt[(e % q1) * ldk + e / q1] = B1[e];
+  __syncthreads();
+  const bool has_row = P.hdr[3] != 0;
+  const int nA4 = q0 * r1 / 4, n1 = r1 * q1;
+  float accB[NB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) accB[u] = 0.f;
+  for (int j = w; j < len; j += kWaves) {
+    const int4 rec = P.lrec[start + j];
+    const int n = rec.x;
+    const long long row = has_row ? (long long)P.lrow[start + j] : rowidx[n];
+    const int table = PC.tableidx ? (int)PC.tableidx[n] : s / d.p[1];
+    const float sw = PC.psw ? PC.psw[n] : 1.f;
+    const float* gsrc = d_output + ((size_t)table * B + row) * D;
+    const float4* A4 = (const float4*)(C.c[0] + (size_t)rec.y * d.slice[0]);
+    for (int e = lane; e < nA4; e += kWave) {
+      const float4 v = A4[e];
+      const int a = (4 * e) / r1, k = (4 * e) % r1;
+      *(float4*)(As + a * ldk + k) = v;
+    }
+    for (int e = lane; e < D; e += kWave) Gs[e] = gsrc[e] * sw;
+    // d core_0[a][k .. k+3] = sum_b G[a][b] * core_1[k .. k+3][b]: the lookup's partial row (sorted order, Plan::ipos)
+    float* o0 = PC.pc[0] + (size_t)P.ipos[0][n] * d.slice[0];
+    for (int e = lane; e < nA4; e += kWave) {
+      const int a = (4 * e) / r1, k = (4 * e) % r1;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int b = 0; b < q1; ++b) {
+        const float g = Gs[a * q1 + b];
+        const float4 y = *(const float4*)(Bt + b * ldk + k);
+        acc.x = fmaf(g, y.x, acc.x); acc.y = fmaf(g, y.y, acc.y); acc.z = fmaf(g, y.z, acc.z); acc.w = fmaf(g, y.w, acc.w);
+      }
+      ((float4*)o0)[e] = acc;
+    }
+    // d core_1[k][b] += sum_a core_0[a][k] * G[a][b]: this wave's running sum over its lookups of the chunk
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int o = lane + u * kWave;
+      if (o < n1) {
+        const int k = o / q1, b = o - k * q1;
+        float v = accB[u];
+        for (int a = 0; a < q0; ++a) v = fmaf(As[a * ldk + k], Gs[a * q1 + b], v);
+        accB[u] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const int o = lane + u * kWave;
+    if (o < n1) Rd[w * n1 + o] = accB[u];
+  }
+  __syncthreads();
+  float* pc1 = PC.pc[1] + (size_t)cr.w * d.slice[1];
+  for (int e = tid; e < n1; e += kT2Threads) {
+    float v = Rd[e];
+    for (int ww = 1; ww < kWaves; ++ww) v += Rd[ww * n1 + e];
+    pc1[e] = v;
+  }
+}
+
 // ---- four cores through the three-core kernels (round 4) -------------------------------------------------------------------
 // The reference contracts a lookup's cores left to right whatever their number (tt_embeddings_cuda.cu:754-918, 993-1054); for four
 // cores that is x_0 [q0 q1 x r2] times core 2's [r2 x q2 r3] -- two thirds of the lookup's multiply-adds -- on a slice that is the
@@ -1302,6 +1440,16 @@ static int run_rows(const Dims& d, long long nnz, const Plan& P, const float* co
     const PoolFuse none{};
     return run_rows_spec(id, P, C, rows, zout, nzero, none, &did, pad, R, st);
   }
+  if (t2_shape(d)) {  // two cores: the dedicated kernels (t2_fwd_kernel)
+    const T2Lds L = t2_lds(d, false);
+    CorePtrs C;
+    for (int t = 0; t < TTX_MAX_CORES; ++t) C.c[t] = t < d.T ? (float*)cores[t] : nullptr;
+    ProfScope ps(TTX_PROF_FWD, st);
+    hipLaunchKernelGGL(t2_fwd_kernel, dim3(P.max_chunks), dim3(kT2Threads), L.floats * sizeof(float), st, d, P, C, rows, zout,
+                       nzero, L);
+    TTX_HIP(hipGetLastError());
+    return TTX_OK;
+  }
   if (const SpecId id = spec_match(d, &pad)) {
     CorePtrs C;
     for (int t = 0; t < TTX_MAX_CORES; ++t) C.c[t] = t < d.T ? (float*)cores[t] : nullptr;
@@ -1364,7 +1512,7 @@ int ttx_debug_tiles(const ttx_geom* g, int32_t* out) {
   if (rc) return rc;
   if (!out) TTX_FAIL(TTX_EINVAL, "out is NULL");
   for (int i = 0; i < 6; ++i) out[i] = 0;
-  if (spec_shape(d) || t4_merge_dims(d, nullptr)) return TTX_OK;
+  if (spec_shape(d) || t4_merge_dims(d, nullptr) || t2_shape(d)) return TTX_OK;
   const TileCfg cfg = choose_tiles(d);
   if (cfg.MC <= 0) return TTX_OK;
   const Lds L = make_lds(d, cfg.MC, true, cfg.bpp, cfg.KB);
@@ -1652,6 +1800,23 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
 #undef TTX_T4_CALL
     TTX_HIP(hipGetLastError());
     t4_route = true;
+  } else if (t2_shape(d)) {
+    const T2Lds L = t2_lds(d, true);
+    const int n1 = d.r[1] * d.q[1];
+    ProfScope ps(TTX_PROF_BWD, st);
+#define TTX_T2_BWD(NB)                                                                                                        \
+    do {                                                                                                                       \
+      rc = allow_lds(t2_bwd_kernel<NB>, L.floats * (int)sizeof(float));                                                        \
+      if (rc) return rc;                                                                                                       \
+      hipLaunchKernelGGL(t2_bwd_kernel<NB>, dim3(P.max_chunks), dim3(kT2Threads), L.floats * sizeof(float), st, d, P, C, B,   \
+                         rowidx, d_output, PC, L);                                                                             \
+    } while (0)
+    if (n1 <= 4 * kWave) TTX_T2_BWD(4);
+    else if (n1 <= 8 * kWave) TTX_T2_BWD(8);
+    else if (n1 <= 16 * kWave) TTX_T2_BWD(16);
+    else TTX_T2_BWD(32);
+#undef TTX_T2_BWD
+    TTX_HIP(hipGetLastError());
   } else if (const SpecId id = spec_match(d, &pad)) {
     ProfScope ps(TTX_PROF_BWD, st);
     rc = run_bwd_spec(id, d, P, C, B, rowidx, d_output, PC, pad, real_dims(d), st);

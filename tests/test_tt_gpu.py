@@ -579,3 +579,40 @@ def test_four_cores_run_on_the_three_core_kernels(q, ranks):
                 else:
                     assert_close(got["state"][k], orc["state"][k], f"T=4 {ranks}{q} state{k}")
                     assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"T=4 {ranks}{q} adagrad core{k}")
+
+
+@pytest.mark.parametrize("q,ranks", [([8, 8], [32]), ([4, 16], [128]), ([2, 2], [4]), ([16, 8], [64]), ([5, 7], [20]), ([3, 4], [12])])
+def test_two_cores_on_the_dedicated_kernels(q, ranks):
+    """Round 4: a T = 2 geometry with r1 % 4 == 0 (r1 <= 128, q <= 16) runs on the dedicated two-core kernels (csrc/ttx_tt.hip
+    t2_fwd_kernel / t2_bwd_kernel: a lookup is one [q0 x r1] x [r1 x q1] product -- byte work, no matrix tiles to pad).  Against the
+    oracle and against the generic kernels; forward, dense / SGD / Adagrad; one and three tables, ragged bags, partial chunks."""
+    import tt_embeddings as E
+
+    p = [9, 8]
+    r = [1] + ranks + [1]
+    E_, D = int(np.prod(p)), int(np.prod(q))
+    assert E.debug_tiles(1, p, q, r)["MC"] == 0, "the geometry is expected to take the two-core kernels"
+    for tables, B, pf, std in ((1, 90, 3, 2), (3, 40, 5, 4), (1, 7, 1, 0)):
+        idx, off = G.make_bags(71 + B, B, E_, pf, std, tables)
+        c = dict(tables=tables, T=2, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+                 cores=G.make_cores(72 + B, tables, p, q, r, "signed"), d_out=G.make_grad(73, tables, B, D))
+        for mode in ("dense", "sgd", "adagrad"):
+            got = run_case(c, mode, plan_shared=True)
+            orc = oracle_case(c, mode)
+            E.lib().ttx_debug_skip(256)  # generic kernels
+            try:
+                gen = run_case(c, mode, plan_shared=False)
+            finally:
+                E.lib().ttx_debug_skip(0)
+            assert_close(got["out"], orc["out"], f"T=2 {ranks}{q} out vs oracle")
+            assert_close(got["out"], gen["out"], f"T=2 {ranks}{q} out vs generic")
+            gref = oracle_case(c, "dense")["grads"] if mode == "adagrad" else None
+            for k in range(2):
+                if mode == "dense":
+                    assert_close(got["grads"][k], orc["grads"][k], f"T=2 {ranks}{q} grad{k} vs oracle")
+                    assert_close(got["grads"][k], gen["grads"][k], f"T=2 {ranks}{q} grad{k} vs generic")
+                elif mode == "sgd":
+                    assert_close(got["cores"][k], orc["cores"][k], f"T=2 {ranks}{q} sgd core{k}")
+                else:
+                    assert_close(got["state"][k], orc["state"][k], f"T=2 {ranks}{q} state{k}")
+                    assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"T=2 {ranks}{q} adagrad core{k}")
