@@ -436,6 +436,18 @@ def main():
             "kernel_us_note": ("HIP-event brackets around each launch in an eager pass: every bracket includes ~2 us of launch "
                                "gap, so their sum exceeds the replayed step; rocprofv3 durations: profiles/"),
         }
+        if len(Q_SHAPES) == 2 and n_bwd:
+            # two cores: a lookup is one [q0 x r1] x [r1 x q1] product -- 2 FLOP per byte fetched: the bound is bandwidth, not the
+            # matrix pipe.  Algorithmic bytes of the backward per lookup: core-0 slice read + its partial row written (q0 r1 floats
+            # each) + the bag's gradient row read (D floats); per chunk the core-1 slice read and its partial written.
+            per = 4.0 * (2 * Q_SHAPES[0] * RANKS[0] + D)
+            byt = per * rank0_nnz + 2 * 4.0 * RANKS[0] * Q_SHAPES[1] * (rank0_nnz / 16.0)
+            gbs = byt / (bwd_us * 1e-6) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": "t2_bwd_kernel (two-core backward)", "achieved": round(gbs, 1),
+                                "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": round(gbs / (PEAK_HBM_TBS * 1e3), 5), "traffic": None,
+                                "launches": n_bwd, "avg_us": round(bwd_us, 2), "timed_by": bwd_src, "bytes_per_launch": byt,
+                                "note": "core slices of 1 KB per lookup come from L2 / Infinity Cache, the partial rows go to HBM",
+                                "kernel_build": source_hash()}
         if a2a is not None:
             line["all_to_all"] = a2a
         if note:
