@@ -238,8 +238,19 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         if self.local is not None and hasattr(self.local, "_prefetched"):
             self.local._prefetched.clear()
 
-    def forward(self, indices: torch.Tensor, offsets: torch.Tensor, fixed_pooling: Optional[int] = None) -> torch.Tensor:
+    def forward(self, indices: torch.Tensor, offsets: torch.Tensor, fixed_pooling: Optional[int] = None,
+                max_pooling: Optional[int] = None) -> torch.Tensor:
+        """`fixed_pooling=L`: every bag holds exactly L lookups -- the exchanges' split sizes are known without a host
+        read-back (and the step is capturable / can be planned ahead).  `max_pooling=L` (round 4): RAGGED bags of at most L
+        lookups each take the same route -- every bag is padded to L lookups of weight zero (index 0), the bags' lengths
+        travel beside the indices (a fixed-size exchange of B ints per table), and the owner looks the padded bags up with
+        per_sample_weights = [l < length]: fixed shapes everywhere, no `.tolist()`, capturable, at the price of contracting the
+        padding (L / mean length times the lookups).  A bag longer than L is TRUNCATED -- the caller's contract, like
+        fixed_pooling's; `TTX_CHECK_POOLING=1` verifies it with a host read-back.  Neither: ragged bags with one host
+        read-back of the split sizes per step."""
         W, NT, D = self.world, self.num_tables, self.embedding_dim
+        if max_pooling is not None and fixed_pooling is None and not (W == 1 and not _FORCE_EXCHANGE):
+            return self._forward_padded(indices.long(), offsets.long(), int(max_pooling))
         # a batch planned ahead is found by the caller's own tensor objects -- before the casts below replace them
         planned = getattr(self, "_planned", None)
         hit = planned.pop((id(indices), id(offsets)), None) if planned else None
@@ -315,6 +326,51 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
             send = torch.zeros((0, D), device=dev, dtype=torch.float32, requires_grad=True)
         # ---- 3. pooled out ---------------------------------------------------
         if self.direct is not None and fixed_pooling is not None:
+            got = _DirectPooledAllToAll.apply(self.direct, send, [n_me * B] * W, [k * B for k in n_own])
+        else:
+            got = _PooledAllToAll.apply(self.group, send, [n_me * B] * W, [k * B for k in n_own])
+        out = got.view(NT, B, D)
+        if self._identity:
+            return out
+        return out[self._cached(("inv", dev), lambda: torch.tensor(self._inv, device=dev))]
+
+    def _forward_padded(self, indices: torch.Tensor, offsets: torch.Tensor, Lp: int) -> torch.Tensor:
+        """ragged bags as fixed bags of Lp lookups, the padding weighted zero (see forward)"""
+        W, NT, D = self.world, self.num_tables, self.embedding_dim
+        B = (offsets.numel() - 1) // NT
+        dev = indices.device
+        n_own = [len(o) for o in self.owned]
+        n_me = n_own[self.rank]
+        lengths = offsets[1:] - offsets[:-1]                                   # [NT * B]
+        if os.environ.get("TTX_CHECK_POOLING") and lengths.numel() and int(lengths.max()) > Lp:
+            raise ValueError(f"max_pooling={Lp}: a bag holds {int(lengths.max())} lookups")
+        pos = self._cached(("pos", dev, Lp), lambda: torch.arange(Lp, device=dev, dtype=torch.int64))
+        valid = pos[None, :] < lengths[:, None]                               # [NT * B, Lp]
+        if indices.numel():
+            src = (offsets[:-1, None] + pos[None, :]).clamp_(max=indices.numel() - 1)
+            idx_pad = torch.where(valid, indices[src], indices.new_zeros(()))
+        else:
+            idx_pad = indices.new_zeros((NT * B, Lp))
+        order = self._cached(("order", dev), lambda: torch.tensor(self._order, device=dev))
+        send_idx = (idx_pad.view(NT, B * Lp) if self._identity else idx_pad.view(NT, B * Lp)[order]).contiguous().view(-1)
+        send_len = (lengths.view(NT, B) if self._identity else lengths.view(NT, B)[order]).contiguous().view(-1)
+        recv_idx = indices.new_empty(W * n_me * B * Lp)
+        recv_len = lengths.new_empty(W * n_me * B)
+        ex = self.direct.all_to_all if self.direct is not None else self._a2a
+        ex(recv_idx, send_idx, [n_me * B * Lp] * W, [k * B * Lp for k in n_own])
+        ex(recv_len, send_len, [n_me * B] * W, [k * B for k in n_own])
+        # wire order [src][k][b] -> table-major [k][src][b]
+        loc_idx = recv_idx.view(W, n_me, B * Lp).permute(1, 0, 2).contiguous().view(-1)
+        loc_len = recv_len.view(W, n_me, B).permute(1, 0, 2).reshape(-1)
+        loc_w = (pos[None, :] < loc_len[:, None]).to(torch.float32).view(-1)
+        loc_off = self._cached(("off", dev, n_me * W * B, Lp), lambda: torch.arange(
+            0, n_me * W * B * Lp + 1, Lp, device=dev, dtype=torch.int64))
+        if n_me:
+            pooled = self.local(loc_idx, loc_off, per_sample_weights=loc_w)   # [n_me, W*B, D]
+            send = pooled.view(n_me, W, B, D).permute(1, 0, 2, 3).reshape(W * n_me * B, D)
+        else:
+            send = torch.zeros((0, D), device=dev, dtype=torch.float32, requires_grad=True)
+        if self.direct is not None:
             got = _DirectPooledAllToAll.apply(self.direct, send, [n_me * B] * W, [k * B for k in n_own])
         else:
             got = _PooledAllToAll.apply(self.group, send, [n_me * B] * W, [k * B for k in n_own])

@@ -99,6 +99,34 @@ torch.cuda.synchronize()
 for x, y in zip(c.local.tt_cores, d.local.tt_cores):
     assert torch.equal(x, y), "cores differ after the captured planned-ahead round"
 assert not d._planned, "the replayed round left planned batches behind"
+# ---- ragged bags without a host read-back (round 4): forward(.., max_pooling=L) pads every bag to L zero-weight lookups and takes
+# the fixed-size exchanges -- against the ragged route (one .tolist() per step), eagerly and captured
+Lmax = 7
+rs = np.random.RandomState(64)
+rag = []
+for k in range(3 if ops._native_node() is not None else 0):  # (zero-weight padding needs per_sample_weights: the C++ node)
+    lens = rs.randint(0, Lmax + 1, size=B)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = rs.randint(0, E_, size=int(lens.sum())).astype(np.int64)
+    rag.append((torch.from_numpy(idx).to(dev), torch.from_numpy(off).to(dev)))
+e, f = module(), module()
+f.enable_direct_exchange()
+for i, o in rag:
+    oc, od = e(i, o), f(i, o, max_pooling=Lmax)
+    assert torch.allclose(oc, od, rtol=1e-6, atol=1e-7), f"padded ragged forward differs: {(oc - od).abs().max().item()}"
+    oc.backward(grad)
+    od.backward(grad)
+for x, y in zip(e.local.tt_cores, f.local.tt_cores):
+    assert torch.allclose(x, y, rtol=1e-5, atol=1e-7), "cores differ after the padded ragged steps"
+if rag:
+    rnd2 = ttx_graph.GraphedRound(lambda i, o: f(i, o, max_pooling=Lmax).backward(grad), rag, warmup=0)
+    rnd2.replay()
+for i, o in rag:
+    e(i, o).backward(grad)
+torch.cuda.synchronize()
+for x, y in zip(e.local.tt_cores, f.local.tt_cores):
+    assert torch.allclose(x, y, rtol=1e-5, atol=1e-7), "cores differ after the captured padded ragged round"
+print("RAGGED-PADDED-OK", flush=True)
 print("DIRECT-EXCHANGE-OK", flush=True)
 # communicator teardown under a timeout (bench.py's exit path): report, do not insist -- it was seen to hang here
 import threading
@@ -115,3 +143,4 @@ def teardown():
 threading.Thread(target=teardown, daemon=True).start()
 print("TEARDOWN-" + ("OK" if done.wait(20) else "HUNG"), flush=True)
 os._exit(0)
+

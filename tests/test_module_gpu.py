@@ -532,7 +532,7 @@ def test_direct_rccl_exchange_one_rank():
 
     worker = os.path.join(os.path.dirname(__file__), "_direct_exchange_worker.py")
     res = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=240)
-    assert "DIRECT-EXCHANGE-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+    assert "DIRECT-EXCHANGE-OK" in res.stdout and "RAGGED-PADDED-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
 
 @pytest.mark.parametrize("use_cache", [False, True])
