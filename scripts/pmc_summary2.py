@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel averages of rocprofv3 PMC counters (*_counter_collection.csv) WITH the dispatch duration and the figures
 derived from them (MI355X_MICROARCH.md, "rocprofv3 PMC slots"):
-  clock      = GRBM_GUI_ACTIVE / duration                      (effective shader clock while the kernel ran)
-  mfma_busy  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE)      (share of the run the matrix pipes were busy)
+  clock      = GRBM_GUI_ACTIVE / 8 XCDs / duration             (effective shader clock while the kernel ran; the counter sums the XCDs)
+  mfma_busy  = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)  (share of the run the matrix pipes were busy)
   parked / issue-stall / active = SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES
 usage: pmc_summary2.py <csv> [<csv> ...]      (markdown on stdout, ttx kernels only)"""
 import collections
@@ -34,7 +34,8 @@ for k, cs in acc.items():
     if gui:
         der.append(f"clock {gui / 8 / d / 1e3:.2f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration)")
         if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
-            der.append(f"MFMA pipes busy {m["SQ_VALU_MFMA_BUSY_CYCLES"] / (128 * gui):.3f} of the run (busy cycles / (1024 SIMDs x GUI_ACTIVE / 8 XCDs))")
+            busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (128 * gui)
+            der.append(f"MFMA pipes busy {busy:.3f} of the run (busy cycles / (1024 SIMDs x GUI_ACTIVE / 8 XCDs))")
     if "SQ_WAVE_CYCLES" in m:
         w = m["SQ_WAVE_CYCLES"]
         for c, nm in (("SQ_WAIT_ANY", "parked (waitcnt / barrier)"), ("SQ_WAIT_INST_ANY", "issue-stalled"), ("SQ_ACTIVE_INST_ANY", "issuing")):
