@@ -85,6 +85,9 @@ WORKLOADS = {
     "r128": dict(q=[4, 4, 4], ranks=[128, 128], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "r13": dict(q=[4, 4, 4], ranks=[13, 12], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d512": dict(q=[8, 8, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    # the reference's default factorings of D = 768 / 1024: q2 = 12 / 16 (round 4: templates with q2 <= 16 at ranks <= 32)
+    "d768": dict(q=[8, 8, 12], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    "d1024": dict(q=[8, 8, 16], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d256b1024": dict(q=[4, 8, 8], ranks=[32, 32], tables=1, B=1024, optimizer="sgd", alpha=1.0, populate=False),
     "r96": dict(q=[4, 4, 4], ranks=[96, 96], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "r256": dict(q=[4, 4, 4], ranks=[256, 256], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),

@@ -924,7 +924,8 @@ def test_discarded_planned_batches_are_counted_once_and_the_module_copies(node):
 
 
 @pytest.mark.parametrize("q,ranks,tables", [([8, 8, 8], [16, 16], 1), ([8, 4, 4], [32, 32], 3), ([6, 4, 8], [16, 24], 2),
-                                             ([12, 4, 4], [16, 16], 1), ([16, 2, 4], [13, 12], 1)])
+                                             ([12, 4, 4], [16, 16], 1), ([16, 2, 4], [13, 12], 1),
+                                             ([8, 8, 16], [16, 16], 1), ([8, 8, 12], [32, 32], 1), ([8, 8, 10], [24, 32], 2)])
 def test_first_factor_beyond_four_runs_as_part_lookups(q, ranks, tables):
     """q0 > 4 (the reference's default factoring of D = 512 is [8, 8, 8]): core 0 [p0, q0, r1] IS [k p0, q0 / k, r1], every
     index becomes k part lookups whose rows are the k parts of the bag's output row (include/ttx.h "core-0 row split"), and the
