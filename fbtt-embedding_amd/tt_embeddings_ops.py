@@ -34,6 +34,7 @@ import itertools
 import logging
 import math
 import os
+from operator import is_ as _is
 import random
 from enum import Enum, unique
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
@@ -480,8 +481,11 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             self.warmup = True
             self._drop_prefetched(counted=False)  # (the frequency table is empty again)
 
+    @torch.no_grad()
     def _write_back(self, lr: float, steps: int = 1) -> None:
-        """`steps` SGD steps of size `lr` on the cores toward every CACHED row (see cache_populate)."""
+        """`steps` SGD steps of size `lr` on the cores toward every CACHED row (see cache_populate).  Plain SGD whatever the
+        module's optimizer (a correction of the cores toward the cached rows, not a training step: Adagrad's accumulators are not
+        touched); batches planned ahead hold no plan of the cores' VALUES (plans are index work), so they stay valid."""
         slots = torch.nonzero(self.cache_state >= 0).flatten()
         n = int(slots.numel())
         if n == 0:
@@ -608,9 +612,9 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         load_state_dict(assign=True), m.tt_cores[i] = nn.Parameter(..), register_buffer over an old name -- must not leave the
         native node training the orphaned tensors.  Identity checks against the module's own dicts: no attribute protocol, ~1 us."""
         pc, ps = self.tt_cores._parameters, self.optimizer_state._buffers  # (BufferList: registered buffers, in order)
-        if len(pc) != len(cores) or any(a is not b for a, b in zip(cores, pc.values())):
+        if len(pc) != len(cores) or not all(map(_is, cores, pc.values())):
             return True
-        if len(ps) != len(state) or any(a is not b for a, b in zip(state, ps.values())):
+        if len(ps) != len(state) or not all(map(_is, state, ps.values())):
             return True
         bufs = self._buffers
         return any(t is not None and bufs.get(name) is not t for name, t in buffers)

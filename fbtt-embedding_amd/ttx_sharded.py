@@ -235,8 +235,8 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         exchange runs is decided per rank from this table)."""
         if getattr(self, "_planned", None):
             self._planned.clear()
-        if self.local is not None and hasattr(self.local, "_prefetched"):
-            self.local._prefetched.clear()
+        if self.local is not None and hasattr(self.local, "_drop_prefetched"):
+            self.local._drop_prefetched()  # (through the module's own bookkeeping: a cache-using local module counts each batch once)
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, fixed_pooling: Optional[int] = None,
                 max_pooling: Optional[int] = None) -> torch.Tensor:
