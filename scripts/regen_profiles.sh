@@ -16,8 +16,8 @@ set -u
 TAG=${1:-r04}
 REPO=$(pwd); OUT=$REPO/gpurun_out/profiles_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 PMC_W=${PMC_WORKLOADS:-"cfg2 cfg5shard cfg4 r128 r256 t4"}
-KPROF_W=${KPROF_WORKLOADS:-"cfg3 cfg3warm cfg4 cfg5shard tb4 d32 d16 d256 r128 r13 d512 r256 t2 t4 t2big"}
-BENCH_W=${BENCH_WORKLOADS:-"cfg3 cfg3a105 cfg3warm cfg4 cfg5shard r128 r13 d512 t2 t4"}
+KPROF_W=${KPROF_WORKLOADS:-"cfg3 cfg3warm cfg4 cfg5shard tb4 d32 d16 d256 r128 r13 d512 d768 d1024 r256 t2 t4 t2big"}
+BENCH_W=${BENCH_WORKLOADS:-"cfg3 cfg3a105 cfg3warm cfg4 cfg5shard r128 r13 d512 d768 d1024 t2 t4"}
 scripts/measure_traffic.sh "$TAG" > "$OUT/measure_traffic.log" 2>&1
 cp gpurun_out/prof_$TAG/${TAG}_kernel_stats.md gpurun_out/prof_$TAG/pmc_bwd_bytes.json "$OUT/" 2>/dev/null
 for W in $PMC_W; do
