@@ -355,6 +355,18 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
         self.tt_ranks = [1] + tt_ranks + [1]
         self._split0 = _split0_factor(self.tt_q_shapes, tt_ranks)  # (q0 > 4: part lookups on the q0 <= 4 kernels)
+        if self._split0 > 1 and getattr(_engine, "debug_tiles", None) is not None and not isinstance(self.tt_p_shapes[0], (list, tuple)):
+            # ... if the engine has a specialised kernel for the PART geometry (a padded template may be refused for wasting
+            # more than 8x its work, the specialised kernels may be switched off): k times the lookups on the generic kernels
+            # would be slower than the unsplit table on them (round 3 advisor)
+            try:
+                k = self._split0
+                part = _engine.debug_tiles(num_tables, [k * self.tt_p_shapes[0]] + list(self.tt_p_shapes[1:]),
+                                           [self.tt_q_shapes[0] // k] + list(self.tt_q_shapes[1:]), list(self.tt_ranks))
+                if part["MC"] != 0:
+                    self._split0 = 0
+            except Exception:  # noqa: BLE001 -- the query is advice, never a reason to fail construction
+                pass
         self.sparse, self.optimizer, self.learning_rate, self.eps = sparse, optimizer, learning_rate, eps
         logging.info("Creating TTEmbeddingBag tt_p_shapes: %s, tt_q_shapes: %s, tt_ranks: %s, sparse: %s, "
                      "optimizer: %s, learning_rate: %s, eps: %s, use_cache: %s, cache_size: %s, hashtbl_size: %s",
