@@ -88,6 +88,9 @@ WORKLOADS = {
     # the reference's default factorings of D = 768 / 1024: q2 = 12 / 16 (round 4: templates with q2 <= 16 at ranks <= 32)
     "d768": dict(q=[8, 8, 12], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d1024": dict(q=[8, 8, 16], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    # ... of D = 320 / 448: q0 = 5 / 7 has no exact part split -- core 0 zero-padded to 8 slots (round 4)
+    "d320": dict(q=[5, 8, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    "d448": dict(q=[7, 8, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d256b1024": dict(q=[4, 8, 8], ranks=[32, 32], tables=1, B=1024, optimizer="sgd", alpha=1.0, populate=False),
     "r96": dict(q=[4, 4, 4], ranks=[96, 96], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "r256": dict(q=[4, 4, 4], ranks=[256, 256], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),

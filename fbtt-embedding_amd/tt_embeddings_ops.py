@@ -104,6 +104,19 @@ def _split0_factor(q: Sequence[int], ranks: Sequence[int]) -> int:
     return 0
 
 
+def _pad0_target(q: Sequence[int], ranks: Sequence[int]) -> int:
+    """Q > q0: a T = 3 table whose q0 > 4 has no exact part split (5, 7, 10, 11, 13, 14, 15) is contracted with core 0 stored
+    zero-padded to Q = the next multiple of 4 slots -- [p0, Q, r1] IS [Q/4 p0, 4, r1], the part lookups of `_split0_factor` --
+    and the output rows' first D values kept (q0 is the outermost factor of an output row: the real values are a prefix of
+    the padded row).  Exact: the padded slots of core 0 are zero and stay zero (their gradient has the zero output gradient
+    as a factor); costs the multiply-adds on them.  The reference's default factorings of D = 320 / 448 are [5, 8, 8] /
+    [7, 8, 8].  0: no padding."""
+    if len(q) != 3 or q[0] <= 4 or q[0] > 16 or _split0_factor(q, ranks):
+        return 0
+    Q = -(-q[0] // 4) * 4
+    return Q if _split0_factor([Q] + list(q[1:]), ranks) else 0
+
+
 class BufferList(nn.Module):
     """An indexable list of registered buffers named `<name><i>` (state_dict
     keys `optimizer_state.optimizer_state0`, ...)."""
@@ -355,6 +368,9 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
         self.tt_ranks = [1] + tt_ranks + [1]
         self._split0 = _split0_factor(self.tt_q_shapes, tt_ranks)  # (q0 > 4: part lookups on the q0 <= 4 kernels)
+        self._pad0 = _pad0_target(self.tt_q_shapes, tt_ranks)       # (... of core 0 padded to a multiple of 4 slots, round 4)
+        if self._pad0:
+            self._split0 = self._pad0 // 4
         if self._split0 > 1 and getattr(_engine, "debug_tiles", None) is not None and not isinstance(self.tt_p_shapes[0], (list, tuple)):
             # ... if the engine has a specialised kernel for the PART geometry (a padded template may be refused for wasting
             # more than 8x its work, the specialised kernels may be switched off): k times the lookups on the generic kernels
@@ -362,9 +378,9 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             try:
                 k = self._split0
                 part = _engine.debug_tiles(num_tables, [k * self.tt_p_shapes[0]] + list(self.tt_p_shapes[1:]),
-                                           [self.tt_q_shapes[0] // k] + list(self.tt_q_shapes[1:]), list(self.tt_ranks))
+                                           [(self._pad0 or self.tt_q_shapes[0]) // k] + list(self.tt_q_shapes[1:]), list(self.tt_ranks))
                 if part["MC"] != 0:
-                    self._split0 = 0
+                    self._split0 = self._pad0 = 0
             except Exception:  # noqa: BLE001 -- the query is advice, never a reason to fail construction
                 pass
         self.sparse, self.optimizer, self.learning_rate, self.eps = sparse, optimizer, learning_rate, eps
@@ -705,15 +721,56 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             _engine.update_cache_state(indices, self.hashtbl, self.cache_freq)
         p, q, nt = self.tt_p_shapes, self.tt_q_shapes, self.num_tables
         vi, vo = _engine.split0_expand(indices, offsets, k, p[1] * p[2])
+        Q = self.__dict__.get("_pad0", 0) or q[0]
         c0 = self.tt_cores[0]
+        s0 = self.optimizer_state[0] if use_state else None
+        if Q != q[0]:  # core 0 (and its optimizer state) zero-padded to Q slots: `_pad0_target`
+            c0, s0 = self._padded0(Q, optim, use_state)
         cores = [c0.view(nt, k * p[0], c0.size(2) // k), self.tt_cores[1], self.tt_cores[2]]
-        state = []
-        if use_state:
-            s0 = self.optimizer_state[0]
-            state = [s0.view(nt, k * p[0], s0.size(2) // k), self.optimizer_state[1], self.optimizer_state[2]]
-        out = fast.lookup(vi, vo, nt, [k * p[0], p[1], p[2]], [q[0] // k, q[1], q[2]], self.tt_ranks, optim,
+        state = [s0.view(nt, k * p[0], s0.size(2) // k), self.optimizer_state[1], self.optimizer_state[2]] if use_state else []
+        out = fast.lookup(vi, vo, nt, [k * p[0], p[1], p[2]], [Q // k, q[1], q[2]], self.tt_ranks, optim,
                           self.learning_rate, self.eps, None, None, state, cores, None, None, None, None)
-        return out.view(nt, (offsets.numel() - 1) // nt, self.embedding_dim)
+        B = (offsets.numel() - 1) // nt
+        if Q == q[0]:
+            return out.view(nt, B, self.embedding_dim)
+        if optim != 2 and out.grad_fn is not None:
+            # the fused optimizer has updated the padded copies when this node's backward returns: the real slots go back
+            # into the module's own core 0 / state 0 (what state_dict(), full_weight() and every other route read)
+            out.grad_fn.register_hook(lambda gi, go: self._padded0_store())
+        # (a copy, not the strided prefix view: callers of the reference's module get a contiguous [tables, B, D])
+        return out.view(nt, B, Q * q[1] * q[2])[:, :, :self.embedding_dim].contiguous()
+
+    def _padded0(self, Q: int, optim: int, use_state: bool):
+        """core 0 [tables, p0, q0 r1] zero-padded to [tables, p0, Q r1] (and the same of its optimizer state).  Dense gradients
+        (sparse=False): an autograd pad of the Parameter, every step.  Fused optimizers: a buffer the module keeps, refreshed
+        from the Parameter only when that was written or re-bound since the last step's write-back (its `_version`; under stream
+        capture always -- a replay has no such check)."""
+        c, w = self.tt_cores[0], (Q - self.tt_q_shapes[0]) * self.tt_ranks[1]
+        if optim == 2:
+            return torch.nn.functional.pad(c, (0, w)), None
+        sh = self.__dict__.get("_sh0")
+        if sh is None or sh[0].device != c.device:
+            mk = lambda: torch.zeros(c.size(0), c.size(1), c.size(2) + w, device=c.device, dtype=c.dtype)  # noqa: E731
+            sh = self._sh0 = [mk().requires_grad_(True), mk() if use_state else None, None, -1, None, -1]
+        capt = c.is_cuda and torch.cuda.is_current_stream_capturing()
+        srcs = [(0, c, 2)] + ([(1, self.optimizer_state[0], 4)] if use_state else [])
+        with torch.no_grad():
+            for j, src, at in srcs:
+                if sh[j] is None:
+                    sh[j] = torch.zeros_like(sh[0])
+                if capt or sh[at] is not src or sh[at + 1] != src._version:
+                    sh[j][:, :, :src.size(2)].copy_(src)
+                    sh[at], sh[at + 1] = src, src._version
+        return sh[0], sh[1]
+
+    @torch.no_grad()
+    def _padded0_store(self) -> None:
+        sh = self._sh0
+        for j, at in ((0, 2), (1, 4)):
+            src = sh[at]
+            if src is not None and sh[j] is not None:
+                src.copy_(sh[j][:, :, :src.size(2)])
+                sh[at + 1] = src._version
 
     def _dedup_may_share(self, nnz: int) -> bool:
         d = getattr(self, "dedup", False)

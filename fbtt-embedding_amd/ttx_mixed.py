@@ -61,8 +61,14 @@ class VarTableTTEmbeddingBag(TableBatchedTTEmbeddingBag):
                  optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
                  sparse: bool = True, weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
                  device: Optional[torch.device] = None, include_last_offset: bool = True,
-                 table_ranks: Optional[Sequence[List[int]]] = None) -> None:
-        """`table_ranks` (one list per table, every entry <= the matching `tt_ranks` entry): tables of SMALLER TT ranks ride in the
+                 table_ranks: Optional[Sequence[List[int]]] = None, table_q: Optional[Sequence[List[int]]] = None) -> None:
+        """`table_q` (one factoring per table, entry by entry <= `tt_q_shapes`, every one a factoring of `embedding_dim`; round 4):
+        tables whose output rows are factored DIFFERENTLY ride in the same batched lookup.  `tt_q_shapes` is then the common
+        (padded) factoring the kernels run -- prod(tt_q_shapes) >= embedding_dim values per padded output row -- table k's cores are
+        stored zero-padded to it like the ranks below, and forward() gathers every table's own embedding_dim values out of its
+        padded rows (one gather launch; its backward scatters the gradient into zeros, so the padding's gradient is zero and the
+        padding stays zero).
+        `table_ranks` (one list per table, every entry <= the matching `tt_ranks` entry): tables of SMALLER TT ranks ride in the
         same batched lookup -- table k is initialised as a table of its own ranks and its slices are stored zero-padded to the
         common ranks.  The padding stays zero under the fused optimizers (every gradient term of a padded entry has a zero factor),
         so table k keeps behaving as a rank-`table_ranks[k]` table; what it costs is the multiply-adds on the zeros."""
@@ -83,9 +89,17 @@ class VarTableTTEmbeddingBag(TableBatchedTTEmbeddingBag):
             assert len(ps[-1]) == nd and int(np.prod(np.asarray(ps[-1], dtype=np.int64))) >= e
         self.tt_q_shapes = [int(x) for x in tt_q_shapes] if tt_q_shapes is not None \
             else suggested_tt_shapes(int(embedding_dim), nd, allow_round_up=not enforce_embedding_dim)
-        assert int(np.prod(self.tt_q_shapes)) == int(embedding_dim)
+        self.table_q = None if table_q is None else [[int(x) for x in q] for q in table_q]
+        self.out_dim = int(embedding_dim)  # what forward() returns per bag
+        if self.table_q is None:
+            assert int(np.prod(self.tt_q_shapes)) == int(embedding_dim)
+        else:
+            assert tt_q_shapes is not None and len(self.table_q) == len(Es), "table_q: with the common tt_q_shapes, one per table"
+            assert all(len(q) == nd and int(np.prod(q)) == self.out_dim and all(a <= b for a, b in zip(q, self.tt_q_shapes))
+                       for q in self.table_q), "table_q: per table a factoring of embedding_dim, entry by entry <= tt_q_shapes"
         self.num_tables, self.tt_ndim = len(Es), nd
-        self.table_num_embeddings, self.embedding_dim = Es, int(embedding_dim)
+        # (the parent's forward sizes its output rows by embedding_dim: the PADDED row length when the factorings differ)
+        self.table_num_embeddings, self.embedding_dim = Es, int(np.prod(self.tt_q_shapes))
         self.num_embeddings = max(Es)
         self.tt_ranks = [1] + [int(x) for x in tt_ranks] + [1]
         self.tt_p_shapes = ps                                  # one list per table (the ctypes route)
@@ -109,13 +123,24 @@ class VarTableTTEmbeddingBag(TableBatchedTTEmbeddingBag):
             rk = self.tt_ranks if self.table_ranks is None else self.table_ranks[k]
             one = TableBatchedTTEmbeddingBag.__new__(TableBatchedTTEmbeddingBag)
             nn.Module.__init__(one)
-            one.num_tables, one.tt_ndim, one.num_embeddings, one.embedding_dim = 1, nd, e, self.embedding_dim
-            one.tt_ranks, one.tt_p_shapes, one.tt_q_shapes = rk, ps[k], self.tt_q_shapes
-            one.tt_cores = [torch.empty((1, ps[k][t], rk[t] * self.tt_q_shapes[t] * rk[t + 1]), device=device) for t in range(nd)]
+            qk = self.tt_q_shapes if self.table_q is None else self.table_q[k]
+            one.num_tables, one.tt_ndim, one.num_embeddings, one.embedding_dim = 1, nd, e, self.out_dim
+            one.tt_ranks, one.tt_p_shapes, one.tt_q_shapes = rk, ps[k], qk
+            one.tt_cores = [torch.empty((1, ps[k][t], rk[t] * qk[t] * rk[t + 1]), device=device) for t in range(nd)]
             TableBatchedTTEmbeddingBag.reset_parameters(one, weight_dist)
             with torch.no_grad():
                 for t in range(nd):
                     self.set_table_core(k, t, one.tt_cores[t][0])
+        if self.table_q is not None:  # column k, j: where value j of table k's output row sits in its padded row
+            cols = []
+            for q in self.table_q:
+                at = np.zeros(q, dtype=np.int64)
+                for t in range(nd):
+                    shape = [1] * nd
+                    shape[t] = q[t]
+                    at += np.arange(q[t], dtype=np.int64).reshape(shape) * int(np.prod(self.tt_q_shapes[t + 1:]))
+                cols.append(at.reshape(-1))
+            self.register_buffer("_cols", torch.from_numpy(np.stack(cols)).to(device), persistent=False)
         self.use_cache = False
         self.register_buffer("hashtbl", torch.empty(0, device=device, dtype=torch.int64))
         self.register_buffer("cache_freq", torch.empty(0, device=device, dtype=torch.int64))
@@ -124,25 +149,37 @@ class VarTableTTEmbeddingBag(TableBatchedTTEmbeddingBag):
         self.cache_weight = None
         self.warmup = True
 
+    def _table_dims(self, k: int, t: int):
+        rk = self.tt_ranks if self.table_ranks is None else self.table_ranks[k]
+        return rk[t], (self.tt_q_shapes if self.table_q is None else self.table_q[k])[t], rk[t + 1]
+
     def set_table_core(self, k: int, t: int, core: torch.Tensor) -> None:
-        """core t of table k from its natural shape [p_k_t, r_t q_t r_{t+1}] (the table's own ranks), zero-padded to the common ranks"""
+        """core t of table k from its natural shape [p_k_t, r_t q_t r_{t+1}] (the table's own ranks and factoring), zero-padded to
+        the common ones"""
         rows = self.table_rows(t)[k]
-        if self.table_ranks is None:
+        if self.table_ranks is None and self.table_q is None:
             rows.copy_(core.reshape(rows.shape))
             return
-        R0, q, R1 = self.tt_ranks[t], self.tt_q_shapes[t], self.tt_ranks[t + 1]
-        r0, r1 = self.table_ranks[k][t], self.table_ranks[k][t + 1]
+        R0, Q, R1 = self.tt_ranks[t], self.tt_q_shapes[t], self.tt_ranks[t + 1]
+        r0, q, r1 = self._table_dims(k, t)
         rows.zero_()
-        rows.view(-1, R0, q, R1)[:, :r0, :, :r1] = core.reshape(-1, r0, q, r1)
+        rows.view(-1, R0, Q, R1)[:, :r0, :q, :r1] = core.reshape(-1, r0, q, r1)
 
     def table_core(self, k: int, t: int) -> torch.Tensor:
-        """core t of table k in its natural shape [p_k_t, r_t q_t r_{t+1}] (a copy when the table's ranks are padded)"""
+        """core t of table k in its natural shape [p_k_t, r_t q_t r_{t+1}] (a copy when the table's ranks / factoring are padded)"""
         rows = self.table_rows(t)[k]
-        if self.table_ranks is None:
+        if self.table_ranks is None and self.table_q is None:
             return rows
-        R0, q, R1 = self.tt_ranks[t], self.tt_q_shapes[t], self.tt_ranks[t + 1]
-        r0, r1 = self.table_ranks[k][t], self.table_ranks[k][t + 1]
-        return rows.view(-1, R0, q, R1)[:, :r0, :, :r1].reshape(rows.shape[0], -1)
+        R0, Q, R1 = self.tt_ranks[t], self.tt_q_shapes[t], self.tt_ranks[t + 1]
+        r0, q, r1 = self._table_dims(k, t)
+        return rows.view(-1, R0, Q, R1)[:, :r0, :q, :r1].reshape(rows.shape[0], -1)
+
+    def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True,
+                per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+        res = super().forward(indices, offsets, warmup, per_sample_weights)
+        if self.table_q is None:
+            return res
+        return torch.gather(res, 2, self._cols.unsqueeze(1).expand(-1, res.size(1), -1))  # [tables, B, out_dim]
 
     def table_rows(self, t: int) -> List[torch.Tensor]:
         """views [p_k_t, slice] of core t, one per table"""
@@ -159,7 +196,7 @@ def _lookup_node(fn):
     seen = 0
     while fn is not None and seen < 8:
         name = type(fn).__name__
-        if not any(v in name for v in ("View", "Reshape", "Alias", "Unsqueeze", "Squeeze", "Permute", "Transpose", "Clone", "Contiguous")):
+        if not any(v in name for v in ("View", "Reshape", "Slice", "Gather", "Expand", "Alias", "Unsqueeze", "Squeeze", "Permute", "Transpose", "Clone", "Contiguous")):
             return fn
         nxt = [f for f, _ in fn.next_functions if f is not None]
         if len(nxt) != 1:
@@ -178,7 +215,10 @@ class MixedTTEmbeddingBag(nn.Module):
       fused=True : a group = tables of equal factoring q whatever their row factors p AND their ranks, a `VarTableTTEmbeddingBag`:
                    ONE launch set per q -- tables of smaller ranks are stored zero-padded to the group's largest (exact: the padding
                    stays zero under the fused optimizers; costs the multiply-adds on the zeros: done by default when that is at most
-                   twice the tables' own work, `pad_ranks=True / False` forces it / keeps one group per (q, ranks)).  Tables that differ in q produce output rows of different layouts: separate launch sets.
+                   twice the tables' own work, `pad_ranks=True / False` forces it / keeps one group per (q, ranks)).  Tables that differ in q produce
+                   output rows of different layouts: separate launch sets, or -- `pad_q` (round 4; same default rule and switch) -- ONE
+                   set over the entry-by-entry largest factoring, every table's cores zero-padded to it and its own values gathered
+                   out of the padded rows (`VarTableTTEmbeddingBag(table_q=)`).
     `streams=True` gives every group a HIP stream of its own: eagerly the step is host-bound and nothing is gained, but
     captured into a hipGraph (ttx_graph.GraphedRound) the groups become parallel branches and their kernels -- each too
     small to fill the chip at DLRM batch sizes -- run side by side (scripts/bench_mixed.py).
@@ -191,7 +231,8 @@ class MixedTTEmbeddingBag(nn.Module):
                  optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
                  sparse: bool = True, weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
                  device: Optional[torch.device] = None, include_last_offset: bool = False,
-                 streams: bool = False, fused: bool = False, pad_ranks: Optional[bool] = None) -> None:
+                 streams: bool = False, fused: bool = False, pad_ranks: Optional[bool] = None,
+                 pad_q: Optional[bool] = None) -> None:
         super().__init__()
         self.num_embeddings = [int(e) for e in num_embeddings]
         n = len(self.num_embeddings)
@@ -211,12 +252,34 @@ class MixedTTEmbeddingBag(nn.Module):
             nd = len(ranks[k]) + 1
             given = tt_p_shapes[k] if tt_p_shapes is not None else None
             shapes.append(tuple(int(x) for x in given) if given is not None else tuple(suggested_tt_shapes(e, nd)))
+        if fused:  # (every table's factoring, spelled out: the grouping below compares them)
+            qs = [q if q is not None else suggested_tt_shapes(self.embedding_dim, len(ranks[k]) + 1, allow_round_up=not enforce_embedding_dim)
+                  for k, q in enumerate(qs)]
+
+        def madds(rk, q):
+            return sum(rk[i] * q[i] * rk[i + 1] for i in range(len(q)))
+
+        if pad_q is None and fused:
+            # auto: tables of different factorings in ONE launch set (cores zero-padded to the entry-by-entry largest factoring,
+            # `VarTableTTEmbeddingBag(table_q=)`) when that costs at most twice the tables' own multiply-adds, ranks padded as well
+            pad_q = False
+            by_nd: Dict[int, List[int]] = {}
+            for k in range(n):
+                by_nd.setdefault(len(ranks[k]), []).append(k)
+            for tabs in by_nd.values():
+                if len({tuple(qs[k]) for k in tabs}) < 2 or pad_ranks is False and len({tuple(ranks[k]) for k in tabs}) > 1:
+                    continue
+                nd1 = len(ranks[tabs[0]])
+                qmax = [max(qs[k][i] for k in tabs) for i in range(nd1 + 1)]
+                rmax = [max(ranks[k][i] for k in tabs) for i in range(nd1)]
+                real = sum(madds([1] + ranks[k] + [1], qs[k]) for k in tabs)
+                if madds([1] + rmax + [1], qmax) * len(tabs) <= 2 * real:
+                    pad_q, pad_ranks = True, True
+        pad_q = bool(pad_q) and fused
         if pad_ranks is None and fused:
             # auto: one launch set per factoring when the zero padding costs at most twice the tables' own multiply-adds
             # (measured, scripts/bench_mixed.py: ranks 32 / 16 in one set 0.278 vs 0.297 ms/step in two; ranks 64 / 32 / 16 /
             # [13,12] in one set 0.72 vs 0.43 in four)
-            def madds(rk, q):
-                return sum(rk[i] * q[i] * rk[i + 1] for i in range(len(q)))
             pad_ranks = True
             by_q: Dict[tuple, List[int]] = {}
             for k in range(n):
@@ -231,8 +294,8 @@ class MixedTTEmbeddingBag(nn.Module):
         for k in range(n):
             # fused: tables of one factoring q share a batched lookup whatever their ranks (smaller ranks are zero-padded to the
             # group's largest, VarTableTTEmbeddingBag(table_ranks=)); pad_ranks=False keeps one group per (q, ranks)
-            key = ((len(ranks[k]),) if fused and pad_ranks else (tuple(ranks[k]),)) + (None if qs[k] is None else tuple(qs[k]),) + \
-                  (() if fused else (shapes[k],))
+            key = ((len(ranks[k]),) if fused and pad_ranks else (tuple(ranks[k]),)) + \
+                  ((len(ranks[k]),) if pad_q else (None if qs[k] is None else tuple(qs[k]),)) + (() if fused else (shapes[k],))
             groups.setdefault(key, []).append(k)
         self.group_tables = list(groups.values())
         self.groups = nn.ModuleList()
@@ -241,10 +304,12 @@ class MixedTTEmbeddingBag(nn.Module):
             if fused:  # ONE batched lookup for the group's tables, whatever their row factors (VarTableTTEmbeddingBag)
                 rmax = [max(ranks[k][i] for k in tables) for i in range(len(ranks[k0]))]
                 mixed_ranks = any(ranks[k] != rmax for k in tables)
+                qmax = [max(qs[k][i] for k in tables) for i in range(len(qs[k0]))]
+                mixed_q = any(qs[k] != qmax for k in tables)
                 self.groups.append(VarTableTTEmbeddingBag(
                     [self.num_embeddings[k] for k in tables], self.embedding_dim, rmax, [list(shapes[k]) for k in tables],
-                    qs[k0], optimizer, learning_rate, eps, sparse, weight_dist, enforce_embedding_dim, device, True,
-                    [ranks[k] for k in tables] if mixed_ranks else None))
+                    qmax, optimizer, learning_rate, eps, sparse, weight_dist, enforce_embedding_dim, device, True,
+                    [ranks[k] for k in tables] if mixed_ranks else None, [qs[k] for k in tables] if mixed_q else None))
             else:
                 self.groups.append(TableBatchedTTEmbeddingBag(
                     len(tables), max(self.num_embeddings[k] for k in tables), self.embedding_dim, list(ranks[k0]),

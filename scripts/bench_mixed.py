@@ -80,3 +80,19 @@ for pad in (False, True):
     torch.cuda.synchronize()
     print(f"ranks 32 / 16 ({len(m3.groups)} launch sets, {n_l} kernel launches per step), pad_ranks={pad!s:5}: eager {ms:.3f} ms/step, "
           f"hipGraph round {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step")
+# tables that differ in the factoring q of D = 64 (round 4): [4,4,4] x4 and [2,4,8] x4, ranks 32 -- two launch sets (streams: parallel
+# branches of the graph) against ONE over q = [4,4,8] with every table's cores zero-padded to it (pad_q)
+q4 = [[4, 4, 4], [2, 4, 8]] * 4
+for streams, padq in ((False, False), (True, False), (False, True)):
+    m4 = ttx_mixed.MixedTTEmbeddingBag(Es, D, r, ps, q4, include_last_offset=False, streams=streams, fused=True, pad_q=padq, **kw)
+    def step4(idx, off):
+        torch.autograd.backward(m4(idx, off), grads)
+    ms = timeit(step4)
+    n_l = launches(lambda: step4(*reqs[0]))
+    r4 = ttx_graph.GraphedRound(step4, reqs, warmup=2)
+    for _ in range(3): r4.replay()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): r4.replay()
+    torch.cuda.synchronize()
+    print(f"q = [4,4,4] / [2,4,8] ({len(m4.groups)} launch sets, {n_l} engine launches per step), streams={streams!s:5} pad_q={padq!s:5}: eager {ms:.3f} ms/step, "
+          f"hipGraph round {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step")

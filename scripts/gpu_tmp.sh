@@ -1,4 +1,4 @@
 #!/bin/bash
+# scratch: the round's current GPU check
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 | tee gpurun_out/t_full.log
-scripts/regen_profiles.sh r04 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_module_gpu.py -x -q -m gpu -k "padded_first" 2>&1 | tail -15

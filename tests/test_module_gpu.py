@@ -425,7 +425,7 @@ def test_mixed_cardinality_tables(node, streams):
                          f"table {k} core{c} after two SGD steps")
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "pad_q"])
 def test_mixed_ranks_one_graph(node, fused):
     """f4: tables of different TT ranks AND factorings behind one MixedTTEmbeddingBag -- specialised (r = 32, 16) and generic
     (r = 13 / 12, q = [2, 4, 8]) launch sets, one per shape group, each on a HIP stream of its own and captured into ONE
@@ -443,10 +443,16 @@ def test_mixed_ranks_one_graph(node, fused):
     ranks = [[32, 32], [16, 16], [32, 32], [13, 12], [16, 16], [16, 16]]
     qs = [[4, 4, 4], [4, 4, 4], [4, 4, 4], [4, 4, 4], [4, 4, 4], [2, 4, 8]]
     kw = dict(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, weight_dist="uniform", device=DEV)
-    mm = ttx_mixed.MixedTTEmbeddingBag(Es, D, ranks, ps, qs, include_last_offset=False, streams=True, fused=fused, pad_ranks=True, **kw)
+    pad_q = fused == "pad_q"
+    fused = bool(fused)
+    mm = ttx_mixed.MixedTTEmbeddingBag(Es, D, ranks, ps, qs, include_last_offset=False, streams=True, fused=fused, pad_ranks=True,
+                                       pad_q=pad_q, **kw)
     # fused: ONE batched lookup per factoring q -- the five q = [4,4,4] tables of ranks 32 / 16 / [13,12] ride together, the smaller
-    # ranks zero-padded to 32 -- and one for q = [2,4,8]; not fused: a group per (p, q, ranks)
-    assert len(mm.groups) == (2 if fused else 4) and sorted(sum(mm.group_tables, [])) == list(range(6))
+    # ranks zero-padded to 32 -- and one for q = [2,4,8]; not fused: a group per (p, q, ranks); pad_q (round 4): ONE batched lookup
+    # for all six, over q = [4,4,8] -- every table's cores zero-padded to it, its 64 values gathered out of the 128-value rows
+    assert len(mm.groups) == (1 if pad_q else 2 if fused else 4) and sorted(sum(mm.group_tables, [])) == list(range(6))
+    if pad_q:
+        assert mm.groups[0].tt_q_shapes == [4, 4, 8] and mm.groups[0].out_dim == D
     ones = []
     for k in range(len(Es)):
         g = next(i for i, tb in enumerate(mm.group_tables) if k in tb)
@@ -925,7 +931,10 @@ def test_discarded_planned_batches_are_counted_once_and_the_module_copies(node):
 
 @pytest.mark.parametrize("q,ranks,tables", [([8, 8, 8], [16, 16], 1), ([8, 4, 4], [32, 32], 3), ([6, 4, 8], [16, 24], 2),
                                              ([12, 4, 4], [16, 16], 1), ([16, 2, 4], [13, 12], 1),
-                                             ([8, 8, 16], [16, 16], 1), ([8, 8, 12], [32, 32], 1), ([8, 8, 10], [24, 32], 2)])
+                                             ([8, 8, 16], [16, 16], 1), ([8, 8, 12], [32, 32], 1), ([8, 8, 10], [24, 32], 2),
+                                             # q0 without an exact split (round 4): core 0 zero-padded to 8 / 12 / 16 slots
+                                             ([5, 8, 8], [32, 32], 1), ([7, 4, 4], [16, 16], 2), ([10, 4, 8], [16, 24], 1),
+                                             ([13, 2, 4], [13, 12], 1)])
 def test_first_factor_beyond_four_runs_as_part_lookups(q, ranks, tables):
     """q0 > 4 (the reference's default factoring of D = 512 is [8, 8, 8]): core 0 [p0, q0, r1] IS [k p0, q0 / k, r1], every
     index becomes k part lookups whose rows are the k parts of the bag's output row (include/ttx.h "core-0 row split"), and the
@@ -973,6 +982,77 @@ def test_first_factor_beyond_four_runs_as_part_lookups(q, ranks, tables):
     for k in range(3):
         assert_close(ms.optimizer_state[k].cpu().numpy(), state[k], f"split q={q} adagrad state{k}")
         assert_adagrad_close(ms.tt_cores[k].detach().cpu().numpy(), cores[k], ref_g[k], f"split q={q} adagrad core{k}")
+
+
+@pytest.mark.parametrize("optimizer", ["SGD", "EXACT_ADAGRAD"])
+def test_padded_first_factor_over_several_steps(node, optimizer):
+    """q = [5, 8, 8] (the reference's default factoring of D = 320): the part lookups run on a zero-padded copy of core 0 (and of
+    its optimizer state) that the module keeps -- refreshed from the Parameter when that was written, written back after every
+    fused update.  Several steps, an in-place write and a load_state_dict between them, then a captured step: the module's own
+    core 0 / state 0 must follow the same module on the generic kernels (split off) all the way."""
+    import tt_embeddings_ops as ops
+    import ttx_graph
+
+    p, q, ranks = [6, 7, 8], [5, 8, 8], [16, 16]
+    r = [1] + ranks + [1]
+    E_, D, B, tables = int(np.prod(p)), int(np.prod(q)), 40, 2
+    c = dict(tables=tables, T=3, p=p, q=q, r=r, B=B, D=D, cores=G.make_cores(82, tables, p, q, r, "signed"))
+    opt = getattr(ops.OptimType, optimizer)
+    a = module_for(c, sparse=True, optimizer=opt, learning_rate=LR, eps=EPS)
+    b = module_for(c, sparse=True, optimizer=opt, learning_rate=LR, eps=EPS)
+    assert a._pad0 == 8 and a._split0 == 2
+    b._split0 = 0  # the generic kernels on the natural geometry
+    batches = [G.make_bags(90 + k, B, E_, 4, 3, tables) for k in range(4)]
+    grad = t(G.make_grad(83, tables, B, D))
+
+    def same(what):
+        for k in range(3):
+            x, y = a.tt_cores[k].detach().cpu().numpy(), b.tt_cores[k].detach().cpu().numpy()
+            if optimizer == "SGD":
+                assert_close(x, y, f"{what}: core{k}")
+                continue
+            # Adagrad: the state (sum of squared gradients) at the gradient tolerance; the cores' update g / (sqrt(state) + eps)
+            # amplifies the rounding of a near-zero gradient (util.assert_adagrad_close) -- a few entries may differ, by less
+            # than one update
+            assert_close(a.optimizer_state[k].cpu().numpy(), b.optimizer_state[k].cpu().numpy(), f"{what}: state{k}")
+            bad = np.abs(x - y) > 1e-5 * np.abs(y) + 1e-6 * np.abs(y).max()
+            assert bad.mean() < 0.05 and np.abs(x - y).max() < 6 * LR, f"{what}: core{k}: {int(bad.sum())}/{bad.size} differ"
+
+    def outs_close(oa, ob, what):  # (Adagrad: the cores agree up to the ill-conditioned entries, see same())
+        x, y = oa.detach().cpu().numpy(), ob.detach().cpu().numpy()
+        if optimizer == "SGD":
+            assert_close(x, y, what)
+        else:
+            np.testing.assert_allclose(x, y, rtol=2e-3, atol=2e-3 * float(np.abs(y).max()), err_msg=what)
+
+    for k in range(2):
+        oa, ob = a(t(batches[k][0]), t(batches[k][1])), b(t(batches[k][0]), t(batches[k][1]))
+        assert oa.is_contiguous() and oa.shape == ob.shape
+        outs_close(oa, ob, f"step {k} out")
+        oa.backward(grad)
+        ob.backward(grad)
+        same(f"step {k}")
+    with torch.no_grad():  # an in-place write of the Parameter: the padded copy must be refreshed
+        for m in (a, b):
+            m.tt_cores[0].mul_(0.5)
+    sd = {k_: v.clone() for k_, v in b.state_dict().items()}
+    for k in range(2, 4):
+        oa, ob = a(t(batches[k][0]), t(batches[k][1])), b(t(batches[k][0]), t(batches[k][1]))
+        outs_close(oa, ob, f"step {k} out (after the in-place write)")
+        oa.backward(grad)
+        ob.backward(grad)
+        same(f"step {k}")
+    a.load_state_dict(sd)
+    b.load_state_dict(sd)
+    fixed = G.make_requests(95, 3, B, tables, 3, E_)  # (a captured step replays one shape)
+    step = ttx_graph.GraphedStep(lambda i, o: a(i, o).backward(grad), (t(fixed[0][0]), t(fixed[0][1])), warmup=0)
+    before = [x.detach().clone() for x in a.tt_cores]
+    for i, o in fixed[1:]:
+        step(t(i), t(o))
+        b(t(i), t(o)).backward(grad)
+    torch.cuda.synchronize()
+    assert not torch.equal(before[0], a.tt_cores[0].detach()), "the captured step did not write core 0 back"
+    same("captured steps")
 
 
 def test_rebinding_parameters_and_buffers_reaches_the_native_node(node):
