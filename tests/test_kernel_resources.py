@@ -45,7 +45,7 @@ def plan_res():
 def tt_res():
     # (the shape-specialised kernels are a translation unit per rank family)
     res = {}
-    for src in ("ttx_tt.hip", "ttx_tt_spec32.hip", "ttx_tt_spec128a.hip"):
+    for src in ("ttx_tt.hip", "ttx_tt_spec32.hip", "ttx_tt_spec64.hip", "ttx_tt_spec128a.hip"):
         res.update(resources(src))
     return res
 
@@ -82,6 +82,12 @@ def test_contraction_and_reduce_kernels_budget(tt_res):
     for k, n in (("spec_fwd_kernel", r128 + "ELb0ELb0E"), ("spec_bwd_kernel", r128 + "ELb0E"), ("spec_bwd_kernel", r128 + "ELb1E")):
         r = pick(tt_res, k, n)
         assert r["ScratchSize"] == 0, (k, n, r)
+    # r = 64 (cfg4; round 4): gradient rows staged per column pass leave 51.8 KB of LDS -- a THIRD work-group per CU, if the
+    # backward holds 168 registers without spilling (the next core_1 block is fetched late in the pass for that)
+    for r64 in ("Shape3ILi64ELi4ELi64ELi8ELi4ELi16ELi4EEELb0ELb0E", "Shape3ILi64ELi8ELi64ELi8ELi8ELi16ELi4EEELb0ELb0E",
+                "Shape3ILi64ELi4ELi64ELi4ELi4ELi16ELi4EEELb0ELb0E"):
+        r = pick(tt_res, "spec_bwd_kernel", r64)
+        assert r["ScratchSize"] == 0 and r["VGPRs"] <= 168 and r["Occupancy"] >= 3, (r64, r)
     red = pick(tt_res, "reduce_apply_kernel")
     assert red["Occupancy"] >= 6, f"reduce_apply_kernel must leave room for three 512-thread work-groups per CU: {red}"
     assert pick(tt_res, "pool4_small_kernel")["ScratchSize"] == 0
