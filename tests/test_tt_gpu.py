@@ -542,9 +542,13 @@ def test_padded_shapes_run_on_the_specialised_kernels(q, ranks):
 
 @pytest.mark.parametrize("q,ranks", [([2, 4, 4, 2], [32, 32, 32]), ([4, 4, 2, 2], [16, 32, 16]), ([3, 4, 2, 3], [13, 12, 7]),
                                       ([2, 2, 4, 2], [16, 16, 8]), ([4, 4, 4, 2], [32, 32, 8]), ([2, 8, 2, 4], [64, 40, 20]),
-                                      ([2, 3, 1, 5], [20, 30, 33])])
+                                      ([2, 3, 1, 5], [20, 30, 33]),
+                                      # merged last factor up to 16 (templates with q2 <= 16 at ranks <= 32): the default four-core
+                                      # factorings of D = 256 / 128, and odd ones
+                                      ([4, 4, 4, 4], [32, 32, 32]), ([2, 4, 4, 4], [16, 16, 16]), ([4, 8, 5, 3], [32, 24, 9]),
+                                      ([3, 5, 2, 6], [20, 32, 16])])
 def test_four_cores_run_on_the_three_core_kernels(q, ranks):
-    """Round 4: a T = 4 geometry with q2 q3 <= 8 runs on the shape-specialised three-core kernels -- the last two cores of a
+    """Round 4: a T = 4 geometry with q2 q3 <= 16 (q3 <= 8) runs on the shape-specialised three-core kernels -- the last two cores of a
     lookup are contracted first (per lookup, M = core_2[i2] * core_3[i3]: matrix-chain order, a tenth of the multiply-adds the
     reference's left-to-right order spends on core 2), the three-core kernel reads M where it reads core 2's slice, and the
     backward's d M is turned into the partial rows of cores 2 and 3 (csrc/ttx_tt.hip t4_merge_kernel / t4_unmerge_kernel).
