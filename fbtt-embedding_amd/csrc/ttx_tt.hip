@@ -952,21 +952,30 @@ static int spec_mc(const Dims& d, long long nnz) {
 // core-0 slice (and gradient row) with one coalesced load each and every lane produces its outputs from float4 LDS reads.
 // Backward: d core_0 of the lookup goes out as its partial row, d core_1 accumulates in registers over the wave's lookups and
 // the four waves' sums leave as the chunk's partial -- the layouts reduce_apply expects from any backward kernel.
-// Shapes: r1 % 4 == 0, r1 <= 128, q0, q1 <= 16 (everything else stays on the generic kernels).
+// Shapes: r1 <= 128, q0, q1 <= 16 (everything else stays on the generic kernels); r1 % 4 != 0 runs over zero-padded k tiles.
 constexpr int kT2Threads = 256;
 static bool t2_shape(const Dims& d) {
-  return d.T == 2 && !g_disable_spec && d.r[1] % 4 == 0 && d.r[1] <= 128 && d.q[0] <= 16 && d.q[1] <= 16;
+  return d.T == 2 && !g_disable_spec && d.r[1] <= 128 && d.q[0] <= 16 && d.q[1] <= 16;
 }
 struct T2Lds { int ldk, oBt, oA, oG, oR, floats; };  // ldk: row stride of the k-major tiles (r1 + 4: float4 rows, spread over the banks)
 static T2Lds t2_lds(const Dims& d, bool bwd) {
   T2Lds L;
-  L.ldk = d.r[1] + 4;
+  L.ldk = (d.r[1] + 3) / 4 * 4 + 4;  // (r1 rounded up to whole float4s: the k loops run over zero padding when r1 % 4 != 0)
   L.oBt = 0;
   L.oA = L.oBt + d.q[1] * L.ldk;
   L.oG = L.oA + kWaves * d.q[0] * L.ldk;
   L.oR = L.oG + (bwd ? kWaves * (d.D + 4) : 0);
   L.floats = L.oR + (bwd ? kWaves * d.r[1] * d.q[1] : 0);
   return L;
+}
+
+// r1 % 4 != 0 (the reference tests' r = 13): columns r1 .. r1p of the k-major tiles are zero -- the staged core_1 (all threads) and
+// this wave's core-0 rows (the slices' loads never touch them)
+__device__ __forceinline__ void t2_zero_pads(float* Bt, float* As, int q0, int q1, int r1, int r1p, int ldk, int tid, int lane) {
+  const int np = r1p - r1;
+  if (np == 0) return;
+  for (int e = tid; e < q1 * np; e += kT2Threads) Bt[(e / np) * ldk + r1 + e % np] = 0.f;
+  for (int e = lane; e < q0 * np; e += kWave) As[(e / np) * ldk + r1 + e % np] = 0.f;
 }
 
 __global__ __launch_bounds__(kT2Threads) void t2_fwd_kernel(Dims d, Plan P, CorePtrs C, float* __restrict__ rows,
@@ -982,15 +991,23 @@ __global__ __launch_bounds__(kT2Threads) void t2_fwd_kernel(Dims d, Plan P, Core
   float* As = sm + L.oA + w * q0 * ldk;   // [q0][ldk]: this wave's lookup
   const float* B1 = C.c[1] + (size_t)s * d.slice[1];
   for (int e = tid; e < r1 * q1; e += kT2Threads) Bt[(e % q1) * ldk + e / q1] = B1[e];
+  const int r1p = (r1 + 3) & ~3;
+  const bool v4 = r1p == r1;  // (work-group-uniform) whole float4 rows: vector loads of core 0's slices
+  t2_zero_pads(Bt, As, q0, q1, r1, r1p, ldk, tid, lane);
   __syncthreads();
   const int nA4 = q0 * r1 / 4;
   for (int j = w; j < len; j += kWaves) {
     const int4 rec = P.lrec[start + j];
-    const float4* A4 = (const float4*)(C.c[0] + (size_t)rec.y * d.slice[0]);
-    for (int e = lane; e < nA4; e += kWave) {  // (one coalesced round for q0 r1 <= 256)
-      const float4 v = A4[e];
-      const int a = (4 * e) / r1, k = (4 * e) % r1;
-      *(float4*)(As + a * ldk + k) = v;
+    const float* A1 = C.c[0] + (size_t)rec.y * d.slice[0];
+    if (v4) {
+      const float4* A4 = (const float4*)A1;
+      for (int e = lane; e < nA4; e += kWave) {  // (one coalesced round for q0 r1 <= 256)
+        const float4 v = A4[e];
+        const int a = (4 * e) / r1, k = (4 * e) % r1;
+        *(float4*)(As + a * ldk + k) = v;
+      }
+    } else {
+      for (int e = lane; e < q0 * r1; e += kWave) As[(e / r1) * ldk + e % r1] = A1[e];
     }
     // (wave-private region: LDS operations of a wave complete in order, no barrier)
     for (int o = lane; o < D; o += kWave) {
@@ -998,7 +1015,7 @@ __global__ __launch_bounds__(kT2Threads) void t2_fwd_kernel(Dims d, Plan P, Core
       const float4* ar = (const float4*)(As + a * ldk);
       const float4* br = (const float4*)(Bt + b * ldk);
       float acc = 0.f;
-      for (int k4 = 0; k4 < r1 / 4; ++k4) {  // k ascending: the reference's order of additions
+      for (int k4 = 0; k4 < r1p / 4; ++k4) {  // k ascending: the reference's order of additions (+ 0 * 0 on the padding)
         const float4 x = ar[k4], y = br[k4];
         acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
       }
@@ -1023,9 +1040,12 @@ __global__ __launch_bounds__(kT2Threads) void t2_bwd_kernel(Dims d, Plan P, Core
   float* Rd = sm + L.oR;                  // [waves][r1 q1] the waves' d core_1 sums
   const float* B1 = C.c[1] + (size_t)s * d.slice[1];
   for (int e = tid; e < r1 * q1; e += kT2Threads) Bt[(e % q1) * ldk + e / q1] = B1[e];
+  const int r1p = (r1 + 3) & ~3;
+  const bool v4 = r1p == r1;
+  t2_zero_pads(Bt, As, q0, q1, r1, r1p, ldk, tid, lane);
   __syncthreads();
   const bool has_row = P.hdr[3] != 0;
-  const int nA4 = q0 * r1 / 4, n1 = r1 * q1;
+  const int nA4 = q0 * r1p / 4, n1 = r1 * q1, k4n = r1p / 4;
   float accB[NB];
 #pragma unroll
   for (int u = 0; u < NB; ++u) accB[u] = 0.f;
@@ -1036,24 +1056,37 @@ __global__ __launch_bounds__(kT2Threads) void t2_bwd_kernel(Dims d, Plan P, Core
     const int table = PC.tableidx ? (int)PC.tableidx[n] : s / d.p[1];
     const float sw = PC.psw ? PC.psw[n] : 1.f;
     const float* gsrc = d_output + ((size_t)table * B + row) * D;
-    const float4* A4 = (const float4*)(C.c[0] + (size_t)rec.y * d.slice[0]);
-    for (int e = lane; e < nA4; e += kWave) {
-      const float4 v = A4[e];
-      const int a = (4 * e) / r1, k = (4 * e) % r1;
-      *(float4*)(As + a * ldk + k) = v;
+    const float* A1 = C.c[0] + (size_t)rec.y * d.slice[0];
+    if (v4) {
+      const float4* A4 = (const float4*)A1;
+      for (int e = lane; e < nA4; e += kWave) {
+        const float4 v = A4[e];
+        const int a = (4 * e) / r1, k = (4 * e) % r1;
+        *(float4*)(As + a * ldk + k) = v;
+      }
+    } else {
+      for (int e = lane; e < q0 * r1; e += kWave) As[(e / r1) * ldk + e % r1] = A1[e];
     }
     for (int e = lane; e < D; e += kWave) Gs[e] = gsrc[e] * sw;
     // d core_0[a][k .. k+3] = sum_b G[a][b] * core_1[k .. k+3][b]: the lookup's partial row (sorted order, Plan::ipos)
     float* o0 = PC.pc[0] + (size_t)P.ipos[0][n] * d.slice[0];
     for (int e = lane; e < nA4; e += kWave) {
-      const int a = (4 * e) / r1, k = (4 * e) % r1;
+      const int a = e / k4n, k = 4 * (e - a * k4n);
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int b = 0; b < q1; ++b) {
         const float g = Gs[a * q1 + b];
         const float4 y = *(const float4*)(Bt + b * ldk + k);
         acc.x = fmaf(g, y.x, acc.x); acc.y = fmaf(g, y.y, acc.y); acc.z = fmaf(g, y.z, acc.z); acc.w = fmaf(g, y.w, acc.w);
       }
-      ((float4*)o0)[e] = acc;
+      if (v4) {
+        ((float4*)o0)[e] = acc;
+      } else {  // (rows of r1 floats: not 16-byte aligned)
+        float* o = o0 + a * r1 + k;
+        o[0] = acc.x;
+        if (k + 1 < r1) o[1] = acc.y;
+        if (k + 2 < r1) o[2] = acc.z;
+        if (k + 3 < r1) o[3] = acc.w;
+      }
     }
     // d core_1[k][b] += sum_a core_0[a][k] * G[a][b]: this wave's running sum over its lookups of the chunk
 #pragma unroll

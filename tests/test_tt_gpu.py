@@ -586,9 +586,11 @@ def test_four_cores_run_on_the_three_core_kernels(q, ranks):
                     assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"T=4 {ranks}{q} adagrad core{k}")
 
 
-@pytest.mark.parametrize("q,ranks", [([8, 8], [32]), ([4, 16], [128]), ([2, 2], [4]), ([16, 8], [64]), ([5, 7], [20]), ([3, 4], [12])])
+@pytest.mark.parametrize("q,ranks", [([8, 8], [32]), ([4, 16], [128]), ([2, 2], [4]), ([16, 8], [64]), ([5, 7], [20]), ([3, 4], [12]),
+                                      # r1 % 4 != 0 (zero-padded k tiles, scalar loads / stores of core 0's rows): the reference tests' r = 13
+                                      ([3, 4], [13]), ([5, 7], [10]), ([16, 16], [17]), ([2, 3], [1])])
 def test_two_cores_on_the_dedicated_kernels(q, ranks):
-    """Round 4: a T = 2 geometry with r1 % 4 == 0 (r1 <= 128, q <= 16) runs on the dedicated two-core kernels (csrc/ttx_tt.hip
+    """Round 4: a T = 2 geometry with r1 <= 128, q <= 16 runs on the dedicated two-core kernels (csrc/ttx_tt.hip
     t2_fwd_kernel / t2_bwd_kernel: a lookup is one [q0 x r1] x [r1 x q1] product -- byte work, no matrix tiles to pad).  Against the
     oracle and against the generic kernels; forward, dense / SGD / Adagrad; one and three tables, ragged bags, partial chunks."""
     import tt_embeddings as E
