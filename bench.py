@@ -91,6 +91,7 @@ WORKLOADS = {
     # ... of D = 320 / 448: q0 = 5 / 7 has no exact part split -- core 0 zero-padded to 8 slots (round 4)
     "d320": dict(q=[5, 8, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d448": dict(q=[7, 8, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    "d1024r64": dict(q=[8, 8, 16], ranks=[64, 64], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d256b1024": dict(q=[4, 8, 8], ranks=[32, 32], tables=1, B=1024, optimizer="sgd", alpha=1.0, populate=False),
     "r96": dict(q=[4, 4, 4], ranks=[96, 96], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "r256": dict(q=[4, 4, 4], ranks=[256, 256], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),

@@ -96,7 +96,7 @@ def _split0_factor(q: Sequence[int], ranks: Sequence[int]) -> int:
     [8, 8, 8]).  0: no split."""
     if len(q) != 3 or q[0] <= 4 or q[1] > 8 or q[2] > 16 or max(ranks) > 128 or os.environ.get("TTX_NO_SPLIT0"):
         return 0
-    if q[2] > 8 and max(ranks) > 32:  # (q2 up to 16 -- D = 640 / 768 / 1024 -- has templates at ranks <= 32 only)
+    if q[2] > 8 and max(ranks) > 64:  # (q2 up to 16 -- D = 640 / 768 / 1024 -- has templates at ranks <= 64 only)
         return 0
     for k in (2, 3, 4):
         if q[0] % k == 0 and 2 <= q[0] // k <= 4:

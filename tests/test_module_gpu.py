@@ -932,6 +932,7 @@ def test_discarded_planned_batches_are_counted_once_and_the_module_copies(node):
 @pytest.mark.parametrize("q,ranks,tables", [([8, 8, 8], [16, 16], 1), ([8, 4, 4], [32, 32], 3), ([6, 4, 8], [16, 24], 2),
                                              ([12, 4, 4], [16, 16], 1), ([16, 2, 4], [13, 12], 1),
                                              ([8, 8, 16], [16, 16], 1), ([8, 8, 12], [32, 32], 1), ([8, 8, 10], [24, 32], 2),
+                                             ([8, 8, 16], [64, 64], 1),
                                              # q0 without an exact split (round 4): core 0 zero-padded to 8 / 12 / 16 slots
                                              ([5, 8, 8], [32, 32], 1), ([7, 4, 4], [16, 16], 2), ([10, 4, 8], [16, 24], 1),
                                              ([13, 2, 4], [13, 12], 1)])
