@@ -387,6 +387,21 @@ def main():
                     rocprof_note = "profiles/pmc_bwd_bytes.json belongs to another build of the kernels (source hash differs)"
             except Exception:  # noqa: BLE001
                 pass
+        rk = os.path.join(ROOT, "profiles", "rocprof_kernels.json")
+        if rocprof_us is None and os.path.exists(rk) and args.workload != "cfg2" and not sharded and len(Q_SHAPES) != 4:
+            # the other workloads: scripts/kprof.sh's per-kernel durations of THIS build (eager launches); the backward contraction is
+            # one launch per step there (four cores: its FLOP are spread over helper kernels -- no single-kernel figure)
+            try:
+                j = json.load(open(rk))
+                if j.get("source_hash") == source_hash():
+                    ks = j["workloads"].get(args.workload, {})
+                    us = next((v["avg_us"] for k, v in ks.items() if k.startswith(("spec_bwd_kernel", "bwd_kernel", "t2_bwd_kernel"))), None)
+                    if us:
+                        rocprof_us, rocprof_note = float(us), f"rocprofv3 --kernel-trace --stats, {j.get('how', 'scripts/kprof.sh')} (profiles/rocprof_kernels.json)"
+                else:
+                    rocprof_note = "profiles/rocprof_kernels.json belongs to another build of the kernels (source hash differs)"
+            except Exception:  # noqa: BLE001
+                pass
         if sharded:
             own_txt = f"; {tables_total} tables sharded t -> rank t % {world} (tables per rank {owned}), RCCL all-to-all; B_local={B_local}"
         else:

@@ -16,8 +16,9 @@ set -u
 TAG=${1:-r04}
 REPO=$(pwd); OUT=$REPO/gpurun_out/profiles_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 PMC_W=${PMC_WORKLOADS:-"cfg2 cfg5shard cfg4 r128 r256 t4"}
-KPROF_W=${KPROF_WORKLOADS:-"cfg3 cfg3warm cfg4 cfg5shard tb4 d32 d16 d256 r128 r13 d512 d768 d1024 r256 t2 t4 t2big"}
-BENCH_W=${BENCH_WORKLOADS:-"cfg3 cfg3a105 cfg3warm cfg4 cfg5shard r128 r13 d512 d768 d1024 t2 t4"}
+KPROF_W=${KPROF_WORKLOADS:-"cfg3 cfg3warm cfg4 cfg5shard tb4 d32 d16 d256 r128 r13 d320 d512 d768 d1024 d1024r64 r256 t2 t4 t4d256 t2big"}
+BENCH_W=${BENCH_WORKLOADS:-"cfg3 cfg3a105 cfg3warm cfg4 cfg5shard r128 r13 d320 d512 d768 d1024 d1024r64 t2 t4 t4d256"}
+if [ -z "${REGEN_ONLY_BENCH:-}" ]; then   # (REGEN_ONLY_BENCH=1: the counters of this build are in ./profiles already -- bench lines only)
 scripts/measure_traffic.sh "$TAG" > "$OUT/measure_traffic.log" 2>&1
 cp gpurun_out/prof_$TAG/${TAG}_kernel_stats.md gpurun_out/prof_$TAG/pmc_bwd_bytes.json "$OUT/" 2>/dev/null
 for W in $PMC_W; do
@@ -30,6 +31,7 @@ cp gpurun_out/kprof_$TAG/rocprof_kernels.json "$OUT/" 2>/dev/null
 cp gpurun_out/kprof_$TAG/rocprof_kernels.json profiles/ 2>/dev/null   # (on the box: the bench lines below read it)
 scripts/cache_rocprof.sh "$TAG" > /dev/null 2>&1
 cp gpurun_out/cache_prof_$TAG/summary.md "$OUT/${TAG}_cache_bandwidth.md" 2>/dev/null
+fi
 python bench.py --steps 200 --repeats 5 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 for W in $BENCH_W; do
   python bench.py --workload $W --steps 100 --repeats 3 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_$W.json"
