@@ -118,7 +118,10 @@ def test_contraction_tails_stay_off_the_lds_pipe():
         fused = fwd and "EEELb0ELb1E" in name  # (the fused-pooling variant hands bag counters round with three shuffles)
         if not fused:
             assert c.get("bpermute", 0) == 0, (name, c)
-        assert c.get("cndmask", 0) <= 16, (name, c)  # (a handful of address selects; the butterfly was 126)
+        padded = "ELb1EEEv" in name  # (the last template flag of both kernels)
+        # a handful of address selects -- the padded variants pick an element's address or a valid dummy address per guarded
+        # float4 --; the butterfly was 126
+        assert c.get("cndmask", 0) <= (40 if padded else 16), (name, c)
         assert c.get("scratch", 0) == 0, (name, c)
         if fwd:
             assert c.get("permlane_swap", 0) >= 12, (name, c)
