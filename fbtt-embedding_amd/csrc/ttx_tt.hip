@@ -1193,7 +1193,71 @@ __global__ __launch_bounds__(256) void t4_merge_kernel(Plan P, const float* __re
         for (int x = 0; x < Q3; ++x) acc[x] = fmaf(av, b[k * Q3 + x], acc[x]);
       }
     }
-    float* o = M + (size_t)e * Q3;
+    float* o = M + ((size_t)rec.x * r2q2 + rq) * Q3;  // (M goes by LOOKUP: RealDims::c2n)
+#pragma unroll
+    for (int x = 0; x < Q3; ++x) o[x] = acc[x];
+  }
+}
+
+// The same product in core 2's SORTED order (r3 <= 32, r2 q2 <= 256: what the benchmark shapes are).  The kernel above reads a
+// lookup's 16 KB core-2 slice from L2 for every lookup (168 MB at 10k lookups: 33 us); lookups of one slice are consecutive in the
+// sorted order, so a thread keeps ITS row of the slice in registers across the run and only the 256-byte core-3 slices -- staged
+// for the whole segment at once -- and the result rows move.  Step 1 leaves {n, sid_2, sid_3, ipos_3} at the lookups' places in
+// that order (Plan::t4o, also what the gradient kernel walks); step 2 takes 4 .. 32 positions per work-group (by batch size).  Same order of
+// additions as above: bit-identical M.
+__global__ __launch_bounds__(256) void t4_order_kernel(Plan P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.hdr[2]) return;
+  const int4 rec = P.lrec[i];
+  P.t4o[P.ipos[2][rec.x]] = make_int4(rec.x, rec.z, rec.w, P.ipos[3][rec.x]);
+}
+constexpr int kT4MSeg = 32;  // positions per work-group at most; t4_mseg() picks by batch size
+template <int Q3>
+__global__ __launch_bounds__(256) void t4_merge_sorted_kernel(Plan P, const float* __restrict__ c2, const float* __restrict__ c3,
+                                                              float* __restrict__ M, int r2q2, int r3, int seg) {
+  extern __shared__ __attribute__((aligned(16))) float bs[];  // [seg][r3 Q3]: the segment's core-3 slices
+  __shared__ int4 recs[kT4MSeg];
+  const int nnz = P.hdr[2];
+  const int p0 = blockIdx.x * seg, cnt = min(seg, nnz - p0);
+  if (cnt <= 0) return;
+  const int tid = threadIdx.x, n3 = r3 * Q3;
+  if (tid < cnt) recs[tid] = P.t4o[p0 + tid];
+  __syncthreads();
+  for (int e = tid; e < cnt * n3; e += blockDim.x) {
+    const int j = e / n3;
+    bs[e] = c3[(size_t)recs[j].z * n3 + (e - j * n3)];
+  }
+  __syncthreads();
+  const int rq = tid;
+  if (rq >= r2q2) return;
+  float a[32];
+  int cur = -1;
+  for (int j = 0; j < cnt; ++j) {
+    const int4 rc = recs[j];
+    if (rc.y != cur) {  // (work-group-uniform) a new slice: this thread's row of it
+      cur = rc.y;
+      const float* ar = c2 + ((size_t)cur * r2q2 + rq) * r3;
+      if ((r3 & 3) == 0) {
+#pragma unroll
+        for (int k = 0; k < 32; k += 4)
+          if (k < r3) { const float4 t = *(const float4*)(ar + k); a[k] = t.x; a[k + 1] = t.y; a[k + 2] = t.z; a[k + 3] = t.w; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+          if (k < r3) a[k] = ar[k];
+      }
+    }
+    const float* b = bs + j * n3;
+    float acc[Q3];
+#pragma unroll
+    for (int x = 0; x < Q3; ++x) acc[x] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+      if (k < r3) {  // (uniform; k ascending)
+#pragma unroll
+        for (int x = 0; x < Q3; ++x) acc[x] = fmaf(a[k], b[k * Q3 + x], acc[x]);
+      }
+    float* o = M + ((size_t)rc.x * r2q2 + rq) * Q3;
 #pragma unroll
     for (int x = 0; x < Q3; ++x) o[x] = acc[x];
   }
@@ -1394,7 +1458,11 @@ static int t4_grid(long long work) {
 }
 // positions of core 2's sorted order per work-group of the gradient kernel: few enough rows per slice at large batches, enough
 // work-groups at small ones
-static int t4_seg(long long nnz) { return nnz >= (1 << 18) ? 128 : (nnz >= (1 << 16) ? 64 : 32); }
+static int t4_seg(long long nnz) {
+  static const int forced = getenv("TTX_T4_SEG") ? atoi(getenv("TTX_T4_SEG")) : 0;  // (A/B)
+  if (forced > 0) return forced;
+  return nnz >= (1 << 18) ? 128 : (nnz >= (1 << 16) ? 64 : 32);
+}
 #define TTX_T4_Q3(Q3, CALL)                                  \
   switch (Q3) {                                              \
     case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
@@ -1402,6 +1470,20 @@ static int t4_seg(long long nnz) { return nnz >= (1 << 18) ? 128 : (nnz >= (1 <<
   }
 static int t4_merge(const Dims& d, long long nnz, const Plan& P, const float* c2, const float* c3, hipStream_t st) {
   const int r2q2 = d.r[2] * d.q[2];
+  static const bool old_form = getenv("TTX_T4_OLD_MERGE") != nullptr;  // (A/B)
+  if (d.r[3] <= 32 && r2q2 <= 256 && !old_form) {  // the sorted-order form (t4_merge_sorted_kernel)
+    hipLaunchKernelGGL(t4_order_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, P);
+    const int threads = (r2q2 + 63) / 64 * 64;
+    // positions per work-group: the slice's rows are re-read once per segment, but a small batch needs the work-groups more than
+    // the reuse (10k lookups, ms/step: 4 -> 0.221, 8 -> 0.225, 16 -> 0.244, 32 -> 0.273; the per-lookup form 0.247)
+    const int seg = nnz >= (1 << 17) ? 32 : (nnz >= (1 << 15) ? 16 : 4);
+    const size_t lds = (size_t)seg * d.r[3] * d.q[3] * sizeof(float);
+#define TTX_T4_CALL(Q) hipLaunchKernelGGL(t4_merge_sorted_kernel<Q>, dim3((unsigned)((nnz + seg - 1) / seg)), dim3(threads), lds, st, P, c2, c3, P.t4m, r2q2, d.r[3], seg)
+    TTX_T4_Q3(d.q[3], TTX_T4_CALL)
+#undef TTX_T4_CALL
+    TTX_HIP(hipGetLastError());
+    return TTX_OK;
+  }
 #define TTX_T4_CALL(Q) hipLaunchKernelGGL(t4_merge_kernel<Q>, dim3(t4_grid(nnz * r2q2)), dim3(256), 0, st, P, c2, c3, P.t4m, r2q2, d.r[3])
   TTX_T4_Q3(d.q[3], TTX_T4_CALL)
 #undef TTX_T4_CALL
