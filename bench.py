@@ -646,21 +646,33 @@ def main():
 
     if rank == 0:
         line = build_line(mode, regions, breakdown, a2a)
+        if wl["populate"] and "cache_gather_us" not in breakdown and "bag_pool_us" in breakdown and hit_rate is not None:
+            # (round 4) the gather runs in the pooling launch (ttx_tt_forward_cached): the roofline of that launch -- the cache
+            # rows as below plus the contraction's rows of the misses (4*D + 8 bytes each)
+            breakdown = dict(breakdown)
+            breakdown["cache_gather_us"] = breakdown["bag_pool_us"]
+            fused_gather = True
+        else:
+            fused_gather = False
         if wl["populate"] and "cache_gather_us" in breakdown and hit_rate is not None:
             # cache-hit gather (a11): 4*D + 4 + 8 bytes per cached lookup + 4*D per bag, HBM-bound
             cached = hit_rate * nnz_step_total
             bytes_ = cached * (4 * D + 12) + B_GLOBAL * 4 * D
+            if fused_gather:
+                bytes_ += (nnz_step_total - cached) * (4 * D + 8)
             gbs = bytes_ / (breakdown["cache_gather_us"] * 1e-6) / 1e9
             line["cache_gather_roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
                                              "frac": round(gbs / (PEAK_HBM_TBS * 1e3), 4), "cached_lookups_per_launch": round(cached),
                                              "bytes_per_launch": round(bytes_), "avg_us": breakdown["cache_gather_us"],
-                                             "timed_by": "HIP events around each launch (includes launch gap); rocprof figures: profiles/"}
+                                             "timed_by": "HIP events around each launch (includes launch gap); rocprof figures: profiles/",
+                                             "kernel": ("pool4_small_cached_kernel (bag sums of the contraction's rows and of the cache's rows, "
+                                                        "one launch)" if fused_gather else "cache_forward4_kernel")}
             # the same kernel as rocprofv3 --kernel-trace --stats timed it on THIS build (scripts/kprof.sh -> profiles/rocprof_kernels.json)
             rk = os.path.join(ROOT, "profiles", "rocprof_kernels.json")
             try:
                 j = json.load(open(rk))
                 ks = j["workloads"].get(args.workload, {}) if j.get("source_hash") == source_hash() else {}
-                us = next((v["avg_us"] for k, v in ks.items() if k.startswith("cache_forward")), None)
+                us = next((v["avg_us"] for k, v in ks.items() if k.startswith("pool4_small_cached" if fused_gather else "cache_forward")), None)
             except Exception:  # noqa: BLE001
                 us = None
             if us:

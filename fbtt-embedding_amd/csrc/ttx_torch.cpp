@@ -459,12 +459,18 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     // (a gradient for the weights needs every lookup's forward row: the contraction's for the misses, the cache's for the hits)
     Tensor rows_keep;
     if (psw_grad) rows_keep = at::empty({nnz, D}, cores[0].options());
-    check(ttx_tt_forward_wr(&g, (int32_t)B, (int32_t)D, nnz, pcol_p, prow_p, tableidx_p,
-                            weighted ? ppsw.data_ptr<float>() : nullptr, cp,
-                            out.data_ptr<float>(), psw_grad ? rows_keep.data_ptr<float>() : nullptr, plan_p,
-                            ws.data_ptr(), wb, stream));
-    check(ttx_cache_forward_nw((int32_t)B, nnz, ntt_p, ploc_p, prow_p, weighted ? ppsw.data_ptr<float>() : nullptr, (int32_t)D,
-                               cache_weight.data_ptr<float>(), out.data_ptr<float>(), stream));
+    if (!weighted && ttx_tt_forward_cached_supported(&g, (int32_t)D, nnz)) {
+      // contraction of the misses, then ONE launch for the bag sums of both parts (pooling + cache gather)
+      check(ttx_tt_forward_cached(&g, (int32_t)B, (int32_t)D, nnz, pcol_p, prow_p, tableidx_p, cp, ploc_p,
+                                  cache_weight.data_ptr<float>(), out.data_ptr<float>(), plan_p, ws.data_ptr(), wb, stream));
+    } else {
+      check(ttx_tt_forward_wr(&g, (int32_t)B, (int32_t)D, nnz, pcol_p, prow_p, tableidx_p,
+                              weighted ? ppsw.data_ptr<float>() : nullptr, cp,
+                              out.data_ptr<float>(), psw_grad ? rows_keep.data_ptr<float>() : nullptr, plan_p,
+                              ws.data_ptr(), wb, stream));
+      check(ttx_cache_forward_nw((int32_t)B, nnz, ntt_p, ploc_p, prow_p, weighted ? ppsw.data_ptr<float>() : nullptr, (int32_t)D,
+                                 cache_weight.data_ptr<float>(), out.data_ptr<float>(), stream));
+    }
     if (psw_grad)
       check(ttx_cache_rows_n(nnz, ntt_p, ploc_p, (int32_t)D, cache_weight.data_ptr<float>(), rows_keep.data_ptr<float>(), stream));
 

@@ -221,6 +221,56 @@ __global__ __launch_bounds__(kThreads) void pool4_small_kernel(int Nmax, const i
   }
 }
 
+// Cache live (one table): the bag sums of the contraction's rows AND of the cache's rows in ONE launch.  The batch is
+// partitioned -- misses at [0, n_tt) in index order, hits behind them (cache locations in loc[]) -- and a bag may have a run in
+// both parts; the reference adds the cache rows in a second kernel (cache_forward, cu:1498-1572), this path used to do the same
+// (pool4_small_kernel, then cache_forward4_kernel reading the output back).  Here every run head of either part adds ITS sum to
+// the zeroed output row with fp32 atomics: a row receives at most two terms, 0 + A + B is the same number in either order, so the
+// result does not depend on the order of arrival.  One launch less per step and the gather overlaps the pooling (cfg3).
+__global__ __launch_bounds__(kThreads) void pool4_small_cached_kernel(int nnz, const int* __restrict__ hdr, int D4,
+                                                                     const int64_t* __restrict__ rowidx,
+                                                                     const float4* __restrict__ rows,
+                                                                     const int32_t* __restrict__ loc,
+                                                                     const float4* __restrict__ cw, float* __restrict__ out) {
+  const int n = blockIdx.x * (kThreads / 16) + threadIdx.x / 16;
+  const int l = threadIdx.x & 15;
+  if (n >= nnz) return;
+  const int ntt = min(nnz, hdr[2]);          // (the plan was built over the misses: its live count is the split point)
+  const bool hit = n >= ntt;
+  const int lo = hit ? ntt : 0, hi = hit ? nnz : ntt;  // this lookup's part
+  const int64_t r = rowidx[n];
+  if (n > lo && rowidx[n - 1] == r) return;  // not a run head
+  const int sh = threadIdx.x & 48;           // this group's 16 bits of the wave ballot
+  int sl = 1;
+  for (;;) {
+    const int c = n + sl + l;
+    const bool same = c < hi && rowidx[c] == r;
+    const unsigned m = (unsigned)(__ballot(!same) >> sh) & 0xffffu;
+    if (m) { sl += __builtin_ctz(m); break; }
+    sl += 16;
+  }
+  float* o = out + (size_t)r * D4 * 4;
+  for (int e = l; e < D4; e += 16) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = 0; j0 < sl; j0 += 8) {  // eight rows in flight, added in index order
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < sl) v[u] = hit ? cw[(size_t)loc[n + j] * D4 + e] : rows[(size_t)(n + j) * D4 + e];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + u < sl) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    unsafeAtomicAdd(o + 4 * e, acc.x);
+    unsafeAtomicAdd(o + 4 * e + 1, acc.y);
+    unsafeAtomicAdd(o + 4 * e + 2, acc.z);
+    unsafeAtomicAdd(o + 4 * e + 3, acc.w);
+  }
+}
+
 // ---- duplicate lookups (DedupMap): pooling through uid[], and the bag gradients of a pair's occurrences ----
 // Bag sums when the contraction ran once per DISTINCT (table, index) pair: row of lookup n = rows[uid[n]].  Same
 // runs, same order of addition as pool4_small_kernel (index order), so the output is bit-identical to the plain
@@ -1694,10 +1744,43 @@ int64_t ttx_tt_forward_arrive_ints(const ttx_geom* g, int64_t nnz) {
   return nnz;
 }
 
+static int tt_forward_impl(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const int64_t* indices,
+                           const int64_t* rowidx, const int64_t* tableidx, const float* psw,
+                           const float* const* tt_cores, float* output, float* rows_keep, const int64_t* offsets,
+                           int32_t* arrive, const void* plan, void* workspace, size_t workspace_bytes, ttx_stream_t stream,
+                           const int32_t* cache_loc, const float* cache_weight);
+
 int ttx_tt_forward_o(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const int64_t* indices,
                      const int64_t* rowidx, const int64_t* tableidx, const float* psw,
                      const float* const* tt_cores, float* output, float* rows_keep, const int64_t* offsets,
                      int32_t* arrive, const void* plan, void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
+  return tt_forward_impl(g, B, D, nnz, indices, rowidx, tableidx, psw, tt_cores, output, rows_keep, offsets, arrive, plan, workspace,
+                         workspace_bytes, stream, nullptr, nullptr);
+}
+
+// 1 when ttx_tt_forward_cached pools the contraction's rows and gathers the cache's in one launch for this call; 0: the caller runs
+// ttx_tt_forward + ttx_cache_forward_n (large batches, D % 4 != 0, more than one table)
+int ttx_tt_forward_cached_supported(const ttx_geom* g, int32_t D, int64_t nnz) {
+  static const bool off = getenv("TTX_NO_FUSED_CACHE_GATHER") != nullptr;  // (A/B)
+  return !off && g && g->num_tables == 1 && nnz > 0 && nnz <= kPoolSpanMin && D % 4 == 0 && D / 4 <= 4 * kThreads;
+}
+
+int ttx_tt_forward_cached(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const int64_t* indices,
+                          const int64_t* rowidx, const int64_t* tableidx, const float* const* tt_cores,
+                          const int32_t* cache_loc, const float* cache_weight, float* output, const void* plan,
+                          void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
+  if (!ttx_tt_forward_cached_supported(g, D, nnz)) TTX_FAIL(TTX_EUNSUPPORTED, "ttx_tt_forward_cached: not for this call");
+  if (!plan || !cache_loc || !cache_weight) TTX_FAIL(TTX_EINVAL, "ttx_tt_forward_cached needs the plan of the misses, loc and cache_weight");
+  if ((((uintptr_t)cache_weight) | ((uintptr_t)output)) & 15) TTX_FAIL(TTX_EINVAL, "cache_weight / output must be 16-byte aligned");
+  return tt_forward_impl(g, B, D, nnz, indices, rowidx, tableidx, nullptr, tt_cores, output, nullptr, nullptr, nullptr, plan, workspace,
+                         workspace_bytes, stream, cache_loc, cache_weight);
+}
+
+static int tt_forward_impl(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const int64_t* indices,
+                           const int64_t* rowidx, const int64_t* tableidx, const float* psw,
+                           const float* const* tt_cores, float* output, float* rows_keep, const int64_t* offsets,
+                           int32_t* arrive, const void* plan, void* workspace, size_t workspace_bytes, ttx_stream_t stream,
+                           const int32_t* cache_loc, const float* cache_weight) {
   Dims d;
   int rc = make_dims(g, &d);
   if (rc) return rc;
@@ -1739,7 +1822,12 @@ int ttx_tt_forward_o(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz, const
   bool fused = false;
   rc = run_rows(d, nnz, P, tt_cores, rows, output, nout, st, offer ? &F : nullptr, &fused);  // also zeroes `output`
   if (rc) return rc;
-  if (!(g_skip_launch & 1) && !fused) {
+  if (cache_loc) {  // (ttx_tt_forward_cached: both parts of the batch in one launch)
+    ProfScope ps(TTX_PROF_POOL, st);
+    hipLaunchKernelGGL(pool4_small_cached_kernel, dim3(((int)nnz + kThreads / 16 - 1) / (kThreads / 16)), dim3(kThreads), 0, st,
+                       (int)nnz, P.hdr, d.D / 4, rowidx, (const float4*)rows, cache_loc, (const float4*)cache_weight, output);
+    TTX_HIP(hipGetLastError());
+  } else if (!(g_skip_launch & 1) && !fused) {
     ProfScope ps(TTX_PROF_POOL, st);
     if (d.D % 4 == 0 && (((uintptr_t)rows | (uintptr_t)output) & 15) == 0) {
       if (nnz <= kPoolSpanMin)

@@ -129,6 +129,20 @@ int ttx_tt_forward_wr(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz,
                       float* output, float* rows_keep, const void* plan, void* workspace,
                       size_t workspace_bytes, ttx_stream_t stream);
 
+/* Not in the reference (round 4): the cache-live forward of ONE table in one call -- tt_embeddings_forward_cuda on the misses
+ * followed by cache_forward_cuda (tt_embeddings_cuda.cu:1498-1572) on the hits -- with the bag sums of both parts in ONE launch.
+ * The batch is the partitioned one of ttx_preprocess_indices_async: `nnz` lookups, the misses in front; `plan` is the plan of the
+ * misses (ttx_plan_build_n with the device-side split point), `rowidx` / `cache_loc` are the partitioned bag rows / cache
+ * locations of all `nnz` positions.  A bag's row receives at most two terms (its contraction sum, its cache sum) through fp32
+ * atomics on the zeroed output: the result does not depend on their order.  ttx_tt_forward_cached_supported says whether the
+ * call is taken this way (one table, D % 4 == 0, at most 65536 lookups); otherwise run ttx_tt_forward + ttx_cache_forward_n. */
+int ttx_tt_forward_cached_supported(const ttx_geom* g, int32_t D, int64_t nnz);
+int ttx_tt_forward_cached(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz,
+                          const int64_t* indices, const int64_t* rowidx, const int64_t* tableidx,
+                          const float* const* tt_cores, const int32_t* cache_loc, const float* cache_weight,
+                          float* output, const void* plan, void* workspace, size_t workspace_bytes,
+                          ttx_stream_t stream);
+
 /* Not in the reference: ttx_tt_forward_wr with the bag pooling done INSIDE the contraction kernel (no pooling launch:
  * the lookup that completes a bag sums its rows in index order, same result bit for bit) where the shape and the
  * batch allow it -- the call falls back to the separate pooling launch otherwise, so it is always valid.
