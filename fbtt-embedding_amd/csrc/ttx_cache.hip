@@ -407,117 +407,14 @@ __global__ __launch_bounds__(kCT) void cache_forward4_kernel(int N, int D4, cons
   }
 }
 
-// cache_backward_sgd_kernel cu:1574-1621 / dense cu:1659-1697: hardware fp32
-// atomic add (the same row can be hit from several bags).  scale = -lr (SGD)
-// or +1 (dense gradient).
-// Hot rows.  cache_populate numbers the rows by descending frequency, so under a skewed stream the
-// first few rows take most of the hits (Zipf 1.2: the first 32 rows half of them, row 0 alone a sixth
-// of the batch).  Even with one add per bag that is hundreds of atomic row adds on ONE row, which
-// the L2 serialises (15 us at cfg3).  Rows [0, K) are therefore taken out of the per-lookup path:
-// work-group (k, s) scans segment s of kHotSeg lookups for row k, gathers the matching bags'
-// gradient rows 16 bytes per lane with every thread busy, folds them in LDS and issues ONE row add.
-constexpr int kHotRows = 64;
-constexpr int kHotSeg = 1024;
-static int hot_rows(long long nnz, int D) {
-  if (D % 4 != 0 || D > 4 * kCT) return 0;
-  const long long k = (1ll << 24) / (nnz > 0 ? nnz : 1);  // bounds the extra reads of `loc` to 64 MB
-  return k >= kHotRows ? kHotRows : (k >= 4 ? (int)k : 0);
-}
-
+#include "ttx_cache_scatter.inc"
 __global__ __launch_bounds__(kCT) void cache_scatter_add_kernel(int N, int D, float scale,
                                                                const int* __restrict__ skip_dev,
                                                                const float* __restrict__ grad,
                                                                const int32_t* __restrict__ loc,
                                                                const int64_t* __restrict__ rowidx,
                                                                float* dst, int nmain, int K) {
-  if (skip_dev) { const int k = max(0, min(N, *skip_dev)); N -= k; rowidx += k; loc += k; }
-  if ((int)blockIdx.x >= nmain) {
-    // ---- hot work-group (k, s) ----
-    __shared__ int list[kHotSeg];
-    __shared__ int nlist;
-    __shared__ float4 red[kCT];
-    const int hb = blockIdx.x - nmain, k = hb % K, sbeg = (hb / K) * kHotSeg, tid = threadIdx.x;
-    if (sbeg >= N) return;
-    if (tid == 0) nlist = 0;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kHotSeg / kCT; ++j) {
-      const int i = sbeg + j * kCT + tid;
-      const bool hit = i < N && loc[i] == k;
-      const unsigned long long m = __ballot(hit);
-      int base = 0;
-      if (m) {
-        if (lane_id() == 0) base = atomicAdd(&nlist, __popcll(m));
-        base = __shfl(base, 0, kWave);
-        if (hit) list[base + __popcll(m & lanemask_lt())] = (int)rowidx[i];
-      }
-    }
-    __syncthreads();
-    const int n = nlist;
-    if (n == 0) return;
-    const int D4 = D / 4, parts = kCT / D4;  // thread = (float4 column, part); part p takes matches p, p+parts, ..
-    const int e4 = tid % D4, part = tid / D4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (part < parts) {
-      const float4* g4 = (const float4*)grad;
-      int j = part;
-      for (; j + 3 * parts < n; j += 4 * parts) {
-        const float4 a = g4[(size_t)list[j] * D4 + e4], b = g4[(size_t)list[j + parts] * D4 + e4];
-        const float4 cc = g4[(size_t)list[j + 2 * parts] * D4 + e4], dd = g4[(size_t)list[j + 3 * parts] * D4 + e4];
-        acc.x += (a.x + b.x) + (cc.x + dd.x); acc.y += (a.y + b.y) + (cc.y + dd.y);
-        acc.z += (a.z + b.z) + (cc.z + dd.z); acc.w += (a.w + b.w) + (cc.w + dd.w);
-      }
-      for (; j < n; j += parts) {
-        const float4 a = g4[(size_t)list[j] * D4 + e4];
-        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
-      }
-    }
-    red[tid] = acc;
-    __syncthreads();
-    if (tid < D4) {
-      for (int p = 1; p < parts; ++p) {
-        const float4 x = red[p * D4 + tid];
-        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-      }
-      float* w = dst + (size_t)k * D + (size_t)tid * 4;
-      unsafeAtomicAdd(&w[0], acc.x * scale);
-      unsafeAtomicAdd(&w[1], acc.y * scale);
-      unsafeAtomicAdd(&w[2], acc.z * scale);
-      unsafeAtomicAdd(&w[3], acc.w * scale);
-    }
-    return;
-  }
-  const int n = blockIdx.x * (kCT / 32) + threadIdx.x / 32;
-  const int l = threadIdx.x & 31;
-  if (n >= N) return;
-  // A bag that hits the same cache row m times adds m * g once instead of g m times: its lookups
-  // are contiguous, so the 32 lanes scan the run for earlier copies (-> nothing to do) and count
-  // the later ones.  Under a skewed stream a hot row takes thousands of atomic row adds per step;
-  // this removes the within-bag share of them (and is exact up to the rounding of m * g).
-  const int64_t r = rowidx[n];
-  const int32_t c = loc[n];
-  if (c < K) return;  // a hot row: the hot work-groups own it
-  const int sh = threadIdx.x & 32;
-  const unsigned long long half = sh ? 0xffffffff00000000ull : 0x00000000ffffffffull;
-  for (int base = 1;; base += 32) {  // an earlier copy in this bag?
-    const int j = n - base - l;
-    const bool in_run = j >= 0 && rowidx[j] == r;
-    const bool hit = in_run && loc[j] == c;
-    if (__ballot(hit) & half) return;
-    if (__ballot(!in_run) & half) break;
-  }
-  int m = 1;
-  for (int base = 1;; base += 32) {  // later copies in this bag
-    const int j = n + base + l;
-    const bool in_run = j < N && rowidx[j] == r;
-    const bool hit = in_run && loc[j] == c;
-    m += __popcll(__ballot(hit) & half);
-    if (__ballot(!in_run) & half) break;
-  }
-  const float* g = grad + (size_t)r * D;
-  float* w = dst + (size_t)c * D;
-  const float sc = scale * (float)m;
-  for (int e = l; e < D; e += 32) unsafeAtomicAdd(&w[e], g[e] * sc);
+  cache_scatter_add_body((int)blockIdx.x, N, D, scale, skip_dev, grad, loc, rowidx, dst, nmain, K);
 }
 
 // cache_backward_rowwise_adagrad_approx_kernel cu:1735-1795.  One wave per

@@ -558,11 +558,17 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     }
     const size_t wb = ttx_tt_backward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
     Tensor ws = bytes_on(cache_weight, wb);
-    check(ttx_tt_backward_w(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz,
-                            pcol_p, prow_p, tableidx_p,
-                            ppsw.defined() ? ppsw.data_ptr<float>() : nullptr, go.data_ptr<float>(), cp,
-                            optim == TTX_OPTIM_ADAGRAD ? sp : nullptr, optim == TTX_OPTIM_DENSE ? gp : nullptr,
-                            plan_p, ws.data_ptr(), wb, stream));
+    int32_t scatter_done = 0;  // the cache rows' SGD scatter rode in the optimizer's launch (ttx_tt_backward_wc)
+    if (optim == TTX_OPTIM_SGD && !ppsw.defined())
+      check(ttx_tt_backward_wc(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz, pcol_p, prow_p, tableidx_p,
+                               nullptr, go.data_ptr<float>(), cp, nullptr, nullptr, plan_p, ws.data_ptr(), wb, stream,
+                               n_tt, ploc_p, go.data_ptr<float>(), -(float)lr, cache_weight.data_ptr<float>(), &scatter_done));
+    else
+      check(ttx_tt_backward_w(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz,
+                              pcol_p, prow_p, tableidx_p,
+                              ppsw.defined() ? ppsw.data_ptr<float>() : nullptr, go.data_ptr<float>(), cp,
+                              optim == TTX_OPTIM_ADAGRAD ? sp : nullptr, optim == TTX_OPTIM_DENSE ? gp : nullptr,
+                              plan_p, ws.data_ptr(), wb, stream));
     if (psw_grad) {  // gradient of the per_sample_weights (argument slot 13), in the caller's order
       const Tensor &rows_keep = rows_keep_s, &porig = porig_s;
       Tensor d_part = at::empty({nnz}, rows_keep.options());
@@ -585,8 +591,9 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
       rows = iota.data_ptr<int64_t>();
     }
     if (optim == TTX_OPTIM_SGD) {
-      check(ttx_cache_backward_sgd_n(nnz, n_tt, (int32_t)D, gcache, loc, rows, (float)lr,
-                                     cache_weight.data_ptr<float>(), stream));
+      if (!scatter_done)
+        check(ttx_cache_backward_sgd_n(nnz, n_tt, (int32_t)D, gcache, loc, rows, (float)lr,
+                                       cache_weight.data_ptr<float>(), stream));
     } else if (optim == TTX_OPTIM_ADAGRAD) {
       TORCH_CHECK(cache_opt_state.defined(), "tt_embeddings: Adagrad with a live cache needs cache_optimizer_state");
       check(ttx_cache_backward_rowwise_adagrad_approx_n(nnz, n_tt, (int32_t)D, gcache, loc, rows, (float)lr,

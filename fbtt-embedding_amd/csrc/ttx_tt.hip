@@ -773,6 +773,18 @@ struct SegRow {  // final fold of a hot slice: segment j's slot (1 = the slice s
   __device__ __forceinline__ size_t operator()(int i) const { return (size_t)(2 * (j_first + i) + (i == 0 ? first_slot : 0)); }
 };
 
+#include "ttx_cache_scatter.inc"
+// the cache rows' SGD scatter riding in reduce_apply's launch (ttx_tt_backward_wc): work-groups [first, first + nmain + hot) of the
+// grid run cache_scatter_add_body on their first kScatterThreads threads; dst == NULL: none
+struct CacheTail {
+  int first, N, D, nmain, K;
+  float scale;
+  const int* skip_dev;
+  const float* grad;
+  const int32_t* loc;
+  const int64_t* rowidx;
+  float* dst;
+};
 #ifndef TTX_REDUCE_WAVES
 #define TTX_REDUCE_WAVES 6
 #endif
@@ -781,7 +793,12 @@ struct SegRow {  // final fold of a hot slice: segment j's slot (1 = the slice s
 __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply_kernel(Dims d, Plan P, Partials PC,
                                                                int optim, float lr, float eps,
                                                                CorePtrs W, CorePtrs St,
-                                                               CorePtrs DW, int nslices, int rows_max) {
+                                                               CorePtrs DW, int nslices, int rows_max, CacheTail CT) {
+  if (CT.dst && (int)blockIdx.x >= CT.first) {  // (work-group-uniform) a work-group of the cache rows' scatter
+    if (threadIdx.x < kScatterThreads)
+      cache_scatter_add_body((int)blockIdx.x - CT.first, CT.N, CT.D, CT.scale, CT.skip_dev, CT.grad, CT.loc, CT.rowidx, CT.dst, CT.nmain, CT.K);
+    return;
+  }
   __shared__ float4 red[kReduceThreads];
   __shared__ int s_last, s_nhot, s_hot[kReduceThreads];
   const int nthreads = blockDim.x, tid = threadIdx.x;
@@ -1911,11 +1928,47 @@ int ttx_tt_backward(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, floa
                            optimizer_state, d_tt_cores, plan, workspace, workspace_bytes, stream);
 }
 
+static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, float lr, float eps,
+                            int64_t nnz, const int64_t* indices, const int64_t* rowidx,
+                            const int64_t* tableidx, const float* psw, const float* d_output,
+                            float* const* tt_cores, float* const* optimizer_state, float* const* d_tt_cores,
+                            const void* plan, void* workspace, size_t workspace_bytes, ttx_stream_t stream,
+                            const CacheTail* tail, int32_t* tail_done);
+
 int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, float lr, float eps,
                       int64_t nnz, const int64_t* indices, const int64_t* rowidx,
                       const int64_t* tableidx, const float* psw, const float* d_output,
                       float* const* tt_cores, float* const* optimizer_state, float* const* d_tt_cores,
                       const void* plan, void* workspace, size_t workspace_bytes, ttx_stream_t stream) {
+  return tt_backward_impl(g, optim, B, D, lr, eps, nnz, indices, rowidx, tableidx, psw, d_output, tt_cores, optimizer_state,
+                          d_tt_cores, plan, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+int ttx_tt_backward_wc(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, float lr, float eps,
+                       int64_t nnz, const int64_t* indices, const int64_t* rowidx,
+                       const int64_t* tableidx, const float* psw, const float* d_output,
+                       float* const* tt_cores, float* const* optimizer_state, float* const* d_tt_cores,
+                       const void* plan, void* workspace, size_t workspace_bytes, ttx_stream_t stream,
+                       const int32_t* skip_dev, const int32_t* cache_loc, const float* cache_grad, float cache_scale,
+                       float* cache_dst, int32_t* tail_done) {
+  static const bool off = getenv("TTX_NO_FUSED_CACHE_SCATTER") != nullptr;  // (A/B)
+  if (!tail_done) TTX_FAIL(TTX_EINVAL, "tail_done is NULL");
+  *tail_done = 0;
+  CacheTail CT{};
+  if (!off && cache_dst && cache_loc && cache_grad && nnz > 0 && nnz < (1ll << 31)) {
+    CT.N = (int)nnz; CT.D = D; CT.scale = cache_scale; CT.skip_dev = skip_dev; CT.grad = cache_grad; CT.loc = cache_loc;
+    CT.rowidx = rowidx; CT.dst = cache_dst;
+  }
+  return tt_backward_impl(g, optim, B, D, lr, eps, nnz, indices, rowidx, tableidx, psw, d_output, tt_cores, optimizer_state,
+                          d_tt_cores, plan, workspace, workspace_bytes, stream, &CT, tail_done);
+}
+
+static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, float lr, float eps,
+                            int64_t nnz, const int64_t* indices, const int64_t* rowidx,
+                            const int64_t* tableidx, const float* psw, const float* d_output,
+                            float* const* tt_cores, float* const* optimizer_state, float* const* d_tt_cores,
+                            const void* plan, void* workspace, size_t workspace_bytes, ttx_stream_t stream,
+                            const CacheTail* tail, int32_t* tail_done) {
   Dims d;
   int rc = make_dims(g, &d);
   if (rc) return rc;
@@ -2050,7 +2103,7 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
     const int rthreads = smax <= 4096 ? TTX_RTHREADS_SMALL : kReduceThreads;
     ProfScope ps(TTX_PROF_APPLY, st);
     hipLaunchKernelGGL(reduce_apply_kernel, dim3(ns2 + nsg2), dim3(rthreads), 0, st, d2, P, PC, optim, lr, eps, C, S, DW, ns2,
-                       (int)nnz);
+                       (int)nnz, CacheTail{});
     TTX_HIP(hipGetLastError());
     hipLaunchKernelGGL(t4_apply23_kernel, dim3(d.S[2] + d.S[3]), dim3(kT4Threads), 0, st, P, PC.pc[2], PC.pc[3], d.S[2],
                        d.slice[2], d.slice[3], t4_seg(nnz), optim, lr, eps, C.c[2], C.c[3], S.c[2], S.c[3], DW.c[2], DW.c[3]);
@@ -2063,8 +2116,18 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, fl
     for (int t = 0; t < d.T; ++t) smax = d.slice[t] > smax ? d.slice[t] : smax;
     const int rthreads = smax <= 4096 ? TTX_RTHREADS_SMALL : kReduceThreads;  // (measured: 512 is 1.7 us faster at r = 32, 1024 at r = 64)
     ProfScope ps(TTX_PROF_APPLY, st);
-    hipLaunchKernelGGL(reduce_apply_kernel, dim3(blocks), dim3(rthreads), 0, st, d, P, PC, optim, lr,
-                       eps, C, S, DW, nslices, (g_skip_launch & 4) ? -(int)nnz : (int)nnz);
+    CacheTail CT{};
+    int tail_blocks = 0;
+    if (tail && tail->dst) {  // the cache rows' scatter in the same launch (launch_scatter_add's grid, ttx_cache.hip)
+      CT = *tail;
+      CT.first = blocks;
+      CT.nmain = (int)((CT.N + kScatterThreads / 32 - 1) / (kScatterThreads / 32));
+      CT.K = (((uintptr_t)CT.grad & 15) == 0) ? hot_rows(CT.N, CT.D) : 0;
+      tail_blocks = CT.nmain + CT.K * (int)((CT.N + kHotSeg - 1) / kHotSeg);
+      if (tail_done) *tail_done = 1;
+    }
+    hipLaunchKernelGGL(reduce_apply_kernel, dim3(blocks + tail_blocks), dim3(rthreads), 0, st, d, P, PC, optim, lr,
+                       eps, C, S, DW, nslices, (g_skip_launch & 4) ? -(int)nnz : (int)nnz, CT);
     TTX_HIP(hipGetLastError());
   }
   return TTX_OK;

@@ -197,6 +197,19 @@ int ttx_tt_backward_w(const ttx_geom* g, int32_t optim, int32_t B, int32_t D,
                       float* const* d_tt_cores, const void* plan, void* workspace,
                       size_t workspace_bytes, ttx_stream_t stream);
 
+/* Not in the reference (round 4): ttx_tt_backward_w of a cache-live batch with the cache rows' scatter
+ * (cache_backward_sgd_cuda / _dense, tt_embeddings_cuda.cu:1574-1697: cache_dst[loc[n], :] += cache_scale * cache_grad[rowidx[n], :]
+ * for the lookups behind the device-side split point *skip_dev) done by work-groups of the optimizer's launch instead of a launch of
+ * its own.  *tail_done = 1 when it was; 0 (four-core route, an empty batch, switched off) = the caller runs
+ * ttx_cache_backward_sgd_n / _dense_n itself.  rowidx is the partitioned bag rows of all nnz positions, as for ttx_tt_forward_cached. */
+int ttx_tt_backward_wc(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, float lr, float eps,
+                       int64_t nnz, const int64_t* indices, const int64_t* rowidx,
+                       const int64_t* tableidx, const float* per_sample_weights, const float* d_output,
+                       float* const* tt_cores, float* const* optimizer_state, float* const* d_tt_cores,
+                       const void* plan, void* workspace, size_t workspace_bytes, ttx_stream_t stream,
+                       const int32_t* skip_dev, const int32_t* cache_loc, const float* cache_grad, float cache_scale,
+                       float* cache_dst, int32_t* tail_done);
+
 /* ----------------------------------------------- duplicate lookups -----
  * Not in the reference (which contracts every lookup on its own): a batch's lookups are mapped onto their
  * DISTINCT (table, index) pairs, the contraction runs once per pair, bag pooling gathers each lookup's row
