@@ -15,11 +15,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session")
-def small_cases():
+def _load_cases(fname):
     import numpy as np
 
-    z = np.load(os.path.join(HERE, "golden", "small_cases.npz"))
+    z = np.load(os.path.join(HERE, "golden", fname))
     names = sorted({k.split("/")[0] for k in z.files})
     cases = {}
     for name in names:
@@ -37,3 +36,16 @@ def small_cases():
         c["D"] = int(np.prod(c["q"]))
         cases[name] = c
     return cases
+
+
+@pytest.fixture(scope="session")
+def small_cases():
+    """the reference's own test shapes (tt_embeddings_test.py:65-70) + the README toy: tests/golden/small_cases.npz"""
+    return _load_cases("small_cases.npz")
+
+
+@pytest.fixture(scope="session")
+def round4_cases():
+    """the geometry classes round 4 moved onto new routes, expanded by the reference's Python (tests/golden/make_golden.py
+    round4_cases): tests/golden/round4_cases.npz"""
+    return _load_cases("round4_cases.npz")

@@ -89,9 +89,38 @@ def small_cases():
     return cases
 
 
-def write_small():
+def round4_cases():
+    """the geometry classes round 4 moved onto new routes, as small tables the reference expands: a first factor with no exact part
+    split (q0 = 5, 7: core 0 zero-padded by the module), q0 = 8 (part lookups), q2 = 12 / 16 (the q2 <= 16 templates, padded and
+    exact, ranks 32 and 64), four cores with a merged last factor of 8 and of 16, two cores at a rank that is not a multiple of 4"""
+    shapes = {
+        "t3_q5": ([6, 7, 8], [5, 4, 4], [16, 16]),
+        "t3_q7": ([5, 6, 7], [7, 4, 8], [16, 32]),
+        "t3_q8": ([6, 7, 8], [8, 4, 4], [16, 16]),
+        "t3_q2_12": ([5, 6, 7], [4, 4, 12], [32, 32]),
+        "t3_q2_16_r64": ([3, 3, 3], [4, 8, 16], [64, 64]),
+        "t4_m8": ([4, 5, 3, 4], [2, 4, 4, 2], [16, 16, 16]),
+        "t4_m16": ([4, 5, 3, 4], [2, 4, 4, 4], [16, 16, 16]),
+        "t2_r13": ([9, 8], [5, 7], [13]),
+        "t2_r6": ([9, 8], [16, 3], [6]),
+    }
+    cases = {}
+    for cid, (name, (p, q, r)) in enumerate(shapes.items()):
+        for tables in ((1,) if max(r) > 32 else (1, 2)):  # (the r = 64 cores are a megabyte per table)
+            E = int(np.prod(p))
+            cores = G.make_cores(400 + 2 * cid + tables, tables, p, q, r, "signed")
+            idx, off = G.make_bags(500 + 2 * cid + tables, 29, E, 3, 2, tables)
+            if idx.size > 4:
+                idx[1] = idx[0]
+                idx[-1] = idx[0]
+            d_out = G.make_grad(600 + 2 * cid + tables, tables, 29, int(np.prod(q)))
+            cases[f"{name}_tb{tables}"] = (tables, p, q, r, cores, idx, off, d_out)
+    return cases
+
+
+def write_small(cases=None, fname="small_cases.npz"):
     blob = {}
-    for name, (tables, p, q, r, cores, idx, off, d_out) in small_cases().items():
+    for name, (tables, p, q, r, cores, idx, off, d_out) in (cases or small_cases()).items():
         out, grads, sgd, ada, state = reference_case(tables, p, q, r, cores, idx, off, d_out)
         blob[f"{name}/meta"] = np.array([tables, len(p)] + list(p) + list(q) + list(r), dtype=np.int64)
         blob[f"{name}/indices"] = idx
@@ -102,7 +131,7 @@ def write_small():
             blob[f"{name}/core{t}"] = cores[t]
             blob[f"{name}/grad{t}"] = grads[t]
         print(name, "nnz", idx.size, "out", out.shape)
-    np.savez_compressed(os.path.join(HERE, "small_cases.npz"), **blob)
+    np.savez_compressed(os.path.join(HERE, fname), **blob)
 
 
 def write_big(tag, cfg, seed, nrows=16):
@@ -151,7 +180,11 @@ def write_cfg5():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--round4" in sys.argv:  # (only the round-4 file: the others are not touched)
+        write_small(round4_cases(), "round4_cases.npz")
+        sys.exit(0)
     write_small()
+    write_small(round4_cases(), "round4_cases.npz")
     if "--small" not in sys.argv:
         write_big("cfg2", G.CFG2, 1234)
         write_big("cfg4", G.CFG4, 4321)

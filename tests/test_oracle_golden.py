@@ -50,6 +50,13 @@ def test_small_cases_sgd_adagrad(small_cases):
             assert_adagrad_close(r["cores"][k], exp[k], c["grads"][k], f"{name} ada{k}")
 
 
+def test_round4_cases(round4_cases):
+    """the geometry classes round 4 moved onto new routes (tests/golden/round4_cases.npz, expanded by the reference's Python):
+    the oracle first -- the GPU tests compare the new routes with these vectors AND with the oracle"""
+    test_small_cases_forward_and_dense(round4_cases)
+    test_small_cases_sgd_adagrad(round4_cases)
+
+
 def big_case(tag):
     cfg, seed = {"cfg2": (G.CFG2, 1234), "cfg4": (G.CFG4, 4321), "r128": (G.R128, 2468)}[tag]
     z = np.load(os.path.join(HERE, "golden", f"{tag}.npz"))

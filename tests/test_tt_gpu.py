@@ -120,6 +120,30 @@ def test_backward_adagrad_golden(small_cases):
             assert_adagrad_close(got["cores"][k], orc["cores"][k], c["grads"][k], f"{name} adagrad core{k} vs oracle")
 
 
+def test_round4_geometries_golden(round4_cases):
+    """tests/golden/round4_cases.npz -- what the reference's Python gives for the geometry classes round 4 moved onto new routes:
+    q2 = 12 / 16 on the q2 <= 16 templates (padded, and exact at r = 64), four cores with a merged last factor of 8 / 16 on the
+    three-core kernels, two cores at ranks that are not multiples of 4 on the dedicated kernels (q0 = 5, 7, 8 run their part
+    lookups in the module: tests/test_module_gpu.py; here they take the generic kernels).  Forward, dense, SGD, Adagrad."""
+    import tt_embeddings as E
+
+    for name, c in round4_cases.items():
+        spec = E.debug_tiles(c["tables"], c["p"], c["q"], c["r"])["MC"] == 0
+        assert spec == (not name.startswith(("t3_q5", "t3_q7", "t3_q8"))), f"{name}: route"
+        got = run_case(c, "dense", True)
+        assert_close(got["out"], c["out"], f"{name} out vs golden")
+        for k in range(c["T"]):
+            assert_close(got["grads"][k], c["grads"][k], f"{name} grad{k} vs golden")
+        got = run_case(c, "sgd")
+        for k, e in enumerate(sgd_expected(c["cores"], c["grads"])):
+            assert_close(got["cores"][k], e, f"{name} sgd core{k} vs golden")
+        got = run_case(c, "adagrad", True)
+        exp, st = adagrad_expected(c["cores"], c["grads"])
+        for k in range(c["T"]):
+            assert_close(got["state"][k], st[k], f"{name} adagrad state{k} vs golden")
+            assert_adagrad_close(got["cores"][k], exp[k], c["grads"][k], f"{name} adagrad core{k} vs golden")
+
+
 def _random_case(seed, T, tables, B, pf, std, dist="uniform"):
     p, q, r = G.test_shape(T)
     r = G.pad_ranks(r, T)
