@@ -116,6 +116,15 @@ def flop_per_nnz_fwd(q, r):
     return 2.0 * sum(float(np.prod(q[:t])) * rr[t - 1] * q[t] * rr[t] for t in range(1, len(q)))
 
 
+def flop_per_nnz_fwd_executed(q, r):
+    """what the kernels here execute per lookup (forward).  Two and three cores: the reference's left-to-right count.  Four cores with
+    q2 q3 <= 16 (the route through the three-core kernels): the last two cores are contracted first --
+    r2 q2 r3 q3 multiply-adds for M = core_2 . core_3 -- and the lookup is a three-core lookup with the merged last factor."""
+    if len(q) == 4 and q[2] * q[3] <= 16:
+        return 2.0 * (r[1] * q[2] * r[2] * q[3]) + flop_per_nnz_fwd([q[0], q[1], q[2] * q[3]], [r[0], r[1]])
+    return flop_per_nnz_fwd(q, r)
+
+
 def source_hash():
     """identifies the kernel build a PMC measurement belongs to (same on the build container and the GPU box)"""
     h = hashlib.sha256()
@@ -210,6 +219,52 @@ def secondary_record(workload="cfg5shard", steps=40, repeats=3):
         return {"error": f"{type(ex).__name__}: {ex}", "workload": workload}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started by itself (no WORLD_SIZE in the environment): one rank per GPU under
+    torch.distributed.run on 127.0.0.1 with the same arguments -- the command the driver uses for --gpus 1 works unchanged for
+    --gpus 2/4/8.  Returns the exit code of the job; rank 0's JSON line goes to stdout as it is."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        print(f"[bench] --gpus {n} needs {n} visible GPUs; this box shows {have} "
+              f"(torch.cuda.device_count(); HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')})",
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as so:  # a free rendezvous port
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] self-launch:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def n1_record(workload, steps, warmup, device_index):
+    """The SAME workload on ONE GPU (rank 0's device, after the other ranks have left it alone): the denominator of the scaling
+    efficiency, measured in the same job on the same box.  A process of its own, like secondary_record."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "TORCHELASTIC_RUN_ID", "TTX_FORCE_EXCHANGE")}
+    vis = os.environ.get("HIP_VISIBLE_DEVICES")
+    env["HIP_VISIBLE_DEVICES"] = vis.split(",")[device_index] if vis else str(device_index)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--steps", str(steps), "--warmup", str(warmup),
+           "--repeats", "3", "--no-cpu-baseline", "--no-secondary"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "timed_mode": j["timed_mode"],
+                "workload": j["config"]["workload"], "nnz_per_step_total": j["config"]["nnz_per_step_total"],
+                "what": "bench.py --gpus 1 of the same workload, run by rank 0 on its own GPU after the sharded region (same box, same job)"}
+    except Exception as ex:  # noqa: BLE001 -- never take the sharded line with it
+        return {"error": f"{type(ex).__name__}: {ex}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,7 +286,12 @@ def main():
                     help="default workload only: skip the appended large-batch record (cfg5's per-GPU shard, 327,680 lookups per step)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="(test) take the N > 1 code path -- process group, sharded module, all-to-all -- with one rank")
+    ap.add_argument("--no-n1", action="store_true",
+                    help="N > 1: skip rank 0's one-GPU run of the same workload (the `n1` record of the line)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by itself: spawn the ranks (the driver's `python bench.py --gpus N` and its torch.distributed.run form both work)
+        sys.exit(self_launch(args.gpus))
     wl = WORKLOADS[args.workload]
     global P_SHAPES
     P_SHAPES = wl.get("p", P_SHAPES)
@@ -251,8 +311,9 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world != args.gpus and not (args.force_sharded and args.gpus == 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` (it spawns its ranks) or "
+                         f"torch.distributed.run --nproc-per-node N bench.py --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -276,6 +337,7 @@ def main():
     opt = ops.OptimType.SGD if args.optimizer == "sgd" else ops.OptimType.EXACT_ADAGRAD
     iters = 10  # request batches, like the reference's --iters
     hit_rate = None
+    n_tt_per_step = None
     cfg5 = args.workload == "cfg5"
     assert B_GLOBAL % world == 0, "the global batch must split evenly over the ranks"
     B_local = B_GLOBAL // world
@@ -311,6 +373,7 @@ def main():
             mod.cache_populate()
             n_tt = sum(E.preprocess_indices_sync(i, o, 1, False, mod.hashtbl, mod.cache_state)[3] for i, o in reqs)
             hit_rate = 1.0 - n_tt / float(iters * nnz_step_total)
+            n_tt_per_step = n_tt / float(iters)  # lookups the contraction kernels actually see per launch (the misses)
     else:
         # cfg2 (default): `world` tables, one per rank.  cfg5: 26 tables, t -> rank t % world (uneven ownership).
         tables_total = ntab if cfg5 else world
@@ -323,6 +386,9 @@ def main():
         grad = torch.from_numpy(G.make_grad(1236 + rank, tables_total, B_local, D)).to(dev)
         step = lambda i, o: mod(i, o, fixed_pooling=POOL).backward(grad)  # noqa: E731
         nnz_step_total = tables_total * B_GLOBAL * POOL  # every table sees the whole global batch
+
+    rank_regions = []  # sharded: per timed region, every rank's elapsed seconds
+    reported_ranks = []  # ... of the last region of the REPORTED mode
 
     def sync():
         if sharded:
@@ -337,6 +403,9 @@ def main():
         sync()
         el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if sharded:
+            every = [torch.zeros_like(el) for _ in range(world)]
+            dist.all_gather(every, el)  # every rank's own clock around the region (the line carries them beside the MAX)
+            rank_regions.append([float(e.item()) for e in every])
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item())
 
@@ -363,7 +432,10 @@ def main():
         gflops = 3.0 * fl_fwd * nnz_step_total / (elapsed / args.steps) / 1e9
         # lookups the dominant kernel of THIS rank contracts per launch (rank 0 owns the most tables)
         rank0_nnz = (owned[0] if sharded else tables_total) * B_GLOBAL * POOL
-        bwd_flop_per_launch = 2.0 * fl_fwd * rank0_nnz  # backward contraction = 2/3 of the algorithmic fwd+bwd FLOP
+        # a KERNEL's roofline counts the lookups the launch contracts: with a live cache only the misses reach the contraction
+        # (cfg3: ~12 % of the batch) -- the step-level GFLOP/s above keeps the full numerator, this does not
+        launch_nnz = n_tt_per_step if n_tt_per_step is not None else rank0_nnz
+        bwd_flop_per_launch = 2.0 * fl_fwd * launch_nnz  # backward contraction = 2/3 of the algorithmic fwd+bwd FLOP
         bwd_us = ms_bwd / max(n_bwd, 1) * 1e3
         achieved = bwd_flop_per_launch / (bwd_us * 1e-6) / 1e12 if n_bwd else 0.0
         traffic, traffic_note = None, "no PMC measurement (scripts/measure_traffic.sh) for this workload"
@@ -377,8 +449,27 @@ def main():
                     traffic_note = "profiles/pmc_bwd_bytes.json was measured on another build of the kernels (source hash differs): not reported"
             except Exception:  # noqa: BLE001
                 pass
+        pmc_all = os.path.join(ROOT, "profiles", "pmc_bytes.json")  # every measured workload (scripts/measure_traffic.sh --workload W)
         rocprof_us, rocprof_note = None, "no rocprofv3 summary of this build under profiles/ (scripts/regen_profiles.sh)"
-        if os.path.exists(pmc) and args.workload == "cfg2" and not sharded:
+        if os.path.exists(pmc_all) and not sharded:
+            try:
+                j = json.load(open(pmc_all))
+                if j.get("source_hash") == source_hash():
+                    w_ = j["workloads"].get(args.workload, {})
+                    kk = next((k for k in w_.get("kernels", {}) if k.startswith(("spec_bwd_kernel", "bwd_kernel", "t2_bwd_kernel"))), None)
+                    if kk:
+                        rec_ = w_["kernels"][kk]
+                        traffic = rec_["hbm_bytes_per_launch"]
+                        traffic_note = (f"{w_.get('source', '')}; {kk}: FETCH_SIZE x2 + WRITE_SIZE, per-launch average over "
+                                        f"{rec_.get('pmc_launches')} launches (profiles/pmc_bytes.json)")
+                        if rec_.get("rocprof_avg_us") and len(Q_SHAPES) != 4:
+                            rocprof_us = float(rec_["rocprof_avg_us"])
+                            rocprof_note = f"rocprofv3 --kernel-trace --stats, {rec_.get('rocprof_calls')} launches ({w_.get('source', '')})"
+                elif traffic is None:
+                    traffic_note = "profiles/pmc_bytes.json was measured on another build of the kernels (source hash differs): not reported"
+            except Exception:  # noqa: BLE001
+                pass
+        if rocprof_us is None and os.path.exists(pmc) and args.workload == "cfg2" and not sharded:
             try:
                 j = json.load(open(pmc))
                 if j.get("source_hash") == source_hash() and j.get("rocprof_avg_us"):
@@ -432,6 +523,12 @@ def main():
             "config": {"workload": (f"{args.workload}: {what} E={E_} D={D} p={P_SHAPES} q={Q_SHAPES} ranks={RANKS} "
                                     f"B={B_GLOBAL} L=20 nnz/step={nnz_step_total} sparse {args.optimizer.upper()}, use_cache={cache_txt}{own_txt}"),
                        "nnz_per_step_total": nnz_step_total, "flop_per_nnz_fwd_bwd": 3.0 * fl_fwd,
+                       # `value` counts the REFERENCE's left-to-right FLOP (its benchmark's formula) whatever order the kernels
+                       # contract in: for four cores that is reference-equivalent throughput, not matrix-pipe utilisation
+                       "flop_per_nnz_fwd_reference": fl_fwd, "flop_per_nnz_fwd_executed": flop_per_nnz_fwd_executed(Q_SHAPES, RANKS),
+                       **({"flop_note": "four cores: value is reference-equivalent GFLOP/s (left-to-right count); the kernels contract "
+                                        "the last two cores first and execute flop_per_nnz_fwd_executed per lookup -- no fraction "
+                                        "of the fp32 peak is claimed for this line"} if len(Q_SHAPES) == 4 else {}),
                        "path": "Python module -> C++ autograd node (or ctypes) -> C ABI -> HIP" + (graph_txt or "; eager")},
             "timed_mode": mode,
             "repeats": len(regions),
@@ -447,16 +544,24 @@ def main():
             "ref_formula_gflops_x_iters": round(gflops * 10, 1),
             "reference_readme_true_gflops": 265.8,
             "kernel_us": breakdown,
-            "roofline": {"bound": "mfma", "kernel": "spec_bwd_kernel / bwd_kernel (backward contraction)", "achieved": round(achieved, 3),
-                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 5),
-                         "traffic": traffic, "traffic_source": traffic_note, "launches": n_bwd, "avg_us": round(bwd_us, 2),
-                         "timed_by": bwd_src, "flop_per_launch": bwd_flop_per_launch, "kernel_build": source_hash(),
-                         # the same kernel's duration as rocprofv3 --kernel-trace --stats reports it for THIS build (no launch
-                         # gap inside the bracket): the figure profiles/ documents; `frac` above is the conservative one
-                         "rocprof_avg_us": rocprof_us,
-                         "frac_rocprof": (round(bwd_flop_per_launch / (rocprof_us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 5)
-                                          if rocprof_us else None),
-                         "rocprof_source": rocprof_note},
+            # ONE figure per kernel (round 5): `achieved` / `frac` divide the algorithmic FLOP of a launch by the kernel's average
+            # duration as rocprofv3 --kernel-trace --stats reports it for THIS build (profiles/, reproducible by hand from
+            # <tag>_kernel_stats*.md); the live HIP-event bracket of this run -- which includes event overhead and, in an eager
+            # region, launch gap -- stays beside it as `events_*` / `frac_events` and is what `frac` falls back to (and says so in
+            # `frac_source`) when profiles/ holds no rocprofv3 summary of this build of the kernels.
+            "roofline": (lambda ach_r: {
+                "bound": "mfma", "kernel": "spec_bwd_kernel / bwd_kernel (backward contraction)",
+                "achieved": round(ach_r if ach_r else achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": round((ach_r if ach_r else achieved) / PEAK_FP32_TFLOPS, 5),
+                "frac_source": ("rocprofv3 --kernel-trace --stats average of this build (profiles/)" if ach_r else
+                                "live HIP events of this run (no rocprofv3 summary of this build under profiles/)"),
+                "avg_us": rocprof_us if ach_r else round(bwd_us, 2), "rocprof_avg_us": rocprof_us, "rocprof_source": rocprof_note,
+                "frac_events": round(achieved / PEAK_FP32_TFLOPS, 5), "events_avg_us": round(bwd_us, 2), "events_launches": n_bwd,
+                "events_timed_by": bwd_src,
+                "traffic": traffic, "traffic_source": traffic_note, "launches": n_bwd,
+                "flop_per_launch": bwd_flop_per_launch, "lookups_per_launch": round(launch_nnz, 1),
+                "kernel_build": source_hash()})(
+                    (bwd_flop_per_launch / (rocprof_us * 1e-6) / 1e12) if rocprof_us else None),
             "kernel_us_note": ("HIP-event brackets around each launch in an eager pass: every bracket includes ~2 us of launch "
                                "gap, so their sum exceeds the replayed step; rocprofv3 durations: profiles/"),
         }
@@ -474,6 +579,9 @@ def main():
                                 "kernel_build": source_hash()}
         if a2a is not None:
             line["all_to_all"] = a2a
+        if sharded and reported_ranks:
+            # the ranks' own clocks around the LAST timed region of the reported mode (value uses the MAX, as the contract says)
+            line["per_rank_ms_per_step"] = [round(t / args.steps * 1e3, 4) for t in reported_ranks]
         if note:
             line["note"] = note
         return line
@@ -563,6 +671,7 @@ def main():
                 dog.start()
             graph_steps(max(args.warmup, iters))
             regions = [timed(graph_steps, args.steps) for _ in range(max(1, args.repeats))]
+            reported_ranks[:] = rank_regions[-1] if rank_regions else []
             mode = (("hipgraph+direct-rccl" + ("+prefetch-round" if pipelined else "")) if sharded
                     else (f"hipgraph+prefetch-{args.prefetch}" if pipelined else "hipgraph"))
             if pipelined:  # the same round without the overlap, for the record
@@ -595,6 +704,7 @@ def main():
     if regions is None:  # eager is the reported mode: repeat it like the graph region
         eager_regions += [timed(eager_steps, args.steps) for _ in range(max(0, args.repeats - 1))]
         regions = eager_regions
+        reported_ranks[:] = rank_regions[-1] if rank_regions else []
 
     # N > 1: the two exchanges of a step in isolation (xGMI all-to-all bandwidth vs the link roofline), with the
     # step's own per-peer message sizes (uneven when the tables do not divide by the ranks)
@@ -689,7 +799,8 @@ def main():
             line["degraded"] = degraded
         if args.workload == "cfg2" and not sharded and not args.no_secondary:
             line["secondary"] = secondary_record()
-        print(json.dumps(line), flush=True)
+        if not (sharded and world > 1):
+            print(json.dumps(line), flush=True)
     if sharded:
         dist.barrier()
         sys.stdout.flush()
@@ -716,6 +827,18 @@ def main():
             print(f"[bench] rank {rank}: communicator teardown did not finish in time; leaving it to process exit",
                   file=sys.stderr, flush=True)
         rc = 4 if (degraded and world > 1) else 0
+        if rank == 0 and world > 1:
+            # N > 1: the ONE line is printed here, after the communicators are gone and the other ranks have left rank 0's GPU alone,
+            # with the one-GPU value of the same workload beside it (the driver computes the scaling efficiency itself; this is the
+            # same-box, same-job denominator for anyone reading the line alone)
+            if not args.no_n1:
+                line["n1"] = n1_record(args.workload, args.steps, args.warmup, local_rank)
+                if "value" in line["n1"] and line["n1"]["value"] > 0:
+                    # weak scaling: per-GPU work fixed -> ideal = N x n1; strong: total work fixed -> ideal = N x n1 as well (value is the
+                    # whole-job rate either way)
+                    line["n1"]["value_over_n_times_n1"] = round(line["value"] / (world * line["n1"]["value"]), 4)
+            print(json.dumps(line), flush=True)
+        sys.stdout.flush()
         sys.stderr.flush()
         os._exit(rc)
 

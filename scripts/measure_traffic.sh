@@ -9,7 +9,9 @@
 set -u
 TAG=${1:-r02}; shift || true
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/prof_$TAG
+WSUF=""   # (--workload W: a directory of its own, profiles/<tag>_kernel_stats_W.md; every workload lands in profiles/pmc_bytes.json)
+prev=""; for a in "$@"; do [ "$prev" = "--workload" ] && WSUF="_$a"; prev=$a; done
+OUT=$REPO/gpurun_out/prof_$TAG$WSUF
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 ARGS="--steps 50 --warmup 10 --repeats 1 --no-cpu-baseline --no-secondary $*"

@@ -9,6 +9,7 @@ import collections
 import csv
 import sys
 
+CLOCK_LO, CLOCK_HI, CLOCK_LONG = 2.0, 2.6, 2.4  # GHz: plausible shader clocks; what long kernels measure (r04: 2.35 .. 2.43)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 seen = set()
@@ -32,10 +33,22 @@ for k, cs in acc.items():
     der = []
     gui = m.get("GRBM_GUI_ACTIVE")
     if gui:
-        der.append(f"clock {gui / 8 / d / 1e3:.2f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration)")
+        clock = gui / 8 / d / 1e3
+        if CLOCK_LO <= clock <= CLOCK_HI:
+            run_cycles = gui / 8  # per XCD
+            der.append(f"clock {clock:.2f} GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration)")
+            how = "busy cycles / (1024 SIMDs x GUI_ACTIVE / 8 XCDs)"
+        else:
+            # GRBM_GUI_ACTIVE includes the counters' start / stop time around a short dispatch: the "clock" it implies is not one
+            # (round 4 printed 3.2 .. 7.1 GHz for kernels under ~30 us and understated everything divided by it).  Long kernels
+            # of the same runs come out at 2.35 .. 2.43 GHz: the run's cycles are taken as duration x that clock instead.
+            run_cycles = d * 1e3 * CLOCK_LONG
+            der.append(f"(GRBM_GUI_ACTIVE / 8 / duration = {clock:.2f} GHz is outside {CLOCK_LO}-{CLOCK_HI} GHz: the counter includes its "
+                       f"own start / stop time around a {d:.1f} us dispatch -- run cycles taken as duration x {CLOCK_LONG} GHz)")
+            how = f"busy cycles / (1024 SIMDs x duration x {CLOCK_LONG} GHz)"
         if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
-            busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (128 * gui)
-            der.append(f"MFMA pipes busy {busy:.3f} of the run (busy cycles / (1024 SIMDs x GUI_ACTIVE / 8 XCDs))")
+            busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * run_cycles)
+            der.append(f"MFMA pipes busy {busy:.3f} of the run ({how})")
     if "SQ_WAVE_CYCLES" in m:
         w = m["SQ_WAVE_CYCLES"]
         for c, nm in (("SQ_WAIT_ANY", "parked (waitcnt / barrier)"), ("SQ_WAIT_INST_ANY", "issue-stalled"), ("SQ_ACTIVE_INST_ANY", "issuing")):

@@ -54,13 +54,45 @@ if os.path.exists(log):
         lines.append(f"\nbench line of the same run (under rocprofv3): {j['value']} GFLOP/s, {j['ms_per_step']} ms/step ({j['timed_mode']}), "
                      f"eager {j['eager_ms_per_step']} ms/step; workload: {j['config']['workload']}")
 for d in (os.path.join(ROOT, "profiles"), out):  # (gpurun only brings gpurun_out/ back: copy from there into profiles/)
-    open(os.path.join(d, f"{tag}_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(d, f"{tag}_kernel_stats{'' if '--workload' not in bench_args else '_' + bench_args.split()[bench_args.split().index('--workload') + 1]}.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
+
+# every workload: profiles/pmc_bytes.json -- HBM bytes per launch and the rocprofv3 duration of every ttx kernel, per workload,
+# stamped with the hash of the kernel sources (bench.py reports roofline.traffic / rocprof_avg_us from it for the build it matches)
+import bench  # noqa: E402
+
+wl = "cfg2"
+toks = bench_args.split()
+if "--workload" in toks:
+    wl = toks[toks.index("--workload") + 1]
+blob_all = {"source_hash": bench.source_hash(), "fetch_correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, "
+            "MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KiB -> bytes x1024; separate --pmc passes", "workloads": {}}
+for d in (os.path.join(ROOT, "profiles"), out):
+    fn = os.path.join(d, "pmc_bytes.json")
+    cur = blob_all
+    if os.path.exists(fn):
+        try:
+            j = json.load(open(fn))
+            if j.get("source_hash") == blob_all["source_hash"]:
+                cur = j
+        except Exception:  # noqa: BLE001
+            pass
+    ks = {}
+    for k in counters:
+        rd, wr = avg(counters[k].get("FETCH_SIZE", [])), avg(counters[k].get("WRITE_SIZE", []))
+        if rd is None or wr is None:
+            continue
+        ks[k] = {"read_bytes": int(2 * rd * 1024), "write_bytes": int(wr * 1024), "hbm_bytes_per_launch": int((2 * rd + wr) * 1024),
+                 "pmc_launches": len(counters[k]["FETCH_SIZE"]),
+                 "rocprof_avg_us": round(float(stats[k]["AverageNs"]) / 1e3, 3) if k in stats else None,
+                 "rocprof_calls": int(stats[k]["Calls"]) if k in stats else 0}
+    cur["workloads"][wl] = {"kernels": ks, "source": f"scripts/measure_traffic.sh {tag} {bench_args}: rocprofv3 --kernel-trace --stats "
+                            f"(durations), --pmc FETCH_SIZE and --pmc WRITE_SIZE in passes of their own (--no-graph)"}
+    json.dump(cur, open(fn, "w"), indent=1)
+print("wrote profiles/pmc_bytes.json for", wl)
 
 bwd = [k for k in counters if "bwd_kernel" in k]
 if bwd and "--workload" not in bench_args:
-    import bench
-
     k = bwd[0]
     rd, wr = avg(counters[k].get("FETCH_SIZE", [])), avg(counters[k].get("WRITE_SIZE", []))
     if rd is not None and wr is not None:

@@ -21,6 +21,11 @@ BENCH_W=${BENCH_WORKLOADS:-"cfg3 cfg3a105 cfg3warm cfg4 cfg5shard r128 r13 d320 
 if [ -z "${REGEN_ONLY_BENCH:-}" ]; then   # (REGEN_ONLY_BENCH=1: the counters of this build are in ./profiles already -- bench lines only)
 scripts/measure_traffic.sh "$TAG" > "$OUT/measure_traffic.log" 2>&1
 cp gpurun_out/prof_$TAG/${TAG}_kernel_stats.md gpurun_out/prof_$TAG/pmc_bwd_bytes.json "$OUT/" 2>/dev/null
+for W in ${TRAFFIC_WORKLOADS:-"cfg3 cfg4 cfg5shard"}; do   # (round 5: HBM bytes for the workloads where bytes are the argument)
+  scripts/measure_traffic.sh "$TAG" --workload $W > "$OUT/measure_traffic_$W.log" 2>&1
+  cp gpurun_out/prof_${TAG}_$W/${TAG}_kernel_stats_$W.md "$OUT/" 2>/dev/null
+done
+cp profiles/pmc_bytes.json "$OUT/" 2>/dev/null
 for W in $PMC_W; do
   scripts/pmc_large.sh "$TAG" $W > "$OUT/pmc_$W.log" 2>&1
   cp gpurun_out/pmc_${TAG}_$W/summary.md "$OUT/${TAG}_sq_pmc_$W.md" 2>/dev/null

@@ -1,0 +1,52 @@
+"""bench.py's command line as the driver uses it: `python bench.py --gpus N` must run by itself."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_more_gpus_than_the_box_has_is_refused_with_the_device_count():
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    want = have + 1 if have >= 1 else 2
+    out = subprocess.run([sys.executable, BENCH, "--gpus", str(want)], capture_output=True, text=True, timeout=300, env=_env())
+    assert out.returncode == 2, out.stderr[-2000:]
+    assert f"needs {want} visible GPUs" in out.stderr and f"shows {have}" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]  # no bench line from a refused run
+
+
+def test_world_size_that_contradicts_gpus_is_refused():
+    env = _env()
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "4"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in (out.stderr + out.stdout)
+
+
+@pytest.mark.gpu
+def test_sharded_code_path_runs_as_a_subprocess_and_prints_one_line():
+    """the N > 1 path (process group over RCCL, sharded module, direct all-to-all, captured round) with one rank"""
+    env = _env()
+    env.setdefault("TTX_DIRECT_TIMEOUT", "200")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--force-sharded", "--steps", "4", "--warmup", "2", "--repeats", "1",
+                          "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["value"] > 0 and j["unit"] == "GFLOP/s"
+    assert "degraded" not in j, j.get("degraded")
+    assert j["roofline"]["frac"] > 0 and j["roofline"]["peak"] == 157.3
+    a2a = j["all_to_all"]
+    assert "error" not in a2a and a2a["pooled_out"]["us"] > 0 and "frac_of_xgmi" in a2a["indices_in"]
+    assert j["per_rank_ms_per_step"] and len(j["per_rank_ms_per_step"]) == 1
