@@ -333,6 +333,14 @@ def main():
     import tt_embeddings_ops as ops
     import ttx_sharded
 
+    # the library's process-global test / ablation knobs (ttx_debug_skip, ttx_set_chunk, ...) must be at their defaults: a line
+    # timed with phases skipped or tiles overridden is not a measurement.  Ablation scripts say TTX_ALLOW_DEBUG=1 and get a line
+    # that carries the mask and the word INVALID.
+    debug_state = int(E.lib().ttx_debug_state())
+    if debug_state and not os.environ.get("TTX_ALLOW_DEBUG"):
+        raise SystemExit(f"bench.py: libttx's debug knobs are set (ttx_debug_state() = {debug_state}; TTX_DEBUG_SKIP / TTX_LDS_BUDGET in "
+                         f"the environment?) -- refusing to time an ablated build; TTX_ALLOW_DEBUG=1 overrides (the line is marked INVALID)")
+
     E_, D = int(np.prod(P_SHAPES)), int(np.prod(Q_SHAPES))
     opt = ops.OptimType.SGD if args.optimizer == "sgd" else ops.OptimType.EXACT_ADAGRAD
     iters = 10  # request batches, like the reference's --iters
@@ -579,6 +587,9 @@ def main():
                                 "kernel_build": source_hash()}
         if a2a is not None:
             line["all_to_all"] = a2a
+        line["debug_knobs"] = debug_state  # (ttx_debug_state(): 0 = every test / ablation knob of the library at its default)
+        if debug_state:
+            line["INVALID"] = f"timed with libttx debug knobs set (mask {debug_state}, TTX_ALLOW_DEBUG=1): an ablation, not a measurement"
         if sharded and reported_ranks:
             # the ranks' own clocks around the LAST timed region of the reported mode (value uses the MAX, as the contract says)
             line["per_rank_ms_per_step"] = [round(t / args.steps * 1e3, 4) for t in reported_ranks]

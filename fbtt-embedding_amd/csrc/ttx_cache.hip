@@ -986,6 +986,8 @@ int ttx_set_reference_exact(int32_t flags) {
 
 static int g_cache_fwd_lookup_groups = 0;
 int ttx_debug_cache_fwd(int32_t lookup_groups) { g_cache_fwd_lookup_groups = lookup_groups; return TTX_OK; }
+// (for ttx_debug_state, ttx_tt.hip: bit 0 = reference-exact populate, bit 1 = the cache forward's A/B knob)
+int ttx_cache_debug_state(void) { return (g_reference_exact ? 1 : 0) | (g_cache_fwd_lookup_groups ? 2 : 0); }
 
 int ttx_cache_forward(int32_t B, int64_t nnz, const int32_t* loc, const int64_t* rowidx, int32_t D,
                       const float* cache_weight, float* output, ttx_stream_t stream) {

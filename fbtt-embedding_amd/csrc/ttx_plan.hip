@@ -27,6 +27,8 @@
 //   * plan_small_kernel -- nnz <= 1024: one work-group per core, keys stay in registers/LDS.
 // The plan is integer work of ~ (8 + 8*passes) bytes per lookup per core; its cost is launch
 // latency and dependent-load chains, not bandwidth -- hence the effort to keep it to one launch.
+#include <stdlib.h>
+
 #include "ttx_internal.h"
 
 namespace ttx {
@@ -1426,10 +1428,67 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
   return TTX_OK;
 }
 
+// ---- opt-in index range check (TTX_CHECK_INDICES=1) ----------------------------------------------------------------------
+// The reference decodes any int64 it is handed (i_0 = idx / L_0 with no bound: an index >= prod(p) reads past core 0,
+// tt_embeddings_cuda.cu:795-799); the plan kernels here CLAMP every factor into its range instead, so a bad index silently
+// becomes another row.  With TTX_CHECK_INDICES=1 every entry point that reads a batch's indices first verifies 0 <= idx < prod(p)
+// of the lookup's table (and 0 <= table < num_tables) and returns TTX_EINVAL naming the first offender.  One small launch plus a
+// host read-back per batch: a debugging aid -- off by default, skipped (with the clamp as the behaviour) while the stream is
+// being captured.
+__global__ __launch_bounds__(256) void check_indices_kernel(Dims d, int Nmax, const int* __restrict__ n_dev,
+                                                            const int64_t* __restrict__ indices,
+                                                            const int64_t* __restrict__ tableidx, long long* __restrict__ bad) {
+  const int N = live_n(Nmax, n_dev);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    const long long tb = tableidx ? tableidx[i] : 0;
+    bool ok = tb >= 0 && tb < d.num_tables;
+    if (ok) {
+      const long long E = d.tab ? d.tab->L[tb][0] * d.tab->p[tb][0] : d.L[0] * d.p[0];
+      ok = indices[i] >= 0 && indices[i] < E;
+    }
+    if (!ok) {
+      atomicAdd((unsigned long long*)&bad[0], 1ull);
+      atomicMin((unsigned long long*)&bad[1], (unsigned long long)i);
+    }
+  }
+}
+bool check_indices_on() {
+  static const bool on = getenv("TTX_CHECK_INDICES") && atoi(getenv("TTX_CHECK_INDICES")) != 0;
+  return on;
+}
+int check_indices(const Dims& d, long long nnz, const int* n_dev, const int64_t* indices, const int64_t* tableidx, hipStream_t stream) {
+  if (!check_indices_on() || nnz <= 0 || !indices) return TTX_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return TTX_OK; }
+  if (cs != hipStreamCaptureStatusNone) return TTX_OK;  // (a read-back cannot be captured: the plan's clamp applies)
+  long long* bad = nullptr;
+  TTX_HIP(hipMalloc((void**)&bad, 2 * sizeof(long long)));  // (a debugging path: the synchronising allocator is fine)
+  const long long init[2] = {0, 0x7fffffffffffffffll};
+  TTX_HIP(hipMemcpyAsync(bad, init, sizeof(init), hipMemcpyHostToDevice, stream));
+  const int blocks = (int)((nnz + 255) / 256 < 1024 ? (nnz + 255) / 256 : 1024);
+  hipLaunchKernelGGL(check_indices_kernel, dim3(blocks), dim3(256), 0, stream, d, (int)nnz, n_dev, indices, tableidx, bad);
+  long long got[2] = {0, 0};
+  TTX_HIP(hipMemcpyAsync(got, bad, sizeof(got), hipMemcpyDeviceToHost, stream));
+  TTX_HIP(hipStreamSynchronize(stream));
+  (void)hipFree(bad);
+  if (got[0] == 0) return TTX_OK;
+  long long idx = 0, tb = 0;
+  (void)hipMemcpy(&idx, indices + got[1], sizeof(idx), hipMemcpyDeviceToHost);
+  if (tableidx) (void)hipMemcpy(&tb, tableidx + got[1], sizeof(tb), hipMemcpyDeviceToHost);
+  const long long E = (d.tab && tb >= 0 && tb < d.num_tables) ? -1 : d.L[0] * d.p[0];
+  TTX_FAIL(TTX_EINVAL, "TTX_CHECK_INDICES: %lld of %lld lookups are out of range; the first is lookup %lld: index %lld of table %lld "
+           "(valid: 0 <= index < %s%lld, 0 <= table < %d)", got[0], nnz, got[1], idx, tb, E < 0 ? "prod(p) of its table; shown: " : "",
+           E < 0 ? -1ll : E, d.num_tables);
+}
+
 int plan_build(const Dims& d, long long nnz, const int64_t* indices,
                const int64_t* tableidx, const int64_t* rowidx, const Plan& P, hipStream_t stream,
                const int* n_dev, const int64_t* offsets, int bags_per_table) {
   if (nnz < 0 || nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz=%lld out of range", nnz);
+  {
+    const int rc_chk = check_indices(d, nnz, n_dev, indices, tableidx, stream);
+    if (rc_chk) return rc_chk;
+  }
   if (P.MC <= 0) TTX_FAIL(TTX_EUNSUPPORTED, "TT shape does not fit the LDS of any kernel variant (core-1 slice %d x %d floats)", d.k[0], d.n[0]);
   ProfScope ps(TTX_PROF_PLAN, stream);
   if (nnz > 1024 || !d.idx32 || n_dev)
@@ -1469,6 +1528,10 @@ int plan_build_batches(const Dims& d, int nbatch, long long nnz, const int* n_de
                        const int64_t* tableidx, const int64_t* rowidx, void* plans, size_t plan_stride,
                        hipStream_t stream) {
   if (!plan_batches_ok(d, nnz)) TTX_FAIL(TTX_EINVAL, "plan_build_batches: batch shape needs the multi-launch plans");
+  for (int z = 0; z < nbatch && check_indices_on(); ++z) {
+    const int rc_chk = check_indices(d, nnz, n_dev ? n_dev + z : nullptr, indices + (size_t)z * nnz, tableidx ? tableidx + (size_t)z * nnz : nullptr, stream);
+    if (rc_chk) return rc_chk;
+  }
   ProfScope ps(TTX_PROF_PLAN, stream);
   const Plan P = carve_plan(d, nnz, plans);
   ProBatch mb{};
@@ -1848,6 +1911,10 @@ bool prologue_fusable(const Dims& d, long long nnz, long long nb) {
 
 int prologue_launch(const Dims& d, int N, const int64_t* indices, const Prologue& pg, const Plan& P, hipStream_t stream,
                     const ProBatch* mb = nullptr, int nbatch = 1) {
+  for (int z = 0; z < nbatch && check_indices_on(); ++z) {  // (one table, tableidx == 0: the prologue's own contract)
+    const int rc_chk = check_indices(d, N, nullptr, (mb && z > 0) ? mb->indices[z] : indices, nullptr, stream);
+    if (rc_chk) return rc_chk;
+  }
   ProfScope ps(TTX_PROF_PLAN, stream);
   hipLaunchKernelGGL(mb_single_kernel<true>,
                      dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit) + TTX_PLAN_XWG, d.T, nbatch),

@@ -795,8 +795,8 @@ __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply
                                                                CorePtrs W, CorePtrs St,
                                                                CorePtrs DW, int nslices, int rows_max, CacheTail CT) {
   if (CT.dst && (int)blockIdx.x >= CT.first) {  // (work-group-uniform) a work-group of the cache rows' scatter
-    if (threadIdx.x < kScatterThreads)
-      cache_scatter_add_body((int)blockIdx.x - CT.first, CT.N, CT.D, CT.scale, CT.skip_dev, CT.grad, CT.loc, CT.rowidx, CT.dst, CT.nmain, CT.K);
+    // (all threads: the body's hot-row path has work-group barriers; threads beyond kScatterThreads only wait at them)
+    cache_scatter_add_body((int)blockIdx.x - CT.first, CT.N, CT.D, CT.scale, CT.skip_dev, CT.grad, CT.loc, CT.rowidx, CT.dst, CT.nmain, CT.K);
     return;
   }
   __shared__ float4 red[kReduceThreads];
@@ -1705,6 +1705,15 @@ int ttx_debug_tiles(const ttx_geom* g, int32_t* out) {
   const Lds L = make_lds(d, cfg.MC, true, cfg.bpp, cfg.KB);
   out[0] = L.MC; out[1] = L.bpp; out[2] = L.KB; out[3] = L.ncp; out[4] = L.nkb; out[5] = L.bytes;
   return TTX_OK;
+}
+
+// Which of the process-global TEST / ablation knobs are away from their defaults (0 = none): bit 0 ttx_debug_skip, 1
+// ttx_debug_lds_budget, 2 ttx_set_chunk, 3 ttx_debug_stamps, 4 ttx_set_reference_exact, 5 ttx_debug_cache_fwd.  The knobs are plain
+// globals of the library -- not per stream, not thread-safe (forward runs on the caller's thread, backward on autograd's): they
+// exist for tests and A/B timing, a product run must find this 0 (bench.py asserts it).
+int ttx_debug_state(void) {
+  return ((g_debug_skip | g_skip_launch | g_disable_spec | g_disable_pad) ? 1 : 0) | (g_lds_budget != 160 * 1024 ? 2 : 0) |
+         (g_chunk_override ? 4 : 0) | (g_stamps ? 8 : 0) | (ttx_cache_debug_state() << 4);
 }
 
 int ttx_set_chunk(int32_t mc) {

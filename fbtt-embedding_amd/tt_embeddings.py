@@ -96,6 +96,8 @@ def lib():
     L.ttx_profile_enable.argtypes = [C.c_int]
     L.ttx_profile_read.argtypes = [C.c_int, C.POINTER(i64), C.POINTER(C.c_double)]
     L.ttx_set_chunk.argtypes = [i32]
+    L.ttx_debug_state.argtypes = []
+    L.ttx_debug_state.restype = C.c_int
     L.ttx_debug_lds_budget.argtypes = [i32]
     L.ttx_debug_tiles.argtypes = [G, C.POINTER(i32)]
     for name in ("ttx_dedup_bytes", "ttx_tt_forward_dd_workspace_bytes", "ttx_tt_backward_dd_workspace_bytes"):

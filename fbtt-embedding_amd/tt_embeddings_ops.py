@@ -652,6 +652,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         """module.to() / .cuda() / .float(): buffers are replaced by new tensors -- forget the cached argument lists"""
         self.__dict__.pop("_fa", None)
         self.__dict__.pop("_fc", None)
+        self.__dict__.pop("_sh0", None)  # (the padded copy of core 0 belongs to the old tensors' device / dtype)
         return super()._apply(fn, *a, **kw)
 
     def _evict_oldest_prefetched(self) -> None:
@@ -744,9 +745,11 @@ class TableBatchedTTEmbeddingBag(nn.Module):
 
     def _padded0(self, Q: int, optim: int, use_state: bool):
         """core 0 [tables, p0, q0 r1] zero-padded to [tables, p0, Q r1] (and the same of its optimizer state).  Dense gradients
-        (sparse=False): an autograd pad of the Parameter, every step.  Fused optimizers: a buffer the module keeps, refreshed
-        from the Parameter only when that was written or re-bound since the last step's write-back (its `_version`; under stream
-        capture always -- a replay has no such check)."""
+        (sparse=False): an autograd pad of the Parameter, every step.  Fused optimizers: a buffer the module keeps, refreshed from
+        the Parameter (and the optimizer state) EVERY step -- p0 q0 r1 floats, one small copy.  (Round 4 refreshed only when the
+        Parameter's `_version` moved or it was re-bound; writes through `.data` -- p.data.mul_(..), EMA / averaging code -- do not
+        move the version, the next step then trained the stale copy and the write-back hook overwrote the caller's update: round 4
+        advisor.)"""
         c, w = self.tt_cores[0], (Q - self.tt_q_shapes[0]) * self.tt_ranks[1]
         if optim == 2:
             return torch.nn.functional.pad(c, (0, w)), None
@@ -754,15 +757,13 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         if sh is None or sh[0].device != c.device:
             mk = lambda: torch.zeros(c.size(0), c.size(1), c.size(2) + w, device=c.device, dtype=c.dtype)  # noqa: E731
             sh = self._sh0 = [mk().requires_grad_(True), mk() if use_state else None, None, -1, None, -1]
-        capt = c.is_cuda and torch.cuda.is_current_stream_capturing()
         srcs = [(0, c, 2)] + ([(1, self.optimizer_state[0], 4)] if use_state else [])
         with torch.no_grad():
             for j, src, at in srcs:
                 if sh[j] is None:
                     sh[j] = torch.zeros_like(sh[0])
-                if capt or sh[at] is not src or sh[at + 1] != src._version:
-                    sh[j][:, :, :src.size(2)].copy_(src)
-                    sh[at], sh[at + 1] = src, src._version
+                sh[j][:, :, :src.size(2)].copy_(src)  # (the padded slots stay zero: nothing ever writes a non-zero there)
+                sh[at], sh[at + 1] = src, src._version
         return sh[0], sh[1]
 
     @torch.no_grad()

@@ -259,10 +259,13 @@ class MixedTTEmbeddingBag(nn.Module):
         def madds(rk, q):
             return sum(rk[i] * q[i] * rk[i + 1] for i in range(len(q)))
 
+        # tables of different FACTORINGS in one launch set (cores zero-padded to the entry-by-entry largest factoring,
+        # `VarTableTTEmbeddingBag(table_q=)`, ranks padded with them): decided per group of tables with the same number of cores
+        # (round 4 advisor: one global flag q- and rank-padded EVERY group as soon as one passed the test -- possibly onto a
+        # factoring outside the specialised templates).  padq_nd = the core counts whose tables share one padded set.
+        padq_nd = set()
         if pad_q is None and fused:
-            # auto: tables of different factorings in ONE launch set (cores zero-padded to the entry-by-entry largest factoring,
-            # `VarTableTTEmbeddingBag(table_q=)`) when that costs at most twice the tables' own multiply-adds, ranks padded as well
-            pad_q = False
+            # auto: when the padding costs at most twice the tables' own multiply-adds
             by_nd: Dict[int, List[int]] = {}
             for k in range(n):
                 by_nd.setdefault(len(ranks[k]), []).append(k)
@@ -274,8 +277,10 @@ class MixedTTEmbeddingBag(nn.Module):
                 rmax = [max(ranks[k][i] for k in tabs) for i in range(nd1)]
                 real = sum(madds([1] + ranks[k] + [1], qs[k]) for k in tabs)
                 if madds([1] + rmax + [1], qmax) * len(tabs) <= 2 * real:
-                    pad_q, pad_ranks = True, True
-        pad_q = bool(pad_q) and fused
+                    padq_nd.add(nd1)
+        elif pad_q and fused:
+            padq_nd = {len(r) for r in ranks}
+        pad_q = bool(padq_nd)
         if pad_ranks is None and fused:
             # auto: one launch set per factoring when the zero padding costs at most twice the tables' own multiply-adds
             # (measured, scripts/bench_mixed.py: ranks 32 / 16 in one set 0.278 vs 0.297 ms/step in two; ranks 64 / 32 / 16 /
@@ -283,6 +288,8 @@ class MixedTTEmbeddingBag(nn.Module):
             pad_ranks = True
             by_q: Dict[tuple, List[int]] = {}
             for k in range(n):
+                if len(ranks[k]) in padq_nd:  # (q-padded groups pad their ranks anyway: they do not vote on the others' rule)
+                    continue
                 by_q.setdefault((len(ranks[k]), None if qs[k] is None else tuple(qs[k])), []).append(k)
             for tabs in by_q.values():
                 qq = qs[tabs[0]] or suggested_tt_shapes(self.embedding_dim, len(ranks[tabs[0]]) + 1, allow_round_up=not enforce_embedding_dim)
@@ -294,8 +301,9 @@ class MixedTTEmbeddingBag(nn.Module):
         for k in range(n):
             # fused: tables of one factoring q share a batched lookup whatever their ranks (smaller ranks are zero-padded to the
             # group's largest, VarTableTTEmbeddingBag(table_ranks=)); pad_ranks=False keeps one group per (q, ranks)
-            key = ((len(ranks[k]),) if fused and pad_ranks else (tuple(ranks[k]),)) + \
-                  ((len(ranks[k]),) if pad_q else (None if qs[k] is None else tuple(qs[k]),)) + (() if fused else (shapes[k],))
+            inq = len(ranks[k]) in padq_nd  # this table's core-count group shares ONE padded factoring (ranks padded with it)
+            key = ((len(ranks[k]),) if fused and (pad_ranks or inq) else (tuple(ranks[k]),)) + \
+                  ((len(ranks[k]),) if inq else (None if qs[k] is None else tuple(qs[k]),)) + (() if fused else (shapes[k],))
             groups.setdefault(key, []).append(k)
         self.group_tables = list(groups.values())
         self.groups = nn.ModuleList()

@@ -249,7 +249,13 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         fixed_pooling's; `TTX_CHECK_POOLING=1` verifies it with a host read-back.  Neither: ragged bags with one host
         read-back of the split sizes per step."""
         W, NT, D = self.world, self.num_tables, self.embedding_dim
-        if max_pooling is not None and fixed_pooling is None and not (W == 1 and not _FORCE_EXCHANGE):
+        if max_pooling is not None and fixed_pooling is None:
+            # (round 4 advisor) the SAME semantics at every world size -- one rank included: bags longer than L are truncated, the
+            # padding is weighted zero -- and the same guard as below: batches planned ahead and not consumed are an error here
+            # too (a rank that takes this route while its peers consume a planned batch would issue other collectives)
+            if getattr(self, "_planned", None):
+                raise RuntimeError("ShardedTableBatchedTTEmbeddingBag.forward(max_pooling=..): batches planned ahead "
+                                   "(prefetch_many) are pending; consume them or call drop_planned() on every rank")
             return self._forward_padded(indices.long(), offsets.long(), int(max_pooling))
         # a batch planned ahead is found by the caller's own tensor objects -- before the casts below replace them
         planned = getattr(self, "_planned", None)
@@ -354,11 +360,15 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         order = self._cached(("order", dev), lambda: torch.tensor(self._order, device=dev))
         send_idx = (idx_pad.view(NT, B * Lp) if self._identity else idx_pad.view(NT, B * Lp)[order]).contiguous().view(-1)
         send_len = (lengths.view(NT, B) if self._identity else lengths.view(NT, B)[order]).contiguous().view(-1)
-        recv_idx = indices.new_empty(W * n_me * B * Lp)
-        recv_len = lengths.new_empty(W * n_me * B)
-        ex = self.direct.all_to_all if self.direct is not None else self._a2a
-        ex(recv_idx, send_idx, [n_me * B * Lp] * W, [k * B * Lp for k in n_own])
-        ex(recv_len, send_len, [n_me * B] * W, [k * B for k in n_own])
+        alone = W == 1 and not _FORCE_EXCHANGE  # one rank: nothing to exchange, the same padded lookup
+        if alone:
+            recv_idx, recv_len = send_idx, send_len
+        else:
+            recv_idx = indices.new_empty(W * n_me * B * Lp)
+            recv_len = lengths.new_empty(W * n_me * B)
+            ex = self.direct.all_to_all if self.direct is not None else self._a2a
+            ex(recv_idx, send_idx, [n_me * B * Lp] * W, [k * B * Lp for k in n_own])
+            ex(recv_len, send_len, [n_me * B] * W, [k * B for k in n_own])
         # wire order [src][k][b] -> table-major [k][src][b]
         loc_idx = recv_idx.view(W, n_me, B * Lp).permute(1, 0, 2).contiguous().view(-1)
         loc_len = recv_len.view(W, n_me, B).permute(1, 0, 2).reshape(-1)
@@ -370,7 +380,9 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
             send = pooled.view(n_me, W, B, D).permute(1, 0, 2, 3).reshape(W * n_me * B, D)
         else:
             send = torch.zeros((0, D), device=dev, dtype=torch.float32, requires_grad=True)
-        if self.direct is not None:
+        if alone:
+            got = send
+        elif self.direct is not None:
             got = _DirectPooledAllToAll.apply(self.direct, send, [n_me * B] * W, [k * B for k in n_own])
         else:
             got = _PooledAllToAll.apply(self.group, send, [n_me * B] * W, [k * B for k in n_own])

@@ -504,6 +504,12 @@ int ttx_debug_tiles(const ttx_geom* g, int32_t* out);
 /* ablation knob (scripts/ablate.py only): bit mask of kernel phases to skip;
  * results are INVALID while it is non-zero.  0 = normal operation. */
 int ttx_debug_skip(int32_t mask);
+/* Bit mask of the process-global TEST / ablation knobs that are away from their defaults (0 = none set): bit 0 ttx_debug_skip,
+ * 1 ttx_debug_lds_budget, 2 ttx_set_chunk, 3 ttx_debug_stamps, 4 ttx_set_reference_exact, 5 ttx_debug_cache_fwd.  These knobs are
+ * plain globals of the library -- not per stream, not thread-safe -- and exist for tests and A/B timing only; a product run must
+ * find this 0 (bench.py asserts it before it times anything). */
+int ttx_debug_state(void);
+int ttx_cache_debug_state(void); /* (internal helper of the above) */
 /* A/B knob (scripts/bench_cache.py only): 1 = ttx_cache_forward uses the one-group-per-lookup kernel for every D */
 int ttx_debug_cache_fwd(int32_t lookup_groups);
 /* debug (scripts/phase_times.py only): device buffer receiving 16 int64 wall-clock

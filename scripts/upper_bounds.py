@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MASKS = [("baseline", 0), ("no pool launch", 512), ("no reduce_apply launch", 1024), ("no pivot partials (store + reduce)", 2048 + 128),
          ("no pool, no pivot partials", 512 + 2048 + 128), ("no pool, no reduce_apply", 512 + 1024)]
 for name, mask in MASKS:
-    env = dict(os.environ, TTX_DEBUG_SKIP=str(mask))
+    env = dict(os.environ, TTX_DEBUG_SKIP=str(mask), TTX_ALLOW_DEBUG="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "200", "--repeats", "3"],
                          capture_output=True, text=True, env=env)
     try:

@@ -96,7 +96,7 @@ def run_plan_cases(seed=0, max_cases=None, budget=None):
             out = E.tt_forward(1000, tables, B, D, ps, q, r, Lt, nnz, t(idx), ri, ti, gc, plan=plan)
             grads = E.tt_dense_backward(1000, D, ps, q, r, Lt, nnz, t(idx), ri, ti, t(d_out), gc, plan=plan)
             what = f"case {n} (mixed): T={T} p={ps} q={q} r={r} B={B} nnz={nnz}"
-            tol = dict(rtol=1e-4, atol_scale=2e-5)
+            tol = dict(rtol=2e-5, atol_scale=4e-6)  # (measured worst: 0.8x the default bound, profiles/r05_tolerances.md)
             gsplit = [torch.split(grads[c_][0], [pk[c_] for pk in ps], dim=0) for c_ in range(T)]
             for k in range(tables):
                 gk = O.make_geom(1, ps[k], q, r)
@@ -128,7 +128,7 @@ def run_plan_cases(seed=0, max_cases=None, budget=None):
         out = E.tt_forward(1000, tables, B, D, p, q, r, Lt, nnz, t(idx), ri, ti, gc, plan=plan)
         grads = E.tt_dense_backward(1000, D, p, q, r, Lt, nnz, t(idx), ri, ti, t(d_out), gc, plan=plan)
         what = f"case {n}: T={T} tables={tables} p={p} q={q} r={r} B={B} nnz={nnz} walk={walk}"
-        tol = dict(rtol=1e-4, atol_scale=2e-5)  # (hot slices: thousands of terms in an order of their own)
+        tol = dict(rtol=5e-5, atol_scale=1e-5)  # (hot slices: thousands of terms in an order of their own; measured worst: 1.5x the default bound)
         assert_close(out.cpu().numpy(), ref_out, what + " out", **tol)
         for k in range(T):
             assert_close(grads[k].cpu().numpy(), ref_g[k], what + f" grad{k}", **tol)
@@ -178,7 +178,7 @@ def run_cache_cases(seed=0, max_cases=None, budget=None):
             O.cache_forward(B, loc, rowidx, w, ref[0])
             dout = t(out0)
             E.cache_forward(B, nnz - ntt, t(loc), t(rowidx), t(w), dout)
-            assert_close(dout.cpu().numpy(), ref, what + f" cache_forward D={D}", rtol=1e-4, atol_scale=2e-5)
+            assert_close(dout.cpu().numpy(), ref, what + f" cache_forward D={D}")
             grad = (rs.rand(B, D) * 0.1).astype(np.float32)
             # reference in float64 (a row can take tens of thousands of adds here: the fp32 oracle's own sequential
             # rounding is then larger than the GPU's, whose partial sums are shorter)
@@ -186,6 +186,6 @@ def run_cache_cases(seed=0, max_cases=None, budget=None):
             np.subtract.at(w_ref, loc, 0.1 * grad[rowidx].astype(np.float64))
             dw = t(w)
             E.cache_backward_sgd(nnz - ntt, t(grad), t(loc), t(rowidx), 0.1, dw)
-            assert_close(dw.cpu().numpy(), w_ref, what + f" cache_backward_sgd D={D}", rtol=3e-4, atol_scale=2e-5)
+            assert_close(dw.cpu().numpy(), w_ref, what + f" cache_backward_sgd D={D}", rtol=5e-5, atol_scale=1e-5)  # (float atomics in hardware order; measured worst: 0.2x the default bound)
         n += 1
     return n

@@ -191,9 +191,9 @@ def test_cache_gather_forward_backward():
         O.cache_backward_sgd(grad, loc, rowidx, 0.1, w_sgd)
         dw = t(w)
         E.cache_backward_sgd(n, t(grad), t(loc), t(rowidx), 0.1, dw)
-        assert_close(dw.cpu().numpy(), w_sgd, f"cache_backward_sgd D={D}", atol_scale=4e-6)
+        assert_close(dw.cpu().numpy(), w_sgd, f"cache_backward_sgd D={D}")
         gd = E.cache_backward_dense(n, t(grad), t(loc), t(rowidx), 0.1, t(w))
-        assert_close(gd.cpu().numpy(), O.cache_backward_dense(grad, loc, rowidx, cs, D), f"cache_backward_dense D={D}", atol_scale=4e-6)
+        assert_close(gd.cpu().numpy(), O.cache_backward_dense(grad, loc, rowidx, cs, D), f"cache_backward_dense D={D}")
         # row-wise adagrad: deterministic when every cache row is hit by at most one lookup
         loc_u = rs.permutation(cs)[:200].astype(np.int32)
         row_u = np.sort(rs.randint(0, B, size=200)).astype(np.int64)
@@ -202,12 +202,12 @@ def test_cache_gather_forward_backward():
         O.cache_backward_rowwise_adagrad_approx(grad, loc_u, row_u, 0.1, 1e-4, st, w_a)
         E.cache_backward_rowwise_adagrad_approx(200, t(grad), t(loc_u), t(row_u), 0.1, 1e-4, dst, dwa)
         assert_close(dst.cpu().numpy(), st, f"rowwise adagrad state D={D}")
-        assert_close(dwa.cpu().numpy(), w_a, f"rowwise adagrad weights D={D}", rtol=2e-5, atol_scale=4e-6)
+        assert_close(dwa.cpu().numpy(), w_a, f"rowwise adagrad weights D={D}")
         # rows hit from several bags: the state total is order independent
         st2, dst2 = np.zeros(cs, dtype=np.float32), t(np.zeros(cs, dtype=np.float32))
         O.cache_backward_rowwise_adagrad_approx(grad, loc, rowidx, 0.1, 1e-4, st2, w.copy())
         E.cache_backward_rowwise_adagrad_approx(n, t(grad), t(loc), t(rowidx), 0.1, 1e-4, dst2, t(w))
-        assert_close(dst2.cpu().numpy(), st2, f"rowwise adagrad state total D={D}", rtol=2e-5, atol_scale=4e-6)
+        assert_close(dst2.cpu().numpy(), st2, f"rowwise adagrad state total D={D}")
 
 
 @pytest.mark.parametrize("n,D", [(5000, 64), (20000, 128), (300000, 64), (5000, 6)])
@@ -266,9 +266,9 @@ def test_cache_backward_rowwise_adagrad_hot_rows(n, D, cs):
     dst, dw = t(st), t(w)
     O.cache_backward_rowwise_adagrad_approx(grad, loc, rowidx, 0.1, 1e-4, st, w_o)
     E.cache_backward_rowwise_adagrad_approx(n, t(grad), t(loc), t(rowidx), 0.1, 1e-4, dst, dw)
-    assert_close(dst.cpu().numpy(), st, "rowwise adagrad state totals", rtol=1e-4, atol_scale=2e-5)
+    assert_close(dst.cpu().numpy(), st, "rowwise adagrad state totals", rtol=2e-5, atol_scale=4e-6)
     if n <= 1024 and cs <= 64 and D % 4 == 0:
-        assert_close(dw.cpu().numpy(), w_o, "rowwise adagrad weights, sequential order", rtol=1e-4, atol_scale=2e-5)
+        assert_close(dw.cpu().numpy(), w_o, "rowwise adagrad weights, sequential order", rtol=2e-5, atol_scale=4e-6)
     else:
         assert bool(torch.isfinite(dw).all())
         # every row moved against its gradients by at least the smallest and at most the largest possible step

@@ -116,7 +116,7 @@ def test_dedup_vs_oracle_and_plain_path(case):
         gref = oracle(c, "dense")["grads"] if mode == "adagrad" else None
         # a hot row's gradient is an fp32 sum over thousands of occurrences, added in an order of its own by either
         # side (the oracle: sequentially): the rounding random walk is ~sqrt(n) ulp
-        tol = dict(rtol=1e-4, atol_scale=2e-5) if frac >= 0.9 else {}
+        tol = dict(rtol=5e-5, atol_scale=1e-5) if frac >= 0.9 else {}  # (measured worst: 1.5x the default bound, profiles/r05_tolerances.md)
         for k in range(len(p)):
             if mode == "dense":
                 assert_close(got["grads"][k], orc["grads"][k], f"case {case} grad{k}", **tol)
@@ -125,7 +125,7 @@ def test_dedup_vs_oracle_and_plain_path(case):
                 assert_close(got["cores"][k], orc["cores"][k], f"case {case} sgd core{k}", **tol)
                 assert np.array_equal(got["cores"][k], again["cores"][k]), "not deterministic"
             else:
-                assert_close(got["state"][k], orc["state"][k], f"case {case} adagrad state{k}", **(dict(rtol=2e-4, atol_scale=4e-5) if tol else {}))
+                assert_close(got["state"][k], orc["state"][k], f"case {case} adagrad state{k}", **(dict(rtol=1e-4, atol_scale=2e-5) if tol else {}))
                 assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"case {case} adagrad core{k}")
 
 
@@ -171,7 +171,7 @@ def test_dedup_of_large_batches_vs_oracle_and_plain_path(case):
         assert got["nu"] == distinct, "number of distinct (table, index) pairs"
         assert np.array_equal(got["out"], plain["out"]), "forward must be bit-identical to the plain path"
         assert_close(got["out"], orc["out"], f"large case {case} out")
-        tol = dict(rtol=1e-4, atol_scale=2e-5)  # (hot rows: sums over thousands of occurrences in an order of their own)
+        tol = dict(rtol=5e-5, atol_scale=1e-5)  # (hot rows: sums over thousands of occurrences in an order of their own; measured worst: 1.0x the default bound)
         for k in range(len(p)):
             if mode == "dense":
                 assert_close(got["grads"][k], orc["grads"][k], f"large case {case} grad{k}", **tol)
@@ -208,12 +208,12 @@ def test_module_with_dedup_tracks_the_plain_module(route, monkeypatch):
         oa, ob = a(idx, off), b(idx, off)
         if step == 0:
             assert torch.equal(oa, ob), "first forward: identical cores -> identical output"
-        assert_close(oa.detach().cpu().numpy(), ob.detach().cpu().numpy(), f"step {step} output", rtol=1e-4, atol_scale=2e-5)
+        assert_close(oa.detach().cpu().numpy(), ob.detach().cpu().numpy(), f"step {step} output", rtol=2e-5, atol_scale=4e-6)
         oa.backward(grad)
         ob.backward(grad)
     for k in range(3):
         assert_close(a.tt_cores[k].detach().cpu().numpy(), b.tt_cores[k].detach().cpu().numpy(), f"core{k} after 4 steps",
-                     rtol=1e-4, atol_scale=2e-5)
+                     rtol=2e-5, atol_scale=4e-6)
     fa, fb = a.cache_freq.cpu().numpy(), b.cache_freq.cpu().numpy()
     assert int(fa.sum()) == int(fb.sum()) == 4 * B * Lp or abs(int(fa.sum()) - int(fb.sum())) < 8
 
@@ -266,7 +266,7 @@ def test_dedup_auto_follows_the_streams_duplicate_share(monkeypatch):
     oa.backward(g)
     ob.backward(g)
     for k in range(3):
-        assert_close(a.tt_cores[k].detach().cpu().numpy(), b.tt_cores[k].detach().cpu().numpy(), f"core{k}", rtol=1e-4, atol_scale=2e-5)
+        assert_close(a.tt_cores[k].detach().cpu().numpy(), b.tt_cores[k].detach().cpu().numpy(), f"core{k}", rtol=2e-5, atol_scale=4e-6)
 
 
 @pytest.mark.parametrize("case", [0, 2, 6])
@@ -298,7 +298,7 @@ def test_dedup_with_per_sample_weights(case):
         E.tt_sgd_backward(1000, D, LR, p, q, rp, Lt, nnz, idx, rowidx, tableidx, d_out, cores, plan=plan, per_sample_weights=w)
         res[dedup] = (out.cpu().numpy(), [g.cpu().numpy() for g in grads], [x.cpu().numpy() for x in cores])
     assert np.array_equal(res[True][0], res[False][0]), "weighted forward must be bit-identical to the plain weighted path"
-    tol = dict(rtol=1e-4, atol_scale=2e-5)
+    tol = dict(rtol=2e-5, atol_scale=4e-6)
     for k in range(len(p)):
         assert_close(res[True][1][k], res[False][1][k], f"weighted grad{k}", **tol)
         assert_close(res[True][2][k], res[False][2][k], f"weighted sgd core{k}", **tol)

@@ -96,3 +96,20 @@ def test_equal_ranks_different_factorings_group_by_default():
     m = ttx_mixed.MixedTTEmbeddingBag(Es, 64, [[32, 32]] * 3, ps, [[4, 4, 4], [4, 4, 4], [2, 4, 8]], fused=True,
                                       device=torch.device("cpu"), weight_dist="uniform")
     assert m.group_tables == [[0, 1, 2]] and m.groups[0].table_q == [[4, 4, 4], [4, 4, 4], [2, 4, 8]] and m.groups[0].table_ranks is None
+
+
+def test_padding_is_decided_per_group_of_equal_core_count():
+    """Round 4 advisor: the auto rule was ONE flag -- three-core tables that pass the 2x test switched q- and rank-padding on for
+    the two-core tables as well (here: [8,8] r = 32 and [2,32] r = 4 would have become [8,32] r = 32: 8x the multiply-adds, and a
+    factoring outside the specialised templates).  Now every group of equal core count decides for itself."""
+    Es = [9000, 8000, 64000, 5000, 6000]
+    ps = [[20, 22, 25], [20, 22, 25], [40, 40, 40], [70, 80], [80, 90]]
+    ranks = [[32, 32], [32, 32], [32, 32], [32], [4]]
+    qs = [[4, 4, 4], [4, 4, 4], [2, 4, 8], [8, 8], [2, 32]]
+    m = ttx_mixed.MixedTTEmbeddingBag(Es, 64, ranks, ps, qs, fused=True, device=torch.device("cpu"), weight_dist="uniform")
+    assert m.group_tables == [[0, 1, 2], [3], [4]]
+    assert m.groups[0].table_q == [[4, 4, 4], [4, 4, 4], [2, 4, 8]]
+    assert m.groups[1].tt_q_shapes == [8, 8] and m.groups[2].tt_q_shapes == [2, 32] and m.groups[2].tt_ranks == [1, 4, 1]
+    # asked for explicitly, every group pads
+    m2 = ttx_mixed.MixedTTEmbeddingBag(Es, 64, ranks, ps, qs, fused=True, pad_q=True, device=torch.device("cpu"), weight_dist="uniform")
+    assert m2.group_tables == [[0, 1, 2], [3, 4]] and m2.groups[1].tt_q_shapes == [8, 32] and m2.groups[1].tt_ranks == [1, 32, 1]

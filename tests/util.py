@@ -9,6 +9,42 @@ ATOL_SCALE = 2e-6
 LR, EPS = 0.1, 1.0e-4  # tt_embeddings_test.py:268-269
 
 
+# Every comparison WIDER than the default (rtol 1e-5, atol 2e-6 max|ref|) is recorded with the worst error it actually saw, so
+# that DESIGN.md section 5 can carry one table of widened comparisons -- bound next to measurement -- and a regression inside the
+# slack is visible (round 4 verdict).  TTX_TOL_REPORT=<file>: the records are written there as JSON lines when the process ends
+# (scripts/tolerance_table.py turns them into the table).
+_WIDE = {}
+
+
+def _record_wide(what, rtol, atol_scale, err, ref, atol):
+    import atexit
+    import json
+    import os
+
+    path = os.environ.get("TTX_TOL_REPORT")
+    if not path:
+        return
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    bound = atol + rtol * np.abs(ref)
+    used = float((err / bound).max()) if err.size else 0.0                       # share of the WIDENED bound used (1 = at the limit)
+    dflt = ATOL_SCALE * atol / max(atol_scale, 1e-300) + RTOL * np.abs(ref)      # what the default tolerance would have allowed
+    over = float((err / dflt).max()) if err.size else 0.0                        # worst error in units of the DEFAULT bound
+    if not _WIDE:
+        def dump():
+            with open(path, "a") as f:
+                for (t, w), v in _WIDE.items():
+                    f.write(json.dumps({"test": t, "what": w, **v}) + "\n")
+        atexit.register(dump)
+    import re
+    key = (test.split("[")[0], re.sub(r"[0-9]+", "#", what)[:80])
+    cur = _WIDE.get(key)
+    if cur is None or over > cur["worst_over_default"]:
+        _WIDE[key] = {"rtol": rtol, "atol_scale": atol_scale, "share_of_bound_used": round(used, 4),
+                      "worst_over_default": round(over, 3), "calls": (cur["calls"] + 1 if cur else 1)}
+    else:
+        cur["calls"] += 1
+
+
 def assert_close(got, ref, what="", rtol=RTOL, atol_scale=ATOL_SCALE):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
@@ -17,6 +53,8 @@ def assert_close(got, ref, what="", rtol=RTOL, atol_scale=ATOL_SCALE):
     assert np.isfinite(got).all(), f"{what}: result has non-finite values"
     atol = atol_scale * max(float(np.abs(ref).max()) if ref.size else 0.0, 1e-30)
     err = np.abs(got - ref)
+    if rtol > RTOL or atol_scale > ATOL_SCALE:
+        _record_wide(what, rtol, atol_scale, err, ref, atol)
     bad = err > atol + rtol * np.abs(ref)
     if bad.any():
         i = np.unravel_index(np.argmax(err - (atol + rtol * np.abs(ref))), err.shape)
