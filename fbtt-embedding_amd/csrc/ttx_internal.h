@@ -87,8 +87,12 @@ int make_dims(const ttx_geom* g, Dims* d);  // TTX_OK or TTX_EINVAL (+message)
 constexpr int kSegThin = TTX_SEG_THIN;    // partial rows per segment of a thin core's sorted order; hot: > 2 segments
 constexpr int kHotRowsPivot = TTX_HOT_PIVOT;  // chunk partials beyond which a pivot slice is hot
 
+// hdr[kHdrT4Valid .. +4]: four cores on the three-core kernels -- 1 while Plan::t4m / t4o hold the merged last cores M of THIS plan's
+// lookups for the core tensors whose addresses follow (two ints each: core 2, core 3).  Set by the forward's merge, read by the
+// backward's (which then skips its own), cleared by every plan build and by the fused optimizer's write to cores 2 / 3.
+constexpr int kHdrT4Valid = 20;
 struct Plan {
-  int* hdr;  // [0] = number of chunks, [1] = MC, [2] = nnz, [3] = lrow valid, [8 + t] = hot slices of core t (-1: unknown)
+  int* hdr;  // [0] = number of chunks, [1] = MC, [2] = nnz, [3] = lrow valid, [8 + t] = hot slices of core t (-1: unknown), [20..24]: kHdrT4Valid
   int* sid[TTX_MAX_CORES];
   int* perm[TTX_MAX_CORES];
   int* ipos[TTX_MAX_CORES];  // inverse of perm: position of lookup n in core t's sorted order (thin cores)

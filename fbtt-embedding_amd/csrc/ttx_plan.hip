@@ -29,6 +29,8 @@
 // latency and dependent-load chains, not bandwidth -- hence the effort to keep it to one launch.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ttx_internal.h"
 
 namespace ttx {
@@ -379,6 +381,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_small_kernel(
       P.hdr[1] = MC;
       P.hdr[2] = N;
       P.hdr[3] = rowidx ? 1 : 0;
+      P.hdr[kHdrT4Valid] = 0;  // (a new plan: no merged last cores yet)
       for (int tt = 0; tt < TTX_MAX_CORES; ++tt) P.hdr[8 + tt] = -1;  // hot slices per core: unknown (reduce_apply looks)
     }
     PSTAMP(5);
@@ -539,6 +542,7 @@ __device__ __forceinline__ void finish_single_pass(const Dims& d, int t, int dg,
     hdr[1] = MC;
     hdr[2] = N;
     hdr[3] = has_row ? 1 : 0;
+    hdr[kHdrT4Valid] = 0;
   }
 }
 
@@ -952,7 +956,7 @@ __device__ __forceinline__ void finish_wide(const Dims& d, int t, const int (&to
     const int dg = tid * K + j;
     nf[j] = dg < S ? tot[j] / MC : 0;
     pr[j] = dg < S ? tot[j] - nf[j] * MC : 0;
-    packed[j] = (nf[j] << 12) | (pr[j] ? 1 : 0);  // <= 2048 slices: the partial counts stay below 4096
+    packed[j] = (nf[j] << 13) | (pr[j] ? 1 : 0);  // <= 4096 slices: the partial counts stay below 8192 (full chunks: < 2^18 on this route)
     psum += packed[j];
   }
   const int cinc = wave_incl_scan(psum);
@@ -962,12 +966,12 @@ __device__ __forceinline__ void finish_wide(const Dims& d, int t, const int (&to
   int cb = 0, call = 0;
   for (int k = 0; k < kWideWaves; ++k) { const int v = wt[k]; if (k < w) cb += v; call += v; }
   int exq = cb + cinc - psum;
-  const int ftot = call >> 12, ptot = call & 4095;
+  const int ftot = call >> 13, ptot = call & 8191;
   const int ctot = ftot + ptot;
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     const int dg = tid * K + j;
-    const int fbase = exq >> 12, pbase = exq & 4095;  // full / partial chunks of earlier slices
+    const int fbase = exq >> 13, pbase = exq & 8191;  // full / partial chunks of earlier slices
     const int ex = fbase + pbase;                     // first slot of this slice
     if (dg < S) {
       P.chunk_off[dg] = ex;
@@ -983,6 +987,7 @@ __device__ __forceinline__ void finish_wide(const Dims& d, int t, const int (&to
     P.hdr[1] = MC;
     P.hdr[2] = N;
     P.hdr[3] = has_row ? 1 : 0;
+    P.hdr[kHdrT4Valid] = 0;
     for (int tt = 0; tt < TTX_MAX_CORES; ++tt) P.hdr[8 + tt] = -1;  // hot slices per core: unknown (reduce_apply looks)
   }
 }
@@ -993,9 +998,15 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
     const int64_t* __restrict__ tableidx, const int64_t* __restrict__ rowidx, const int* __restrict__ cnt, Plan P,
     GrpArgs ga) {
   constexpr int BINS = 1 << BITS, K = BINS / kWideThreads;
+  // 12 bits (round 5: 2048 < slices <= 4096 -- a two-core table of 11 M rows is p = [3317, 3317] -- took the multi-pass plan, nine
+  // launches and 58 us at the benchmark's batch): sixteen per-wave rows of 4096 ints would be 256 KB, so the rows are 16-bit
+  // and RELATIVE to the digit's first position of this work-group (a work-group spans 4096 positions), which lives in hbase.
+  constexpr bool REL = BITS >= 12;
+  using Cnt = typename std::conditional<REL, unsigned short, int>::type;
   extern __shared__ int wide_lds[];
-  int (*hrun)[BINS] = (int (*)[BINS])wide_lds;  // [kWideWaves][BINS]
-  int* wt = wide_lds + kWideWaves * BINS;       // [kWideWaves]
+  Cnt (*hrun)[BINS] = (Cnt (*)[BINS])wide_lds;  // [kWideWaves][BINS]
+  int* wt = wide_lds + kWideWaves * BINS * (int)sizeof(Cnt) / (int)sizeof(int);  // [kWideWaves]
+  int* hbase = wt + kWideWaves;                 // (REL) [BINS]
   __shared__ int gpos[GRP ? kMaxGroups + 1 : 1], gwg[GRP ? kMaxGroups + 1 : 1];
   const int t = blockIdx.y, tid = threadIdx.x, lane = lane_id(), w = tid / kWave;
   const int N = live_n(Nmax, n_dev);
@@ -1050,7 +1061,7 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
     const bool valid = i < end;
     kv[k] = valid ? min(max(slice_id(d, ct, t, tb[k], ix[k]) - sb, 0), BINS - 1) : 0;
     peers[k] = wave_match<BITS>((unsigned)kv[k], valid);
-    if (valid && (peers[k] & lanemask_lt()) == 0) hrun[w][kv[k]] += __popcll(peers[k]);
+    if (valid && (peers[k] & lanemask_lt()) == 0) hrun[w][kv[k]] = (Cnt)(hrun[w][kv[k]] + __popcll(peers[k]));
   }
   __syncthreads();
 #pragma unroll
@@ -1066,9 +1077,10 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     const int dg = tid * K + j;
-    int b = dbase[j] + bef[j];
+    int b = REL ? 0 : dbase[j] + bef[j];
+    if (REL) hbase[dg] = dbase[j] + bef[j];
 #pragma unroll
-    for (int k = 0; k < kWideWaves; ++k) { const int m = hrun[k][dg]; hrun[k][dg] = b; b += m; }
+    for (int k = 0; k < kWideWaves; ++k) { const int m = hrun[k][dg]; hrun[k][dg] = (Cnt)b; b += m; }
   }
   __syncthreads();
   if (!GRP) {
@@ -1087,8 +1099,8 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
     const bool valid = i < end;
     if (valid) {
       const int before = hrun[w][kv[k]];
-      const int pos = before + __popcll(peers[k] & lanemask_lt());
-      if ((peers[k] & lanemask_lt()) == 0) hrun[w][kv[k]] = before + __popcll(peers[k]);
+      const int pos = (REL ? hbase[kv[k]] : 0) + before + __popcll(peers[k] & lanemask_lt());
+      if ((peers[k] & lanemask_lt()) == 0) hrun[w][kv[k]] = (Cnt)(before + __popcll(peers[k]));
       if (t != 1) {
         P.perm[t][pos] = i;
         P.ipos[t][i] = pos;
@@ -1265,7 +1277,8 @@ __global__ __launch_bounds__(kWideThreads) void mbp_scatter_kernel(
 template <int BITS, bool GRP>
 static int plan_build_wide(const Dims& d, int N, const int* n_dev, const int64_t* indices, const int64_t* tableidx,
                            const int64_t* rowidx, const Plan& P, hipStream_t stream, const GrpArgs& ga) {
-  constexpr size_t lds = (size_t)(kWideWaves * (1 << BITS) + kWideWaves) * sizeof(int);
+  constexpr size_t lds = BITS >= 12 ? (size_t)kWideWaves * (1 << BITS) * sizeof(unsigned short) + (size_t)(kWideWaves + (1 << BITS)) * sizeof(int)
+                                    : (size_t)(kWideWaves * (1 << BITS) + kWideWaves) * sizeof(int);
   if (lds > 64 * 1024) {
     const int rc_attr = allow_dynamic_lds((const void*)mbw_scatter_kernel<BITS, GRP>, (int)lds);
     if (rc_attr) return rc_attr;
@@ -1328,6 +1341,7 @@ __global__ __launch_bounds__(1024) void mb_chunks_kernel(Dims d, int Nmax, const
     P.hdr[1] = MC;
     P.hdr[2] = N;
     P.hdr[3] = has_row;
+    P.hdr[kHdrT4Valid] = 0;
     for (int tt = 0; tt < TTX_MAX_CORES; ++tt) P.hdr[8 + tt] = -1;  // hot slices per core: unknown (reduce_apply looks)
   }
 }
@@ -1345,7 +1359,7 @@ bool plan_groups_tables(const Dims& d, long long N) {
   int smax = 1;
   for (int t = 0; t < d.T; ++t) if (d.S[t] > smax) smax = d.S[t];
   if (smax <= 256) return false;                                                    // one 8-bit pass
-  if (smax <= 2048 && (N + kWideSpan - 1) / kWideSpan <= kWideMaxG) return false;   // one wide digit, no groups
+  if (smax <= 4096 && (N + kWideSpan - 1) / kWideSpan <= kWideMaxG) return false;   // one wide digit, no groups
   return true;
 }
 
@@ -1377,6 +1391,7 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
     for (int t = 0; t < d.T; ++t) if (d.S[t] > smax) smax = d.S[t];
     if (smax <= 1024) return plan_build_wide<10, false>(d, N, n_dev, indices, tableidx, rowidx, P, stream, GrpArgs{});
     if (smax <= 2048) return plan_build_wide<11, false>(d, N, n_dev, indices, tableidx, rowidx, P, stream, GrpArgs{});
+    if (smax <= 4096) return plan_build_wide<12, false>(d, N, n_dev, indices, tableidx, rowidx, P, stream, GrpArgs{});
   }
   if (offsets && d.num_tables > 1 && maxp > 1) {
     // more slice ids than one digit holds, bags known to be table-major (the module's offsets): table groups.

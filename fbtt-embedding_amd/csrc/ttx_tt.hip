@@ -621,6 +621,7 @@ __device__ __forceinline__ float apply_one(int optim, float g, float w, float lr
 // g+G, .. in index order, the G group sums are then added in group order
 // through LDS.  Long slices: 4 floats per thread, partials summed in order.
 constexpr int kReduceThreads = 1024;  // upper bound; launched with 512 when the largest slice is <= 4096 floats
+static size_t reduce_lds_bytes(int threads) { return (size_t)threads * (sizeof(float4) + sizeof(int)); }  // red[] + s_hot[]
 constexpr int kSegPivot = 32;         // chunk partials per segment of the pivot core
 // A slice is HOT when it holds more than two segments' worth of partials (a skewed index stream puts
 // a third of a batch on one slice): one work-group per SEGMENT then sums its share, and the last one
@@ -645,6 +646,10 @@ __device__ __forceinline__ int seg_len(int t) { return t == 1 ? kSegPivot : kSeg
 #endif
 constexpr int kHotNF = TTX_HOT_NF;  // rows in flight per lane on the hot-slice paths
 constexpr int kHotColsPivot = TTX_HOT_COLS;  // (kHotRowsPivot, kSegThin: ttx_internal.h)
+#ifndef TTX_MAX_HOT_PIVOT
+#define TTX_MAX_HOT_PIVOT 8
+#endif
+constexpr int kMaxHotPivot = TTX_MAX_HOT_PIVOT;  // hot pivot slices beyond which their owners keep them (reduce_apply_kernel)
 // column work-groups of the launch: one per block of kHotColsPivot float4 columns, each walks ALL hot slices of the pivot
 // (a launch without hot slices pays for V / C work-groups that look at the offsets once and leave)
 __host__ __device__ __forceinline__ int hot_wgs(int total_max, int sl, int t) {
@@ -799,8 +804,12 @@ __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply
     cache_scatter_add_body((int)blockIdx.x - CT.first, CT.N, CT.D, CT.scale, CT.skip_dev, CT.grad, CT.loc, CT.rowidx, CT.dst, CT.nmain, CT.K);
     return;
   }
-  __shared__ float4 red[kReduceThreads];
-  __shared__ int s_last, s_nhot, s_hot[kReduceThreads];
+  // (round 5) sized by the launch (blockDim.x float4 + blockDim.x int: reduce_lds_bytes): 20 KB of static LDS for 1024 threads held a
+  // launch of 128-thread work-groups to eight per CU
+  extern __shared__ __attribute__((aligned(16))) float4 ra_lds[];
+  float4* red = ra_lds;
+  int* s_hot = (int*)(ra_lds + blockDim.x);
+  __shared__ int s_last, s_nhot;
   const int nthreads = blockDim.x, tid = threadIdx.x;
   int b = blockIdx.x;
   const bool skip_pivot = rows_max < 0;  // (ablation only)
@@ -815,6 +824,10 @@ __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply
       b -= nseg;
     }
     if (P.hdr[8 + t] == 0) return;  // the plan kernel found no hot slice in this core (-1: it did not look)
+    // (round 5) MANY hot pivot slices -- a large batch over few slices: p_1 = 58 at 327k lookups makes all 232 of them hot -- stay
+    // with their owners: every column work-group walks EVERY hot slice, one barrier-bounded round per slice, so the launch took
+    // 919 us there (t4big) for 170 MB of partials.  The column split is for the few hot slices of a skewed stream.
+    if (t == 1 && P.hdr[8 + 1] > kMaxHotPivot) return;
     if (t == 1) {  // ---- pivot: column work-group j -- float4 columns [j C, (j + 1) C) of EVERY hot slice ----
       const int sl = d.slice[1], V = sl / 4, C = kHotColsPivot;
       const int c0 = b * C, c1 = min(V, c0 + C);
@@ -874,7 +887,7 @@ __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply
     // the offset table goes to LDS in one coalesced round when it fits (a segment work-group of a
     // uniform stream has nothing to do and should find that out in one memory round trip, not ten)
     int* soff = (int*)red;
-    const bool in_lds = d.S[t] + 1 <= (int)(kReduceThreads * sizeof(float4) / sizeof(int));
+    const bool in_lds = d.S[t] + 1 <= (int)(nthreads * sizeof(float4) / sizeof(int));
     if (in_lds) {
       for (int e = tid; e <= d.S[t]; e += nthreads) soff[e] = off[e];
       __syncthreads();
@@ -951,7 +964,8 @@ __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply
   }
   const float* __restrict__ pc = PC.pc[t];
   if ((sl & 3) == 0) {
-    if (end - beg > (t == 1 ? kHotRowsPivot : 2 * seg_len(t)) && PC.hot_cnt) return;  // hot: the segment / column work-groups own it
+    if (end - beg > (t == 1 ? kHotRowsPivot : 2 * seg_len(t)) && PC.hot_cnt && !(t == 1 && P.hdr[8 + 1] > kMaxHotPivot))
+      return;  // hot: the segment / column work-groups own it (unless the pivot has too many hot slices for the column split)
     const ApplyEmit ap{optim, lr, eps, wt + base, stt ? stt + base : nullptr, dw ? dw + base : nullptr};
     if (list) sum_rows4(pc, sl, beg, end, red, ListRow{list}, ap);
     else sum_rows4(pc, sl, beg, end, red, IotaRow{}, ap);
@@ -1272,8 +1286,23 @@ __global__ __launch_bounds__(256) void t4_merge_kernel(Plan P, const float* __re
 // for the whole segment at once -- and the result rows move.  Step 1 leaves {n, sid_2, sid_3, ipos_3} at the lookups' places in
 // that order (Plan::t4o, also what the gradient kernel walks); step 2 takes 4 .. 32 positions per work-group (by batch size).  Same order of
 // additions as above: bit-identical M.
-__global__ __launch_bounds__(256) void t4_order_kernel(Plan P) {
+// (round 5) the backward of a step needs the SAME M and order the forward of the step left in the plan -- the cores do not change
+// between the two -- so the forward's merge marks them valid (hdr[kHdrT4Valid], with the cores' addresses) and the backward's
+// launches leave at once when they find that mark: 21 us of the 210 us step at the benchmark's batch.  Cleared by a plan build and
+// by t4_apply23_kernel when a fused optimizer writes cores 2 / 3.
+__device__ __forceinline__ bool t4_valid(const Plan& P, const float* c2, const float* c3) {
+  const int* h = P.hdr + kHdrT4Valid;
+  return h[0] == 1 && h[1] == (int)(uintptr_t)c2 && h[2] == (int)((uintptr_t)c2 >> 32) && h[3] == (int)(uintptr_t)c3 &&
+         h[4] == (int)((uintptr_t)c3 >> 32);
+}
+__global__ __launch_bounds__(256) void t4_order_kernel(Plan P, const float* c2, const float* c3, int reuse) {
+  if (reuse && t4_valid(P, c2, c3)) return;  // (grid-uniform: nobody writes the mark while a reusing launch runs)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && !reuse) {  // the forward's launch: the stream orders every later reader behind this launch AND the merge after it
+    int* h = P.hdr + kHdrT4Valid;
+    h[1] = (int)(uintptr_t)c2; h[2] = (int)((uintptr_t)c2 >> 32); h[3] = (int)(uintptr_t)c3; h[4] = (int)((uintptr_t)c3 >> 32);
+    h[0] = 1;
+  }
   if (i >= P.hdr[2]) return;
   const int4 rec = P.lrec[i];
   P.t4o[P.ipos[2][rec.x]] = make_int4(rec.x, rec.z, rec.w, P.ipos[3][rec.x]);
@@ -1281,9 +1310,10 @@ __global__ __launch_bounds__(256) void t4_order_kernel(Plan P) {
 constexpr int kT4MSeg = 32;  // positions per work-group at most; t4_mseg() picks by batch size
 template <int Q3>
 __global__ __launch_bounds__(256) void t4_merge_sorted_kernel(Plan P, const float* __restrict__ c2, const float* __restrict__ c3,
-                                                              float* __restrict__ M, int r2q2, int r3, int seg) {
+                                                              float* __restrict__ M, int r2q2, int r3, int seg, int reuse) {
   extern __shared__ __attribute__((aligned(16))) float bs[];  // [seg][r3 Q3]: the segment's core-3 slices
   __shared__ int4 recs[kT4MSeg];
+  if (reuse && t4_valid(P, c2, c3)) return;  // (the forward of this step left M in the plan: t4_order_kernel)
   const int nnz = P.hdr[2];
   const int p0 = blockIdx.x * seg, cnt = min(seg, nnz - p0);
   if (cnt <= 0) return;
@@ -1338,20 +1368,48 @@ __global__ __launch_bounds__(256) void t4_merge_sorted_kernel(Plan P, const floa
 // multiples of SEG inside its range -- no list, and SEG times fewer 16 KB rows than one per lookup (168 MB at 10k lookups).
 // The next lookup's d M row and core-3 slice are fetched into registers while the current one is multiplied.
 constexpr int kT4Threads = 256;
-constexpr int kT4Batch = 4;  // lookups staged per step of the gradient kernel (their loads are in flight together)
+constexpr int kT4Batch = 16;  // lookups staged per step of the gradient kernel: ALL their loads are in flight together
+// Round 5: the kernel was 89 us of a 210 us step at the benchmark's batch for 0.3 GFLOP -- a chain of eight steps of four lookups
+// per work-group, two work-group barriers per LOOKUP around a cross-thread reduction of (b).  Now a step stages sixteen lookups'
+// d M rows and core-3 slices in one round of loads, (a) runs over them out of registers without a barrier, and (b) is computed
+// for all lookups of the step at once, every thread reducing its outputs over rq by itself: three barriers per sixteen lookups.
+// Q consecutive floats from LDS at a multiple of Q floats behind a 16-byte aligned base: one ds_read_b128 / b64 where Q allows
+template <int Q>
+__device__ __forceinline__ void lds_row(const float* p, float (&v)[Q]) {
+  if constexpr (Q % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < Q; i += 4) { const float4 t = *(const float4*)(p + i); v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w; }
+  } else if constexpr (Q % 2 == 0) {
+#pragma unroll
+    for (int i = 0; i < Q; i += 2) { const float2 t = *(const float2*)(p + i); v[i] = t.x; v[i + 1] = t.y; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < Q; ++i) v[i] = p[i];
+  }
+}
 template <int Q3, int NO>    // NO: outputs of (a) per thread (n2 <= NO * 256)
 __global__ __launch_bounds__(kT4Threads) void t4_grad23_kernel(Plan P, const float* __restrict__ c2, const float* __restrict__ c3,
                                                               const float* __restrict__ dM, float* __restrict__ pc2,
                                                               float* __restrict__ pc3, int r2q2, int r3, int SEG) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ int4 recs[kT4Batch];
   const int n2 = r2q2 * r3, n3 = r3 * Q3, pm = r2q2 * Q3;
   float* c2s = sm;                       // [r2q2][r3]         the run's core-2 slice
-  float* gms = c2s + n2;                 // [LB][r2q2][Q3]     d M of the step's lookups
+  float* gms = c2s + (n2 + 3) / 4 * 4;   // [LB][r2q2][Q3]     d M of the step's lookups (16-byte aligned: lds_row)
   float* c3s = gms + kT4Batch * pm;      // [LB][r3][Q3]       their core-3 slices
-  float* red = c3s + kT4Batch * n3;      // [parts][n3]        partial sums of (b)
   const int tid = threadIdx.x, nnz = P.hdr[2];
   const int beg = blockIdx.x * SEG, end = min(nnz, beg + SEG);
   if (beg >= end) return;
+  // r3 divides the work-group (every benchmark shape): a thread's outputs of (a) all have k = tid % r3, its rq advance by
+  // 256 / r3 -- the core-3 row is read ONCE per lookup, d M's rows by vector, broadcast over the lanes that share rq
+#ifndef TTX_T4_AFAST
+#define TTX_T4_AFAST 1
+#endif
+#ifndef TTX_T4_BNEW
+#define TTX_T4_BNEW 1
+#endif
+  const bool kfix = TTX_T4_AFAST && (kT4Threads % r3) == 0;
+  const int kk = tid % r3, rq0 = tid / r3, rqs = kT4Threads / r3;
   float acc[NO];
   int ork[NO];  // (rq << 16 | k) of output tid + 256 u: the division happens once, not per lookup
 #pragma unroll
@@ -1360,26 +1418,26 @@ __global__ __launch_bounds__(kT4Threads) void t4_grad23_kernel(Plan P, const flo
     ork[u] = (rq << 16) | (o - rq * r3);
     acc[u] = 0.f;
   }
-  const int parts = n3 >= kT4Threads ? 1 : kT4Threads / n3;   // (b): the rq range is cut into `parts`
-  const int rqper = (r2q2 + parts - 1) / parts;
   int run0 = beg, cur_sid = -1;
   for (int j0 = beg; j0 < end; j0 += kT4Batch) {
     const int nb = min(kT4Batch, end - j0);
-    int4 rc[kT4Batch];
-#pragma unroll
-    for (int b = 0; b < kT4Batch; ++b) rc[b] = P.t4o[min(j0 + b, end - 1)];
-    __syncthreads();  // (the previous step's staged rows are free)
-#pragma unroll
-    for (int b = 0; b < kT4Batch; ++b) {
-      if (b < nb) {
-        for (int e = tid; e < pm; e += kT4Threads) gms[b * pm + e] = dM[(size_t)rc[b].x * pm + e];
-        for (int e = tid; e < n3; e += kT4Threads) c3s[b * n3 + e] = c3[(size_t)rc[b].z * n3 + e];
-      }
+    __syncthreads();  // (the previous step's records and staged rows are free)
+    if (tid < nb) recs[tid] = P.t4o[j0 + tid];
+    __syncthreads();
+    for (int e = tid; e < nb * pm; e += kT4Threads) {
+      const int b = e / pm;
+      gms[e] = dM[(size_t)recs[b].x * pm + (e - b * pm)];
     }
-#pragma unroll
-    for (int b = 0; b < kT4Batch; ++b) {
-      if (b >= nb) break;
-      if (rc[b].y != cur_sid) {  // a new run: flush the previous sum, stage this slice (work-group-uniform)
+    for (int e = tid; e < nb * n3; e += kT4Threads) {
+      const int b = e / n3;
+      c3s[e] = c3[(size_t)recs[b].z * n3 + (e - b * n3)];
+    }
+    int b0 = 0;
+    while (b0 < nb) {  // the runs (lookups of one core-2 slice) inside the step: one, rarely two  (work-group-uniform)
+      const int sid = recs[b0].y;
+      int b1 = b0 + 1;
+      while (b1 < nb && recs[b1].y == sid) ++b1;
+      if (sid != cur_sid) {  // a new run: flush the previous sum, stage this slice
         if (cur_sid >= 0) {
 #pragma unroll
           for (int u = 0; u < NO; ++u) {
@@ -1387,51 +1445,89 @@ __global__ __launch_bounds__(kT4Threads) void t4_grad23_kernel(Plan P, const flo
             if (o < n2) pc2[(size_t)run0 * n2 + o] = acc[u];
             acc[u] = 0.f;
           }
+          __syncthreads();  // (everyone is done with the previous slice)
         }
-        __syncthreads();  // (everyone is done with the previous slice)
-        for (int e = tid; e < n2; e += kT4Threads) c2s[e] = c2[(size_t)rc[b].y * n2 + e];
-        cur_sid = rc[b].y;
-        run0 = j0 + b;
+        for (int e = tid; e < n2; e += kT4Threads) c2s[e] = c2[(size_t)sid * n2 + e];
+        cur_sid = sid;
+        run0 = j0 + b0;
       }
       __syncthreads();  // (the step's rows -- and a new slice -- are staged)
-      const float* gm = gms + b * pm;
-      const float* c3l = c3s + b * n3;
-      // (a) d core_2[rq][k] += sum_x3 dM[rq][x3] * core_3[k][x3]
+      // (a) d core_2[rq][k] += sum_x3 dM[rq][x3] * core_3[k][x3], lookup after lookup
+      for (int b = b0; b < b1; ++b) {
+        const float* gm = gms + b * pm;
+        const float* c3l = c3s + b * n3;
+        if (kfix) {
+          float cv[Q3];
+          lds_row<Q3>(c3l + kk * Q3, cv);
 #pragma unroll
-      for (int u = 0; u < NO; ++u) {
-        const int o = tid + u * kT4Threads;
-        if (o < n2) {
-          const int rq = ork[u] >> 16, k = ork[u] & 0xffff;
-          float v = acc[u];
+          for (int u = 0; u < NO; ++u) {
+            if (tid + u * kT4Threads < n2) {
+              float g[Q3];
+              lds_row<Q3>(gm + (rq0 + u * rqs) * Q3, g);
+              float v = acc[u];
 #pragma unroll
-          for (int x = 0; x < Q3; ++x) v = fmaf(gm[rq * Q3 + x], c3l[k * Q3 + x], v);
-          acc[u] = v;
-        }
-      }
-      // (b) the lookup's row of d core_3: [k][x3] = sum_rq core_2[rq][k] * dM[rq][x3], rq ascending inside a part, parts in order
-      const int row3 = rc[b].w;
-      for (int o0 = 0; o0 < n3; o0 += kT4Threads) {
-        const int part = n3 >= kT4Threads ? 0 : tid / n3, o3 = n3 >= kT4Threads ? o0 + tid : tid - part * n3;
-        float v = 0.f;
-        if (part < parts && o3 < n3) {
-          const int k = o3 / Q3, x = o3 - k * Q3;
-          const int q0 = part * rqper, q1 = min(r2q2, q0 + rqper);
-#pragma unroll 8
-          for (int rq = q0; rq < q1; ++rq) v = fmaf(c2s[rq * r3 + k], gm[rq * Q3 + x], v);
-          if (parts > 1) red[part * n3 + o3] = v;
-        }
-        if (parts > 1) {
-          __syncthreads();
-          if (tid < n3) {
-            float t = red[tid];
-            for (int pp = 1; pp < parts; ++pp) t += red[pp * n3 + tid];
-            pc3[(size_t)row3 * n3 + tid] = t;
+              for (int x = 0; x < Q3; ++x) v = fmaf(g[x], cv[x], v);
+              acc[u] = v;
+            }
           }
-          __syncthreads();  // (red is free for the next lookup)
-        } else if (part < parts && o3 < n3) {
-          pc3[(size_t)row3 * n3 + o3] = v;
+          continue;
+        }
+#pragma unroll
+        for (int u = 0; u < NO; ++u) {
+          const int o = tid + u * kT4Threads;
+          if (o < n2) {
+            const int rq = ork[u] >> 16, k = ork[u] & 0xffff;
+            float v = acc[u];
+#pragma unroll
+            for (int x = 0; x < Q3; ++x) v = fmaf(gm[rq * Q3 + x], c3l[k * Q3 + x], v);
+            acc[u] = v;
+          }
         }
       }
+      // (b) the lookups' rows of d core_3: [k][x3] = sum_rq core_2[rq][k] * dM[rq][x3], rq ascending.  Thread = (k, lookup group):
+      // two lookups and all Q3 values of x3 per pass, so that one read of core_2[rq][k] feeds 2 Q3 multiply-adds and d M's rows
+      // come by vector (three LDS reads per 2 Q3 multiply-adds; one read per multiply-add made the kernel LDS-bound)
+      if (!TTX_T4_BNEW) {
+        for (int o = tid; o < (b1 - b0) * n3; o += kT4Threads) {
+          const int bl = o / n3, o3 = o - bl * n3, b = b0 + bl;
+          const int k = o3 / Q3, x = o3 - k * Q3;
+          const float* gm = gms + b * pm + x;
+          const float* cc = c2s + k;
+          float v = 0.f;
+#pragma unroll 8
+          for (int rq = 0; rq < r2q2; ++rq) v = fmaf(cc[rq * r3], gm[rq * Q3], v);
+          pc3[(size_t)recs[b].w * n3 + o3] = v;
+        }
+      } else if (rq0 < rqs) {
+        for (int bA = b0 + rq0; bA < b1; bA += 2 * rqs) {
+          const int bB = bA + rqs;
+          const bool hasB = bB < b1;
+          const float* gA = gms + bA * pm;
+          const float* gB = gms + (hasB ? bB : bA) * pm;
+          const float* cc = c2s + kk;
+          float vA[Q3], vB[Q3];
+#pragma unroll
+          for (int x = 0; x < Q3; ++x) { vA[x] = 0.f; vB[x] = 0.f; }
+#pragma unroll 4
+          for (int rq = 0; rq < r2q2; ++rq) {
+            const float c = cc[rq * r3];
+            float a[Q3], bq[Q3];
+            lds_row<Q3>(gA + rq * Q3, a);
+            lds_row<Q3>(gB + rq * Q3, bq);
+#pragma unroll
+            for (int x = 0; x < Q3; ++x) { vA[x] = fmaf(c, a[x], vA[x]); vB[x] = fmaf(c, bq[x], vB[x]); }
+          }
+          float* oA = pc3 + (size_t)recs[bA].w * n3 + kk * Q3;
+#pragma unroll
+          for (int x = 0; x < Q3; ++x) oA[x] = vA[x];
+          if (hasB) {
+            float* oB = pc3 + (size_t)recs[bB].w * n3 + kk * Q3;
+#pragma unroll
+            for (int x = 0; x < Q3; ++x) oB[x] = vB[x];
+          }
+        }
+      }
+      b0 = b1;
     }
   }
 #pragma unroll
@@ -1441,16 +1537,162 @@ __global__ __launch_bounds__(kT4Threads) void t4_grad23_kernel(Plan P, const flo
   }
 }
 
-// ... and their reduction + optimizer: one work-group per slice of core 2 (partial rows at off[2][s] and at the multiples of SEG
-// inside the slice's range, in that order) and of core 3 (one row per lookup, rows [off[3][s], off[3][s+1]), in order).
+// The same on the matrix pipe (round 5), for r2 q2 and r3 multiples of 16 -- the benchmark shapes.  Both products are small GEMMs
+// once a step's sixteen lookups are stacked:
+//   (a) d core_2[rq][k]  = sum over (lookup b, x3)  dM_b[rq][x3] * core_3_b[k][x3]     M = r2 q2, N = r3, K = lookups * q3
+//   (b) d core_3_b[k][x3] = sum over rq             core_2[rq][k] * dM_b[rq][x3]       M = r3, N = lookups * q3, K = r2 q2
+// v_mfma_f32_16x16x4_f32 (exact fp32): (a) keeps NA accumulator tiles per wave over the whole run, (b) one tile at a time.  The VALU
+// form above spends ~4 k wave instructions of 4 cycles per step and work-group for 0.5 MFLOP: 40 of the 175 us step at the
+// benchmark's batch, 850 us at 327k lookups.  Same staging, same partial-row contract; products added in another order (K in steps
+// of four): equal to the VALU form to rounding.
+// LDS layout of the matrix-pipe form: row strides chosen for conflict-free operand reads -- d M rows of a lookup pmS floats apart with
+// pmS = 2 q3 (mod 32) (the 16 columns (lookup, x3) of a (b) tile x the two k rows of a half-wave fall on 32 different banks), core 2's
+// rows r3S = 16 (mod 32) floats apart; both multiples of 4 (float4 staging).
+struct T4Lds { int pmS, r3S, oG, oC, floats; };
+static T4Lds t4_lds(int r2q2, int r3, int q3) {
+  T4Lds L;
+  const int pm = r2q2 * q3;
+  L.pmS = (q3 == 2 || q3 == 4 || q3 == 8) ? pm + (((2 * q3 - pm) % 32) + 32) % 32 : (pm + 3) / 4 * 4;
+  L.r3S = r3 + (((16 - r3) % 32) + 32) % 32;
+  L.oG = r2q2 * L.r3S;
+  L.oC = L.oG + kT4Batch * L.pmS;
+  L.floats = L.oC + kT4Batch * r3 * q3;
+  return L;
+}
+template <int Q3, int NA>  // NA: accumulator tiles of (a) per wave (r2 q2 r3 / 256 <= 4 NA)
+__global__ __launch_bounds__(kT4Threads) void t4_grad23_mfma_kernel(Plan P, const float* __restrict__ c2, const float* __restrict__ c3,
+                                                                   const float* __restrict__ dM, float* __restrict__ pc2,
+                                                                   float* __restrict__ pc3, int r2q2, int r3, int SEG, T4Lds L) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ int4 recs[kT4Batch];
+  const int n2 = r2q2 * r3, n3 = r3 * Q3, pm = r2q2 * Q3, pmS = L.pmS, r3S = L.r3S;
+  float* c2s = sm;            // [r2q2][r3S]
+  float* gms = sm + L.oG;     // [LB][pmS]     d M of the step's lookups, rows [rq][x3]
+  float* c3s = sm + L.oC;     // [LB][r3][Q3]  their core-3 slices
+  const int tid = threadIdx.x, nnz = P.hdr[2];
+  const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kq = lane >> 4;
+  const int beg = blockIdx.x * SEG, end = min(nnz, beg + SEG);
+  if (beg >= end) return;
+  const int NT = r3 / 16, ntiles = (r2q2 / 16) * NT;  // tiles of (a): t = mt NT + nt; wave w owns t = w NA .. w NA + NA - 1
+  f32x4 acc[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto flush = [&](int run0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int t = w * NA + i;
+      if (t < ntiles) {
+        const int mt = t / NT, nt = t - mt * NT;
+        float* o = pc2 + (size_t)run0 * n2 + (size_t)(mt * 16 + kq * 4) * r3 + nt * 16 + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r * r3] = acc[i][r];
+      }
+      acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int run0 = beg, cur_sid = -1;
+  const int sb = tid >> 4, sl = tid & 15;  // staging: sixteen threads per lookup, float4 each
+  // (measured and not kept: the NEXT step's records, d M rows and core-3 slices fetched into registers while the current step is
+  //  multiplied -- 339 -> 409 us at 327k lookups, 20.2 -> 22.9 us at 10k: the steps are not latency-bound, the 40 extra registers cost
+  //  more than the overlap gives)
+  for (int j0 = beg; j0 < end; j0 += kT4Batch) {
+    const int nb = min(kT4Batch, end - j0);
+    __syncthreads();
+    if (tid < nb) recs[tid] = P.t4o[j0 + tid];
+    __syncthreads();
+    if (sb < nb) {  // every load of the step in flight at once: the lookup's d M row and core-3 slice
+      const float4* src = (const float4*)(dM + (size_t)recs[sb].x * pm);
+      float4* dst = (float4*)(gms + sb * pmS);
+      for (int e = sl; e < pm / 4; e += 16) dst[e] = src[e];
+      const float4* s3 = (const float4*)(c3 + (size_t)recs[sb].z * n3);
+      float4* d3 = (float4*)(c3s + sb * n3);
+      for (int e = sl; e < n3 / 4; e += 16) d3[e] = s3[e];
+    }
+    int b0 = 0;
+    while (b0 < nb) {  // the runs inside the step (work-group-uniform)
+      const int sid = recs[b0].y;
+      int b1 = b0 + 1;
+      while (b1 < nb && recs[b1].y == sid) ++b1;
+      if (sid != cur_sid) {
+        if (cur_sid >= 0) {
+          flush(run0);
+          __syncthreads();
+        }
+        const float4* src = (const float4*)(c2 + (size_t)sid * n2);
+        for (int e = tid; e < n2 / 4; e += kT4Threads) {  // (r3 % 16 == 0: a float4 stays inside one row)
+          const int row = (e * 4) / r3, col = e * 4 - row * r3;
+          *(float4*)(c2s + row * r3S + col) = src[e];
+        }
+        cur_sid = sid;
+        run0 = j0 + b0;
+      }
+      __syncthreads();
+      // (a): K = (b1 - b0) Q3 in steps of four; lane (kq, i16) feeds K index 4 ks + kq = (lookup, x3)
+      const int K = (b1 - b0) * Q3;
+      for (int ks = 0; ks < K; ks += 4) {
+        const int kidx = ks + kq;
+        const bool kv = kidx < K;
+        const int b = b0 + (kv ? kidx / Q3 : 0), x = kv ? kidx % Q3 : 0;
+        const float* ga = gms + b * pmS + x;
+        const float* cb = c3s + b * n3 + x;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const int t = w * NA + i;
+          if (t < ntiles) {  // (wave-uniform)
+            const int mt = t / NT, nt = t - mt * NT;
+            const float av = kv ? ga[(mt * 16 + i16) * Q3] : 0.f;
+            const float bv = kv ? cb[(nt * 16 + i16) * Q3] : 0.f;
+            acc[i] = mfma4(av, bv, acc[i]);
+          }
+        }
+      }
+      // (b), transposed: rows = the run's (lookup, x3) pairs, columns = k, K = r2 q2 -- the accumulator's four registers are then
+      // four consecutive (lookup, x3): with q3 = 4 one lookup's x3 = 0..3 (a float4 of its partial row), with q3 = 2 two lookups'
+      // (a float2 each), and the sixteen lanes of a quarter write consecutive k: whole 64 .. 256-byte pieces of the rows instead of
+      // scattered dwords (2.6 MB of 4-byte stores were most of this phase)
+      const int Nb = (b1 - b0) * Q3, mtb = (Nb + 15) / 16, tb = mtb * NT;
+      for (int t = w; t < tb; t += kT4Threads / 64) {
+        const int mt = t / NT, nt = t - mt * NT;
+        const int m = mt * 16 + i16;             // A operand: row (lookup, x3) = m
+        const bool mv = m < Nb;
+        const float* ga = gms + (b0 + (mv ? m / Q3 : 0)) * pmS + (mv ? m % Q3 : 0);
+        const float* cb = c2s + nt * 16 + i16;   // B operand: column k
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int rq = kq; rq < r2q2; rq += 4) o = mfma4(mv ? ga[rq * Q3] : 0.f, cb[rq * r3S], o);
+        const int m0 = mt * 16 + kq * 4, k = nt * 16 + i16;  // this lane's rows m0 .. m0 + 3, column k
+        if constexpr (Q3 == 4) {
+          if (m0 < Nb) *(float4*)(pc3 + (size_t)recs[b0 + m0 / 4].w * n3 + k * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        } else if constexpr (Q3 == 2) {
+          if (m0 < Nb) *(float2*)(pc3 + (size_t)recs[b0 + m0 / 2].w * n3 + k * 2) = make_float2(o[0], o[1]);
+          if (m0 + 2 < Nb) *(float2*)(pc3 + (size_t)recs[b0 + m0 / 2 + 1].w * n3 + k * 2) = make_float2(o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (m0 + r < Nb) pc3[(size_t)recs[b0 + (m0 + r) / Q3].w * n3 + k * Q3 + (m0 + r) % Q3] = o[r];
+        }
+      }
+      b0 = b1;
+    }
+  }
+  flush(run0);
+}
+
+// ... and their reduction + optimizer.  Core 2: partial rows at off[2][s] and at the multiples of SEG inside the slice's range, in
+// that order -- few, long rows: a slice is cut into blocks of 4 x 256 elements, one work-group each (round 5: one work-group per
+// slice left 58 + 58 work-groups to do the step's 33 us at the benchmark's batch).  Core 3: one row per lookup, rows
+// [off[3][s], off[3][s+1]) -- many short rows: one work-group per slice, G = 256 / V row groups, eight rows in flight per thread.
 // DENSE writes the gradient (zeros for an untouched slice); SGD / Adagrad touch every element of every touched slice.
+constexpr int kT4ApplyBlock = 4 * kT4Threads;
 __global__ __launch_bounds__(kT4Threads) void t4_apply23_kernel(Plan P, const float* __restrict__ pc2, const float* __restrict__ pc3,
                                                                int S2, int n2, int n3, int SEG, int optim, float lr, float eps,
                                                                float* w2, float* w3, float* st2, float* st3, float* dw2,
                                                                float* dw3) {
   __shared__ float red[kT4Threads];
-  const bool is2 = (int)blockIdx.x < S2;
-  const int s = is2 ? blockIdx.x : blockIdx.x - S2;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && optim != TTX_OPTIM_DENSE) P.hdr[kHdrT4Valid] = 0;  // (cores 2 / 3 change: the plan's M is stale)
+  const int nb2 = (n2 + kT4ApplyBlock - 1) / kT4ApplyBlock;  // blocks of a core-2 slice
+  const bool is2 = (int)blockIdx.x < S2 * nb2;
+  const int s = is2 ? blockIdx.x / nb2 : blockIdx.x - S2 * nb2;
   const int* off = is2 ? P.off[2] : P.off[3];
   const int beg = off[s], end = off[s + 1], sl = is2 ? n2 : n3;
   const float* pc = is2 ? pc2 : pc3;
@@ -1467,46 +1709,67 @@ __global__ __launch_bounds__(kT4Threads) void t4_apply23_kernel(Plan P, const fl
       if (optim == TTX_OPTIM_ADAGRAD) st[(size_t)s * sl + e] = sv;
     }
   };
+  if (is2) {
+    const int e0 = (blockIdx.x - s * nb2) * kT4ApplyBlock;
+    if (beg >= end) {
+      if (optim == TTX_OPTIM_DENSE)
+        for (int e = e0 + tid; e < min(sl, e0 + kT4ApplyBlock); e += kT4Threads) dw[(size_t)s * sl + e] = 0.f;
+      return;
+    }
+    const int r1 = (beg / SEG + 1) * SEG;  // rows: beg, then r1, r1 + SEG, .. below end; added in that order
+    float g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + tid + u * kT4Threads;
+      g[u] = e < sl ? pc[(size_t)beg * sl + e] : 0.f;
+    }
+    int r = r1;
+    for (; r + 3 * SEG < end; r += 4 * SEG) {  // four rows x four elements in flight
+      float x[4][4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + tid + u * kT4Threads;
+          x[v][u] = e < sl ? pc[(size_t)(r + v * SEG) * sl + e] : 0.f;
+        }
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] += x[v][u];
+    }
+    for (; r < end; r += SEG)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + tid + u * kT4Threads;
+        if (e < sl) g[u] += pc[(size_t)r * sl + e];
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + tid + u * kT4Threads;
+      if (e < sl) emit(e, g[u]);
+    }
+    return;
+  }
   if (beg >= end) {
     if (optim == TTX_OPTIM_DENSE)
       for (int e = tid; e < sl; e += kT4Threads) dw[(size_t)s * sl + e] = 0.f;
     return;
   }
-  if (is2) {  // few rows (the run sums), long: four elements of four rows in flight per thread
-    const int r1 = (beg / SEG + 1) * SEG;  // rows: beg, then r1, r1 + SEG, .. below end
-    for (int e0 = 0; e0 < sl; e0 += 4 * kT4Threads) {
-      float g[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + tid + u * kT4Threads;
-        g[u] = e < sl ? pc[(size_t)beg * sl + e] : 0.f;
-      }
-      for (int r = r1; r < end; r += SEG)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = e0 + tid + u * kT4Threads;
-          if (e < sl) g[u] += pc[(size_t)r * sl + e];
-        }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + tid + u * kT4Threads;
-        if (e < sl) emit(e, g[u]);
-      }
-    }
-    return;
-  }
-  // core 3: many rows (one per lookup), short: G = 256 / V row groups of V = min(sl, 256) lanes, group g sums rows beg + g,
-  // beg + g + G, .. with four in flight; the group sums are added in group order
+  // core 3: G = 256 / V row groups of V = min(sl, 256) lanes, group g sums rows beg + g, beg + g + G, .. with eight in flight; the
+  // group sums are added in group order
   for (int e0 = 0; e0 < sl; e0 += kT4Threads) {
     const int V = min(sl - e0, kT4Threads), G = kT4Threads / V;
     const int g = tid / V, v = tid - g * V;
     float acc = 0.f;
     if (g < G) {
       int r = beg + g;
-      for (; r + 3 * G < end; r += 4 * G) {
-        const float x0 = pc[(size_t)r * sl + e0 + v], x1 = pc[(size_t)(r + G) * sl + e0 + v];
-        const float x2 = pc[(size_t)(r + 2 * G) * sl + e0 + v], x3 = pc[(size_t)(r + 3 * G) * sl + e0 + v];
-        acc += x0; acc += x1; acc += x2; acc += x3;
+      for (; r + 7 * G < end; r += 8 * G) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = pc[(size_t)(r + u * G) * sl + e0 + v];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += x[u];
       }
       for (; r < end; r += G) acc += pc[(size_t)r * sl + e0 + v];
     }
@@ -1528,24 +1791,24 @@ static int t4_grid(long long work) {
 static int t4_seg(long long nnz) {
   static const int forced = getenv("TTX_T4_SEG") ? atoi(getenv("TTX_T4_SEG")) : 0;  // (A/B)
   if (forced > 0) return forced;
-  return nnz >= (1 << 18) ? 128 : (nnz >= (1 << 16) ? 64 : 32);
+  return nnz >= (1 << 18) ? 128 : (nnz >= (1 << 16) ? 64 : (nnz >= (1 << 14) ? 32 : 16));  // (a step of the kernel = 16 positions)
 }
 #define TTX_T4_Q3(Q3, CALL)                                  \
   switch (Q3) {                                              \
     case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
     case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; default: CALL(8); break; \
   }
-static int t4_merge(const Dims& d, long long nnz, const Plan& P, const float* c2, const float* c3, hipStream_t st) {
+static int t4_merge(const Dims& d, long long nnz, const Plan& P, const float* c2, const float* c3, hipStream_t st, int reuse) {
   const int r2q2 = d.r[2] * d.q[2];
   static const bool old_form = getenv("TTX_T4_OLD_MERGE") != nullptr;  // (A/B)
   if (d.r[3] <= 32 && r2q2 <= 256 && !old_form) {  // the sorted-order form (t4_merge_sorted_kernel)
-    hipLaunchKernelGGL(t4_order_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(t4_order_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, P, c2, c3, reuse);
     const int threads = (r2q2 + 63) / 64 * 64;
     // positions per work-group: the slice's rows are re-read once per segment, but a small batch needs the work-groups more than
     // the reuse (10k lookups, ms/step: 4 -> 0.221, 8 -> 0.225, 16 -> 0.244, 32 -> 0.273; the per-lookup form 0.247)
     const int seg = nnz >= (1 << 17) ? 32 : (nnz >= (1 << 15) ? 16 : 4);
     const size_t lds = (size_t)seg * d.r[3] * d.q[3] * sizeof(float);
-#define TTX_T4_CALL(Q) hipLaunchKernelGGL(t4_merge_sorted_kernel<Q>, dim3((unsigned)((nnz + seg - 1) / seg)), dim3(threads), lds, st, P, c2, c3, P.t4m, r2q2, d.r[3], seg)
+#define TTX_T4_CALL(Q) hipLaunchKernelGGL(t4_merge_sorted_kernel<Q>, dim3((unsigned)((nnz + seg - 1) / seg)), dim3(threads), lds, st, P, c2, c3, P.t4m, r2q2, d.r[3], seg, reuse)
     TTX_T4_Q3(d.q[3], TTX_T4_CALL)
 #undef TTX_T4_CALL
     TTX_HIP(hipGetLastError());
@@ -1616,7 +1879,7 @@ static int run_rows(const Dims& d, long long nnz, const Plan& P, const float* co
     if (!P.t4m) TTX_FAIL(TTX_EINVAL, "internal: the plan carries no scratch for the four-core route");
     const SpecId id = spec_match(d3, &pad);
     ProfScope ps(TTX_PROF_FWD, st);
-    const int rcm = t4_merge(d, nnz, P, cores[2], cores[3], st);
+    const int rcm = t4_merge(d, nnz, P, cores[2], cores[3], st, 0);
     if (rcm) return rcm;
     CorePtrs C;
     for (int t = 0; t < TTX_MAX_CORES; ++t) C.c[t] = nullptr;
@@ -2038,7 +2301,7 @@ static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t
     const SpecId id = spec_match(d3, &pad);
     const int r2q2 = d.r[2] * d.q[2], n2 = r2q2 * d.r[3], n3 = d.r[3] * d.q[3], pm = r2q2 * d.q[3];
     ProfScope ps(TTX_PROF_BWD, st);
-    rc = t4_merge(d, nnz, P, tt_cores[2], tt_cores[3], st);
+    rc = t4_merge(d, nnz, P, tt_cores[2], tt_cores[3], st, 1);  // (reuses the forward's M when the plan still holds it)
     if (rc) return rc;
     CorePtrs C3;
     for (int t = 0; t < TTX_MAX_CORES; ++t) C3.c[t] = nullptr;
@@ -2051,11 +2314,32 @@ static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t
     rc = run_bwd_spec(id, d3, P, C3, B, rowidx, d_output, PC3, pad, R, st);
     if (rc) return rc;
     const int SEG = t4_seg(nnz);
-    const int parts = n3 >= kT4Threads ? 1 : kT4Threads / n3;
-    const size_t lds = (size_t)(n2 + kT4Batch * (pm + n3) + (parts > 1 ? parts * n3 : 0)) * sizeof(float);
+    const size_t lds = (size_t)((n2 + 3) / 4 * 4 + kT4Batch * (pm + n3)) * sizeof(float);
     const int gblocks = (int)((nnz + SEG - 1) / SEG);
+    static const bool t4_valu = getenv("TTX_T4_VALU") != nullptr;  // (A/B: the VALU form for every shape)
+    const bool t4_mfma = !t4_valu && r2q2 % 16 == 0 && d.r[3] % 16 == 0 && n2 / 256 <= 32;
+    const T4Lds TL = t4_lds(r2q2, d.r[3], d.q[3]);
+    const size_t lds_m = (size_t)TL.floats * sizeof(float);
+#define TTX_T4_MFMA(Q)                                                                                                          \
+    do {                                                                                                                         \
+      if (n2 / 256 <= 16) {                                                                                                       \
+        if (lds_m > 64 * 1024) { rc = allow_lds(t4_grad23_mfma_kernel<Q, 4>, (int)lds_m); if (rc) return rc; }                    \
+        hipLaunchKernelGGL((t4_grad23_mfma_kernel<Q, 4>), dim3(gblocks), dim3(kT4Threads), lds_m, st, P, tt_cores[2], tt_cores[3],\
+                           P.t4g, PC.pc[2], PC.pc[3], r2q2, d.r[3], SEG, TL);                                                      \
+      } else {                                                                                                                   \
+        if (lds_m > 64 * 1024) { rc = allow_lds(t4_grad23_mfma_kernel<Q, 8>, (int)lds_m); if (rc) return rc; }                    \
+        hipLaunchKernelGGL((t4_grad23_mfma_kernel<Q, 8>), dim3(gblocks), dim3(kT4Threads), lds_m, st, P, tt_cores[2], tt_cores[3],\
+                           P.t4g, PC.pc[2], PC.pc[3], r2q2, d.r[3], SEG, TL);                                                      \
+      }                                                                                                                          \
+    } while (0)
 #define TTX_T4_CALL(Q)                                                                                                          \
     do {                                                                                                                         \
+      if (t4_mfma) { TTX_T4_MFMA(Q); break; }                                                                                     \
+      if (lds > 64 * 1024) {                                                                                                      \
+        rc = n2 <= 8 * kT4Threads ? allow_lds(t4_grad23_kernel<Q, 8>, (int)lds)                                                   \
+                                  : (n2 <= 16 * kT4Threads ? allow_lds(t4_grad23_kernel<Q, 16>, (int)lds) : allow_lds(t4_grad23_kernel<Q, 32>, (int)lds)); \
+        if (rc) return rc;                                                                                                        \
+      }                                                                                                                          \
       if (n2 <= 8 * kT4Threads)                                                                                                   \
         hipLaunchKernelGGL((t4_grad23_kernel<Q, 8>), dim3(gblocks), dim3(kT4Threads), lds, st, P, tt_cores[2], tt_cores[3], P.t4g, \
                            PC.pc[2], PC.pc[3], r2q2, d.r[3], SEG);                                                               \
@@ -2068,6 +2352,7 @@ static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t
     } while (0)
     TTX_T4_Q3(d.q[3], TTX_T4_CALL)
 #undef TTX_T4_CALL
+#undef TTX_T4_MFMA
     TTX_HIP(hipGetLastError());
     t4_route = true;
   } else if (t2_shape(d)) {
@@ -2111,10 +2396,10 @@ static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t
     const int smax = d.slice[0] > d.slice[1] ? d.slice[0] : d.slice[1];
     const int rthreads = smax <= 4096 ? TTX_RTHREADS_SMALL : kReduceThreads;
     ProfScope ps(TTX_PROF_APPLY, st);
-    hipLaunchKernelGGL(reduce_apply_kernel, dim3(ns2 + nsg2), dim3(rthreads), 0, st, d2, P, PC, optim, lr, eps, C, S, DW, ns2,
+    hipLaunchKernelGGL(reduce_apply_kernel, dim3(ns2 + nsg2), dim3(rthreads), reduce_lds_bytes(rthreads), st, d2, P, PC, optim, lr, eps, C, S, DW, ns2,
                        (int)nnz, CacheTail{});
     TTX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(t4_apply23_kernel, dim3(d.S[2] + d.S[3]), dim3(kT4Threads), 0, st, P, PC.pc[2], PC.pc[3], d.S[2],
+    hipLaunchKernelGGL(t4_apply23_kernel, dim3(d.S[2] * ((d.slice[2] + kT4ApplyBlock - 1) / kT4ApplyBlock) + d.S[3]), dim3(kT4Threads), 0, st, P, PC.pc[2], PC.pc[3], d.S[2],
                        d.slice[2], d.slice[3], t4_seg(nnz), optim, lr, eps, C.c[2], C.c[3], S.c[2], S.c[3], DW.c[2], DW.c[3]);
     TTX_HIP(hipGetLastError());
     return TTX_OK;
@@ -2123,7 +2408,12 @@ static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t
     const int blocks = nslices + nsegs;  // slice owners, then the segment work-groups of hot slices
     int smax = 0;
     for (int t = 0; t < d.T; ++t) smax = d.slice[t] > smax ? d.slice[t] : smax;
-    const int rthreads = smax <= 4096 ? TTX_RTHREADS_SMALL : kReduceThreads;  // (measured: 512 is 1.7 us faster at r = 32, 1024 at r = 64)
+    int rthreads = smax <= 4096 ? TTX_RTHREADS_SMALL : kReduceThreads;  // (measured: 512 is 1.7 us faster at r = 32, 1024 at r = 64)
+    // (round 5) small slices, many of them -- two cores over 11 M rows are 2 x 3317 slices of 256 floats: 6634 work-groups of 512
+    // threads for 64 float4 lanes of work each were 6.5 rounds of the chip's wave slots, 30 us -- get work-groups of their size
+    if (smax <= 512) rthreads = 128;
+    else if (smax <= 2048) rthreads = 256;
+    if (tail && tail->dst && rthreads < kScatterThreads) rthreads = kScatterThreads;  // (the cache rows' scatter needs its own threads)
     ProfScope ps(TTX_PROF_APPLY, st);
     CacheTail CT{};
     int tail_blocks = 0;
@@ -2135,7 +2425,7 @@ static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t
       tail_blocks = CT.nmain + CT.K * (int)((CT.N + kHotSeg - 1) / kHotSeg);
       if (tail_done) *tail_done = 1;
     }
-    hipLaunchKernelGGL(reduce_apply_kernel, dim3(blocks + tail_blocks), dim3(rthreads), 0, st, d, P, PC, optim, lr,
+    hipLaunchKernelGGL(reduce_apply_kernel, dim3(blocks + tail_blocks), dim3(rthreads), reduce_lds_bytes(rthreads), st, d, P, PC, optim, lr,
                        eps, C, S, DW, nslices, (g_skip_launch & 4) ? -(int)nnz : (int)nnz, CT);
     TTX_HIP(hipGetLastError());
   }

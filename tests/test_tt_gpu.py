@@ -203,13 +203,16 @@ def test_large_batch_uses_the_global_memory_plan():
     (3, [100, 120, 90], 400, 6),      # slice id = table * p + i_t exceeds one digit because of the table
     (2, [20, 600, 15], 350, 7),       # only the pivot core needs a second pass
     (1, [256, 255, 257], 500, 30),    # digit-boundary slice counts, single/multi pass mixed, N < 16384
-    (1, [2500, 30, 20], 600, 12),     # more than 2048 slices in a core: two 8-bit passes (no wide digit)
+    (1, [2500, 30, 20], 600, 12),     # 2048 < slices <= 4096: the 12-bit wide digit (round 5: 16-bit per-wave rows)
+    (1, [4096, 20, 30], 700, 9),      # ... at its upper edge: 4096 slices, every partial-chunk counter in use
+    (2, [1700, 25, 20], 900, 14),     # ... through the table id: 3400 slice ids
+    (1, [5000, 30, 20], 600, 12),     # more than 4096 slices in a core: two 8-bit passes (no wide digit)
     (7, [250, 260, 240], 300, 8),     # 7 tables: 1820 slice ids -> the 11-bit wide digit
     (4, [250, 220, 200], 1100, 20),   # the table-batched benchmark geometry: 10-bit wide digit, ~10 work-groups
 ])
 def test_plan_paths_vs_oracle(tables, p, B, pf):
     """every route through the lookup plan (ttx_plan.hip): single launch (all sorts one 8-bit pass,
-    N <= 16384) is what the other tests take; here the wide-digit single pass (256 < slices <= 2048,
+    N <= 16384) is what the other tests take; here the wide-digit single pass (256 < slices <= 4096,
     up to 96 work-groups), multi-pass sorts, the separate scan launch and the finish launch.  Forward, dense grads and fused SGD against the oracle."""
     q, r = [2, 3, 2], [1, 4, 5, 1]
     E_, D = int(np.prod(np.array(p, dtype=np.int64))), int(np.prod(q))
@@ -226,7 +229,7 @@ def test_plan_paths_vs_oracle(tables, p, B, pf):
                 assert_close(got["cores"][k], orc["cores"][k], f"plan {p} sgd core{k}")
 
 
-@pytest.mark.parametrize("p,tables", [([100, 120, 90], 3), ([2500, 30, 20], 1)])  # wide digit / two passes
+@pytest.mark.parametrize("p,tables", [([100, 120, 90], 3), ([2500, 30, 20], 1), ([5000, 30, 20], 1)])  # wide digit (10 / 12 bits) / two passes
 @pytest.mark.parametrize("nnz", [4096, 4097, 8191, 12288])
 @pytest.mark.parametrize("skew", [False, True])
 def test_plan_work_group_boundaries(p, tables, nnz, skew):
