@@ -1925,15 +1925,15 @@ bool prologue_fusable(const Dims& d, long long nnz, long long nb) {
 }
 
 int prologue_launch(const Dims& d, int N, const int64_t* indices, const Prologue& pg, const Plan& P, hipStream_t stream,
-                    const ProBatch* mb = nullptr, int nbatch = 1) {
+                    const ProBatch* mb = nullptr, int nbatch = 1, const int* n_dev = nullptr) {
   for (int z = 0; z < nbatch && check_indices_on(); ++z) {  // (one table, tableidx == 0: the prologue's own contract)
-    const int rc_chk = check_indices(d, N, nullptr, (mb && z > 0) ? mb->indices[z] : indices, nullptr, stream);
+    const int rc_chk = check_indices(d, N, n_dev, (mb && z > 0) ? mb->indices[z] : indices, nullptr, stream);
     if (rc_chk) return rc_chk;
   }
   ProfScope ps(TTX_PROF_PLAN, stream);
   hipLaunchKernelGGL(mb_single_kernel<true>,
                      dim3((N + kOneWaves * kOneUnit - 1) / (kOneWaves * kOneUnit) + TTX_PLAN_XWG, d.T, nbatch),
-                     dim3(kOneThreads), 0, stream, d, N, (const int*)nullptr, indices, nullptr, nullptr, P, pg,
+                     dim3(kOneThreads), 0, stream, d, N, n_dev, indices, nullptr, nullptr, P, pg,
                      mb ? *mb : ProBatch{});
   TTX_HIP(hipGetLastError());
   return TTX_OK;
@@ -1946,6 +1946,17 @@ extern "C" {
 int ttx_lookup_prologue(const ttx_geom* g, int64_t nnz, const int64_t* colidx, int64_t nb, const int64_t* offsets,
                         int64_t H, int64_t* upd_hashtbl, int64_t* upd_cache_freq, int64_t* rowidx,
                         int64_t* tableidx, void* plan, size_t plan_bytes, ttx_stream_t stream) {
+  return ttx_lookup_prologue_n(g, nnz, colidx, nb, offsets, H, upd_hashtbl, upd_cache_freq, rowidx, tableidx, plan, plan_bytes,
+                               nullptr, stream);
+}
+
+// ... with the number of LIVE lookups on the device (nnz_dev, <= nnz): colidx holds nnz entries of which only the first
+// *nnz_dev belong to a bag -- offsets[nb] == *nnz_dev -- and only those are planned: every kernel that later runs off this plan
+// (forward, pooling, backward, reduce + apply) works on exactly the live lookups, whatever nnz their launches are sized for.
+// What a table-sharded owner needs for RAGGED bags: the exchange buffers have a fixed capacity, the count stays on the device.
+int ttx_lookup_prologue_n(const ttx_geom* g, int64_t nnz, const int64_t* colidx, int64_t nb, const int64_t* offsets,
+                          int64_t H, int64_t* upd_hashtbl, int64_t* upd_cache_freq, int64_t* rowidx,
+                          int64_t* tableidx, void* plan, size_t plan_bytes, const int32_t* nnz_dev, ttx_stream_t stream) {
   ttx::Dims d;
   int rc = ttx::make_dims(g, &d);
   if (rc != TTX_OK) return rc;
@@ -1960,8 +1971,9 @@ int ttx_lookup_prologue(const ttx_geom* g, int64_t nnz, const int64_t* colidx, i
   if (P.MC <= 0) TTX_FAIL(TTX_EUNSUPPORTED, "TT shape does not fit the LDS of any kernel variant (core-1 slice %d x %d floats)", d.k[0], d.n[0]);
   if (ttx::prologue_fusable(d, nnz, nb)) {
     ttx::Prologue pg{offsets, (int)nb, rowidx, tableidx, upd ? (int)H : 0, upd_hashtbl, upd_cache_freq};
-    return ttx::prologue_launch(d, (int)nnz, colidx, pg, P, (hipStream_t)stream);
+    return ttx::prologue_launch(d, (int)nnz, colidx, pg, P, (hipStream_t)stream, nullptr, 1, nnz_dev);
   }
+  if (nnz_dev && upd) TTX_FAIL(TTX_EUNSUPPORTED, "a device-side lookup count with a frequency table: not on this route");
   // general shape: the separate launches, same results
   int32_t ntt = 0, part = 0;
   rc = ttx_preprocess_indices_sync_fused(nnz, colidx, nb, offsets, d.num_tables, /*warmup=*/1, H, nullptr, nullptr,
@@ -1969,7 +1981,8 @@ int ttx_lookup_prologue(const ttx_geom* g, int64_t nnz, const int64_t* colidx, i
                                          upd_cache_freq, nullptr, 0, stream);
   if (rc != TTX_OK) return rc;
   // (the bags are table-major by construction here: the plan may sort table groups on their own)
-  return ttx::plan_build(d, nnz, colidx, tableidx, rowidx, P, (hipStream_t)stream, nullptr, offsets,
+  // (nnz_dev: positions beyond the live count get the last bag's row from the offsets search -- nothing reads them)
+  return ttx::plan_build(d, nnz, colidx, tableidx, rowidx, P, (hipStream_t)stream, nnz_dev, offsets,
                          (int)(nb / d.num_tables));
 }
 

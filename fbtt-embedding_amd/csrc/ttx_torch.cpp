@@ -298,9 +298,11 @@ Tensor lookup(const Tensor& indices, const Tensor& offsets, int64_t num_tables, 
 // step that depends on the batch's indices only, not on the cores.  Enqueued on the CURRENT stream: the module's
 // prefetch runs it on a side stream while the previous step's backward still occupies the main one, and hands the
 // three tensors to `lookup`.  -> {rowidx, tableidx, plan}
+// n_dev (optional, int32 [1] on the device): the number of LIVE lookups -- indices holds an upper bound, offsets describes exactly
+// n_dev of them; the plan (and with it every kernel of the lookup that takes these three tensors) covers only those.
 std::vector<Tensor> prologue(const Tensor& indices, const Tensor& offsets, int64_t num_tables, std::vector<int64_t> p,
                              std::vector<int64_t> q, std::vector<int64_t> r, c10::optional<Tensor> hashtbl,
-                             c10::optional<Tensor> cache_freq) {
+                             c10::optional<Tensor> cache_freq, c10::optional<Tensor> n_dev) {
   Geom G;
   make_geom(G, num_tables, p, q, r);
   const ttx_geom& g = G.g;
@@ -317,10 +319,15 @@ std::vector<Tensor> prologue(const Tensor& indices, const Tensor& offsets, int64
   const bool upd = hashtbl.has_value() && hashtbl->defined() && hashtbl->numel() > 0 && cache_freq.has_value() &&
                    cache_freq->defined();
   if (upd) TORCH_CHECK(hashtbl->numel() == cache_freq->numel(), "tt_embeddings: hashtbl must match cache_freq");
-  check(ttx_lookup_prologue(&g, nnz, indices.data_ptr<int64_t>(), nb, offsets.data_ptr<int64_t>(),
-                            upd ? hashtbl->numel() : 0, upd ? hashtbl->data_ptr<int64_t>() : nullptr,
-                            upd ? cache_freq->data_ptr<int64_t>() : nullptr, rowidx.data_ptr<int64_t>(),
-                            tableidx.data_ptr<int64_t>(), plan.data_ptr(), pb, stream));
+  const bool live = n_dev.has_value() && n_dev->defined();
+  if (live)
+    TORCH_CHECK(n_dev->is_cuda() && n_dev->scalar_type() == at::kInt && n_dev->numel() == 1,
+                "tt_embeddings: n_dev must be one int32 on the GPU");
+  check(ttx_lookup_prologue_n(&g, nnz, indices.data_ptr<int64_t>(), nb, offsets.data_ptr<int64_t>(),
+                              upd ? hashtbl->numel() : 0, upd ? hashtbl->data_ptr<int64_t>() : nullptr,
+                              upd ? cache_freq->data_ptr<int64_t>() : nullptr, rowidx.data_ptr<int64_t>(),
+                              tableidx.data_ptr<int64_t>(), plan.data_ptr(), pb, live ? n_dev->data_ptr<int32_t>() : nullptr,
+                              stream));
   return {rowidx, tableidx, plan};
 }
 
@@ -783,7 +790,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("prologue", &prologue, "the lookup prologue alone, on the current stream: -> [rowidx, tableidx, plan] for lookup(pre_*=)",
         pybind11::arg("indices"), pybind11::arg("offsets"), pybind11::arg("num_tables"), pybind11::arg("p"),
         pybind11::arg("q"), pybind11::arg("r"), pybind11::arg("hashtbl") = pybind11::none(),
-        pybind11::arg("cache_freq") = pybind11::none());
+        pybind11::arg("cache_freq") = pybind11::none(), pybind11::arg("n_dev") = pybind11::none());
   m.def("prologue_multi", &prologue_multi, "the prologues of several equal-sized batches in one launch: -> [rowidx, tableidx, plans], row k for batch k");
   m.def("lookup_cached", &lookup_cached, "cache-live lookup of one table: partition, contraction of the misses, gather of the hits",
         pybind11::arg("indices"), pybind11::arg("offsets"), pybind11::arg("p"), pybind11::arg("q"), pybind11::arg("r"),

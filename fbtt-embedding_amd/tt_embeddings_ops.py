@@ -775,6 +775,28 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                 src.copy_(sh[j][:, :, :src.size(2)])
                 sh[at + 1] = src._version
 
+    def _forward_n(self, indices: torch.Tensor, offsets: torch.Tensor, n_dev: torch.Tensor) -> torch.Tensor:
+        """forward with a device-side lookup count (see forward): the prologue is built for the live lookups (C++ node:
+        prologue(n_dev=) -> lookup(pre_*=)); routes that cannot take a device count read it back and slice."""
+        fast = _native_node()
+        plain = (fast is not None and self.warmup and indices.is_cuda and indices.numel() > 0 and not self.use_cache
+                 and self.__dict__.get("_split0", 0) <= 1 and not self._dedup_may_share(indices.numel()))
+        if not plain:  # (CPU tensors under the tests' oracle engine, a cache, part lookups, shared duplicates)
+            n = int(n_dev.item())
+            return self.forward(indices[:n].contiguous(), offsets)
+        indices = indices.long() if indices.dtype != torch.int64 else indices
+        offsets = offsets.long() if offsets.dtype != torch.int64 else offsets
+        indices = indices if indices.is_contiguous() else indices.contiguous()
+        offsets = offsets if offsets.is_contiguous() else offsets.contiguous()
+        use_state = self.sparse and self.optimizer not in _SGD_LIKE
+        optim = 2 if not self.sparse else (1 if use_state else 0)
+        p_flat = getattr(self, "_p_flat", self.tt_p_shapes)
+        pre = fast.prologue(indices, offsets, self.num_tables, p_flat, self.tt_q_shapes, self.tt_ranks, None, None,
+                            n_dev.to(torch.int32).reshape(1))
+        return fast.lookup(indices, offsets, self.num_tables, p_flat, self.tt_q_shapes, self.tt_ranks, optim,
+                           self.learning_rate, self.eps, None, None, list(self.optimizer_state) if use_state else [],
+                           list(self.tt_cores), None, *pre)
+
     def _dedup_may_share(self, nnz: int) -> bool:
         d = getattr(self, "dedup", False)
         return bool(d) and (d != "auto" or nnz >= _DEDUP_AUTO_MIN_NNZ)
@@ -790,10 +812,16 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         return st[0], False
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True,
-                per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+                per_sample_weights: Optional[torch.Tensor] = None, n_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
         """-> [num_tables, B, D].  (`warmup` is ignored like in the reference,
         which uses self.warmup, :822,:841.)  int32 indices / offsets are accepted; with
-        include_last_offset=False the closing offset (nnz) is appended here."""
+        include_last_offset=False the closing offset (nnz) is appended here.
+        `n_dev` (round 5; not in the reference): one int32 on the device, the number of LIVE lookups -- `indices` then holds an
+        upper bound (a fixed-capacity buffer), `offsets` (with its closing entry) describes exactly the first n_dev of them, and
+        only those are planned, contracted, pooled and trained: no host read-back of the count (ttx_lookup_prologue_n).  What
+        the table-sharded module's ragged route hands its local lookup."""
+        if n_dev is not None:
+            return self._forward_n(indices, offsets, n_dev)
         if per_sample_weights is not None:
             # nn.EmbeddingBag(mode="sum") semantics: forward, the cores' gradients / fused optimizers and -- if the
             # weights require it -- their own gradient.  Served by the C++ nodes: cache not live, or live over one table

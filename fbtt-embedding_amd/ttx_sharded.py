@@ -27,6 +27,7 @@ from torch import nn
 import tt_embeddings_ops as _ops
 
 # test hook: run the exchange code path even with a single rank (bench.py --force-sharded on a 1-GPU box)
+_COMPACT_RAGGED = os.environ.get("TTX_PADDED_WEIGHTS", "") != "1"  # (A/B: "1" = round 4's zero-weight padding)
 _FORCE_EXCHANGE = bool(os.environ.get("TTX_FORCE_EXCHANGE"))
 
 
@@ -242,10 +243,11 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
                 max_pooling: Optional[int] = None) -> torch.Tensor:
         """`fixed_pooling=L`: every bag holds exactly L lookups -- the exchanges' split sizes are known without a host
         read-back (and the step is capturable / can be planned ahead).  `max_pooling=L` (round 4): RAGGED bags of at most L
-        lookups each take the same route -- every bag is padded to L lookups of weight zero (index 0), the bags' lengths
-        travel beside the indices (a fixed-size exchange of B ints per table), and the owner looks the padded bags up with
-        per_sample_weights = [l < length]: fixed shapes everywhere, no `.tolist()`, capturable, at the price of contracting the
-        padding (L / mean length times the lookups).  A bag longer than L is TRUNCATED -- the caller's contract, like
+        lookups each take the same route -- every bag travels padded to L lookups, the bags' lengths beside the indices (a
+        fixed-size exchange of B ints per table): fixed shapes everywhere, no `.tolist()`, capturable.  Round 5: the OWNER
+        compacts what it received on the device and hands its local lookup the live count as a device scalar
+        (`forward(n_dev=)`, ttx_lookup_prologue_n) -- only the real lookups are planned and contracted (round 4 contracted
+        the padding with weight zero: L / mean length times the lookups).  A bag longer than L is TRUNCATED -- the caller's contract, like
         fixed_pooling's; `TTX_CHECK_POOLING=1` verifies it with a host read-back.  Neither: ragged bags with one host
         read-back of the split sizes per step."""
         W, NT, D = self.world, self.num_tables, self.embedding_dim
@@ -359,6 +361,7 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
             idx_pad = indices.new_zeros((NT * B, Lp))
         order = self._cached(("order", dev), lambda: torch.tensor(self._order, device=dev))
         send_idx = (idx_pad.view(NT, B * Lp) if self._identity else idx_pad.view(NT, B * Lp)[order]).contiguous().view(-1)
+        lengths = lengths.clamp(max=Lp)  # (a bag longer than L is truncated: what travels is what the padded rows hold)
         send_len = (lengths.view(NT, B) if self._identity else lengths.view(NT, B)[order]).contiguous().view(-1)
         alone = W == 1 and not _FORCE_EXCHANGE  # one rank: nothing to exchange, the same padded lookup
         if alone:
@@ -372,10 +375,21 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         # wire order [src][k][b] -> table-major [k][src][b]
         loc_idx = recv_idx.view(W, n_me, B * Lp).permute(1, 0, 2).contiguous().view(-1)
         loc_len = recv_len.view(W, n_me, B).permute(1, 0, 2).reshape(-1)
-        loc_w = (pos[None, :] < loc_len[:, None]).to(torch.float32).view(-1)
-        loc_off = self._cached(("off", dev, n_me * W * B, Lp), lambda: torch.arange(
-            0, n_me * W * B * Lp + 1, Lp, device=dev, dtype=torch.int64))
-        if n_me:
+        if n_me and _COMPACT_RAGGED:
+            # (round 5) the owner contracts the REAL lookups only: the padded rows are compacted on the device -- lookup l of bag b
+            # goes to off[b] + l, the padding to a dump slot behind the buffer (fixed shapes: scatter, no boolean indexing) -- and
+            # the local lookup is told the live count on the device (forward(n_dev=), ttx_lookup_prologue_n).  No host read-back,
+            # capturable, and no longer L / mean-length times the lookups (round 4 contracted the padding with weight zero).
+            cap = n_me * W * B * Lp
+            loc_off = torch.cat([loc_len.new_zeros(1), torch.cumsum(loc_len, 0)])
+            dest = torch.where(pos[None, :] < loc_len[:, None], loc_off[:-1, None] + pos[None, :], loc_off.new_full((), cap))
+            comp = loc_idx.new_zeros(cap + 1).scatter_(0, dest.view(-1), loc_idx)[:cap]
+            pooled = self.local(comp, loc_off, n_dev=loc_off[-1:].to(torch.int32))   # [n_me, W*B, D]
+            send = pooled.view(n_me, W, B, D).permute(1, 0, 2, 3).reshape(W * n_me * B, D)
+        elif n_me:
+            loc_w = (pos[None, :] < loc_len[:, None]).to(torch.float32).view(-1)
+            loc_off = self._cached(("off", dev, n_me * W * B, Lp), lambda: torch.arange(
+                0, n_me * W * B * Lp + 1, Lp, device=dev, dtype=torch.int64))
             pooled = self.local(loc_idx, loc_off, per_sample_weights=loc_w)   # [n_me, W*B, D]
             send = pooled.view(n_me, W, B, D).permute(1, 0, 2, 3).reshape(W * n_me * B, D)
         else:

@@ -380,6 +380,14 @@ int ttx_lookup_prologue(const ttx_geom* g, int64_t nnz, const int64_t* colidx,
                         int64_t num_bags_total, const int64_t* offsets, int64_t hashtbl_size,
                         int64_t* upd_hashtbl, int64_t* upd_cache_freq, int64_t* rowidx,
                         int64_t* tableidx, void* plan, size_t plan_bytes, ttx_stream_t stream);
+/* The same with the number of LIVE lookups on the device (round 5; not in the reference): colidx holds nnz entries, the first
+ * *nnz_dev of them (offsets[nb] == *nnz_dev <= nnz) are the batch -- only they are planned, and every call that later takes this
+ * plan (ttx_tt_forward*, ttx_tt_backward*) works on exactly those, whatever nnz its launches are sized by.  nnz_dev == NULL: all
+ * nnz.  For a table-sharded owner of RAGGED bags: fixed-capacity exchange buffers, no host read-back of the count.
+ * (With a frequency table -- H > 0 -- only on the one-launch route; otherwise TTX_EUNSUPPORTED.) */
+int ttx_lookup_prologue_n(const ttx_geom* g, int64_t nnz, const int64_t* colidx, int64_t nb, const int64_t* offsets,
+                          int64_t H, int64_t* upd_hashtbl, int64_t* upd_cache_freq, int64_t* rowidx,
+                          int64_t* tableidx, void* plan, size_t plan_bytes, const int32_t* nnz_dev, ttx_stream_t stream);
 
 /* The prologues of SEVERAL batches in one launch (plan a round of training batches ahead: a batch's prologue depends on
  * its indices only, not on the cores).  colidx_host / offsets_host: HOST arrays of nbatch device pointers, every batch

@@ -550,6 +550,41 @@ def test_graphed_round_equals_eager_steps(node):
     assert table(me) == table(mg)
 
 
+@pytest.mark.parametrize("tables,B,cap_extra", [(1, 64, 500), (3, 40, 7), (4, 600, 20000)])
+def test_device_side_lookup_count(node, tables, B, cap_extra):
+    """forward(indices, offsets, n_dev=): `indices` is a fixed-capacity buffer whose first n_dev entries are the batch (the rest:
+    arbitrary valid indices that belong to no bag), the count stays on the device (ttx_lookup_prologue_n).  Output and the cores
+    after a fused-SGD / Adagrad step -- and the dense gradients -- equal the plain call on the sliced batch BIT FOR BIT: the same
+    plan, the same kernels on the same lookups (one-launch prologue, multi-launch plan and the large-batch kernels)."""
+    import tt_embeddings_ops as ops
+
+    if node == "python":
+        pytest.skip("the device-side count is the C++ node's route (the python route reads it back)")
+    p, q, r = [20, 22, 25], [4, 4, 4], [16, 16]
+    E_, D = int(np.prod(p)), 64
+    idx, off = G.make_bags(17 + B, B, E_, 9, 4, tables)
+    n = idx.size
+    rs = np.random.RandomState(3)
+    buf = np.concatenate([idx, rs.randint(0, E_, size=cap_extra)]).astype(np.int64)
+    grad = t(G.make_grad(18, tables, B, D))
+    for kw in (dict(sparse=False), dict(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=LR),
+               dict(sparse=True, optimizer=ops.OptimType.EXACT_ADAGRAD, learning_rate=LR, eps=EPS)):
+        torch.manual_seed(1)
+        a = ops.TableBatchedTTEmbeddingBag(tables, E_, D, r, p, q, use_cache=False, weight_dist="uniform", device=DEV, **kw)
+        torch.manual_seed(1)
+        b = ops.TableBatchedTTEmbeddingBag(tables, E_, D, r, p, q, use_cache=False, weight_dist="uniform", device=DEV, **kw)
+        oa = a(t(buf), t(off), n_dev=torch.tensor([n], dtype=torch.int32, device=DEV))
+        ob = b(t(idx), t(off))
+        assert torch.equal(oa, ob), f"forward differs ({kw})"
+        oa.backward(grad)
+        ob.backward(grad)
+        for k in range(3):
+            if not kw["sparse"]:
+                assert torch.equal(a.tt_cores[k].grad, b.tt_cores[k].grad), f"dense grad {k} differs"
+            else:
+                assert torch.equal(a.tt_cores[k].detach(), b.tt_cores[k].detach()), f"core {k} differs ({kw})"
+
+
 def test_max_pooling_truncates_at_one_rank_as_it_does_at_many(node):
     """Round 4 advisor: forward(.., max_pooling=L) was ignored at world size 1 (bags longer than L were summed whole) and truncated at
     W > 1.  One rule everywhere: the first L lookups of every bag, the padding weighted zero -- against the table-batched module on

@@ -31,7 +31,7 @@ def _free_port():
 def _make_inputs(rank, fixed, NT=NT):
     rs = np.random.RandomState(100 + rank)
     E_ = int(np.prod(P))
-    if fixed:
+    if fixed > 0:
         lengths = np.full(NT * B_LOCAL, fixed, dtype=np.int64)
     else:
         lengths = rs.randint(0, 5, size=NT * B_LOCAL).astype(np.int64)
@@ -66,7 +66,10 @@ def _worker(rank, world, port, fixed, q, NT=NT, direct=False):
                 for t, core in enumerate(m.local.tt_cores):
                     core.copy_(torch.from_numpy(cores_all[t][mine]))
         idx, off, grad = _make_inputs(rank, fixed, NT)
-        out = m(torch.from_numpy(idx), torch.from_numpy(off), fixed_pooling=fixed or None)
+        if fixed < 0:  # ragged bags through the fixed-capacity exchange (max_pooling = -fixed; longer bags are truncated)
+            out = m(torch.from_numpy(idx), torch.from_numpy(off), max_pooling=-fixed)
+        else:
+            out = m(torch.from_numpy(idx), torch.from_numpy(off), fixed_pooling=fixed or None)
         out.backward(torch.from_numpy(grad))
         q.put((rank, out.detach().numpy(), mine, [c.detach().numpy() for c in m.local.tt_cores] if m.local is not None else []))
         dist.barrier()
@@ -79,8 +82,11 @@ def _worker(rank, world, port, fixed, q, NT=NT, direct=False):
 
 # NT == world: one table per rank (the bench shape); NT = 5: uneven ownership (3 + 2 tables); NT = 1: a rank that owns
 # no table still has to take part in both exchanges, forward and backward; direct: DirectExchange's split lists
+# fixed < 0 (round 5): RAGGED bags with max_pooling = -fixed -- padded rows on the wire, compacted by the owner, the local lookup
+# told its live count (n_dev); -4 holds every bag (lengths 0..4), -3 truncates the bags of four
 @pytest.mark.parametrize("fixed,NT,direct", [(0, 5, False), (3, 5, False), (3, 2, False), (3, 5, True), (3, 2, True),
-                                             (3, 1, False), (0, 1, False), (3, 1, True), (2, 7, True)])
+                                             (3, 1, False), (0, 1, False), (3, 1, True), (2, 7, True),
+                                             (-4, 5, False), (-3, 5, True), (-4, 1, False), (-3, 2, False)])
 def test_two_rank_table_sharding_matches_single_process(fixed, NT, direct):
     sys.path.insert(0, HERE)
     import gen_inputs as G
@@ -109,6 +115,12 @@ def test_two_rank_table_sharding_matches_single_process(fixed, NT, direct):
     for t in range(NT):
         for r in range(world):
             idx, off, _ = per_rank[r]
+            if fixed < 0:  # max_pooling: the first -fixed lookups of every bag
+                for b in range(t * B_LOCAL, (t + 1) * B_LOCAL):
+                    n = min(int(off[b + 1] - off[b]), -fixed)
+                    idx_g.append(idx[off[b]:off[b] + n])
+                    len_g.append(np.array([n], dtype=np.int64))
+                continue
             lo, hi = off[t * B_LOCAL], off[(t + 1) * B_LOCAL]
             idx_g.append(idx[lo:hi])
             len_g.append(np.diff(off[t * B_LOCAL:(t + 1) * B_LOCAL + 1]))
