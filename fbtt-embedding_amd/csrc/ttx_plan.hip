@@ -1020,7 +1020,11 @@ __global__ __launch_bounds__(kWideThreads) void mbw_scatter_kernel(
     sb = slice_base(d, ct, t, m.tb0);
     sg = slice_base(d, ct, t, m.tb0 + ga.gsz) - sb;
   }
-  for (int e = lane; e < BINS; e += kWave) hrun[w][e] = 0;  // (wave-private row)
+  {  // (wave-private row, zeroed 16 bytes per lane and round: a 12-bit row is 8 KB)
+    int4* z = (int4*)&hrun[w][0];
+    constexpr int kRowVec = BINS * (int)sizeof(Cnt) / 16;
+    for (int e = lane; e < kRowVec; e += kWave) z[e] = make_int4(0, 0, 0, 0);
+  }
   // this wave's kSB x 64 positions: key, peers of equal key in the batch, per-wave digit counts
   long long ix[kSB];
   int tb[kSB], kv[kSB], brow[kSB];

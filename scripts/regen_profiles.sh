@@ -13,7 +13,7 @@
 #   <tag>_cache_bandwidth.md    cache-path kernels: durations and GB/s on the algorithmic bytes
 #   <tag>_bench*.json           the bench lines (default line incl. its cfg5shard `secondary` record)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=$(pwd); OUT=$REPO/gpurun_out/profiles_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 PMC_W=${PMC_WORKLOADS:-"cfg2 cfg5shard cfg4 r128 r256 t4"}
 KPROF_W=${KPROF_WORKLOADS:-"cfg3 cfg3warm cfg4 cfg5shard tb4 d32 d16 d256 r128 r13 d320 d512 d768 d1024 d1024r64 r256 t2 t4 t4d256 t2big"}
@@ -21,7 +21,8 @@ BENCH_W=${BENCH_WORKLOADS:-"cfg3 cfg3a105 cfg3warm cfg4 cfg5shard r128 r13 d320 
 if [ -z "${REGEN_ONLY_BENCH:-}" ]; then   # (REGEN_ONLY_BENCH=1: the counters of this build are in ./profiles already -- bench lines only)
 scripts/measure_traffic.sh "$TAG" > "$OUT/measure_traffic.log" 2>&1
 cp gpurun_out/prof_$TAG/${TAG}_kernel_stats.md gpurun_out/prof_$TAG/pmc_bwd_bytes.json "$OUT/" 2>/dev/null
-for W in ${TRAFFIC_WORKLOADS:-"cfg3 cfg4 cfg5shard"}; do   # (round 5: HBM bytes for the workloads where bytes are the argument)
+TRAFFIC_W=${TRAFFIC_WORKLOADS:-"cfg3 cfg4 cfg5shard"}
+for W in $TRAFFIC_W; do   # (round 5: HBM bytes for the workloads where bytes are the argument)
   scripts/measure_traffic.sh "$TAG" --workload $W > "$OUT/measure_traffic_$W.log" 2>&1
   cp gpurun_out/prof_${TAG}_$W/${TAG}_kernel_stats_$W.md "$OUT/" 2>/dev/null
 done
