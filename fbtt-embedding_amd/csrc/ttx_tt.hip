@@ -1019,6 +1019,8 @@ static int spec_mc(const Dims& d, long long nnz) {
     case SPEC_128_4_128_8: return S_128_4_128_8::MC;
     case SPEC_128_8_128_8: return S_128_8_128_8::MC;
     case SPEC_32_8_32_16: return S_32_8_32_16::MC * (S_32_8_32_16::SUB ? ks : 1);
+    case SPEC_32_16_32_16: return S_32_16_32_16::MC * (S_32_16_32_16::SUB ? ks : 1);
+    case SPEC_16_16_16_16: return S_16_16_16_16::MC * (S_16_16_16_16::SUB ? ks : 1);
     case SPEC_16_8_16_16: return S_16_8_16_16::MC * (S_16_8_16_16::SUB ? ks : 1);
     case SPEC_64_8_64_16: return S_64_8_64_16::MC;
     default: return 0;

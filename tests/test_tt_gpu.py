@@ -564,7 +564,9 @@ def test_fused_pooling_stress_across_xcds():
                                       ([3, 8, 8], [64, 50]), ([2, 2, 4], [12, 12]), ([4, 4, 4], [16, 32]), ([2, 8, 8], [64, 64]),
                                       ([4, 4, 4], [96, 96]), ([4, 4, 4], [80, 100]), ([3, 4, 7], [72, 128]), ([2, 4, 4], [128, 128]), ([4, 6, 8], [100, 90]),
                                       ([4, 8, 16], [32, 32]), ([4, 8, 12], [24, 32]), ([3, 8, 10], [16, 16]), ([4, 8, 16], [16, 16]),
-                                      ([4, 8, 16], [64, 64]), ([4, 8, 12], [48, 64]), ([4, 6, 9], [40, 56])])  # (q2 <= 16 at ranks <= 64)
+                                      ([4, 8, 16], [64, 64]), ([4, 8, 12], [48, 64]), ([4, 6, 9], [40, 56]),  # (q2 <= 16 at ranks <= 64)
+                                      ([4, 9, 10], [32, 32]), ([4, 16, 16], [32, 32]), ([4, 10, 11], [16, 16]), ([3, 12, 12], [24, 32]),
+                                      ([4, 16, 16], [16, 16]), ([2, 10, 12], [20, 28])])  # (round 5: q1 up to 16 at ranks <= 32)
 def test_padded_shapes_run_on_the_specialised_kernels(q, ranks):
     """Round 3: a T = 3 geometry with q0 <= 4, q1 <= 8, q2 <= 8 and ranks <= 128 that is NOT one of the exact shapes --
     ranks that are not multiples of 16 (the reference tests' 13 / 12, tt_embeddings_test.py:65-70), factorings like [3, 4, 5] --
