@@ -92,7 +92,8 @@ WORKLOADS = {
     "d320": dict(q=[5, 8, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d448": dict(q=[7, 8, 8], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d1024r64": dict(q=[8, 8, 16], ranks=[64, 64], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
-    # default factorings NO template holds (generic kernels): a prime last factor, q1 = 16 / 9 / 10
+    # default factorings that were on the generic kernels until round 5: a prime last factor (q2 = 32 templates), q1 = 9 / 10 (q1 = 16
+    # templates); d368 -- q1 = 16 AND a prime last factor -- still is
     "d272": dict(q=[4, 4, 17], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d368": dict(q=[1, 16, 23], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d720": dict(q=[8, 9, 10], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),

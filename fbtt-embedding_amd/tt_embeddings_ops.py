@@ -94,7 +94,9 @@ def _split0_factor(q: Sequence[int], ranks: Sequence[int]) -> int:
     lookups per index in the table [k p0, p1, p2] x [q0', q1, q2] -- core 0 [p0, q0, r1] IS [k p0, q0', r1] -- which the
     shape-specialised kernels take (include/ttx.h "core-0 row split"; the reference's default factoring of D = 512 is
     [8, 8, 8]).  0: no split."""
-    if len(q) != 3 or q[0] <= 4 or q[1] > 16 or q[2] > 16 or max(ranks) > 128 or os.environ.get("TTX_NO_SPLIT0"):
+    if len(q) != 3 or q[0] <= 4 or q[1] > 16 or q[2] > 32 or max(ranks) > 128 or os.environ.get("TTX_NO_SPLIT0"):
+        return 0
+    if q[2] > 16 and (max(ranks) > 32 or q[1] > 8):  # (q2 up to 32 -- a prime last factor 17 .. 31, round 5 -- at q1 <= 8, ranks <= 32)
         return 0
     if q[2] > 8 and max(ranks) > 64:  # (q2 up to 16 -- D = 640 / 768 / 1024 -- has templates at ranks <= 64 only)
         return 0
