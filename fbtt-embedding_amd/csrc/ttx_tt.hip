@@ -1021,6 +1021,9 @@ static int spec_mc(const Dims& d, long long nnz) {
     case SPEC_32_8_32_16: return S_32_8_32_16::MC * (S_32_8_32_16::SUB ? ks : 1);
     case SPEC_32_16_32_16: return S_32_16_32_16::MC * (S_32_16_32_16::SUB ? ks : 1);
     case SPEC_16_16_16_16: return S_16_16_16_16::MC * (S_16_16_16_16::SUB ? ks : 1);
+    case SPEC_64_16_64_16: return S_64_16_64_16::MC;
+    case SPEC_32_16_32_32: return S_32_16_32_32::MC * (S_32_16_32_32::SUB ? ks : 1);
+    case SPEC_16_16_16_32: return S_16_16_16_32::MC * (S_16_16_16_32::SUB ? ks : 1);
     case SPEC_32_4_32_32: return S_32_4_32_32::MC * (S_32_4_32_32::SUB ? ks : 1);
     case SPEC_16_4_16_32: return S_16_4_16_32::MC * (S_16_4_16_32::SUB ? ks : 1);
     case SPEC_32_8_32_32: return S_32_8_32_32::MC * (S_32_8_32_32::SUB ? ks : 1);

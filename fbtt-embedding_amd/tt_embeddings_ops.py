@@ -96,11 +96,11 @@ def _split0_factor(q: Sequence[int], ranks: Sequence[int]) -> int:
     [8, 8, 8]).  0: no split."""
     if len(q) != 3 or q[0] <= 4 or q[1] > 16 or q[2] > 32 or max(ranks) > 128 or os.environ.get("TTX_NO_SPLIT0"):
         return 0
-    if q[2] > 16 and (max(ranks) > 32 or q[1] > 8):  # (q2 up to 32 -- a prime last factor 17 .. 31, round 5 -- at q1 <= 8, ranks <= 32)
+    if q[2] > 16 and max(ranks) > 32:  # (q2 up to 32 -- a prime last factor 17 .. 31, round 5 -- at ranks <= 32)
         return 0
     if q[2] > 8 and max(ranks) > 64:  # (q2 up to 16 -- D = 640 / 768 / 1024 -- has templates at ranks <= 64 only)
         return 0
-    if q[1] > 8 and max(ranks) > 32:  # (q1 up to 16 -- D = 720 / 800 / 864 / 880 / 960 / 1008, round 5 -- at ranks <= 32 only)
+    if q[1] > 8 and max(ranks) > 64:  # (q1 up to 16 -- D = 720 / 800 / 864 / 880 / 960 / 1008, round 5 -- at ranks <= 64)
         return 0
     for k in (2, 3, 4):
         if q[0] % k == 0 and 2 <= q[0] // k <= 4:

@@ -1037,7 +1037,7 @@ def test_discarded_planned_batches_are_counted_once_and_the_module_copies(node):
                                              ([8, 9, 10], [32, 32], 1), ([8, 10, 10], [16, 16], 2), ([8, 10, 12], [24, 32], 1),
                                              ([7, 12, 12], [32, 32], 1),
                                              # ... and a prime last factor (templates with q2 = 32): D = 816 / 912
-                                             ([6, 8, 17], [32, 32], 1), ([6, 8, 19], [16, 16], 2)])
+                                             ([6, 8, 17], [32, 32], 1), ([6, 8, 19], [16, 16], 2), ([8, 9, 10], [64, 64], 1)])
 def test_first_factor_beyond_four_runs_as_part_lookups(q, ranks, tables):
     """q0 > 4 (the reference's default factoring of D = 512 is [8, 8, 8]): core 0 [p0, q0, r1] IS [k p0, q0 / k, r1], every
     index becomes k part lookups whose rows are the k parts of the bag's output row (include/ttx.h "core-0 row split"), and the

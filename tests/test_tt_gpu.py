@@ -568,7 +568,9 @@ def test_fused_pooling_stress_across_xcds():
                                       ([4, 9, 10], [32, 32]), ([4, 16, 16], [32, 32]), ([4, 10, 11], [16, 16]), ([3, 12, 12], [24, 32]),
                                       ([4, 16, 16], [16, 16]), ([2, 10, 12], [20, 28]),  # (round 5: q1 up to 16 at ranks <= 32)
                                       ([4, 4, 17], [32, 32]), ([2, 8, 19], [16, 16]), ([4, 8, 23], [32, 32]), ([3, 8, 17], [24, 32]),
-                                      ([4, 4, 32], [32, 32]), ([4, 8, 32], [16, 16]), ([4, 7, 29], [32, 20]), ([1, 4, 31], [16, 16])])  # (... q2 up to 32)
+                                      ([4, 4, 32], [32, 32]), ([4, 8, 32], [16, 16]), ([4, 7, 29], [32, 20]), ([1, 4, 31], [16, 16]),  # (... q2 up to 32)
+                                      ([4, 16, 16], [64, 64]), ([4, 9, 10], [48, 64]),  # (q1 up to 16 at r = 64: gradient rows per pass)
+                                      ([1, 16, 23], [32, 32]), ([2, 16, 29], [16, 16]), ([4, 16, 32], [32, 32]), ([1, 16, 31], [20, 24])])  # (q1 = 16 AND q2 up to 32)
 def test_padded_shapes_run_on_the_specialised_kernels(q, ranks):
     """Round 3: a T = 3 geometry with q0 <= 4, q1 <= 8, q2 <= 8 and ranks <= 128 that is NOT one of the exact shapes --
     ranks that are not multiples of 16 (the reference tests' 13 / 12, tt_embeddings_test.py:65-70), factorings like [3, 4, 5] --
