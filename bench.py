@@ -109,6 +109,8 @@ WORKLOADS = {
     # ... the default four-core factoring of D = 256 (merged last factor q2 q3 = 16)
     "t4d256": dict(q=[4, 4, 4, 4], ranks=[32, 32, 32], p=[58, 58, 58, 58], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "t4": dict(q=[2, 4, 4, 2], ranks=[32, 32, 32], p=[58, 58, 58, 58], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
+    # ... of D = 512 (merged last factor 32: round 5)
+    "t4d512": dict(q=[4, 4, 4, 8], ranks=[32, 32, 32], p=[58, 58, 58, 58], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "t2big": dict(q=[8, 8], ranks=[32], p=[3317, 3317], tables=4, B=4096, optimizer="sgd", alpha=1.0, populate=False),
     "t4big": dict(q=[2, 4, 4, 2], ranks=[32, 32, 32], p=[58, 58, 58, 58], tables=4, B=4096, optimizer="sgd", alpha=1.0, populate=False),
 }

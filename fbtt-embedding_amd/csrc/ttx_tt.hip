@@ -1216,16 +1216,16 @@ __global__ __launch_bounds__(kT2Threads) void t2_bwd_kernel(Dims d, Plan P, Core
 // the three-core kernel leaves d M_n where it leaves d core_2's partial rows, and
 //     d core_2[i_2] += d M_n * core_3[i_3]^T,      d core_3[i_3] += core_2[i_2]^T * d M_n
 // are the per-lookup partial rows reduce_apply sums like any other core's.  Sums are re-associated, results agree with the
-// left-to-right order to rounding (tested against the oracle at the default tolerance).  Taken when q2 q3 <= 16 and the
+// left-to-right order to rounding (tested against the oracle at the default tolerance).  Taken when q2 q3 <= 32 (round 5; 16 until the q2 = 32 templates) and the
 // three-core geometry has a specialised kernel (exact or padded); everything else stays on the generic kernels.
 // Limits of the route: q3 <= 8 (the helpers' instantiations), a core-2 slice of at most kT4Slice floats (staged in LDS by the
 // gradient kernel: r = 32 with q2 = 4, r = 64 with q2 = 2).
 constexpr int kT4Slice = 8192;
-constexpr int kT4Stage = 1024;  // floats of a lookup's d M row + core-3 slice the gradient kernel stages per step
+constexpr int kT4Stage = 1536;  // floats of a lookup's d M row + core-3 slice the gradient kernel stages per step (round 5: q2 q3 up to 32)
 static bool t4_merge_dims(const Dims& d, Dims* d3) {
   // (merged last factor q2 q3 up to 16 -- the reference's default four-core factorings of D = 128 / 256 are [2,4,4,4] / [4,4,4,4] --
   //  wherever a three-core template holds it: spec_match below; the helpers are instantiated for q3 <= 8)
-  if (d.T != 4 || g_disable_spec || (long long)d.q[2] * d.q[3] > 16 || d.q[3] > 8 || (long long)d.r[2] * d.q[2] * d.r[3] > kT4Slice || d.r[3] > 128 ||
+  if (d.T != 4 || g_disable_spec || (long long)d.q[2] * d.q[3] > 32 || d.q[3] > 8 || (long long)d.r[2] * d.q[2] * d.r[3] > kT4Slice || d.r[3] > 128 ||
       (long long)d.r[2] * d.q[2] * d.q[3] + (long long)d.r[3] * d.q[3] > kT4Stage)
     return false;
   Dims e = d;

@@ -615,7 +615,10 @@ def test_padded_shapes_run_on_the_specialised_kernels(q, ranks):
                                       # merged last factor up to 16 (templates with q2 <= 16 at ranks <= 32): the default four-core
                                       # factorings of D = 256 / 128, and odd ones
                                       ([4, 4, 4, 4], [32, 32, 32]), ([2, 4, 4, 4], [16, 16, 16]), ([4, 8, 5, 3], [32, 24, 9]),
-                                      ([3, 5, 2, 6], [20, 32, 16])])
+                                      ([3, 5, 2, 6], [20, 32, 16]),
+                                      # merged last factor up to 32 (round 5: templates with q2 = 32 at ranks <= 32): the default
+                                      # four-core factorings of D = 320 / 512 / 768
+                                      ([4, 4, 4, 5], [16, 16, 16]), ([4, 4, 4, 8], [32, 32, 32]), ([4, 6, 4, 8], [32, 24, 16])])
 def test_four_cores_run_on_the_three_core_kernels(q, ranks):
     """Round 4: a T = 4 geometry with q2 q3 <= 16 (q3 <= 8) runs on the shape-specialised three-core kernels -- the last two cores of a
     lookup are contracted first (per lookup, M = core_2[i2] * core_3[i3]: matrix-chain order, a tenth of the multiply-adds the
