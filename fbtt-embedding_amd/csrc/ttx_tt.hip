@@ -1043,10 +1043,12 @@ static int spec_mc(const Dims& d, long long nnz) {
 // core-0 slice (and gradient row) with one coalesced load each and every lane produces its outputs from float4 LDS reads.
 // Backward: d core_0 of the lookup goes out as its partial row, d core_1 accumulates in registers over the wave's lookups and
 // the four waves' sums leave as the chunk's partial -- the layouts reduce_apply expects from any backward kernel.
-// Shapes: r1 <= 128, q0, q1 <= 16 (everything else stays on the generic kernels); r1 % 4 != 0 runs over zero-padded k tiles.
+// Shapes: r1 <= 128, q0, q1 <= 32 with r1 q1 <= 2048 (everything else stays on the generic kernels); r1 % 4 != 0 runs over zero-padded k tiles.
 constexpr int kT2Threads = 256;
 static bool t2_shape(const Dims& d) {
-  return d.T == 2 && !g_disable_spec && d.r[1] <= 128 && d.q[0] <= 16 && d.q[1] <= 16;
+  // (round 5: q up to 32 -- the default two-core factorings of D = 320 .. 1024 are [16,20] .. [32,32] -- while core 1's slice is at most 2048
+  //  floats: the backward keeps it in 32 registers per lane)
+  return d.T == 2 && !g_disable_spec && d.r[1] <= 128 && d.q[0] <= 32 && d.q[1] <= 32 && d.r[1] * d.q[1] <= 2048;
 }
 struct T2Lds { int ldk, oBt, oA, oG, oR, floats; };  // ldk: row stride of the k-major tiles (r1 + 4: float4 rows, spread over the banks)
 static T2Lds t2_lds(const Dims& d, bool bwd) {

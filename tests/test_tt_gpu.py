@@ -660,7 +660,9 @@ def test_four_cores_run_on_the_three_core_kernels(q, ranks):
 
 @pytest.mark.parametrize("q,ranks", [([8, 8], [32]), ([4, 16], [128]), ([2, 2], [4]), ([16, 8], [64]), ([5, 7], [20]), ([3, 4], [12]),
                                       # r1 % 4 != 0 (zero-padded k tiles, scalar loads / stores of core 0's rows): the reference tests' r = 13
-                                      ([3, 4], [13]), ([5, 7], [10]), ([16, 16], [17]), ([2, 3], [1])])
+                                      ([3, 4], [13]), ([5, 7], [10]), ([16, 16], [17]), ([2, 3], [1]),
+                                      # q up to 32 (round 5): the default two-core factorings of D = 512 / 640 / 1024
+                                      ([16, 32], [32]), ([20, 32], [24]), ([32, 32], [64])])
 def test_two_cores_on_the_dedicated_kernels(q, ranks):
     """Round 4: a T = 2 geometry with r1 <= 128, q <= 16 runs on the dedicated two-core kernels (csrc/ttx_tt.hip
     t2_fwd_kernel / t2_bwd_kernel: a lookup is one [q0 x r1] x [r1 x q1] product -- byte work, no matrix tiles to pad).  Against the
