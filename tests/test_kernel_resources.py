@@ -88,6 +88,22 @@ def test_contraction_and_reduce_kernels_budget(tt_res):
                 "Shape3ILi64ELi4ELi64ELi4ELi4ELi16ELi4EEELb0ELb0E"):
         r = pick(tt_res, "spec_bwd_kernel", r64)
         assert r["ScratchSize"] == 0 and r["VGPRs"] <= 168 and r["Occupancy"] >= 3, (r64, r)
+    # round 5: q1 = 16 and q2 = 32 -- gradient rows per column pass with two / four float4 per lane (Shape3::NPL) keep two or three
+    # work-groups on a CU; the q2 = 32 backward's 2 x 64 last-core registers stay out of scratch (exact AND padded variant: the
+    # padded one is what a prime last factor runs on)
+    for shp, occ in (("Shape3ILi32ELi16ELi32ELi16ELi8ELi16ELi4EEELb0ELb0E", 3), ("Shape3ILi32ELi16ELi32ELi16ELi8ELi16ELi4EEELb0ELb1E", 2),
+                     ("Shape3ILi32ELi8ELi32ELi32ELi4ELi16ELi4EEELb0ELb0E", 2), ("Shape3ILi32ELi8ELi32ELi32ELi4ELi16ELi4EEELb0ELb1E", 2),
+                     ("Shape3ILi32ELi4ELi32ELi32ELi2ELi16ELi4EEELb0ELb1E", 2), ("Shape3ILi32ELi16ELi32ELi32ELi8ELi16ELi4EEELb0ELb0E", 2)):
+        r = pick(tt_res, "spec_bwd_kernel", shp)
+        assert r["ScratchSize"] == 0 and r["Occupancy"] >= occ, (shp, r)
+    # (the PADDED q = [4,16,32] backward -- q = [1,16,23] and friends -- spills 21 dwords at two work-groups per CU, like the padded
+    #  r = 64 kernels: a second work-group is worth more than those)
+    r = pick(tt_res, "spec_bwd_kernel", "Shape3ILi32ELi16ELi32ELi32ELi8ELi16ELi4EEELb0ELb1E")
+    assert r["ScratchSize"] <= 128 and r["Occupancy"] >= 2, r
+    # ... and the four-core gradient helper on the matrix pipe
+    for q3 in ("ILi2ELi4E", "ILi4ELi4E", "ILi8ELi4E"):
+        r = pick(tt_res, "t4_grad23_mfma_kernel", q3)
+        assert r["ScratchSize"] == 0 and r["VGPRs"] <= 128, (q3, r)
     red = pick(tt_res, "reduce_apply_kernel")
     assert red["Occupancy"] >= 6, f"reduce_apply_kernel must leave room for three 512-thread work-groups per CU: {red}"
     assert pick(tt_res, "pool4_small_kernel")["ScratchSize"] == 0
