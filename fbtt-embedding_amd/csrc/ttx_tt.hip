@@ -2431,7 +2431,7 @@ static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t
     if (tail && tail->dst) {  // the cache rows' scatter in the same launch (launch_scatter_add's grid, ttx_cache.hip)
       CT = *tail;
       CT.first = blocks;
-      CT.nmain = (int)((CT.N + kScatterThreads / 32 - 1) / (kScatterThreads / 32));
+      CT.nmain = (int)((CT.N + rthreads / 32 - 1) / (rthreads / 32));  // (a lookup per 32 lanes, all of the work-group's threads)
       CT.K = (((uintptr_t)CT.grad & 15) == 0) ? hot_rows(CT.N, CT.D) : 0;
       tail_blocks = CT.nmain + CT.K * (int)((CT.N + kHotSeg - 1) / kHotSeg);
       if (tail_done) *tail_done = 1;
