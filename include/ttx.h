@@ -92,7 +92,13 @@ int ttx_version(void);
  * tableidx, rowidx); forward and backward of the same batch can share one plan.
  * rowidx may be NULL (the backward kernel then gathers the bag row per lookup).
  * Passing plan == NULL to ttx_tt_forward / ttx_tt_backward builds it inside
- * their workspace. */
+ * their workspace.
+ * With FOUR cores on the three-core kernels a plan also carries the product of each
+ * lookup's last two core slices, left there by the latest ttx_tt_forward on that plan;
+ * a ttx_tt_backward on the same plan, with cores 2 and 3 at the same addresses, reads it
+ * instead of recomputing it.  This library's fused optimizers and ttx_plan_build drop it;
+ * a caller who rewrites cores 2 / 3 by other means BETWEEN the forward and the backward
+ * of one plan (nothing in the reference's flow does) must rebuild the plan first. */
 size_t ttx_plan_bytes(const ttx_geom* g, int64_t nnz);
 int ttx_plan_build(const ttx_geom* g, int64_t nnz, const int64_t* indices,
                    const int64_t* tableidx, const int64_t* rowidx, void* plan,

@@ -292,6 +292,87 @@ def test_several_training_steps_track_the_oracle(node, optim):
     assert int(m.cache_freq.sum()) > 0  # the frequency table counted along
 
 
+@pytest.mark.parametrize("p,q,ranks", [([4, 5, 3, 4], [4, 4, 4, 4], [32, 32, 32]),   # four cores, the MFMA gradient helper
+                                        ([4, 5, 3, 4], [3, 4, 2, 3], [13, 12, 7]),    # four cores, the VALU helper
+                                        ([9, 8], [16, 32], [32])])                    # two cores
+@pytest.mark.parametrize("optim", ["sgd", "adagrad"])
+def test_two_and_four_cores_over_several_steps_track_the_oracle(node, p, q, ranks, optim):
+    """Round 5: the four-core route keeps state IN THE PLAN between the forward and the backward of a step (the merged last
+    cores, csrc/ttx_tt.hip t4_valid) -- so the multi-step life cycle is checked against the oracle run step by step: six
+    fused-optimizer steps on changing batches, the last three of them planned ahead in one launch (prefetch_many: three
+    plans alive at once while the optimizer rewrites cores 2 / 3 under them).  Two cores ride along (no such state)."""
+    import tt_embeddings_ops as ops
+
+    T = len(p)
+    E_, D, B = int(np.prod(p)), int(np.prod(q)), 48
+    cores = G.make_cores(31, 1, p, q, [1] + ranks + [1], "signed")
+    opt = ops.OptimType.SGD if optim == "sgd" else ops.OptimType.EXACT_ADAGRAD
+    m = ops.TTEmbeddingBag(E_, D, ranks, p, q, sparse=True, optimizer=opt, learning_rate=0.05, eps=1e-3, use_cache=False,
+                           weight_dist="uniform", device=DEV)
+    with torch.no_grad():
+        for dst, src in zip(m.tt_cores, cores):
+            dst.copy_(t(src))
+    g = O.make_geom(1, p, q, ranks)
+    ref = [c.copy() for c in cores]
+    state = [np.zeros_like(c) for c in cores]
+    batches = []
+    for step in range(6):
+        idx, off = G.make_bags(300 + step, B, E_, 5, 3 if step < 3 else 0, 1)  # (a planned round: batches of one size)
+        batches.append((t(idx), t(off), idx, off, G.make_grad(400 + step, 1, B, D)))
+    for step, (ti, to, idx, off, d_out) in enumerate(batches):
+        if step == 3:
+            assert m.prefetch_many([(b[0], b[1]) for b in batches[3:]]) is (node == "native")  # (planning ahead needs the C++ node)
+        out = m(ti, to)
+        rowidx, tableidx = O.rowidx_from_offsets(off, 1)
+        assert_close(out.detach().cpu().numpy(), O.tt_forward(g, B, D, idx, rowidx, tableidx, ref)[0], f"step {step} forward")
+        out.backward(t(d_out[0]))
+        if optim == "sgd":
+            O.tt_backward(g, O.OPTIM_SGD, B, D, 0.05, 0.0, idx, rowidx, tableidx, d_out, ref)
+        else:
+            O.tt_backward(g, O.OPTIM_ADAGRAD, B, D, 0.05, 1e-3, idx, rowidx, tableidx, d_out, ref, state)
+        for k in range(T):
+            a, b = m.tt_cores[k].detach().cpu().numpy().astype(np.float64), ref[k].astype(np.float64)
+            # (Adagrad: lr g / (sqrt(s) + eps) turns a rounding difference of a SMALL g into lr / eps = 50 times as much of the
+            # weight -- 16x here, sums over D = 256 at ranks 32; a stale product would be off by the size of an update, ~1e-2)
+            tol = 4 * (2e-6 * np.abs(b).max() + 1e-5 * np.abs(b)) * (16 if optim == "adagrad" else 1)
+            err = np.abs(a - b)
+            assert (err <= tol).all(), f"step {step} core {k}: max err {err.max():.3e} (worst err / tol {(err / tol).max():.2f})"
+
+
+def test_four_cores_captured_step_tracks_eager(node):
+    """... and behind a captured graph (ttx_graph.GraphedStep): plan build, merge, forward, backward and the mark's reset all
+    replay from one graph -- ten fused-SGD steps leave the four cores bit-identical to the same steps run eagerly."""
+    import tt_embeddings_ops as ops
+    import ttx_graph
+
+    p, q, ranks = [4, 5, 3, 4], [4, 4, 4, 4], [32, 32, 32]
+    E_, D, B, Lp = int(np.prod(p)), 256, 48, 5
+
+    def fresh():
+        m = ops.TTEmbeddingBag(E_, D, ranks, p, q, sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, use_cache=False,
+                               weight_dist="uniform", device=DEV)
+        with torch.no_grad():
+            for dst, src in zip(m.tt_cores, G.make_cores(93, 1, p, q, [1] + ranks + [1], "signed")):
+                dst.copy_(t(src))
+        return m
+
+    me, mg = fresh(), fresh()
+    rs = np.random.RandomState(94)
+    off = torch.arange(0, B * Lp + 1, Lp, device=DEV)
+    batches = [(t(rs.randint(0, E_, size=B * Lp).astype(np.int64)), off, t((rs.rand(B, D) * 0.1).astype(np.float32))) for _ in range(10)]
+    before = [c.detach().clone() for c in mg.tt_cores]
+    step = ttx_graph.GraphedStep(lambda i, o, g_: mg(i, o).backward(g_), batches[0], warmup=2)
+    with torch.no_grad():
+        for c, b in zip(mg.tt_cores, before):
+            c.copy_(b)
+    for i, o, g_ in batches:
+        step(i, o, g_)
+        me(i, o).backward(g_)
+    torch.cuda.synchronize()
+    for a, b in zip(me.tt_cores, mg.tt_cores):
+        assert torch.equal(a, b)
+
+
 def test_drop_in_for_nn_embedding_bag_in_a_dlrm_shaped_model(node):
     """examples/mini_dlrm.py: the TT bags in DLRM's call form (offsets = bag starts only) give the same logits as
     nn.EmbeddingBag tables holding the expanded TT weights, and a few training steps (dense side: torch SGD,
