@@ -438,6 +438,11 @@ def main():
     E.profile_enable(0)
     n_bwd, ms_bwd = E.profile_read(E.PROF_BWD)
     bwd_src = "HIP events around each launch of the eager region"
+    # ... and the same loop with no event brackets in the stream: THE eager figure (`eager_ms_per_step`).  A timing event pair per
+    # launch costs the stream ~2 x 10 us of marker packets -- the bracketed region above ran at about half this one's rate and was
+    # what rounds 1-4 (and this round's first lines) reported as the eager step.
+    eager_profiled = eager_elapsed
+    eager_elapsed = timed(eager_steps, args.steps)
     eager_regions = [eager_elapsed]
 
     def build_line(mode, regions, breakdown, a2a, note=None):
@@ -555,6 +560,9 @@ def main():
                              "what": "the same captured round with every step's prologue in line (no side stream)"}),
             "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
             "eager_value": round(3.0 * fl_fwd * nnz_step_total / (eager_elapsed / args.steps) / 1e9, 2),
+            "eager_what": ("the reference benchmark's loop form, `tt_emb(indices, offsets).backward(grad)` per request "
+                           "(tt_embeddings_benchmark.py:94-108), free-running, no graph, no planning ahead, no event brackets"),
+            "eager_with_event_brackets_ms_per_step": round(eager_profiled / args.steps * 1e3, 4),
             "us_per_nnz": round(elapsed / args.steps / nnz_step_total * 1e6, 5),
             "ref_formula_gflops_x_iters": round(gflops * 10, 1),
             "reference_readme_true_gflops": 265.8,

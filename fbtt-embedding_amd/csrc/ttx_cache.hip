@@ -68,11 +68,18 @@ __global__ __launch_bounds__(kCT) void rowidx_update_kernel(int64_t nb, int32_t 
   }
   const bool valid = gt < N;
   const int64_t key = valid ? colidx[gt] : 0;
-  if (upd_hashtbl) hashtbl_count_wave(key, valid, H, upd_hashtbl, cache_freq);
+  // The reference updates the table in one launch and looks the batch up in the next (cu:1077-1113, then :1356-1375): a look-up
+  // sees EVERY insert of its batch.  That matters for a cached key that sits at its second or third probe since populate emptied
+  // the slot before it: the batch's own count re-inserts the key into the empty slot, the look-up finds it THERE (cache_state -1)
+  // and the key is a TT lookup from then on.  In one launch a plain find would race with the other copies' inserts (hit or miss
+  // by timing -- found as run-to-run differences of a free-running loop, round 5); the slot the count landed in is what the
+  // find of the reference's second launch returns, for every copy of the key alike.
+  int32_t counted = -1;
+  if (upd_hashtbl) counted = hashtbl_count_wave(key, valid, H, upd_hashtbl, cache_freq);
   if (loc) {
     bool tt = false;
     if (valid) {
-      const int32_t slot = hashtbl_find(key, H, hashtbl);
+      const int32_t slot = (upd_hashtbl && upd_hashtbl == hashtbl && key != -1) ? counted : hashtbl_find(key, H, hashtbl);
       int32_t cl = -1;
       if (slot != -1) cl = cache_state[slot];
       tt = (cl == -1);

@@ -270,8 +270,12 @@ __device__ __forceinline__ uint32_t hash64(int64_t key, int32_t C) {
 
 // hashtbl_cuda_utils.cuh:102-133 with accumulate == true: a 64-bit CAS claims the slot (or finds
 // the key already there), a 64-bit atomic add bumps its frequency; dropped after kMaxProbes.
-__device__ __forceinline__ void hashtbl_count(int64_t key, int32_t H, int64_t* hashtbl, int64_t* cache_freq,
-                                              unsigned long long times = 1ull) {
+// -> the slot the key was counted in, -1 if it was dropped.  That slot is the first one of the key's probe sequence that holds
+// the key once this launch's inserts are done -- i.e. what hashtbl_find (ttx_cache.hip) returns AFTER the update, for every copy
+// of the key in the launch alike (a slot seen holding another key keeps it; an empty one goes to whoever's CAS lands, and every
+// later CAS on it returns that winner).
+__device__ __forceinline__ int32_t hashtbl_count(int64_t key, int32_t H, int64_t* hashtbl, int64_t* cache_freq,
+                                                 unsigned long long times = 1ull) {
   int32_t idx = (int32_t)hash64(key, H);
   for (int c = 0; c < kMaxProbes; ++c) {
     // A slot only ever goes from empty to a key while inserts run (eviction is cache_populate's, another launch), so a
@@ -283,10 +287,11 @@ __device__ __forceinline__ void hashtbl_count(int64_t key, int32_t H, int64_t* h
       old = atomicCAS((unsigned long long*)&hashtbl[idx], (unsigned long long)(-1ll), (unsigned long long)key);
     if ((int64_t)old == -1 || (int64_t)old == key) {
       atomicAdd((unsigned long long*)&cache_freq[idx], times);
-      return;
+      return idx;
     }
     idx = (idx + 1) % H;
   }
+  return -1;
 }
 
 // The same for one key per lane, equal keys of a wave combined first: under a skewed index stream a
@@ -294,18 +299,23 @@ __device__ __forceinline__ void hashtbl_count(int64_t key, int32_t H, int64_t* h
 // 10k-key update took 33 us instead of 5).  Lanes are grouped by the low 8 bits of the key's hash
 // (9 ballots); the lowest lane of a group leads; lanes holding the leader's key hand it their count,
 // the rare others (8-bit collisions) go alone.  Same table contents as one insert per lane (counts
-// add up; a dropped key is dropped for all its copies either way).  Wave-uniform call.
-__device__ __forceinline__ void hashtbl_count_wave(int64_t key, bool valid, int32_t H, int64_t* hashtbl,
-                                                   int64_t* cache_freq) {
+// add up; a dropped key is dropped for all its copies either way).  Wave-uniform call.  -> the lane's slot (hashtbl_count above;
+// the lanes that handed their count to a leader get the leader's), -1 for a dropped key or an invalid lane.
+__device__ __forceinline__ int32_t hashtbl_count_wave(int64_t key, bool valid, int32_t H, int64_t* hashtbl,
+                                                      int64_t* cache_freq) {
   const unsigned h = valid ? hash64(key, H) : 0u;
   const unsigned long long peers = wave_match8(h & 255u, valid);
   const int leader = valid ? __ffsll((long long)peers) - 1 : 0;
   const int klo = __shfl((int)(unsigned)key, leader, kWave), khi = __shfl((int)(key >> 32), leader, kWave);
   const bool eq = valid && klo == (int)(unsigned)key && khi == (int)(key >> 32);
   const unsigned long long eqm = __ballot(eq);
-  if (!valid) return;
-  if (!eq) hashtbl_count(key, H, hashtbl, cache_freq);
-  else if (lane_id() == leader) hashtbl_count(key, H, hashtbl, cache_freq, (unsigned long long)__popcll(peers & eqm));
+  int32_t slot = -1;
+  if (valid) {
+    if (!eq) slot = hashtbl_count(key, H, hashtbl, cache_freq);
+    else if (lane_id() == leader) slot = hashtbl_count(key, H, hashtbl, cache_freq, (unsigned long long)__popcll(peers & eqm));
+  }
+  const int32_t ls = __shfl(slot, leader, kWave);  // (all lanes: the leaders' slots for the lanes they counted for)
+  return eq ? ls : slot;
 }
 #endif
 

@@ -15,6 +15,7 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
+#include <torch/csrc/autograd/python_cpp_function.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -777,9 +778,62 @@ void rccl_all_to_allv(int64_t comm, const Tensor& out, const Tensor& in, const s
   rccl_check(rc_end, "ncclGroupEnd");
 }
 
+// ---- out.backward(grad) of a lookup's OWN output, past autograd's engine ---------------------------------------------------
+// The reference benchmark's loop is `tt_emb(indices, offsets).backward(grad)` per request (tt_embeddings_benchmark.py:94-108).
+// With a fused optimizer the graph under that output is ONE node (this file's) whose backward returns no gradient to anybody:
+// the engine's graph task, its hand-over to the device thread and back cost ~40 us of host time per step (scripts/host_time.py) --
+// more than the step's kernels take -- to call one function.  NodeRef::backward calls it on the calling thread.  Only where that
+// is exactly what the engine would do: the module installs it for fused optimizers without a weight gradient only, and every
+// condition below that the engine would treat differently (hooks, anomaly mode, another stream, a gradient that is itself part
+// of a graph, a wrong shape) returns false -> the caller takes Tensor.backward's ordinary route.
+struct NodeRef {
+  std::shared_ptr<torch::autograd::Node> fn;
+  int64_t num_tables = 0, B = 0, D = 0;
+  bool backward(const Tensor& grad) {
+    using torch::autograd::Node;
+    Node* n = fn.get();
+    if (!n || !grad.defined() || !grad.is_cuda() || grad.scalar_type() != at::kFloat || grad.requires_grad()) return false;
+    if (!n->tensor_pre_hooks().empty() || !n->pre_hooks().empty() || !n->post_hooks().empty() ||
+        !n->retains_grad_hooks().empty() || torch::autograd::AnomalyMode::is_enabled())
+      return false;
+    Tensor g = grad;
+    if (g.dim() == 2 && num_tables == 1) g = g.unsqueeze(0);  // (TTEmbeddingBag hands out the squeezed view)
+    if (g.dim() != 3 || g.size(0) != num_tables || g.size(1) != B || g.size(2) != D) return false;
+    // the engine runs a node on the stream its forward ran on; only the same stream is the same thing here
+    const auto fs = n->stream();
+    if (fs.has_value() && (fs->device_index() != g.get_device() ||
+                           *fs != c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(fs->device_index()).unwrap()))
+      return false;
+    at::AutoGradMode no_grad(false);
+    variable_list outs = (*n)(variable_list{g});
+    for (const auto& o : outs) TORCH_INTERNAL_ASSERT(!o.defined(), "tt_embeddings: the direct backward is for fused optimizers only");
+    n->release_variables();  // (as the engine does without retain_graph)
+    return true;
+  }
+  // the node as Python sees it (tensor.grad_fn): a root for torch.autograd.backward when the tensor itself is gone
+  pybind11::object node() const { return pybind11::reinterpret_steal<pybind11::object>(torch::autograd::functionToPyObject(fn)); }
+};
+NodeRef node_of(const Tensor& out) {
+  NodeRef r;
+  r.fn = out.grad_fn();
+  TORCH_CHECK(r.fn && out.dim() == 3 &&
+                  (dynamic_cast<torch::autograd::CppNode<TTLookupOp>*>(r.fn.get()) != nullptr ||
+                   dynamic_cast<torch::autograd::CppNode<TTCachedLookupOp>*>(r.fn.get()) != nullptr),
+              "tt_embeddings: node_of() takes the tensor lookup() / lookup_cached() returned");
+  r.num_tables = out.size(0);
+  r.B = out.size(1);
+  r.D = out.size(2);
+  return r;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  pybind11::class_<NodeRef>(m, "NodeRef")
+      .def("backward", &NodeRef::backward,
+           "run the node's backward (fused optimizer step) on the calling thread; False = not the plain case, use autograd")
+      .def("node", &NodeRef::node, "the node as tensor.grad_fn would return it");
+  m.def("node_of", &node_of, "the autograd node behind an output of lookup() / lookup_cached()");
   m.doc() = "native autograd node of the TT lookup (cache not live) over the C ABI of libttx.so";
   m.def("lookup", &lookup, "prologue + forward; backward = fused optimizer step or dense core gradients",
         pybind11::arg("indices"), pybind11::arg("offsets"), pybind11::arg("num_tables"), pybind11::arg("p"),

@@ -35,6 +35,7 @@ import logging
 import math
 import os
 from operator import is_ as _is
+from weakref import ref as _weakref
 import random
 from enum import Enum, unique
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
@@ -63,6 +64,41 @@ def _native_node():
         except ImportError:
             _native = False
     return _native or None
+
+
+class _DirectBackward:
+    """`out.backward(grad)` of a lookup's own output, installed on the tensor the module returns (an instance attribute
+    shadows Tensor.backward).  The reference benchmark's loop is `tt_emb(indices, offsets).backward(grad)`
+    (tt_embeddings_benchmark.py:94-108); with a fused optimizer the graph under that output is the lookup's one node, which
+    returns no gradient to anybody, and autograd's engine spends ~40 us of host time per step (graph task, hand-over to its
+    device thread and back) on calling it -- more than the step's kernels take.  This calls the node on the calling thread
+    (csrc/ttx_torch.cpp NodeRef::backward) and falls back to Tensor.backward for everything that is not that plain case:
+    retain_graph / create_graph / inputs=, no gradient argument, hooks on the tensor, anomaly mode, another stream, a gradient
+    that is part of a graph.  Any OTHER use of the output (as an operand of further ops, torch.autograd.backward / grad) never
+    comes here.  TTX_NO_DIRECT_BACKWARD=1 switches it off."""
+    __slots__ = ("ref", "owner")
+
+    def __init__(self, ref, owner):
+        self.ref = ref
+        self.owner = _weakref(owner)  # (the tensor holds this object: no cycle)
+
+    def __call__(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        # (`m(i, o).backward(g)` on a temporary: the attribute look-up -- an instance attribute, not a bound method -- lets go of
+        #  the tensor before the call, and the weak reference is dead; nobody can have put a hook on a tensor that had no name)
+        o = self.owner()
+        # (hooks / retain_grad() on the squeezed view live on the VIEW's node, which the direct call does not pass through)
+        if (gradient is not None and not retain_graph and not create_graph and inputs is None
+                and (o is None or (not o._backward_hooks and not o.retains_grad)) and self.ref.backward(gradient)):
+            return None
+        if o is not None:
+            return torch.Tensor.backward(o, gradient, retain_graph, create_graph, inputs)
+        if gradient is not None and gradient.dim() == 2:
+            gradient = gradient.unsqueeze(0)  # (the node's own output is [num_tables, B, D])
+        return torch.autograd.backward(torch.autograd.graph.GradientEdge(self.ref.node(), 0), gradient, retain_graph, create_graph,
+                                       inputs=inputs)
+
+
+_DIRECT_BACKWARD = os.environ.get("TTX_NO_DIRECT_BACKWARD", "0") in ("", "0")
 
 
 @unique
@@ -902,12 +938,15 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                 fa = self._fa = (list(self.tt_cores), list(self.optimizer_state), self.hashtbl if self.use_cache else None,
                                  self.cache_freq if self.use_cache else None,
                                  getattr(self, "_p_flat", self.tt_p_shapes))  # (per-table factors: flattened)
-            return fast.lookup(indices if indices.is_contiguous() else indices.contiguous(),
-                               offsets if offsets.is_contiguous() else offsets.contiguous(), self.num_tables, fa[4],
-                               self.tt_q_shapes, self.tt_ranks, optim, self.learning_rate, self.eps,
-                               fa[2] if count else None, fa[3] if count else None,
-                               fa[1] if use_state else [], fa[0], per_sample_weights,
-                               *(pre if pre is not None else (None, None, None)))
+            out = fast.lookup(indices if indices.is_contiguous() else indices.contiguous(),
+                              offsets if offsets.is_contiguous() else offsets.contiguous(), self.num_tables, fa[4],
+                              self.tt_q_shapes, self.tt_ranks, optim, self.learning_rate, self.eps,
+                              fa[2] if count else None, fa[3] if count else None,
+                              fa[1] if use_state else [], fa[0], per_sample_weights,
+                              *(pre if pre is not None else (None, None, None)))
+            if optim != 2 and _DIRECT_BACKWARD and out.requires_grad and (per_sample_weights is None or not per_sample_weights.requires_grad):
+                out.backward = _DirectBackward(fast.node_of(out), out)  # (fused optimizer: see _DirectBackward)
+            return out
         if (fast is not None and not self.warmup and self.use_cache and self.num_tables == 1 and indices.is_cuda
                 and indices.numel() > 0):
             # cache live: frequency update + hash lookup + stable partition (split point kept on the device),
@@ -925,12 +964,15 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             if fc is None:
                 fc = self._fc = (list(self.tt_cores), list(self.optimizer_state), self.hashtbl, self.cache_freq, self.cache_state,
                                  self.cache_optimizer_state, self.cache_weight)
-            return fast.lookup_cached(indices if indices.is_contiguous() else indices.contiguous(),
-                                      offsets if offsets.is_contiguous() else offsets.contiguous(), self.tt_p_shapes, self.tt_q_shapes,
-                                      self.tt_ranks, optim | (256 if self._pf_counted else 0), self.learning_rate, self.eps,
-                                      fc[2], fc[3], fc[4], fc[5] if use_state else None,
-                                      fc[6], fc[1] if use_state else [],
-                                      fc[0], list(pre) if pre is not None else [], per_sample_weights)
+            out = fast.lookup_cached(indices if indices.is_contiguous() else indices.contiguous(),
+                                     offsets if offsets.is_contiguous() else offsets.contiguous(), self.tt_p_shapes, self.tt_q_shapes,
+                                     self.tt_ranks, optim | (256 if self._pf_counted else 0), self.learning_rate, self.eps,
+                                     fc[2], fc[3], fc[4], fc[5] if use_state else None,
+                                     fc[6], fc[1] if use_state else [],
+                                     fc[0], list(pre) if pre is not None else [], per_sample_weights)
+            if optim != 2 and _DIRECT_BACKWARD and out.requires_grad and (per_sample_weights is None or not per_sample_weights.requires_grad):
+                out.backward = _DirectBackward(fast.node_of(out), out)
+            return out
         prologue = getattr(_engine, "lookup_prologue", None)
         if prologue is not None and self.warmup and indices.numel() > 0:
             # cache not live: frequency update, offsets -> bag rows and the lookup plan in one native call
@@ -982,4 +1024,9 @@ class TTEmbeddingBag(TableBatchedTTEmbeddingBag):
                 per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
         # squeeze is a view both ways: `[0]` would make autograd materialise a zero [1,B,D] buffer
         # and copy the gradient into it (two extra kernels per step)
-        return super().forward(indices, offsets, warmup, per_sample_weights).squeeze(0)
+        out = super().forward(indices, offsets, warmup, per_sample_weights)
+        res = out.squeeze(0)
+        d = out.__dict__.get("backward")
+        if d is not None:  # (the lookup's own node: backward() of the view is backward() of the node, see _DirectBackward)
+            res.backward = _DirectBackward(d.ref, res)
+        return res

@@ -400,3 +400,65 @@ def test_device_side_counts_equal_exact_sizes(n_live, p):
                                       w1.data_ptr(), st) == 0
     E.cache_backward_sgd(nnz - n_live, gr, loc[n_live:], rowidx[n_live:], 0.1, w2)
     assert_close(w1.cpu().numpy(), w2.cpu().numpy(), "cache SGD scatter behind a device-side split point")
+
+
+@pytest.mark.gpu
+def test_fused_update_and_lookup_sees_the_batchs_own_inserts():
+    """Round 5.  The reference counts a batch into the table in one launch and looks it up in the next (cu:1077-1113, 1356-1375),
+    so a look-up sees every insert of ITS batch.  That decides hit or miss for a cached key that sits at its 2nd / 3rd probe
+    behind a slot populate emptied: the batch's count re-inserts the key into the empty slot, the look-up finds that copy
+    (cache_state -1) and the key is a TT lookup.  Here both happen in one launch (rowidx_update_kernel); a plain find raced with
+    the other copies' inserts -- hit or miss by timing.  Constructed: 200 cached keys, every one at its second probe behind an
+    empty slot, each looked up ~150 times across many waves and work-groups, next to keys cached at their first probe and new
+    keys; partition, split point and table against the oracle run in the reference's order (update, then look-up), ten times."""
+    import tt_embeddings as E
+
+    H, cs, E_ = 1 << 14, 512, 1 << 20
+    rs = np.random.RandomState(17)
+    keys = np.full(H, -1, dtype=np.int64)
+    freq = np.zeros(H, dtype=np.int64)
+    state = np.full(H, -1, dtype=np.int32)
+    behind, front = [], []
+    cand = rs.permutation(E_)
+    loc = 0
+    for k in cand:
+        h = O.hash64(int(k), H)
+        if keys[h] != -1 or keys[(h + 1) % H] != -1 or keys[(h + 2) % H] != -1 or keys[(h - 1) % H] != -1:
+            continue  # (keep the probe sequences of the constructed keys apart)
+        if len(behind) < 200:
+            keys[(h + 1) % H], freq[(h + 1) % H], state[(h + 1) % H] = k, 50, loc  # cached at the 2nd probe, 1st probe empty
+            behind.append(int(k))
+        elif len(front) < 200:
+            keys[h], freq[h], state[h] = k, 50, loc  # cached at the 1st probe
+            front.append(int(k))
+        else:
+            break
+        loc += 1
+    # new keys: nowhere near the constructed probe sequences (a new key racing a re-insert for the empty slot would be decided
+    # by hardware order, here as in the reference)
+    taken = np.flatnonzero(keys != -1)
+    near = np.zeros(H, dtype=bool)
+    for d in range(-3, 4):
+        near[(taken + d) % H] = True
+    new = [int(k) for k in cand[-6000:] if not near[O.hash64(int(k), H)]][:1500]
+    assert len(new) == 1500
+    for rep in range(10):
+        idx = np.concatenate([rs.choice(behind, 30000), rs.choice(front, 20000), rs.choice(new, 10000)]).astype(np.int64)
+        rs.shuffle(idx)
+        n, B = idx.size, 512
+        off = np.concatenate([[0], np.cumsum(rs.multinomial(n, np.ones(B) / B))]).astype(np.int64)
+        ok, of = keys.copy(), freq.copy()
+        O.update_cache_state(idx, ok, of)
+        exp = O.preprocess_indices(idx, off, 1, False, ok, state)
+        dk, df = t(keys), t(freq)
+        got = E.preprocess_indices_sync(t(idx), t(off), 1, False, dk, t(state), df)
+        assert exp[3] == 40000, "the oracle, in the reference's order: every key behind an empty slot has become a TT lookup"
+        assert got[3] == exp[3], f"split point {got[3]} (one launch) vs {exp[3]} (update, then look-up)"
+        assert np.array_equal(got[0].cpu().numpy(), exp[0]) and np.array_equal(got[1].cpu().numpy(), exp[1])
+        assert np.array_equal(got[4].cpu().numpy()[exp[3]:], exp[4][exp[3]:])
+        # the table: the constructed keys sit where the oracle put them, with its counts (new keys that collide with EACH OTHER
+        # may swap slots or drop another one of them, as in the reference)
+        gk, gf = dk.cpu().numpy(), df.cpu().numpy()
+        con = np.isin(ok, np.array(behind + front, dtype=np.int64))
+        assert np.array_equal(gk[con], ok[con]) and np.array_equal(gf[con], of[con])
+        assert abs(int(gf.sum()) - int(of.sum())) <= 200  # (which new keys are dropped after 3 probes depends on their order)

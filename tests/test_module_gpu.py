@@ -1452,3 +1452,114 @@ def test_graphed_step_with_static_buffers_tracks_eager_for_20_steps(node):
         assert torch.equal(a, b)
     with pytest.raises(ValueError):
         step(batches[0][0][:-1], off, batches[0][2])
+
+
+@pytest.mark.parametrize("optimizer", ["SGD", "EXACT_ADAGRAD"])
+@pytest.mark.parametrize("live", [False, True])
+def test_backward_of_the_lookups_own_output_past_the_engine(node, optimizer, live, monkeypatch):
+    """Round 5: `tt_emb(indices, offsets).backward(grad)` -- the reference benchmark's loop (tt_embeddings_benchmark.py:94-108) --
+    with a fused optimizer calls the lookup's node on the calling thread instead of going through autograd's engine
+    (tt_embeddings_ops._DirectBackward, csrc/ttx_torch.cpp NodeRef).  Same node, same kernels: four steps leave cores, optimizer
+    state and cache rows BIT-identical to the engine's route, for both module classes, cache counting and cache live; and
+    everything that is not the plain case takes the engine: hooks, retain_graph, dense gradients, weights that need a gradient,
+    the output as an operand of further ops."""
+    import gc
+    import weakref
+    import tt_embeddings_ops as ops
+
+    if node != "native":
+        pytest.skip("the direct backward belongs to the C++ node")
+    p, q, r = [20, 22, 25], [4, 4, 4], [16, 16]
+    E_, D, B = 20 * 22 * 25, 64, 64
+
+    def fresh(cls=ops.TTEmbeddingBag, sparse=True):
+        # (live: a cache that holds every key of the warm-up batches -- nothing is evicted, so no cached key sits behind an emptied
+        #  slot where its re-insert could race a new key's insert for the hit / miss decision, as it can in the reference)
+        extra = dict(use_cache=True, cache_size=4096, hashtbl_size=1 << 14) if live else dict(use_cache=False)
+        args = (E_, D, r, p, q) if cls is ops.TTEmbeddingBag else (1, E_, D, r, p, q)
+        m = cls(*args, sparse=sparse, optimizer=getattr(ops.OptimType, optimizer), learning_rate=0.05, eps=1e-3,
+                weight_dist="uniform", device=DEV, **extra)
+        with torch.no_grad():
+            for dst, src in zip(m.tt_cores, G.make_cores(95, 1, p, q, [1] + r + [1], "signed")):
+                dst.copy_(t(src))
+        return m
+
+    batches = []
+    for step in range(4):
+        idx, off = G.make_bags(500 + step, B, E_, 6, 3, 1)
+        batches.append((t(idx), t(off), t(G.make_grad(600 + step, 1, B, D)[0])))
+
+    def pair(cls=ops.TTEmbeddingBag):
+        a, b = fresh(cls), fresh(cls)
+        if live:  # count two of the four batches, populate (the other two bring keys the cache does not hold: TT lookups);
+            with torch.no_grad():  # b takes a's table and cache as they are
+                for i, o, _ in batches[:2]:
+                    a(i, o)
+            a.cache_populate()
+            b.load_state_dict(a.state_dict())
+            b.warmup = False
+            assert not a.warmup
+        return a, b
+
+    def train(m, single):
+        taken = []
+        for i, o, g in batches:
+            out = m(i, o)
+            taken.append("backward" in out.__dict__)
+            out.backward(g if single else g.unsqueeze(0))
+        torch.cuda.synchronize()
+        return taken
+
+    for cls in (ops.TTEmbeddingBag, ops.TableBatchedTTEmbeddingBag):
+        single = cls is ops.TTEmbeddingBag
+        a, b = pair(cls)
+        assert all(train(a, single)), "the module is expected to install the direct backward on this route"
+        monkeypatch.setattr(ops, "_DIRECT_BACKWARD", False)
+        assert not any(train(b, single))
+        monkeypatch.setattr(ops, "_DIRECT_BACKWARD", True)
+        for x, y in zip(a.tt_cores, b.tt_cores):
+            assert torch.equal(x, y)
+        for x, y in zip(a.optimizer_state, b.optimizer_state):
+            assert torch.equal(x, y)
+        if live:  # (cache rows take their updates through float atomics: equal to rounding)
+            assert torch.allclose(a.cache_weight, b.cache_weight, rtol=0, atol=1e-6)
+
+    # what is not the plain case goes through the engine, with the engine's semantics
+    m, e = pair()
+    i, o, g = batches[0]
+    seen = []
+    out = m(i, o)
+    out.register_hook(lambda gr: seen.append(gr.clone()))
+    out.backward(g)
+    assert len(seen) == 1 and torch.equal(seen[0], g), "a hook on the output must see the gradient"
+    monkeypatch.setattr(ops, "_DIRECT_BACKWARD", False)
+    e(i, o).backward(g)
+    monkeypatch.setattr(ops, "_DIRECT_BACKWARD", True)
+    for x, y in zip(m.tt_cores, e.tt_cores):
+        assert torch.equal(x, y)
+    out = m(i, o)
+    out.backward(g, retain_graph=True)  # (the engine's route; the call form must keep working)
+    with pytest.raises(RuntimeError):
+        m(i, o).backward()  # no gradient for a non-scalar: autograd's own error
+    (m(i, o) * 2.0).sum().backward()  # the output as an operand
+    if not live:
+        dense = fresh(sparse=False)
+        out = dense(i, o)
+        assert "backward" not in out.__dict__
+        out.backward(g)
+        assert all(c.grad is not None for c in dense.tt_cores)
+        w = torch.rand(i.numel(), device=DEV, requires_grad=True)
+        out = m(i, o, per_sample_weights=w)
+        assert "backward" not in out.__dict__
+        out.backward(g)
+        assert w.grad is not None
+    # the tensor holds the callable, the callable only a weak reference to the tensor: freed without the collector
+    gc.disable()
+    try:
+        out = m(i, o)
+        assert "backward" in out.__dict__
+        wr = weakref.ref(out)
+        del out
+        assert wr() is None
+    finally:
+        gc.enable()
