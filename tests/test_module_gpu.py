@@ -1563,3 +1563,81 @@ def test_backward_of_the_lookups_own_output_past_the_engine(node, optimizer, liv
         assert wr() is None
     finally:
         gc.enable()
+
+
+_ROUTES = [
+    # name, module kwargs (beyond the common ones), p, q, ranks, tables
+    ("three cores, r = 32 templates", dict(), [20, 22, 25], [4, 4, 4], [32, 32], 1),
+    ("three cores, Adagrad at r = 64", dict(optimizer="EXACT_ADAGRAD"), [20, 22, 25], [4, 4, 8], [64, 64], 1),
+    ("generic kernels (ranks 20 / 12)", dict(), [20, 22, 25], [4, 4, 4], [20, 12], 1),
+    ("padded factors q = [4, 6, 4]", dict(), [20, 22, 25], [4, 6, 4], [16, 16], 1),
+    ("first factor 8 as part lookups", dict(), [6, 7, 8], [8, 4, 4], [16, 16], 1),
+    ("three tables in one launch set", dict(), [20, 22, 25], [4, 4, 4], [16, 16], 3),
+    ("two cores", dict(), [90, 80], [16, 8], [32], 1),
+    ("four cores (MFMA gradient helper)", dict(), [8, 9, 10, 11], [4, 4, 4, 4], [32, 32, 32], 1),
+    ("four cores (VALU helper)", dict(), [8, 9, 10, 11], [3, 4, 2, 3], [13, 12, 7], 1),
+    ("duplicate lookups share their contraction", dict(dedup=True), [20, 22, 25], [4, 4, 4], [32, 32], 1),
+    ("frequency table counting along", dict(use_cache=True, cache_size=256, hashtbl_size=1 << 14), [20, 22, 25], [4, 4, 4], [32, 32], 1),
+    # (a cache that holds every key of the three warm-up batches: nothing evicted, so no cached key behind an emptied slot whose
+    #  re-insert could race a new key's insert -- the one decision the reference, too, leaves to hardware order)
+    ("cache live (hits and misses)", dict(use_cache=True, cache_size=8192, hashtbl_size=1 << 15, live=3), [20, 22, 25], [4, 4, 4], [32, 32], 1),
+]
+
+
+@pytest.mark.parametrize("route", _ROUTES, ids=[r[0] for r in _ROUTES])
+def test_free_running_training_is_run_to_run_identical(node, route):
+    """Round 5 (after a cache-live look-up turned out to be hit or miss by timing, found only because two modules in one state
+    were run free and compared): every route, eight fused-optimizer steps on a skewed stream with nothing between them but the
+    next call -- twice from the same state: cores and optimizer state BIT-identical.  No float atomics on the TT path, no
+    decision taken by timing."""
+    import tt_embeddings_ops as ops
+
+    name, extra, p, q, ranks, tables = route
+    extra = dict(extra)
+    opt = getattr(ops.OptimType, extra.pop("optimizer", "SGD"))
+    live = extra.pop("live", 0)
+    E_, D, B = int(np.prod(p)), int(np.prod(q)), 192
+    cores = G.make_cores(97, tables, p, q, [1] + ranks + [1], "signed")
+    rs = np.random.RandomState(98)
+    batches = []
+    for step in range(8):
+        idx, off = G.make_bags(700 + step, B, E_, 8, 4, tables)
+        idx = np.where(rs.rand(idx.size) < 0.3, idx[rs.randint(0, idx.size, idx.size)] % 50, idx)  # (a hot head: duplicates, hot slices)
+        g = G.make_grad(800 + step, tables, B, D)
+        batches.append((t(idx), t(off), t(g if tables > 1 else g[0])))
+
+    def run():
+        kw = dict(sparse=True, optimizer=opt, learning_rate=0.05, eps=1e-3, weight_dist="uniform", device=DEV, use_cache=False)
+        kw.update(extra)
+        if tables > 1:
+            m = ops.TableBatchedTTEmbeddingBag(tables, E_, D, ranks, p, q, **kw)
+        else:
+            m = ops.TTEmbeddingBag(E_, D, ranks, p, q, **kw)
+        with torch.no_grad():
+            for dst, src in zip(m.tt_cores, cores):
+                dst.copy_(t(src))
+        if live:
+            with torch.no_grad():
+                for i, o, _ in batches[:live]:
+                    m(i, o)
+            m.cache_populate()
+            assert not m.warmup
+        for i, o, g in batches:
+            m(i, o).backward(g)
+        torch.cuda.synchronize()
+        rows = None
+        if live:  # the cached rows BY KEY (which cache row a key got depends on where racing inserts seated the keys of equal count)
+            k_, s_, w_ = m.hashtbl.cpu().numpy(), m.cache_state.cpu().numpy(), m.cache_weight.detach().cpu().numpy()
+            sel = (k_ >= 0) & (s_ >= 0)
+            order = np.argsort(k_[sel])
+            rows = (k_[sel][order], w_[s_[sel][order]])
+        return [c.detach().clone() for c in m.tt_cores] + [s.detach().clone() for s in m.optimizer_state], rows
+
+    (a, ca), (b, cb) = run(), run()
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), f"{name}: tensor {k} differs between two free-running runs (max {float((x - y).abs().max()):.3e})"
+    if live:  # (cache rows take their updates through float atomics: equal to rounding -- a hot row sums ~500 terms per step in
+        #  hardware order; a hit / miss flip would be ~5e-3)
+        assert np.array_equal(ca[0], cb[0]), "the same keys are cached"
+        err = np.abs(ca[1] - cb[1]).max()
+        assert err <= 2e-5, f"cache rows by key: max difference {err:.3e}"
