@@ -66,39 +66,51 @@ def _native_node():
     return _native or None
 
 
-class _DirectBackward:
-    """`out.backward(grad)` of a lookup's own output, installed on the tensor the module returns (an instance attribute
-    shadows Tensor.backward).  The reference benchmark's loop is `tt_emb(indices, offsets).backward(grad)`
-    (tt_embeddings_benchmark.py:94-108); with a fused optimizer the graph under that output is the lookup's one node, which
-    returns no gradient to anybody, and autograd's engine spends ~40 us of host time per step (graph task, hand-over to its
-    device thread and back) on calling it -- more than the step's kernels take.  This calls the node on the calling thread
-    (csrc/ttx_torch.cpp NodeRef::backward) and falls back to Tensor.backward for everything that is not that plain case:
-    retain_graph / create_graph / inputs=, no gradient argument, hooks on the tensor, anomaly mode, another stream, a gradient
-    that is part of a graph.  Any OTHER use of the output (as an operand of further ops, torch.autograd.backward / grad) never
-    comes here.  TTX_NO_DIRECT_BACKWARD=1 switches it off."""
-    __slots__ = ("ref", "owner")
-
-    def __init__(self, ref, owner):
-        self.ref = ref
-        self.owner = _weakref(owner)  # (the tensor holds this object: no cycle)
-
-    def __call__(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
-        # (`m(i, o).backward(g)` on a temporary: the attribute look-up -- an instance attribute, not a bound method -- lets go of
-        #  the tensor before the call, and the weak reference is dead; nobody can have put a hook on a tensor that had no name)
-        o = self.owner()
-        # (hooks / retain_grad() on the squeezed view live on the VIEW's node, which the direct call does not pass through)
-        if (gradient is not None and not retain_graph and not create_graph and inputs is None
-                and (o is None or (not o._backward_hooks and not o.retains_grad)) and self.ref.backward(gradient)):
-            return None
-        if o is not None:
-            return torch.Tensor.backward(o, gradient, retain_graph, create_graph, inputs)
-        if gradient is not None and gradient.dim() == 2:
-            gradient = gradient.unsqueeze(0)  # (the node's own output is [num_tables, B, D])
-        return torch.autograd.backward(torch.autograd.graph.GradientEdge(self.ref.node(), 0), gradient, retain_graph, create_graph,
-                                       inputs=inputs)
-
-
+# ---- `out.backward(grad)` of a lookup's own output, past autograd's engine ---------------------------------------------------------
+# The reference benchmark's loop is `tt_emb(indices, offsets).backward(grad)` (tt_embeddings_benchmark.py:94-108); with a fused
+# optimizer the graph under that output is the lookup's one node, which returns no gradient to anybody, and autograd's engine
+# spends ~40 us of host time per step (graph task, hand-over to its device thread and back) on calling it -- more than the step's
+# kernels take.  The module registers the tensors it returns on that route (`_direct_register`), and `Tensor.backward` -- wrapped
+# once, below -- calls the node on the calling thread for exactly those tensors (csrc/ttx_torch.cpp NodeRef::backward) when the call
+# is the plain one: a gradient and nothing else (no retain_graph / create_graph / inputs=), no hooks or retain_grad() on the
+# tensor; NodeRef::backward itself declines on hooks on the node, anomaly mode, another current stream than the forward's, a
+# gradient that is part of a graph or has the wrong shape.  Everything declined, every other tensor and every other USE of the
+# output (operand of further ops, torch.autograd.backward / grad) is the original Tensor.backward.  The registry is a side table
+# keyed by id() with a weak reference per entry: nothing is stored ON the tensor (torch.save / pickle of an output see no foreign
+# attribute), an entry goes when its tensor goes.  TTX_NO_DIRECT_BACKWARD=1: no wrapping, no registry.
 _DIRECT_BACKWARD = os.environ.get("TTX_NO_DIRECT_BACKWARD", "0") in ("", "0")
+_direct: Dict[int, tuple] = {}  # id(output tensor) -> (weak reference to it, NodeRef)
+
+
+class _KeyRef(_weakref):
+    __slots__ = ("key",)
+
+
+def _direct_drop(wr) -> None:
+    _direct.pop(wr.key, None)
+
+
+def _direct_register(out: torch.Tensor, ref) -> None:
+    wr = _KeyRef(out, _direct_drop)
+    wr.key = id(out)
+    _direct[wr.key] = (wr, ref)
+
+
+_tensor_backward = torch.Tensor.backward
+
+
+def _backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+    if _direct:
+        e = _direct.get(id(self))
+        if (e is not None and e[0]() is self and _DIRECT_BACKWARD and gradient is not None and not retain_graph and not create_graph
+                and inputs is None and not self._backward_hooks and not self.retains_grad and e[1].backward(gradient)):
+            return None
+    return _tensor_backward(self, gradient, retain_graph, create_graph, inputs)
+
+
+_backward.__doc__ = _tensor_backward.__doc__
+if _DIRECT_BACKWARD:
+    torch.Tensor.backward = _backward
 
 
 @unique
@@ -945,7 +957,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                               fa[1] if use_state else [], fa[0], per_sample_weights,
                               *(pre if pre is not None else (None, None, None)))
             if optim != 2 and _DIRECT_BACKWARD and out.requires_grad and (per_sample_weights is None or not per_sample_weights.requires_grad):
-                out.backward = _DirectBackward(fast.node_of(out), out)  # (fused optimizer: see _DirectBackward)
+                _direct_register(out, fast.node_of(out))  # (fused optimizer: backward() of this tensor may skip autograd's engine)
             return out
         if (fast is not None and not self.warmup and self.use_cache and self.num_tables == 1 and indices.is_cuda
                 and indices.numel() > 0):
@@ -971,7 +983,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                                      fc[6], fc[1] if use_state else [],
                                      fc[0], list(pre) if pre is not None else [], per_sample_weights)
             if optim != 2 and _DIRECT_BACKWARD and out.requires_grad and (per_sample_weights is None or not per_sample_weights.requires_grad):
-                out.backward = _DirectBackward(fast.node_of(out), out)
+                _direct_register(out, fast.node_of(out))
             return out
         prologue = getattr(_engine, "lookup_prologue", None)
         if prologue is not None and self.warmup and indices.numel() > 0:
@@ -1026,7 +1038,7 @@ class TTEmbeddingBag(TableBatchedTTEmbeddingBag):
         # and copy the gradient into it (two extra kernels per step)
         out = super().forward(indices, offsets, warmup, per_sample_weights)
         res = out.squeeze(0)
-        d = out.__dict__.get("backward")
-        if d is not None:  # (the lookup's own node: backward() of the view is backward() of the node, see _DirectBackward)
-            res.backward = _DirectBackward(d.ref, res)
+        e = _direct.get(id(out)) if _direct else None
+        if e is not None and e[0]() is out:  # (the lookup's own node: backward() of the view is backward() of the node)
+            _direct_register(res, e[1])
         return res

@@ -1459,7 +1459,7 @@ def test_graphed_step_with_static_buffers_tracks_eager_for_20_steps(node):
 def test_backward_of_the_lookups_own_output_past_the_engine(node, optimizer, live, monkeypatch):
     """Round 5: `tt_emb(indices, offsets).backward(grad)` -- the reference benchmark's loop (tt_embeddings_benchmark.py:94-108) --
     with a fused optimizer calls the lookup's node on the calling thread instead of going through autograd's engine
-    (tt_embeddings_ops._DirectBackward, csrc/ttx_torch.cpp NodeRef).  Same node, same kernels: four steps leave cores, optimizer
+    (tt_embeddings_ops._backward / _direct_register, csrc/ttx_torch.cpp NodeRef).  Same node, same kernels: four steps leave cores, optimizer
     state and cache rows BIT-identical to the engine's route, for both module classes, cache counting and cache live; and
     everything that is not the plain case takes the engine: hooks, retain_graph, dense gradients, weights that need a gradient,
     the output as an operand of further ops."""
@@ -1505,7 +1505,7 @@ def test_backward_of_the_lookups_own_output_past_the_engine(node, optimizer, liv
         taken = []
         for i, o, g in batches:
             out = m(i, o)
-            taken.append("backward" in out.__dict__)
+            taken.append(id(out) in ops._direct)
             out.backward(g if single else g.unsqueeze(0))
         torch.cuda.synchronize()
         return taken
@@ -1545,22 +1545,29 @@ def test_backward_of_the_lookups_own_output_past_the_engine(node, optimizer, liv
     if not live:
         dense = fresh(sparse=False)
         out = dense(i, o)
-        assert "backward" not in out.__dict__
+        assert id(out) not in ops._direct
         out.backward(g)
         assert all(c.grad is not None for c in dense.tt_cores)
         w = torch.rand(i.numel(), device=DEV, requires_grad=True)
         out = m(i, o, per_sample_weights=w)
-        assert "backward" not in out.__dict__
+        assert id(out) not in ops._direct
         out.backward(g)
         assert w.grad is not None
-    # the tensor holds the callable, the callable only a weak reference to the tensor: freed without the collector
+    # nothing is stored ON the tensor (it pickles / saves as any tensor), and its registry entry goes when it goes
+    import io
+    import pickle
     gc.disable()
     try:
         out = m(i, o)
-        assert "backward" in out.__dict__
-        wr = weakref.ref(out)
+        assert id(out) in ops._direct and not out.__dict__
+        buf = io.BytesIO()
+        torch.save(out, buf)
+        buf.seek(0)
+        assert torch.equal(torch.load(buf, weights_only=False), out)
+        assert torch.equal(pickle.loads(pickle.dumps(out)), out)
+        key, wr = id(out), weakref.ref(out)
         del out
-        assert wr() is None
+        assert wr() is None and key not in ops._direct
     finally:
         gc.enable()
 
