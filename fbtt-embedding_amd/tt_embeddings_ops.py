@@ -102,8 +102,10 @@ _tensor_backward = torch.Tensor.backward
 def _backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
     if _direct:
         e = _direct.get(id(self))
-        if (e is not None and e[0]() is self and _DIRECT_BACKWARD and gradient is not None and not retain_graph and not create_graph
-                and inputs is None and not self._backward_hooks and not self.retains_grad and e[1].backward(gradient)):
+        # (a gradient of another type or shape goes to the engine for the engine's own error)
+        if (e is not None and e[0]() is self and _DIRECT_BACKWARD and type(gradient) is torch.Tensor and not retain_graph
+                and not create_graph and inputs is None and gradient.shape == self.shape and not self._backward_hooks
+                and not self.retains_grad and e[1].backward(gradient)):
             return None
     return _tensor_backward(self, gradient, retain_graph, create_graph, inputs)
 

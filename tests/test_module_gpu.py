@@ -1541,6 +1541,8 @@ def test_backward_of_the_lookups_own_output_past_the_engine(node, optimizer, liv
     out.backward(g, retain_graph=True)  # (the engine's route; the call form must keep working)
     with pytest.raises(RuntimeError):
         m(i, o).backward()  # no gradient for a non-scalar: autograd's own error
+    with pytest.raises(RuntimeError):
+        m(i, o).backward(g.unsqueeze(0))  # a gradient of another shape than the output: autograd's own error
     (m(i, o) * 2.0).sum().backward()  # the output as an operand
     if not live:
         dense = fresh(sparse=False)
