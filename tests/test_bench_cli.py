@@ -93,3 +93,19 @@ print("DONE")
     out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, env=env)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith(("ERROR", "NO-ERROR", "DONE"))]
     assert lines == ["NO-ERROR", "NO-ERROR", "DONE"], out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_the_reference_benchmarks_command_line_runs():
+    """examples/reference_benchmark_cli.py: the reference benchmark's flags and loop form (tt_embeddings_benchmark.py:123-211) on
+    this library -- a small table, both optimizers, the nn.EmbeddingBag baseline: exit 0 and the three printed quantities."""
+    import re
+
+    script = os.path.join(ROOT, "examples", "reference_benchmark_cli.py")
+    for extra in (["--run-baseline"], ["--optimizer", "adagrad", "--int32-index"], ["--dense", "--q-shapes", "2,4,8", "--ranks", "16,8"]):
+        out = subprocess.run([sys.executable, script, "--batch-size", "64", "--iters", "4", "--pooling-factor", "5", "--p-shapes", "20,22,25"]
+                             + extra, capture_output=True, text=True, timeout=600, env=_env())
+        assert out.returncode == 0, out.stderr[-2000:]
+        m = re.search(r"TTEmbeddingBag FWD-BWD time/nnz: +([0-9.]+) usecs.*true GFLOPS: +([0-9.]+), BW", out.stdout)
+        assert m and float(m.group(1)) > 0 and float(m.group(2)) > 0, out.stdout
+        assert ("EmbeddingBag FWD-BWD(+SGD)" in out.stdout) == ("--run-baseline" in extra)
