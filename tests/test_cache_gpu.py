@@ -402,19 +402,12 @@ def test_device_side_counts_equal_exact_sizes(n_live, p):
     assert_close(w1.cpu().numpy(), w2.cpu().numpy(), "cache SGD scatter behind a device-side split point")
 
 
-@pytest.mark.gpu
-def test_fused_update_and_lookup_sees_the_batchs_own_inserts():
-    """Round 5.  The reference counts a batch into the table in one launch and looks it up in the next (cu:1077-1113, 1356-1375),
-    so a look-up sees every insert of ITS batch.  That decides hit or miss for a cached key that sits at its 2nd / 3rd probe
-    behind a slot populate emptied: the batch's count re-inserts the key into the empty slot, the look-up finds that copy
-    (cache_state -1) and the key is a TT lookup.  Here both happen in one launch (rowidx_update_kernel); a plain find raced with
-    the other copies' inserts -- hit or miss by timing.  Constructed: 200 cached keys, every one at its second probe behind an
-    empty slot, each looked up ~150 times across many waves and work-groups, next to keys cached at their first probe and new
-    keys; partition, split point and table against the oracle run in the reference's order (update, then look-up), ten times."""
-    import tt_embeddings as E
-
-    H, cs, E_ = 1 << 14, 512, 1 << 20
-    rs = np.random.RandomState(17)
+def table_with_cached_keys_behind_emptied_slots(seed=17, H=1 << 14, E_=1 << 20):
+    """-> keys, freq, state (a live table), and three key lists: 200 cached keys at their SECOND probe behind an empty first one
+    (what cache_populate leaves when it evicts the key that sat in front), 200 cached at their first probe, 1500 new keys whose
+    probes stay clear of all of them (a new key racing a re-insert for an empty slot is decided by hardware order, here as in
+    the reference), and the generator"""
+    rs = np.random.RandomState(seed)
     keys = np.full(H, -1, dtype=np.int64)
     freq = np.zeros(H, dtype=np.int64)
     state = np.full(H, -1, dtype=np.int32)
@@ -434,14 +427,28 @@ def test_fused_update_and_lookup_sees_the_batchs_own_inserts():
         else:
             break
         loc += 1
-    # new keys: nowhere near the constructed probe sequences (a new key racing a re-insert for the empty slot would be decided
-    # by hardware order, here as in the reference)
     taken = np.flatnonzero(keys != -1)
     near = np.zeros(H, dtype=bool)
     for d in range(-3, 4):
         near[(taken + d) % H] = True
     new = [int(k) for k in cand[-6000:] if not near[O.hash64(int(k), H)]][:1500]
     assert len(new) == 1500
+    return keys, freq, state, behind, front, new, rs
+
+
+@pytest.mark.gpu
+def test_fused_update_and_lookup_sees_the_batchs_own_inserts():
+    """Round 5.  The reference counts a batch into the table in one launch and looks it up in the next (cu:1077-1113, 1356-1375),
+    so a look-up sees every insert of ITS batch.  That decides hit or miss for a cached key that sits at its 2nd / 3rd probe
+    behind a slot populate emptied: the batch's count re-inserts the key into the empty slot, the look-up finds that copy
+    (cache_state -1) and the key is a TT lookup.  Here both happen in one launch (rowidx_update_kernel); a plain find raced with
+    the other copies' inserts -- hit or miss by timing.  Constructed: 200 cached keys, every one at its second probe behind an
+    empty slot, each looked up ~150 times across many waves and work-groups, next to keys cached at their first probe and new
+    keys; partition, split point and table against the oracle run in the reference's order (update, then look-up), ten times."""
+    import tt_embeddings as E
+
+    H = 1 << 14
+    keys, freq, state, behind, front, new, rs = table_with_cached_keys_behind_emptied_slots(17, H)
     for rep in range(10):
         idx = np.concatenate([rs.choice(behind, 30000), rs.choice(front, 20000), rs.choice(new, 10000)]).astype(np.int64)
         rs.shuffle(idx)

@@ -318,3 +318,33 @@ def test_second_populate_differs_from_reference_only_on_evicted_slots():
     finally:
         E.set_reference_exact(0)
         O.set_reference_exact(0)
+
+
+def test_lookup_after_the_batchs_own_update_vs_reference_kernels():
+    """Round 5: the reference counts a batch into the table (update_cache_state_kernel) and looks it up in the NEXT launch
+    (cache_lookup_kernel); the product does both in one.  On a table with cached keys behind emptied slots -- where the batch's
+    own re-insert decides hit or miss -- the reference's two kernels, run here one after the other, and the product's one launch
+    give the same is_tt / cache locations / partition and leave the same counts on the constructed keys."""
+    import tt_embeddings as E
+    from test_cache_gpu import table_with_cached_keys_behind_emptied_slots
+
+    H = 1 << 14
+    keys, freq, state, behind, front, new, rs = table_with_cached_keys_behind_emptied_slots(23, H)
+    for rep in range(3):
+        idx = np.concatenate([rs.choice(behind, 30000), rs.choice(front, 20000), rs.choice(new, 10000)]).astype(np.int64)
+        rs.shuffle(idx)
+        n, B = idx.size, 512
+        off = np.concatenate([[0], np.cumsum(rs.multinomial(n, np.ones(B) / B))]).astype(np.int64)
+        rk, rf = t(keys), t(freq)
+        R.update_cache_state(t(idx), rk, rf)
+        is_tt, loc = R.cache_lookup(t(idx), rk, t(state))
+        is_tt_h, loc_h = is_tt.cpu().numpy(), loc.cpu().numpy()
+        assert int(is_tt_h.sum()) == 40000, "the reference: every key behind an emptied slot is a TT lookup after its batch's update"
+        sel, rej = np.flatnonzero(is_tt_h), np.flatnonzero(~is_tt_h)[::-1]
+        pk, pf = t(keys), t(freq)
+        got = E.preprocess_indices_sync(t(idx), t(off), 1, False, pk, t(state), pf)
+        assert got[3] == sel.size
+        assert np.array_equal(got[0].cpu().numpy(), idx[np.concatenate([sel, rej])]), "partitioned colidx"
+        assert np.array_equal(got[4].cpu().numpy()[sel.size:], loc_h[rej]), "cache locations of the cached entries"
+        con = np.isin(rk.cpu().numpy(), np.array(behind + front, dtype=np.int64))
+        assert np.array_equal(pk.cpu().numpy()[con], rk.cpu().numpy()[con]) and np.array_equal(pf.cpu().numpy()[con], rf.cpu().numpy()[con])
