@@ -127,8 +127,13 @@ def flop_per_nnz_fwd_executed(q, r):
     """what the kernels here execute per lookup (forward).  Two and three cores: the reference's left-to-right count.  Four cores with
     q2 q3 <= 16 (the route through the three-core kernels): the last two cores are contracted first --
     r2 q2 r3 q3 multiply-adds for M = core_2 . core_3 -- and the lookup is a three-core lookup with the merged last factor."""
-    if len(q) == 4 and q[2] * q[3] <= 16:
-        return 2.0 * (r[1] * q[2] * r[2] * q[3]) + flop_per_nnz_fwd([q[0], q[1], q[2] * q[3]], [r[0], r[1]])
+    if len(q) == 4:
+        # (round 6, advisor: the predicate is the LIBRARY's -- csrc/ttx_tt.hip t4_merge_dims, q2 q3 <= 32 with q3 <= 8 where a
+        #  three-core template holds the merged shape -- asked through its stateless tile query: no generic walk = the merged route)
+        import tt_embeddings as E
+
+        if E.debug_tiles(1, [4, 4, 4, 4], list(q), [1] + list(r) + [1])["MC"] == 0:
+            return 2.0 * (r[1] * q[2] * r[2] * q[3]) + flop_per_nnz_fwd([q[0], q[1], q[2] * q[3]], [r[0], r[1]])
     return flop_per_nnz_fwd(q, r)
 
 
@@ -444,6 +449,18 @@ def main():
     eager_profiled = eager_elapsed
     eager_elapsed = timed(eager_steps, args.steps)
     eager_regions = [eager_elapsed]
+    # ... and once more with the OPT-IN direct backward (round 6: importing the module no longer wraps torch.Tensor.backward;
+    # ops.enable_direct_backward() does, explicitly): `out.backward(grad)` of the lookup's own output calls its node on the
+    # calling thread instead of going through autograd's engine.  Reported beside the plain figure, never instead of it.
+    eager_direct = None
+    if not sharded and hasattr(ops, "enable_direct_backward"):
+        ops.enable_direct_backward()
+        try:
+            eager_steps(min(args.warmup, 10))
+            sync()
+            eager_direct = timed(eager_steps, args.steps)
+        finally:
+            ops.disable_direct_backward()
 
     def build_line(mode, regions, breakdown, a2a, note=None):
         fl_fwd = flop_per_nnz_fwd(Q_SHAPES, RANKS)
@@ -561,8 +578,13 @@ def main():
             "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 4),
             "eager_value": round(3.0 * fl_fwd * nnz_step_total / (eager_elapsed / args.steps) / 1e9, 2),
             "eager_what": ("the reference benchmark's loop form, `tt_emb(indices, offsets).backward(grad)` per request "
-                           "(tt_embeddings_benchmark.py:94-108), free-running, no graph, no planning ahead, no event brackets"),
+                           "(tt_embeddings_benchmark.py:94-108), free-running, no graph, no planning ahead, no event brackets, "
+                           "backward() through autograd's engine (the module as imported)"),
             "eager_with_event_brackets_ms_per_step": round(eager_profiled / args.steps * 1e3, 4),
+            "eager_direct_backward": (None if eager_direct is None else {
+                "ms_per_step": round(eager_direct / args.steps * 1e3, 4),
+                "what": "the same loop after ops.enable_direct_backward() (opt-in, off by default: wraps torch.Tensor.backward so "
+                        "that backward() of a fused-optimizer lookup's own output skips autograd's engine)"}),
             "us_per_nnz": round(elapsed / args.steps / nnz_step_total * 1e6, 5),
             "ref_formula_gflops_x_iters": round(gflops * 10, 1),
             "reference_readme_true_gflops": 265.8,

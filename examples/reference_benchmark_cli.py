@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--dense", action="store_true", help="dense core gradients instead of the fused optimizer (the reference's --sparse defaults to on)")
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adagrad"])
     ap.add_argument("--run-baseline", action="store_true")
+    ap.add_argument("--direct-backward", action="store_true",
+                    help="opt in to tt_embeddings_ops.enable_direct_backward(): backward() of the lookup's own output skips autograd's engine")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a GPU (the HIP path has no CPU fallback)")
@@ -82,6 +84,10 @@ def main():
     tt = TTEmbeddingBag(num_embeddings=E, embedding_dim=D, tt_p_shapes=a.p_shapes, tt_q_shapes=q, tt_ranks=a.ranks, sparse=not a.dense,
                         optimizer=OptimType.SGD if a.optimizer == "sgd" else OptimType.EXACT_ADAGRAD, use_cache=True).to(dev)
     grad = torch.rand(B, D, device=dev) * 0.1
+    if a.direct_backward:
+        import tt_embeddings_ops
+
+        tt_embeddings_ops.enable_direct_backward()
     t = seconds_per_request(reqs, lambda i, o: tt(i, o).backward(grad))
     print(f"B: {B}, E: {E}, D: {D}, nnz: {nnz}, p: {a.p_shapes}, q: {q}, ranks: {a.ranks}, optimizer: {a.optimizer}, sparse: {not a.dense}")
     print(f"TTEmbeddingBag FWD-BWD time/nnz: {t / nnz * 1e6:.4f} usecs ({t * 1e6:.1f} us per request), "

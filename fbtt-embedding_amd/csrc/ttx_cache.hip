@@ -688,7 +688,7 @@ __global__ __launch_bounds__(kCT) void mark_popular_kernel(int32_t H, int64_t ca
       // Deliberate fix (the reference leaves cache_state[slot] as it was): after a SECOND populate an evicted slot
       // would keep its old cache row number, and the next key inserted into that slot would be served -- and would
       // update -- another index's cached row.  Identical to the reference on a first populate (state is all -1).
-      // keep_state: ttx_set_reference_exact(1) -- the reference's behaviour, bit for bit, on demand.
+      // keep_state: ttx_cache_populate_f(flags = TTX_POPULATE_REFERENCE_EXACT) -- the reference's behaviour, bit for bit, on demand.
       if (!keep_state) cache_state[slot] = -1;
     }
   } else if (n < cache_size) {
@@ -982,19 +982,13 @@ int ttx_lookup_prologue_cached_multi(const ttx_geom* g, int32_t nbatch, int64_t 
 }
 
 // (A/B knob of scripts/bench_cache.py: 1 = the 32-lane-group kernel for every D)
-// ttx_set_reference_exact: bit 0 = cache_populate leaves the cache_state of an evicted slot as it was, like the reference's
-// mark_popular_colidx_kernel (tt_embeddings_cuda.cu:1131-1133) -- the deliberate fix switched off.
-static int g_reference_exact = 0;
-int ttx_set_reference_exact(int32_t flags) {
-  if (flags < 0 || flags > 1) TTX_FAIL(TTX_EINVAL, "unknown reference-exact flags %d", flags);
-  g_reference_exact = flags;
-  return TTX_OK;
-}
-
-static int g_cache_fwd_lookup_groups = 0;
+static TTX_KNOB(int, g_cache_fwd_lookup_groups, 0);
+#ifdef TTX_TEST_HOOKS
 int ttx_debug_cache_fwd(int32_t lookup_groups) { g_cache_fwd_lookup_groups = lookup_groups; return TTX_OK; }
-// (for ttx_debug_state, ttx_tt.hip: bit 0 = reference-exact populate, bit 1 = the cache forward's A/B knob)
-int ttx_cache_debug_state(void) { return (g_reference_exact ? 1 : 0) | (g_cache_fwd_lookup_groups ? 2 : 0); }
+#endif
+// (for ttx_debug_state, ttx_tt.hip: bit 1 = the cache forward's A/B knob; bit 0 was the process-wide reference-exact switch of
+//  rounds 3-5, now the per-call `flags` of ttx_cache_populate_f)
+int ttx_cache_debug_state(void) { return g_cache_fwd_lookup_groups ? 2 : 0; }
 
 int ttx_cache_forward(int32_t B, int64_t nnz, const int32_t* loc, const int64_t* rowidx, int32_t D,
                       const float* cache_weight, float* output, ttx_stream_t stream) {
@@ -1143,6 +1137,17 @@ int ttx_cache_populate(const ttx_geom* g, const float* const* tt_cores, int64_t 
                        int64_t* cache_freq, int32_t* cache_state, int64_t cache_size, int32_t D,
                        float* cache_weight, void* workspace, size_t workspace_bytes,
                        ttx_stream_t stream) {
+  return ttx_cache_populate_f(g, tt_cores, H, hashtbl, cache_freq, cache_state, cache_size, D, cache_weight, 0, workspace,
+                              workspace_bytes, stream);
+}
+
+// flags bit 0 (TTX_POPULATE_REFERENCE_EXACT): leave the cache_state of an evicted slot as it was, like the reference's
+// mark_popular_colidx_kernel (tt_embeddings_cuda.cu:1131-1133) -- the deliberate fix switched off, per call.
+int ttx_cache_populate_f(const ttx_geom* g, const float* const* tt_cores, int64_t H, int64_t* hashtbl,
+                         int64_t* cache_freq, int32_t* cache_state, int64_t cache_size, int32_t D,
+                         float* cache_weight, int32_t flags, void* workspace, size_t workspace_bytes,
+                         ttx_stream_t stream) {
+  if (flags & ~TTX_POPULATE_REFERENCE_EXACT) TTX_FAIL(TTX_EINVAL, "unknown cache_populate flags %d", flags);
   hipStream_t st = (hipStream_t)stream;
   Dims d;
   int rc = make_dims(g, &d);
@@ -1162,7 +1167,7 @@ int ttx_cache_populate(const ttx_geom* g, const float* const* tt_cores, int64_t 
   unit_shape(H, &WT, &U);
   char* rows_ws = ws + 4 * align_up((size_t)H * 8) + align_up((size_t)256 * U * 4) + 2048;
   hipLaunchKernelGGL(mark_popular_kernel, dim3((unsigned)((H + kCT - 1) / kCT)), dim3(kCT), 0, st, (int32_t)H,
-                     cache_size, sorted_keys, hashtbl, cache_freq, cache_state, g_reference_exact & 1);
+                     cache_size, sorted_keys, hashtbl, cache_freq, cache_state, flags & TTX_POPULATE_REFERENCE_EXACT);
   TTX_HIP(hipGetLastError());
   if (cache_size == 0) return TTX_OK;
   if (!cache_weight) TTX_FAIL(TTX_EINVAL, "cache_weight is NULL");

@@ -6,6 +6,12 @@
 #include <string.h>
 
 #include "../../include/ttx.h"
+#ifdef TTX_TEST_HOOKS  // the test build (libttx_hooks.so): knobs are globals with setters; the product build folds them to constants
+#include "../../include/ttx_test_hooks.h"
+#define TTX_KNOB(type, name, dflt) type name = dflt
+#else
+#define TTX_KNOB(type, name, dflt) constexpr type name = dflt
+#endif
 
 namespace ttx {
 
@@ -89,10 +95,11 @@ constexpr int kHotRowsPivot = TTX_HOT_PIVOT;  // chunk partials beyond which a p
 
 // hdr[kHdrT4Valid .. +4]: four cores on the three-core kernels -- 1 while Plan::t4m / t4o hold the merged last cores M of THIS plan's
 // lookups for the core tensors whose addresses follow (two ints each: core 2, core 3).  Set by the forward's merge, read by the
-// backward's (which then skips its own), cleared by every plan build and by the fused optimizer's write to cores 2 / 3.
+// backward's (which then skips its own), cleared by every plan build and by the fused optimizer's write to cores 2 / 3; [+5] = the
+// device-wide count of such writes (g_t4_epoch, ttx_tt.hip) when M was made: another plan's fused backward invalidates this M too.
 constexpr int kHdrT4Valid = 20;
 struct Plan {
-  int* hdr;  // [0] = number of chunks, [1] = MC, [2] = nnz, [3] = lrow valid, [8 + t] = hot slices of core t (-1: unknown), [20..24]: kHdrT4Valid
+  int* hdr;  // [0] = number of chunks, [1] = MC, [2] = nnz, [3] = lrow valid, [8 + t] = hot slices of core t (-1: unknown), [20..25]: kHdrT4Valid
   int* sid[TTX_MAX_CORES];
   int* perm[TTX_MAX_CORES];
   int* ipos[TTX_MAX_CORES];  // inverse of perm: position of lookup n in core t's sorted order (thin cores)

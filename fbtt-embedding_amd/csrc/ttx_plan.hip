@@ -1390,7 +1390,10 @@ static int plan_build_mb(const Dims& d, int N, const int* n_dev, const int64_t* 
     return TTX_OK;
   }
   // (tables of different row factors, d.tab: only the wide-digit and the multi-pass plan decode them)
-  if ((maxp > 1 || d.tab) && (N + kWideSpan - 1) / kWideSpan <= kWideMaxG) {  // one wide digit instead of two passes?
+  // (finish_wide packs a slice's full-chunk count into the upper 18 bits of an int32 prefix sum: the route is for fewer than 2^18
+  //  full chunks -- always, unless the generic kernels' last-resort tile or the test knob leaves MC = 1 with more than 262,144
+  //  lookups; those take the passes below)
+  if ((maxp > 1 || d.tab) && (N + kWideSpan - 1) / kWideSpan <= kWideMaxG && N / (P.MC > 0 ? P.MC : 1) < (1 << 18)) {  // one wide digit instead of two passes?
     int smax = 1;
     for (int t = 0; t < d.T; ++t) if (d.S[t] > smax) smax = d.S[t];
     if (smax <= 1024) return plan_build_wide<10, false>(d, N, n_dev, indices, tableidx, rowidx, P, stream, GrpArgs{});

@@ -17,6 +17,7 @@
 #include <torch/extension.h>
 #include <torch/csrc/autograd/python_cpp_function.h>
 
+#include <rccl/rccl.h>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -678,35 +679,36 @@ std::vector<Tensor> prologue_cached_multi(std::vector<Tensor> indices, std::vect
 // torch.distributed runs its collectives on a side stream of its own: every all_to_all costs two event hops
 // and ~30 us of wrapper time, and its watchdog aborts when a collective is captured into a hipGraph
 // (DESIGN.md section 7).  These four calls talk to the RCCL library torch already loaded, on the CURRENT
-// stream: equal-split all-to-all (ncclAllToAll) and per-peer counts (a ncclSend/ncclRecv group), both capturable.  Prototypes are declared
-// here rather than taken from rccl.h so that the ROCm header and torch's bundled library need not match.
-extern "C" {
-typedef struct { char internal[128]; } ttx_ncclUniqueId;
-typedef void* ttx_ncclComm_t;
-int ncclGetUniqueId(ttx_ncclUniqueId* id);
-int ncclCommInitRank(ttx_ncclComm_t* comm, int nranks, ttx_ncclUniqueId id, int rank);
-int ncclCommDestroy(ttx_ncclComm_t comm);
-int ncclAllToAll(const void* sendbuff, void* recvbuff, size_t count, int datatype, ttx_ncclComm_t comm, void* stream);
-int ncclSend(const void* sendbuff, size_t count, int datatype, int peer, ttx_ncclComm_t comm, void* stream);
-int ncclRecv(void* recvbuff, size_t count, int datatype, int peer, ttx_ncclComm_t comm, void* stream);
-int ncclGroupStart(void);
-int ncclGroupEnd(void);
-const char* ncclGetErrorString(int result);
+// stream: equal-split all-to-all (ncclAllToAll) and per-peer counts (a ncclSend/ncclRecv group), both capturable.  Types, enums and
+// prototypes are <rccl/rccl.h>'s (the ROCm header; the library is the one torch loaded -- rccl_abi_check() below refuses a library
+// whose major version differs from the header's).
+static void rccl_abi_check() {
+  static const bool ok = [] {
+    int v = 0;
+    TORCH_CHECK(ncclGetVersion(&v) == ncclSuccess, "RCCL ncclGetVersion failed");
+    // (version code: major * 10000 + minor * 100 + patch since 2.9)
+    TORCH_CHECK(v / 10000 == NCCL_MAJOR, "RCCL library version ", v, " does not match the header this file was built with (",
+                NCCL_VERSION_CODE, ")");
+    return true;
+  }();
+  (void)ok;
 }
 
-void rccl_check(int rc, const char* what) { TORCH_CHECK(rc == 0, "RCCL ", what, ": ", ncclGetErrorString(rc)); }
+void rccl_check(ncclResult_t rc, const char* what) { TORCH_CHECK(rc == ncclSuccess, "RCCL ", what, ": ", ncclGetErrorString(rc)); }
 
 pybind11::bytes rccl_unique_id() {
-  ttx_ncclUniqueId id;
+  rccl_abi_check();
+  ncclUniqueId id;
   rccl_check(ncclGetUniqueId(&id), "ncclGetUniqueId");
   return pybind11::bytes(id.internal, sizeof(id.internal));
 }
 
 int64_t rccl_comm_init(const std::string& id_bytes, int64_t rank, int64_t world, int64_t device_index) {
-  TORCH_CHECK(id_bytes.size() == sizeof(ttx_ncclUniqueId), "bad RCCL unique id");
-  ttx_ncclUniqueId id;
+  rccl_abi_check();
+  TORCH_CHECK(id_bytes.size() == sizeof(ncclUniqueId), "bad RCCL unique id");
+  ncclUniqueId id;
   memcpy(id.internal, id_bytes.data(), sizeof(id.internal));
-  ttx_ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;
   {
     pybind11::gil_scoped_release nogil;  // collective call: blocks until every rank has arrived
     c10::hip::HIPGuardMasqueradingAsCUDA guard(c10::Device(c10::kCUDA, (c10::DeviceIndex)device_index));
@@ -716,7 +718,7 @@ int64_t rccl_comm_init(const std::string& id_bytes, int64_t rank, int64_t world,
 }
 
 void rccl_comm_destroy(int64_t comm) {
-  if (comm) (void)ncclCommDestroy((ttx_ncclComm_t)(intptr_t)comm);
+  if (comm) (void)ncclCommDestroy((ncclComm_t)(intptr_t)comm);
 }
 
 // out[p] <- block p of rank p's `in`, blocks of in.numel() / world elements; on the current stream
@@ -724,17 +726,17 @@ void rccl_all_to_all(int64_t comm, const Tensor& out, const Tensor& in, int64_t 
   TORCH_CHECK(out.is_cuda() && in.is_cuda() && out.is_contiguous() && in.is_contiguous() &&
                   out.scalar_type() == in.scalar_type() && out.numel() == in.numel() && in.numel() % world == 0,
               "rccl_all_to_all: contiguous GPU tensors of one dtype and size, divisible by the world size");
-  int dt;
+  ncclDataType_t dt;
   switch (in.scalar_type()) {
-    case at::kFloat: dt = 7; break;  // ncclFloat32
-    case at::kLong: dt = 4; break;   // ncclInt64
-    case at::kInt: dt = 2; break;    // ncclInt32
+    case at::kFloat: dt = ncclFloat32; break;
+    case at::kLong: dt = ncclInt64; break;
+    case at::kInt: dt = ncclInt32; break;
     default: TORCH_CHECK(false, "rccl_all_to_all: float32 / int64 / int32 only");
   }
   c10::hip::HIPGuardMasqueradingAsCUDA guard(in.device());
   auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
   rccl_check(ncclAllToAll(in.data_ptr(), out.data_ptr(), (size_t)(in.numel() / world), dt,
-                          (ttx_ncclComm_t)(intptr_t)comm, (void*)stream), "ncclAllToAll");
+                          (ncclComm_t)(intptr_t)comm, stream), "ncclAllToAll");
 }
 
 // Uneven splits (26 tables on 8 ranks: 4,4,3,3,3,3,3,3 table blocks per owner): block p of `in` holds
@@ -746,11 +748,11 @@ void rccl_all_to_allv(int64_t comm, const Tensor& out, const Tensor& in, const s
   TORCH_CHECK(out.is_cuda() && in.is_cuda() && out.is_contiguous() && in.is_contiguous() &&
                   out.scalar_type() == in.scalar_type() && send_counts.size() == recv_counts.size(),
               "rccl_all_to_allv: contiguous GPU tensors of one dtype, one count per rank and direction");
-  int dt;
+  ncclDataType_t dt;
   switch (in.scalar_type()) {
-    case at::kFloat: dt = 7; break;  // ncclFloat32
-    case at::kLong: dt = 4; break;   // ncclInt64
-    case at::kInt: dt = 2; break;    // ncclInt32
+    case at::kFloat: dt = ncclFloat32; break;
+    case at::kLong: dt = ncclInt64; break;
+    case at::kInt: dt = ncclInt32; break;
     default: TORCH_CHECK(false, "rccl_all_to_allv: float32 / int64 / int32 only");
   }
   int64_t ns = 0, nr = 0;
@@ -763,17 +765,17 @@ void rccl_all_to_allv(int64_t comm, const Tensor& out, const Tensor& in, const s
   const size_t esz = (size_t)in.element_size();
   c10::hip::HIPGuardMasqueradingAsCUDA guard(in.device());
   auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
-  ttx_ncclComm_t c = (ttx_ncclComm_t)(intptr_t)comm;
+  ncclComm_t c = (ncclComm_t)(intptr_t)comm;
   rccl_check(ncclGroupStart(), "ncclGroupStart");
   size_t so = 0, ro = 0;
-  int rc = 0;
-  for (size_t p = 0; p < send_counts.size() && rc == 0; ++p) {
-    if (send_counts[p]) rc = ncclSend((const char*)in.data_ptr() + so * esz, (size_t)send_counts[p], dt, (int)p, c, (void*)stream);
-    if (rc == 0 && recv_counts[p]) rc = ncclRecv((char*)out.data_ptr() + ro * esz, (size_t)recv_counts[p], dt, (int)p, c, (void*)stream);
+  ncclResult_t rc = ncclSuccess;
+  for (size_t p = 0; p < send_counts.size() && rc == ncclSuccess; ++p) {
+    if (send_counts[p]) rc = ncclSend((const char*)in.data_ptr() + so * esz, (size_t)send_counts[p], dt, (int)p, c, stream);
+    if (rc == ncclSuccess && recv_counts[p]) rc = ncclRecv((char*)out.data_ptr() + ro * esz, (size_t)recv_counts[p], dt, (int)p, c, stream);
     so += (size_t)send_counts[p];
     ro += (size_t)recv_counts[p];
   }
-  const int rc_end = ncclGroupEnd();  // (always close the group)
+  const ncclResult_t rc_end = ncclGroupEnd();  // (always close the group)
   rccl_check(rc, "ncclSend/ncclRecv");
   rccl_check(rc_end, "ncclGroupEnd");
 }
@@ -810,6 +812,22 @@ struct NodeRef {
     n->release_variables();  // (as the engine does without retain_graph)
     return true;
   }
+  // `out.backward(grad)` for the registered tensor `out`: additionally requires that out's grad_fn is STILL this node (or, for the
+  // squeezed view TTEmbeddingBag hands out, a SqueezeBackward whose only input edge is this node).  An in-place op on the output
+  // (`out.mul_(2)`, `out += bias`) keeps the tensor's identity but rebases its grad_fn: that is no longer the plain case, and the
+  // engine must run the in-place op's backward first.
+  bool backward_of(const Tensor& out, const Tensor& grad) {
+    using torch::autograd::Node;
+    const std::shared_ptr<Node>& gf = out.grad_fn();
+    if (!gf || !fn) return false;
+    if (gf.get() != fn.get()) {
+      const std::string nm = gf->name();
+      if (nm.rfind("SqueezeBackward", 0) != 0 || gf->num_outputs() != 1 || gf->next_edge(0).function.get() != fn.get() ||
+          !gf->tensor_pre_hooks().empty() || !gf->pre_hooks().empty() || !gf->post_hooks().empty() || !gf->retains_grad_hooks().empty())
+        return false;
+    }
+    return backward(grad);
+  }
   // the node as Python sees it (tensor.grad_fn): a root for torch.autograd.backward when the tensor itself is gone
   pybind11::object node() const { return pybind11::reinterpret_steal<pybind11::object>(torch::autograd::functionToPyObject(fn)); }
 };
@@ -832,6 +850,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   pybind11::class_<NodeRef>(m, "NodeRef")
       .def("backward", &NodeRef::backward,
            "run the node's backward (fused optimizer step) on the calling thread; False = not the plain case, use autograd")
+      .def("backward_of", &NodeRef::backward_of,
+           "backward(grad) after checking that the given tensor's grad_fn still is this node (or a squeeze view of it)")
       .def("node", &NodeRef::node, "the node as tensor.grad_fn would return it");
   m.def("node_of", &node_of, "the autograd node behind an output of lookup() / lookup_cached()");
   m.doc() = "native autograd node of the TT lookup (cache not live) over the C ABI of libttx.so";

@@ -1301,10 +1301,17 @@ __global__ __launch_bounds__(256) void t4_merge_kernel(Plan P, const float* __re
 // between the two -- so the forward's merge marks them valid (hdr[kHdrT4Valid], with the cores' addresses) and the backward's
 // launches leave at once when they find that mark: 21 us of the 210 us step at the benchmark's batch.  Cleared by a plan build and
 // by t4_apply23_kernel when a fused optimizer writes cores 2 / 3.
+// (round 6) ... and by EVERY fused write to cores 2 / 3, whichever plan's backward made it: with two forwards outstanding on one
+// module (`loss = m(i1, o1).sum() + m(i2, o2).sum(); loss.backward()`) backward A rewrites the cores while plan B's mark would still
+// say valid, and backward B would mix a stale M with the updated cores 0 / 1 (the reference recomputes its intermediates from the
+// current cores in every backward).  g_t4_epoch is a device-resident counter of such writes (one per device, part of the code
+// object: no allocation); the forward's merge stores its value beside the mark, t4_apply23_kernel increments it, and a plan's M
+// is valid only while the two agree.  Conservative: a fused four-core step of ANY module invalidates every plan's M.
+__device__ int g_t4_epoch = 0;
 __device__ __forceinline__ bool t4_valid(const Plan& P, const float* c2, const float* c3) {
   const int* h = P.hdr + kHdrT4Valid;
   return h[0] == 1 && h[1] == (int)(uintptr_t)c2 && h[2] == (int)((uintptr_t)c2 >> 32) && h[3] == (int)(uintptr_t)c3 &&
-         h[4] == (int)((uintptr_t)c3 >> 32);
+         h[4] == (int)((uintptr_t)c3 >> 32) && h[5] == __hip_atomic_load(&g_t4_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ __launch_bounds__(256) void t4_order_kernel(Plan P, const float* c2, const float* c3, int reuse) {
   if (reuse && t4_valid(P, c2, c3)) return;  // (grid-uniform: nobody writes the mark while a reusing launch runs)
@@ -1312,6 +1319,7 @@ __global__ __launch_bounds__(256) void t4_order_kernel(Plan P, const float* c2, 
   if (i == 0 && !reuse) {  // the forward's launch: the stream orders every later reader behind this launch AND the merge after it
     int* h = P.hdr + kHdrT4Valid;
     h[1] = (int)(uintptr_t)c2; h[2] = (int)((uintptr_t)c2 >> 32); h[3] = (int)(uintptr_t)c3; h[4] = (int)((uintptr_t)c3 >> 32);
+    h[5] = __hip_atomic_load(&g_t4_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     h[0] = 1;
   }
   if (i >= P.hdr[2]) return;
@@ -1700,7 +1708,10 @@ __global__ __launch_bounds__(kT4Threads) void t4_apply23_kernel(Plan P, const fl
                                                                float* w2, float* w3, float* st2, float* st3, float* dw2,
                                                                float* dw3) {
   __shared__ float red[kT4Threads];
-  if (blockIdx.x == 0 && threadIdx.x == 0 && optim != TTX_OPTIM_DENSE) P.hdr[kHdrT4Valid] = 0;  // (cores 2 / 3 change: the plan's M is stale)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && optim != TTX_OPTIM_DENSE) {  // cores 2 / 3 change: this plan's M, and every other plan's, is stale
+    P.hdr[kHdrT4Valid] = 0;
+    atomicAdd(&g_t4_epoch, 1);
+  }
   const int nb2 = (n2 + kT4ApplyBlock - 1) / kT4ApplyBlock;  // blocks of a core-2 slice
   const bool is2 = (int)blockIdx.x < S2 * nb2;
   const int s = is2 ? blockIdx.x / nb2 : blockIdx.x - S2 * nb2;
@@ -1854,7 +1865,7 @@ static int allow_lds(K kernel, int bytes) {
 
 static size_t rows_bytes(const Dims& d, long long nnz) { return align_up((size_t)nnz * d.D * 4); }
 
-static int g_skip_launch = 0;  // ablation (ttx_debug_skip bits 9..11): results invalid when != 0
+static TTX_KNOB(int, g_skip_launch, 0);  // ablation (ttx_debug_skip bits 9..11): results invalid when != 0
 
 // the family's translation unit takes it (ttx_tt_spec{16,32,64,128a,128b,128c}.hip)
 static int run_rows_spec(TTX_SPEC_FWD_ARGS) {
@@ -1940,6 +1951,7 @@ using namespace ttx;
 
 extern "C" {
 
+#ifdef TTX_TEST_HOOKS  // ---- the knobs' setters: libttx_hooks.so only (include/ttx_test_hooks.h) ----
 // debug: device buffer of 16 int64 stamps per work-group (NULL = off), scripts/phase_times.py
 int ttx_debug_stamps(void* device_buffer) {
   g_stamps = (long long*)device_buffer;
@@ -1964,6 +1976,13 @@ int ttx_debug_lds_budget(int32_t bytes) {
   return TTX_OK;
 }
 
+int ttx_set_chunk(int32_t mc) {
+  if (mc < 0 || mc > 64) TTX_FAIL(TTX_EINVAL, "chunk %d out of range 0..64", mc);
+  g_chunk_override = mc;
+  return TTX_OK;
+}
+#endif  // TTX_TEST_HOOKS
+
 // test helper: how the generic kernels would walk this geometry's core_1 slice
 // out = {lookups per chunk, q1 blocks per column pass, rows per K block, column passes, K blocks, LDS bytes (backward)};
 // all zero when a shape-specialised kernel takes the geometry
@@ -1981,19 +2000,22 @@ int ttx_debug_tiles(const ttx_geom* g, int32_t* out) {
   return TTX_OK;
 }
 
-// Which of the process-global TEST / ablation knobs are away from their defaults (0 = none): bit 0 ttx_debug_skip, 1
-// ttx_debug_lds_budget, 2 ttx_set_chunk, 3 ttx_debug_stamps, 4 ttx_set_reference_exact, 5 ttx_debug_cache_fwd.  The knobs are plain
-// globals of the library -- not per stream, not thread-safe (forward runs on the caller's thread, backward on autograd's): they
-// exist for tests and A/B timing, a product run must find this 0 (bench.py asserts it).
+// Which of the TEST / ablation knobs are away from their defaults (0 = none): bit 0 ttx_debug_skip, 1 ttx_debug_lds_budget,
+// 2 ttx_set_chunk, 3 ttx_debug_stamps, 5 ttx_debug_cache_fwd.  The product build (libttx.so) has no knobs: this is the constant 0
+// there, and bench.py refuses to time a library where it is not.  In libttx_hooks.so the knobs are plain globals -- not per
+// stream, not thread-safe: tests and A/B timing only.
 int ttx_debug_state(void) {
   return ((g_debug_skip | g_skip_launch | g_disable_spec | g_disable_pad) ? 1 : 0) | (g_lds_budget != 160 * 1024 ? 2 : 0) |
          (g_chunk_override ? 4 : 0) | (g_stamps ? 8 : 0) | (ttx_cache_debug_state() << 4);
 }
 
-int ttx_set_chunk(int32_t mc) {
-  if (mc < 0 || mc > 64) TTX_FAIL(TTX_EINVAL, "chunk %d out of range 0..64", mc);
-  g_chunk_override = mc;
-  return TTX_OK;
+/* 1 = this library was built with -DTTX_TEST_HOOKS (libttx_hooks.so), 0 = the product build */
+int ttx_has_test_hooks(void) {
+#ifdef TTX_TEST_HOOKS
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 size_t ttx_tt_forward_workspace_bytes(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz) {

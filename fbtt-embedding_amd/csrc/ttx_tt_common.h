@@ -76,9 +76,17 @@ __device__ __forceinline__ void zero_output(float* __restrict__ out, long long n
   for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < n; e += (long long)gridDim.x * kThreads) out[e] = 0.f;
 }
 
-// debug / ablation state, defined in ttx_tt.hip (ttx_debug_skip, ttx_debug_stamps)
+// test / ablation knobs (include/ttx_test_hooks.h).  They exist in the TEST build only (-DTTX_TEST_HOOKS -> libttx_hooks.so): there
+// they are globals of the library with setters (ttx_debug_skip, ttx_debug_stamps, ...), defined in ttx_tt.hip.  In the product
+// build (libttx.so) every knob is a compile-time constant at its default and no setter is compiled.
+#ifdef TTX_TEST_HOOKS
 extern int g_debug_skip;
 extern int g_disable_spec;
 extern long long* g_stamps;
+#else
+constexpr int g_debug_skip = 0;
+constexpr int g_disable_spec = 0;
+constexpr long long* g_stamps = nullptr;
+#endif
 
 }  // namespace ttx

@@ -42,21 +42,61 @@ class _Geom(C.Structure):
     ]
 
 
-_lib = None
+_lib = None        # the library calls go to: the product build, or the test build while a knob is away from its default
+_product = None    # libttx.so
+_hooks = None      # libttx_hooks.so (same sources, -DTTX_TEST_HOOKS): loaded on the first use of a test / ablation knob
+_SO_HOOKS = os.environ.get("TTX_LIB_HOOKS") or os.path.join(_HERE, "libttx_hooks.so")
 
 
 def lib():
-    """Load libttx.so (once).  Raises RuntimeError if it has not been built."""
-    global _lib
+    """libttx.so, loaded once.  Raises RuntimeError if it has not been built.  (While a test / ablation knob is away from
+    its default -- debug_skip(), set_chunk(), debug_lds_budget(), ... below -- calls go to libttx_hooks.so instead: the
+    product library has no knobs.)"""
+    global _lib, _product
     if _lib is not None:
         return _lib
-    if not os.path.exists(_SO):
+    _product = _load(_SO)
+    _lib = _product
+    if os.environ.get("TTX_LDS_BUDGET"):  # experiments: LDS budget of the generic kernels' tile search (bytes)
+        debug_lds_budget(int(os.environ["TTX_LDS_BUDGET"]))
+    if os.environ.get("TTX_DEBUG_SKIP"):  # ablation runs (scripts/upper_bounds.py): results INVALID while set
+        debug_skip(int(os.environ["TTX_DEBUG_SKIP"]))
+    return _lib
+
+
+def hooks_lib():
+    """libttx_hooks.so (the test build: include/ttx_test_hooks.h), loaded once; calls are routed to it from now on and back
+    to the product library as soon as every knob is at its default again (`_knobs_changed`)."""
+    global _lib, _hooks
+    lib()
+    if _hooks is None:
+        _hooks = _load(_SO_HOOKS)
+        if not _hooks.ttx_has_test_hooks():
+            raise RuntimeError(f"tt_embeddings: {_SO_HOOKS} was built without -DTTX_TEST_HOOKS")
+        i32 = C.c_int32
+        _hooks.ttx_set_chunk.argtypes = [i32]
+        _hooks.ttx_debug_lds_budget.argtypes = [i32]
+        _hooks.ttx_debug_skip.argtypes = [i32]
+        _hooks.ttx_debug_cache_fwd.argtypes = [i32]
+        _hooks.ttx_debug_stamps.argtypes = [C.c_void_p]
+    _lib = _hooks
+    return _hooks
+
+
+def _knobs_changed() -> None:
+    global _lib
+    if _hooks is not None and _lib is _hooks and not _hooks.ttx_debug_state():
+        _lib = _product
+
+
+def _load(path):
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"tt_embeddings: the HIP library {_SO} is missing -- build it with "
+            f"tt_embeddings: the HIP library {path} is missing -- build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
             "There is no CPU / PyTorch fallback."
         )
-    L = C.CDLL(_SO)
+    L = C.CDLL(path)
     L.ttx_last_error.restype = C.c_char_p
     for name in (
         "ttx_plan_bytes",
@@ -95,11 +135,11 @@ def lib():
     L.ttx_cache_backward_rowwise_adagrad_approx.argtypes = [i64, i32, vp, vp, vp, f32, f32, vp, vp, vp]
     L.ttx_profile_enable.argtypes = [C.c_int]
     L.ttx_profile_read.argtypes = [C.c_int, C.POINTER(i64), C.POINTER(C.c_double)]
-    L.ttx_set_chunk.argtypes = [i32]
     L.ttx_debug_state.argtypes = []
     L.ttx_debug_state.restype = C.c_int
-    L.ttx_debug_lds_budget.argtypes = [i32]
+    L.ttx_has_test_hooks.argtypes = []
     L.ttx_debug_tiles.argtypes = [G, C.POINTER(i32)]
+    L.ttx_cache_populate_f.argtypes = [G, vp, i64, vp, vp, vp, i64, i32, vp, i32, vp, sz, vp]
     for name in ("ttx_dedup_bytes", "ttx_tt_forward_dd_workspace_bytes", "ttx_tt_backward_dd_workspace_bytes"):
         getattr(L, name).restype = C.c_size_t
     L.ttx_dedup_bytes.argtypes = [G, i64]
@@ -108,11 +148,6 @@ def lib():
     L.ttx_tt_forward_dd.argtypes = [G, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.ttx_tt_backward_dd_workspace_bytes.argtypes = [G, i32, i64]
     L.ttx_tt_backward_dd.argtypes = [G, i32, i32, i32, f32, f32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
-    if os.environ.get("TTX_LDS_BUDGET"):  # experiments: LDS budget of the generic kernels' tile search (bytes)
-        L.ttx_debug_lds_budget(int(os.environ["TTX_LDS_BUDGET"]))
-    if os.environ.get("TTX_DEBUG_SKIP"):  # ablation runs (scripts/upper_bounds.py): results INVALID while set
-        L.ttx_debug_skip(int(os.environ["TTX_DEBUG_SKIP"]))
-    _lib = L
     return L
 
 
@@ -500,8 +535,9 @@ def update_cache_state(indices: torch.Tensor, hashtbl: torch.Tensor, cache_freq:
 
 
 def cache_populate(num_embeddings: int, tt_p_shapes, tt_q_shapes, tt_ranks, tt_cores, L, hashtbl, cache_freq,
-                   cache_state, cache_weight) -> None:
-    """tt_embeddings.cpp:76-86."""
+                   cache_state, cache_weight, reference_exact: bool = False) -> None:
+    """tt_embeddings.cpp:76-86.  `reference_exact` (trailing keyword, not in the reference): leave the cache_state of evicted
+    slots untouched, as the reference's mark_popular_colidx_kernel does (include/ttx.h TTX_POPULATE_REFERENCE_EXACT)."""
     g = _geom(tt_cores[0].size(0), tt_p_shapes, tt_q_shapes, tt_ranks)
     dev = _dev(cache_weight)
     cores = _cores(list(tt_cores), g)
@@ -519,8 +555,9 @@ def cache_populate(num_embeddings: int, tt_p_shapes, tt_q_shapes, tt_ranks, tt_c
     nb = lb.ttx_cache_populate_workspace_bytes(C.byref(g), H, cs, D)
     ws = _workspace(dev, st, nb)
     with _guard(dev):
-        _check(lb.ttx_cache_populate(C.byref(g), _ptr_array(cores), H, hashtbl.data_ptr(), cache_freq.data_ptr(),
-                                     cache_state.data_ptr(), cs, D, cw.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        _check(lb.ttx_cache_populate_f(C.byref(g), _ptr_array(cores), H, hashtbl.data_ptr(), cache_freq.data_ptr(),
+                                       cache_state.data_ptr(), cs, D, cw.data_ptr(), 1 if reference_exact else 0,
+                                       ws.data_ptr(), ws.numel(), st))
 
 
 def preprocess_indices_sync(colidx: torch.Tensor, offsets: torch.Tensor, num_tables: int, warmup: bool,
@@ -675,11 +712,6 @@ def profile_read(which: int) -> Tuple[int, float]:
     return int(n.value), float(ms.value)
 
 
-def set_reference_exact(flags: int) -> None:
-    """bit 0: cache_populate leaves the cache_state of evicted slots untouched, like the reference (include/ttx.h)"""
-    _check(lib().ttx_set_reference_exact(int(flags)))
-
-
 def debug_sort_pairs_desc(keys: torch.Tensor, vals: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """test hook: cache_populate's stable descending 64-bit radix sort of (key, value) pairs on its own"""
     keys, vals = _i64(keys, "keys"), _i64(vals, "vals")
@@ -698,13 +730,34 @@ def debug_sort_pairs_desc(keys: torch.Tensor, vals: torch.Tensor) -> Tuple[torch
     return ko, vo
 
 
+# ---- test / ablation knobs: libttx_hooks.so (the product library has none) ----
 def set_chunk(mc: int) -> None:
-    _check(lib().ttx_set_chunk(mc))
+    """indices per work-group chunk (0 = heuristic)"""
+    _check(hooks_lib().ttx_set_chunk(int(mc)))
+    _knobs_changed()
 
 
 def debug_lds_budget(nbytes: int) -> None:
-    """Test knob: LDS budget of the generic kernels' tile search (0 = the hardware's 160 KiB)."""
-    _check(lib().ttx_debug_lds_budget(int(nbytes)))
+    """LDS budget of the generic kernels' tile search (0 = the hardware's 160 KiB)."""
+    _check(hooks_lib().ttx_debug_lds_budget(int(nbytes)))
+    _knobs_changed()
+
+
+def debug_skip(mask: int) -> None:
+    """bit 8: force the generic kernels; bit 15: exact-shape templates only; the other bits skip kernel phases / launches
+    (results INVALID).  0 = normal operation."""
+    _check(hooks_lib().ttx_debug_skip(int(mask)))
+    _knobs_changed()
+
+
+def debug_cache_fwd(lookup_groups: int) -> None:
+    _check(hooks_lib().ttx_debug_cache_fwd(int(lookup_groups)))
+    _knobs_changed()
+
+
+def debug_stamps(ptr: Optional[int]) -> None:
+    _check(hooks_lib().ttx_debug_stamps(C.c_void_p(ptr or None)))
+    _knobs_changed()
 
 
 def debug_tiles(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks) -> dict:

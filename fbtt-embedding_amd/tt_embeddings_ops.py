@@ -56,6 +56,8 @@ def _native_node():
     global _native
     if getattr(_engine, "__name__", "") != "tt_embeddings" or os.environ.get("TTX_NO_NATIVE_NODE"):
         return None
+    if _engine._lib is not None and _engine._lib is _engine._hooks:
+        return None  # a test / ablation knob is set: calls go to libttx_hooks.so, which the C++ node is not linked against
     if _native is None:
         try:
             import ttx_torch as _m
@@ -66,20 +68,26 @@ def _native_node():
     return _native or None
 
 
-# ---- `out.backward(grad)` of a lookup's own output, past autograd's engine ---------------------------------------------------------
+# ---- `out.backward(grad)` of a lookup's own output, past autograd's engine: OPT-IN --------------------------------------------------
 # The reference benchmark's loop is `tt_emb(indices, offsets).backward(grad)` (tt_embeddings_benchmark.py:94-108); with a fused
 # optimizer the graph under that output is the lookup's one node, which returns no gradient to anybody, and autograd's engine
 # spends ~40 us of host time per step (graph task, hand-over to its device thread and back) on calling it -- more than the step's
-# kernels take.  The module registers the tensors it returns on that route (`_direct_register`), and `Tensor.backward` -- wrapped
-# once, below -- calls the node on the calling thread for exactly those tensors (csrc/ttx_torch.cpp NodeRef::backward) when the call
-# is the plain one: a gradient and nothing else (no retain_graph / create_graph / inputs=), no hooks or retain_grad() on the
-# tensor; NodeRef::backward itself declines on hooks on the node, anomaly mode, another current stream than the forward's, a
-# gradient that is part of a graph or has the wrong shape.  Everything declined, every other tensor and every other USE of the
-# output (operand of further ops, torch.autograd.backward / grad) is the original Tensor.backward.  The registry is a side table
-# keyed by id() with a weak reference per entry: nothing is stored ON the tensor (torch.save / pickle of an output see no foreign
-# attribute), an entry goes when its tensor goes.  TTX_NO_DIRECT_BACKWARD=1: no wrapping, no registry.
-_DIRECT_BACKWARD = os.environ.get("TTX_NO_DIRECT_BACKWARD", "0") in ("", "0")
+# kernels take.  `enable_direct_backward()` (or TTX_DIRECT_BACKWARD=1 in the environment at import) wraps `torch.Tensor.backward`
+# ONCE; importing this module leaves torch untouched (round 6: a drop-in that rewrites a core torch method on import is not
+# reviewable; in a DLRM the lookup's output is never the tensor `.backward()` is called on, so this serves benchmark-shaped loops
+# only).  While enabled, the module registers the tensors it returns on the C++ node's route (`_direct_register`), and the wrapper
+# calls the node on the calling thread for exactly those tensors (csrc/ttx_torch.cpp NodeRef::backward_of) when the call is the
+# plain one: a gradient and nothing else (no retain_graph / create_graph / inputs=), a plain torch.Tensor (no subclass), no
+# TorchFunctionMode active, no hooks or retain_grad() on the tensor, and the tensor's grad_fn STILL the lookup's node (an in-place
+# op on the output rebases it: the engine's job); NodeRef::backward itself declines on hooks on the node, anomaly mode, another
+# current stream than the forward's, a gradient that is part of a graph or has the wrong shape.  Everything declined, every other
+# tensor and every other USE of the output (operand of further ops, torch.autograd.backward / grad) is the original
+# Tensor.backward.  The registry is a side table keyed by id() with a weak reference per entry: nothing is stored ON the tensor
+# (torch.save / pickle of an output see no foreign attribute), an entry goes when its tensor goes.
+# `disable_direct_backward()` puts the original method back.
+_DIRECT_BACKWARD = False
 _direct: Dict[int, tuple] = {}  # id(output tensor) -> (weak reference to it, NodeRef)
+_tensor_backward = None  # torch.Tensor.backward as it was when enable_direct_backward() wrapped it
 
 
 class _KeyRef(_weakref):
@@ -96,23 +104,44 @@ def _direct_register(out: torch.Tensor, ref) -> None:
     _direct[wr.key] = (wr, ref)
 
 
-_tensor_backward = torch.Tensor.backward
-
-
 def _backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
     if _direct:
         e = _direct.get(id(self))
         # (a gradient of another type or shape goes to the engine for the engine's own error)
-        if (e is not None and e[0]() is self and _DIRECT_BACKWARD and type(gradient) is torch.Tensor and not retain_graph
-                and not create_graph and inputs is None and gradient.shape == self.shape and not self._backward_hooks
-                and not self.retains_grad and e[1].backward(gradient)):
+        if (e is not None and e[0]() is self and _DIRECT_BACKWARD and type(self) is torch.Tensor and type(gradient) is torch.Tensor
+                and not retain_graph and not create_graph and inputs is None and gradient.shape == self.shape
+                and not self._backward_hooks and not self.retains_grad and not torch._C._len_torch_function_stack()
+                and e[1].backward_of(self, gradient)):
             return None
     return _tensor_backward(self, gradient, retain_graph, create_graph, inputs)
 
 
-_backward.__doc__ = _tensor_backward.__doc__
-if _DIRECT_BACKWARD:
-    torch.Tensor.backward = _backward
+def enable_direct_backward() -> None:
+    """Opt in: `out.backward(grad)` of a fused-optimizer lookup's own output calls the lookup's node on the calling thread
+    (see above).  Wraps torch.Tensor.backward once, process-wide, until disable_direct_backward()."""
+    global _DIRECT_BACKWARD, _tensor_backward
+    if torch.Tensor.backward is not _backward:
+        _tensor_backward = torch.Tensor.backward
+        _backward.__doc__ = _tensor_backward.__doc__
+        torch.Tensor.backward = _backward
+    _DIRECT_BACKWARD = True
+
+
+def disable_direct_backward() -> None:
+    """Undo enable_direct_backward(): torch.Tensor.backward is the method it was; registered outputs are forgotten."""
+    global _DIRECT_BACKWARD
+    _DIRECT_BACKWARD = False
+    _direct.clear()
+    if torch.Tensor.backward is _backward:
+        torch.Tensor.backward = _tensor_backward
+
+
+def direct_backward_enabled() -> bool:
+    return _DIRECT_BACKWARD and torch.Tensor.backward is _backward
+
+
+if os.environ.get("TTX_DIRECT_BACKWARD", "0") not in ("", "0"):
+    enable_direct_backward()
 
 
 @unique
@@ -384,8 +413,14 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                  optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
                  sparse: bool = True, use_cache: bool = False, cache_size: int = 0, hashtbl_size: int = 0,
                  weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
-                 device: Optional[torch.device] = None, include_last_offset: bool = True, dedup: bool = False) -> None:
+                 device: Optional[torch.device] = None, include_last_offset: bool = True, dedup: bool = False,
+                 reference_exact_populate: bool = False) -> None:
         super().__init__()
+        # reference_exact_populate (trailing keyword, not in the reference): cache_populate() leaves the cache_state of evicted
+        # slots untouched, bit for bit what the reference's mark_popular_colidx_kernel does (cu:1131-1133).  Default False: an
+        # evicted slot drops its cache row (deviation 5).  Carried per call (TTX_POPULATE_REFERENCE_EXACT);
+        # rounds 3-5 had a process-wide switch for it.
+        self.reference_exact_populate = bool(reference_exact_populate)
         # dedup (not in the reference): lookups of a batch that repeat a (table, row) pair share ONE contraction,
         # forward and backward (include/ttx.h "duplicate lookups").  Same results; pays on skewed index streams
         # while the row cache is not live, costs the key sort and two extra launches on uniform ones.
@@ -597,9 +632,10 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         if self.use_cache and write_back > 0.0 and not self.warmup:
             self._write_back(write_back, write_back_steps)
         if self.use_cache:
+            extra = {"reference_exact": True} if self.reference_exact_populate else {}
             _engine.cache_populate(self.num_embeddings, self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks,
                                    list(self.tt_cores), self.L, self.hashtbl, self.cache_freq, self.cache_state,
-                                   self.cache_weight)
+                                   self.cache_weight, **extra)
             self.warmup = False
             self._drop_prefetched()  # (a planned-ahead batch was split into hits / misses by the OLD cache contents)
 
@@ -877,6 +913,11 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         only those are planned, contracted, pooled and trained: no host read-back of the count (ttx_lookup_prologue_n).  What
         the table-sharded module's ragged route hands its local lookup."""
         if n_dev is not None:
+            if per_sample_weights is not None:  # (round 6, advisor: the weights were silently dropped on this route)
+                raise NotImplementedError("forward(n_dev=) does not take per_sample_weights")
+            if not self.include_last_offset:
+                raise ValueError("forward(n_dev=) needs offsets with their closing entry (include_last_offset=True): the closing "
+                                 "offset IS the live count, which only the device knows")
             return self._forward_n(indices, offsets, n_dev)
         if per_sample_weights is not None:
             # nn.EmbeddingBag(mode="sum") semantics: forward, the cores' gradients / fused optimizers and -- if the
@@ -1031,10 +1072,11 @@ class TTEmbeddingBag(TableBatchedTTEmbeddingBag):
                  optimizer: OptimType = OptimType.SGD, learning_rate: float = 0.1, eps: float = 1.0e-10,
                  sparse: bool = True, use_cache: bool = True, cache_size: int = 0, hashtbl_size: int = 0,
                  weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
-                 device: Optional[torch.device] = None, include_last_offset: bool = True, dedup: bool = False) -> None:
+                 device: Optional[torch.device] = None, include_last_offset: bool = True, dedup: bool = False,
+                 reference_exact_populate: bool = False) -> None:
         super().__init__(1, num_embeddings, embedding_dim, tt_ranks, tt_p_shapes, tt_q_shapes, optimizer,
                          learning_rate, eps, sparse, use_cache, cache_size, hashtbl_size, weight_dist,
-                         enforce_embedding_dim, device, include_last_offset, dedup)
+                         enforce_embedding_dim, device, include_last_offset, dedup, reference_exact_populate)
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True,
                 per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -436,6 +436,18 @@ int ttx_cache_populate(const ttx_geom* g, const float* const* tt_cores,
                        int64_t cache_size, int32_t D, float* cache_weight,
                        void* workspace, size_t workspace_bytes,
                        ttx_stream_t stream);
+/* The same with per-call behaviour flags (round 6: the process-wide ttx_set_reference_exact of rounds 3-5 is gone).
+ * TTX_POPULATE_REFERENCE_EXACT: cache_state[slot] of an EVICTED slot is left untouched, exactly as the reference's
+ * mark_popular_colidx_kernel does (tt_embeddings_cuda.cu:1131-1133).  Default (flags = 0 = ttx_cache_populate): the slot's
+ * cache row is dropped (cache_state = -1) -- otherwise, after a second populate, the next key inserted into that slot is
+ * served, and trains, another index's cached row.  Identical on a first populate. */
+#define TTX_POPULATE_REFERENCE_EXACT 1
+int ttx_cache_populate_f(const ttx_geom* g, const float* const* tt_cores,
+                         int64_t hashtbl_size, int64_t* hashtbl,
+                         int64_t* cache_freq, int32_t* cache_state,
+                         int64_t cache_size, int32_t D, float* cache_weight, int32_t flags,
+                         void* workspace, size_t workspace_bytes,
+                         ttx_stream_t stream);
 
 /* replaces cache_forward_cuda (tt_embeddings.cpp:97-103,
  * tt_embeddings_cuda.cu:1498-1572): output[rowidx[n], :] += cache_weight[
@@ -494,41 +506,23 @@ int ttx_profile_mask(int mask);
 int ttx_profile_reset(void);
 int ttx_profile_read(int which, int64_t* launches, double* total_ms);
 
-/* Behaviour switch.  flags bit 0: ttx_cache_populate leaves cache_state[slot] of an EVICTED slot untouched, exactly as the
- * reference's mark_popular_colidx_kernel does (tt_embeddings_cuda.cu:1131-1133).  Default 0: the slot's cache row is
- * dropped (cache_state = -1) -- otherwise, after a second populate, the next key inserted into that slot is served, and
- * trains, another index's cached row.  Identical on a first populate.  Process-wide. */
-int ttx_set_reference_exact(int32_t flags);
-/* test hooks: the stable descending 64-bit radix sort of (key, value) pairs behind ttx_cache_populate, on its own
- * (what the reference asks of cub::DeviceRadixSort::SortPairsDescending, tt_embeddings_cuda.cu:1280-1308) */
+/* test entry: the stable descending 64-bit radix sort of (key, value) pairs behind ttx_cache_populate, on its own
+ * (what the reference asks of cub::DeviceRadixSort::SortPairsDescending, tt_embeddings_cuda.cu:1280-1308).  Stateless. */
 size_t ttx_debug_sort_workspace_bytes(int64_t n);
 int ttx_debug_sort_pairs_desc(int64_t n, const int64_t* keys, const int64_t* vals, int64_t* keys_out, int64_t* vals_out,
                               void* workspace, size_t workspace_bytes, ttx_stream_t stream);
-
-/* tuning knob (bench / tests): indices per work-group chunk; 0 = heuristic */
-int ttx_set_chunk(int32_t indices_per_chunk);
-/* test knob: LDS budget in bytes (<= 163840; 0 = that) of the generic kernels' tile search.  The generic contraction
- * kernels walk a core_1 slice in K blocks x column passes sized to the budget (csrc/ttx_tt_generic.inc), so a small
- * budget drives small shapes through the walk that ranks >= 80 need.  Set it before sizing workspaces / plans. */
-int ttx_debug_lds_budget(int32_t bytes);
-/* test helper: the walk the generic kernels take for geometry g under the current budget:
+/* host-side query, stateless: the walk the generic kernels take for geometry g:
  * out[6] = {lookups per chunk, q1 blocks per column pass, rows per K block, column passes, K blocks, LDS bytes};
- * all zero when a shape-specialised kernel takes the geometry (or nothing fits the budget). */
+ * all zero when a shape-specialised kernel takes the geometry (or nothing fits the LDS). */
 int ttx_debug_tiles(const ttx_geom* g, int32_t* out);
-/* ablation knob (scripts/ablate.py only): bit mask of kernel phases to skip;
- * results are INVALID while it is non-zero.  0 = normal operation. */
-int ttx_debug_skip(int32_t mask);
-/* Bit mask of the process-global TEST / ablation knobs that are away from their defaults (0 = none set): bit 0 ttx_debug_skip,
- * 1 ttx_debug_lds_budget, 2 ttx_set_chunk, 3 ttx_debug_stamps, 4 ttx_set_reference_exact, 5 ttx_debug_cache_fwd.  These knobs are
- * plain globals of the library -- not per stream, not thread-safe -- and exist for tests and A/B timing only; a product run must
- * find this 0 (bench.py asserts it before it times anything). */
+/* Test / ablation knobs (skip kernel phases, force the generic kernels, LDS budget, chunk size, stamps): NOT in this library.
+ * They exist in the test build of the same sources only (-DTTX_TEST_HOOKS -> libttx_hooks.so; include/ttx_test_hooks.h);
+ * libttx.so compiles every knob as a constant at its default and exports no setter.  ttx_has_test_hooks() tells the builds
+ * apart (0 = product); ttx_debug_state() is the bit mask of knobs away from their defaults -- always 0 in the product build;
+ * bench.py refuses to time a library where it is not. */
+int ttx_has_test_hooks(void);
 int ttx_debug_state(void);
 int ttx_cache_debug_state(void); /* (internal helper of the above) */
-/* A/B knob (scripts/bench_cache.py only): 1 = ttx_cache_forward uses the one-group-per-lookup kernel for every D */
-int ttx_debug_cache_fwd(int32_t lookup_groups);
-/* debug (scripts/phase_times.py only): device buffer receiving 16 int64 wall-clock
- * stamps per backward work-group; NULL (default) = off. */
-int ttx_debug_stamps(void* device_buffer);
 
 #ifdef __cplusplus
 }

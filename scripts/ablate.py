@@ -20,7 +20,7 @@ grad = torch.from_numpy(G.make_grad(2, 1, 512, D)[0]).to(dev)
 names = ["fwd", "bwd", "apply", "plan", "pool"]
 
 def run(mask, chunk=0, steps=30):
-    E.lib().ttx_debug_skip(mask)
+    E.debug_skip(mask)
     E.set_chunk(chunk)
     for k in range(5):
         m(*reqs[k % 10]).backward(grad)
@@ -34,7 +34,7 @@ def run(mask, chunk=0, steps=30):
     for w, nm in enumerate(names):
         n, ms = E.profile_read(w)
         out[nm] = ms / max(n, 1) * 1e3
-    E.lib().ttx_debug_skip(0)
+    E.debug_skip(0)
     return out
 
 for chunk in (0, 8, 32):

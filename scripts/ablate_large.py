@@ -28,7 +28,7 @@ fl = 2.0 * (q[0] * rk * q[1] * rk + q[0] * q[1] * rk * q[2])
 
 
 def run(mask, steps=12):
-    E.lib().ttx_debug_skip(mask)
+    E.debug_skip(mask)
     for k in range(3):
         m(*reqs[k % 4]).backward(grad)
     torch.cuda.synchronize()
@@ -41,7 +41,7 @@ def run(mask, steps=12):
     for w, nm in enumerate(names):
         n, ms = E.profile_read(w)
         out[nm] = ms / max(n, 1) * 1e3
-    E.lib().ttx_debug_skip(0)
+    E.debug_skip(0)
     return out
 
 

@@ -44,9 +44,9 @@ for nnz in (10240, 1 << 20):
         outp = torch.zeros(B, D, device=dev)
         grad = torch.rand(B, D, device=dev)
         t_f = timed(lambda: E.cache_forward(B, nnz, loc, rowidx, w, outp))
-        E.lib().ttx_debug_cache_fwd(1)
+        E.debug_cache_fwd(1)
         t_f_old = timed(lambda: E.cache_forward(B, nnz, loc, rowidx, w, outp))
-        E.lib().ttx_debug_cache_fwd(0)
+        E.debug_cache_fwd(0)
         t_b = timed(lambda: E.cache_backward_sgd(nnz, grad, loc, rowidx, 0.0, w))
         H = 1 << 22
         idx = torch.randint(0, 11_000_000, (nnz,), generator=g, dtype=torch.int64).to(dev)

@@ -17,7 +17,7 @@ cores = [torch.from_numpy(c).to(dev) for c in G.make_cores(2, 1, p, q, r[1:-1])]
 grad = torch.from_numpy(G.make_grad(3, 1, 512, 64)).to(dev)
 Lt = torch.tensor([55000, 250, 1], dtype=torch.int64, device=dev)
 plans = [E.lookup_prologue(i, o, 1, p, q, r) for i, o in reqs]
-E.lib().ttx_debug_skip(mask)
+E.debug_skip(mask)
 for k in range(300):
     i, o = reqs[k % 10]; row, tab, plan = plans[k % 10]
     E.tt_sgd_backward(1000, 64, 0.0, p, q, r, Lt, i.numel(), i, row, tab, grad, cores, plan=plan)

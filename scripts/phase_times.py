@@ -19,10 +19,10 @@ for k in range(5):
     m(*reqs[k]).backward(grad)
 buf = torch.zeros(1100 * 16, dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
-E.lib().ttx_debug_stamps(E.C.c_void_p(buf.data_ptr()))
+E.debug_stamps(buf.data_ptr())
 m(*reqs[5]).backward(grad)
 torch.cuda.synchronize()
-E.lib().ttx_debug_stamps(None)
+E.debug_stamps(None)
 st = buf.cpu().numpy().reshape(-1, 16)[:1000]
 live = st[:, 9] > 0
 st = st[live][:, :10].astype(np.float64) / 100.0  # 100 MHz -> us

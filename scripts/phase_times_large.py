@@ -24,10 +24,10 @@ for k in range(4):
 nwg = 16384
 buf = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
-E.lib().ttx_debug_stamps(E.C.c_void_p(buf.data_ptr()))
+E.debug_stamps(buf.data_ptr())
 m(*reqs[1]).backward(grad)
 torch.cuda.synchronize()
-E.lib().ttx_debug_stamps(None)
+E.debug_stamps(None)
 st = buf.cpu().numpy().reshape(-1, 16)
 live = (st[:, 9] > 0) & (st[:, 0] > 0)
 st = st[live].astype(np.float64) / 100.0  # 100 MHz -> us

@@ -61,7 +61,7 @@ def update_cache_state(indices, hashtbl, cache_freq):
     O.update_cache_state(_np(indices), h, f)
 
 
-def cache_populate(num_embeddings, p, q, r, tt_cores, L, hashtbl, cache_freq, cache_state, cache_weight):
+def cache_populate(num_embeddings, p, q, r, tt_cores, L, hashtbl, cache_freq, cache_state, cache_weight, reference_exact=False):
     cw = _np(cache_weight)
     O.cache_populate(_geom(tt_cores[0].size(0), p, q, r), [_np(c) for c in tt_cores], _np(hashtbl), _np(cache_freq),
                      _np(cache_state), cw)

@@ -34,11 +34,11 @@ def test_every_rank_the_reference_accepts_gets_a_tiling():
         T = len(q)
         p = [200, 220, 250, 7][:T]
         r = [1] + ranks + [1]
-        E.lib().ttx_debug_skip(256)  # (the generic kernels: r = 64 with q = [2,8,8] would also take a padded specialised one)
+        E.debug_skip(256)  # (the generic kernels: r = 64 with q = [2,8,8] would also take a padded specialised one)
         try:
             tiles = E.debug_tiles(1, p, q, r)
         finally:
-            E.lib().ttx_debug_skip(0)
+            E.debug_skip(0)
         assert tiles["MC"] >= 1 and 0 < tiles["bytes"] <= 160 * 1024, (q, ranks, tiles)
         g = E._geom(1, p, q, r)
         assert E.lib().ttx_tt_backward_workspace_bytes(ctypes.byref(g), 512, int(np.prod(q)), 10240) > 0
@@ -59,6 +59,8 @@ def test_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(so)
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, f"libttx.so lacks {missing}"
+    hooks = ctypes.CDLL(os.path.join(ROOT, "fbtt-embedding_amd", "libttx_hooks.so"))  # the test build exports the same ABI
+    assert not [s for s in declared if not hasattr(hooks, s)]
     assert lib.ttx_version() >= 100
     # host-only queries work without a GPU
     import tt_embeddings as E
@@ -73,6 +75,61 @@ def test_abi_exports_every_declared_symbol():
     bad2.T = 7
     assert L.ttx_plan_bytes(ctypes.byref(bad2), 10) == 0
     assert L.ttx_plan_bytes(ctypes.byref(bad), 10) > 0
+
+
+def test_product_library_has_no_test_knobs():
+    """Round 6: the test / ablation knobs (ttx_debug_skip, ttx_set_chunk, ttx_debug_lds_budget, ttx_debug_stamps,
+    ttx_debug_cache_fwd) and the process-wide reference-exact switch are NOT in libttx.so -- neither the setters nor a global to
+    set -- and the library exports its C ABI only.  They live in libttx_hooks.so, the same sources with -DTTX_TEST_HOOKS
+    (include/ttx_test_hooks.h), which the shim loads on the first use of a knob and leaves as soon as every knob is back at
+    its default."""
+    import subprocess
+
+    import tt_embeddings as E
+
+    hooks_hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ttx_test_hooks.h")).read(), flags=re.S)
+    knobs = sorted(set(re.findall(r"\b(ttx_[a-z0-9_]+)\s*\(", hooks_hdr)))
+    assert set(knobs) == {"ttx_set_chunk", "ttx_debug_lds_budget", "ttx_debug_skip", "ttx_debug_cache_fwd", "ttx_debug_stamps"}
+    so = os.path.join(ROOT, "fbtt-embedding_amd", "libttx.so")
+    exported = [ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", so], text=True).splitlines()]
+    assert exported and all(sym.startswith("ttx_") for sym in exported), [x for x in exported if not x.startswith("ttx_")]
+    for sym in knobs + ["ttx_set_reference_exact"]:
+        assert sym not in exported, f"{sym} is exported by the product library"
+    prod = ctypes.CDLL(so)
+    assert prod.ttx_has_test_hooks() == 0 and prod.ttx_debug_state() == 0
+    hooks = ctypes.CDLL(os.path.join(ROOT, "fbtt-embedding_amd", "libttx_hooks.so"))
+    assert hooks.ttx_has_test_hooks() == 1 and all(hasattr(hooks, k) for k in knobs)
+    # the shim: product library until a knob moves, back when it is reset
+    assert E.lib() is E._product and E.lib().ttx_has_test_hooks() == 0
+    E.debug_skip(256)
+    try:
+        assert E.lib() is E._hooks and E.lib().ttx_debug_state() == 1 and E._product.ttx_debug_state() == 0
+    finally:
+        E.debug_skip(0)
+    assert E.lib() is E._product
+
+
+def test_importing_the_module_leaves_torch_untouched():
+    """Round 6: `import tt_embeddings_ops` must not rewrite torch.Tensor.backward (rounds 5's direct backward is opt-in:
+    enable_direct_backward() / TTX_DIRECT_BACKWARD=1), and disable_direct_backward() restores the original method."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "orig = torch.Tensor.backward\n"
+        "import tt_embeddings_ops as ops\n"
+        "assert torch.Tensor.backward is orig and not ops.direct_backward_enabled()\n"
+        "ops.enable_direct_backward(); assert torch.Tensor.backward is ops._backward and ops.direct_backward_enabled()\n"
+        "x = torch.ones(3, requires_grad=True); (x * 2).sum().backward(); assert x.grad.tolist() == [2.0] * 3\n"
+        "ops.disable_direct_backward(); assert torch.Tensor.backward is orig and not ops.direct_backward_enabled()\n"
+        "print('ok')\n" % os.path.join(ROOT, "fbtt-embedding_amd"))
+    env = {k: v for k, v in os.environ.items() if k != "TTX_DIRECT_BACKWARD"}
+    assert subprocess.check_output([sys.executable, "-c", code], text=True, env=env).strip() == "ok"
+    out = subprocess.check_output([sys.executable, "-c", code.replace("assert torch.Tensor.backward is orig and not ops.direct_backward_enabled()\nops.enable",
+                                                                    "assert ops.direct_backward_enabled()\nops.enable")],
+                                  text=True, env=dict(env, TTX_DIRECT_BACKWARD="1"))
+    assert out.strip() == "ok"
 
 
 def test_shim_fails_loudly_without_gpu_tensors():

@@ -339,6 +339,42 @@ def test_two_and_four_cores_over_several_steps_track_the_oracle(node, p, q, rank
             assert (err <= tol).all(), f"step {step} core {k}: max err {err.max():.3e} (worst err / tol {(err / tol).max():.2f})"
 
 
+@pytest.mark.parametrize("p,q,ranks", [([4, 5, 3, 4], [4, 4, 4, 4], [32, 32, 32]), ([4, 5, 3, 4], [3, 4, 2, 3], [13, 12, 7])])
+def test_four_cores_two_forwards_outstanding(node, p, q, ranks):
+    """Round 6 (advisor): forward A, forward B, backward A, backward B on ONE fused-optimizer module.  Backward A rewrites cores 2 / 3
+    while plan B still holds the product of the OLD cores; backward B must recompute it from the current cores, as the reference
+    recomputes every intermediate in every backward (tt_embeddings_cuda.cu:419-652) -- csrc/ttx_tt.hip g_t4_epoch.  Checked against
+    the oracle run in the same order: backward B with B's output gradient on the cores backward A left.  Both autograd orders:
+    `loss.backward()` of a sum (the engine runs B's node first or second) and explicit out.backward() calls."""
+    import tt_embeddings_ops as ops
+
+    E_, D, B = int(np.prod(p)), int(np.prod(q)), 40
+    cores = G.make_cores(41, 1, p, q, [1] + ranks + [1], "signed")
+    g = O.make_geom(1, p, q, ranks)
+    (ia, oa), (ib, ob) = G.make_bags(700, B, E_, 5, 2, 1), G.make_bags(701, B, E_, 5, 2, 1)
+    da, db = G.make_grad(800, 1, B, D), G.make_grad(801, 1, B, D)
+    for order in ("a_then_b", "b_then_a"):
+        m = ops.TTEmbeddingBag(E_, D, ranks, p, q, sparse=True, optimizer=ops.OptimType.SGD, learning_rate=0.05, use_cache=False,
+                               weight_dist="uniform", device=DEV)
+        with torch.no_grad():
+            for dst, src in zip(m.tt_cores, cores):
+                dst.copy_(t(src))
+        out_a, out_b = m(t(ia), t(oa)), m(t(ib), t(ob))
+        first, second = ((out_a, da, ia, oa), (out_b, db, ib, ob)) if order == "a_then_b" else ((out_b, db, ib, ob), (out_a, da, ia, oa))
+        ref = [c.copy() for c in cores]
+        for out, d_out, idx, off in (first, second):
+            out.backward(t(d_out[0]))
+            rowidx, tableidx = O.rowidx_from_offsets(off, 1)
+            O.tt_backward(g, O.OPTIM_SGD, B, D, 0.05, 0.0, idx, rowidx, tableidx, d_out, ref)
+        torch.cuda.synchronize()
+        for k in range(4):
+            a, b = m.tt_cores[k].detach().cpu().numpy().astype(np.float64), ref[k].astype(np.float64)
+            tol = 4 * (2e-6 * np.abs(b).max() + 1e-5 * np.abs(b))
+            err = np.abs(a - b)
+            # (a stale product is off by the size of one update, ~1e-2 of the weights)
+            assert (err <= tol).all(), f"{order} core {k}: max err {err.max():.3e} (worst err / tol {(err / tol).max():.2f})"
+
+
 def test_four_cores_captured_step_tracks_eager(node):
     """... and behind a captured graph (ttx_graph.GraphedStep): plan build, merge, forward, backward and the mark's reset all
     replay from one graph -- ten fused-SGD steps leave the four cores bit-identical to the same steps run eagerly."""
@@ -664,6 +700,39 @@ def test_device_side_lookup_count(node, tables, B, cap_extra):
                 assert torch.equal(a.tt_cores[k].grad, b.tt_cores[k].grad), f"dense grad {k} differs"
             else:
                 assert torch.equal(a.tt_cores[k].detach(), b.tt_cores[k].detach()), f"core {k} differs ({kw})"
+
+
+def test_device_side_lookup_count_of_zero_and_refused_forms(node):
+    """Round 6 (advisor): n_dev == 0 -- every bag empty, what a rank of the compact sharded path sees when it receives only empty
+    bags -- plans, contracts and trains nothing: zero output, cores untouched (fused SGD), zero dense gradients; and
+    per_sample_weights / include_last_offset=False are refused with n_dev instead of being silently dropped."""
+    import tt_embeddings_ops as ops
+
+    if node == "python":
+        pytest.skip("the device-side count is the C++ node's route")
+    p, q, r = [20, 22, 25], [4, 4, 4], [16, 16]
+    E_, D, B, tables = int(np.prod(p)), 64, 32, 2
+    buf = t(np.random.RandomState(5).randint(0, E_, size=500).astype(np.int64))
+    off = torch.zeros(tables * B + 1, dtype=torch.int64, device=DEV)
+    zero = torch.zeros(1, dtype=torch.int32, device=DEV)
+    grad = t(G.make_grad(19, tables, B, D))
+    for kw in (dict(sparse=False), dict(sparse=True, optimizer=ops.OptimType.SGD, learning_rate=LR)):
+        m = ops.TableBatchedTTEmbeddingBag(tables, E_, D, r, p, q, use_cache=False, weight_dist="uniform", device=DEV, **kw)
+        before = [c.detach().clone() for c in m.tt_cores]
+        out = m(buf, off, n_dev=zero)
+        assert out.shape == (tables, B, D) and not out.any()
+        out.backward(grad)
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert torch.equal(m.tt_cores[k].detach(), before[k])
+            if not kw["sparse"]:
+                assert m.tt_cores[k].grad is not None and not m.tt_cores[k].grad.any()
+        with pytest.raises(NotImplementedError):
+            m(buf, off, n_dev=zero, per_sample_weights=torch.ones(500, device=DEV))
+    m = ops.TableBatchedTTEmbeddingBag(tables, E_, D, r, p, q, use_cache=False, weight_dist="uniform", device=DEV,
+                                       include_last_offset=False)
+    with pytest.raises(ValueError):
+        m(buf, off[:-1], n_dev=zero)
 
 
 def test_max_pooling_truncates_at_one_rank_as_it_does_at_many(node):
@@ -1469,6 +1538,19 @@ def test_backward_of_the_lookups_own_output_past_the_engine(node, optimizer, liv
 
     if node != "native":
         pytest.skip("the direct backward belongs to the C++ node")
+    # round 6: opt-in.  Importing the module leaves torch.Tensor.backward alone (tests/test_module_cpu.py); this test enables it
+    # and puts the original method back whatever happens.
+    original = torch.Tensor.backward
+    assert original is not ops._backward and not ops.direct_backward_enabled()
+    ops.enable_direct_backward()
+    try:
+        _direct_backward_cases(ops, optimizer, live, monkeypatch, gc, weakref)
+    finally:
+        ops.disable_direct_backward()
+    assert torch.Tensor.backward is original and not ops._direct
+
+
+def _direct_backward_cases(ops, optimizer, live, monkeypatch, gc, weakref):
     p, q, r = [20, 22, 25], [4, 4, 4], [16, 16]
     E_, D, B = 20 * 22 * 25, 64, 64
 
@@ -1544,6 +1626,37 @@ def test_backward_of_the_lookups_own_output_past_the_engine(node, optimizer, liv
     with pytest.raises(RuntimeError):
         m(i, o).backward(g.unsqueeze(0))  # a gradient of another shape than the output: autograd's own error
     (m(i, o) * 2.0).sum().backward()  # the output as an operand
+    # an in-place op on the registered output keeps the tensor (and its registry entry) but rebases its grad_fn: the node must see
+    # the in-place op's gradient (2 g), i.e. the engine's route -- for the batched module's output and the squeezed view alike
+    for cls in (ops.TTEmbeddingBag, ops.TableBatchedTTEmbeddingBag):
+        single = cls is ops.TTEmbeddingBag
+        a, b = pair(cls)
+        gg = g if single else g.unsqueeze(0)
+        out = a(i, o)
+        assert id(out) in ops._direct
+        out.mul_(2.0)
+        out.backward(gg)
+        monkeypatch.setattr(ops, "_DIRECT_BACKWARD", False)
+        ref = b(i, o)
+        ref.mul_(2.0)
+        ref.backward(gg)
+        monkeypatch.setattr(ops, "_DIRECT_BACKWARD", True)
+        for x, y in zip(a.tt_cores, b.tt_cores):
+            assert torch.equal(x, y), "in-place op on the output before backward(): the direct route must decline"
+    # a TorchFunctionMode sees Tensor.backward of a registered output as of any tensor
+    from torch.overrides import TorchFunctionMode
+
+    class Spy(TorchFunctionMode):
+        calls = 0
+
+        def __torch_function__(self, func, types, args=(), kwargs=None):
+            Spy.calls += "backward" in getattr(func, "__name__", "")
+            return func(*args, **(kwargs or {}))
+
+    out = m(i, o)
+    with Spy():
+        out.backward(g)
+    assert Spy.calls >= 1, "a torch-function mode must see backward() of a registered output"
     if not live:
         dense = fresh(sparse=False)
         out = dense(i, o)

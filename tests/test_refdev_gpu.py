@@ -305,18 +305,32 @@ def test_second_populate_differs_from_reference_only_on_evicted_slots():
     ok, of, ost = keys1.copy(), freq1.copy(), state1.copy()
     O.cache_populate(O.make_geom(1, p, q, r), [c.cpu().numpy() for c in cores], ok, of, ost, np.zeros((cs, 64), dtype=np.float32))
     assert np.array_equal(ost, got) and np.array_equal(ok, pk.cpu().numpy())
-    # ... and with the fix switched off (ttx_set_reference_exact) product, reference kernel and oracle agree on EVERY slot
-    E.set_reference_exact(1)
+    # ... and with the fix switched off PER CALL (round 6: ttx_cache_populate_f(flags = TTX_POPULATE_REFERENCE_EXACT), the module's
+    # ctor keyword `reference_exact_populate`; no process-wide switch) product, reference kernel and oracle agree on EVERY slot
     O.set_reference_exact(1)
     try:
         xk, xf, xstate = t(keys1), t(freq1), t(state1)
-        E.cache_populate(E_, p, q, r, cores, Lt, xk, xf, xstate, dw)
+        E.cache_populate(E_, p, q, r, cores, Lt, xk, xf, xstate, dw, reference_exact=True)
         assert torch.equal(xk, rk) and torch.equal(xf, rf) and torch.equal(xstate, rstate), "reference-exact second populate"
+        # the flag is the call's, not the library's: the next plain call is the default again
+        yk, yf, ystate = t(keys1), t(freq1), t(state1)
+        E.cache_populate(E_, p, q, r, cores, Lt, yk, yf, ystate, dw)
+        assert torch.equal(ystate, pstate)
+        # and through the module: the ctor keyword reaches the call
+        import tt_embeddings_ops as ops
+        for exact, want in ((True, rstate), (False, pstate)):
+            m = ops.TTEmbeddingBag(E_, 64, r[1:-1], p, q, use_cache=True, cache_size=cs, hashtbl_size=H, weight_dist="uniform",
+                                   device=DEV, reference_exact_populate=exact)
+            with torch.no_grad():
+                for dst, src in zip(m.tt_cores, cores):
+                    dst.copy_(src.reshape(dst.shape))
+                m.hashtbl.copy_(t(keys1)); m.cache_freq.copy_(t(freq1)); m.cache_state.copy_(t(state1))
+            m.cache_populate()
+            assert torch.equal(m.cache_state, want) and torch.equal(m.hashtbl, rk)
         ok, of, ost = keys1.copy(), freq1.copy(), state1.copy()
         O.cache_populate(O.make_geom(1, p, q, r), [c.cpu().numpy() for c in cores], ok, of, ost, np.zeros((cs, 64), dtype=np.float32))
         assert np.array_equal(ost, ref) and np.array_equal(ok, rk.cpu().numpy()) and np.array_equal(of, rf.cpu().numpy())
     finally:
-        E.set_reference_exact(0)
         O.set_reference_exact(0)
 
 

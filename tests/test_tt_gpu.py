@@ -229,6 +229,33 @@ def test_plan_paths_vs_oracle(tables, p, B, pf):
                 assert_close(got["cores"][k], orc["cores"][k], f"plan {p} sgd core{k}")
 
 
+def test_wide_digit_plan_declines_more_than_2_to_18_full_chunks():
+    """Round 6 (advisor): the wide-digit plan's chunk list packs a slice's full-chunk count into 18 bits of an int32 prefix sum;
+    with ONE lookup per chunk (the generic kernels' last-resort tile; here the test knob) and more than 262,144 lookups the sum
+    overflowed.  Such a batch now takes the multi-pass plan: forward and fused SGD against the oracle at 280k lookups."""
+    import tt_embeddings as E
+
+    p, q, r, tables = [300, 29, 310], [2, 3, 2], [1, 4, 5, 1], 2
+    E_, D, B = int(np.prod(np.array(p, dtype=np.int64))), int(np.prod(q)), 14000
+    idx, off = G.make_bags(91, B, E_, 10, 1, tables)
+    assert 262144 < idx.size <= 96 * 4096
+    c = dict(tables=tables, T=3, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+             cores=G.make_cores(92, tables, p, q, r, "signed"), d_out=G.make_grad(93, tables, B, D))
+    E.set_chunk(1)
+    try:
+        got = {mode: run_case(c, mode, plan_shared=True) for mode in ("dense", "sgd")}
+    finally:
+        E.set_chunk(0)
+    for mode in ("dense", "sgd"):
+        orc = oracle_case(c, mode)
+        assert_close(got[mode]["out"], orc["out"], "MC = 1 out")
+        for k in range(3):
+            if mode == "dense":
+                assert_close(got[mode]["grads"][k], orc["grads"][k], f"MC = 1 grad{k}")
+            else:
+                assert_close(got[mode]["cores"][k], orc["cores"][k], f"MC = 1 sgd core{k}")
+
+
 @pytest.mark.parametrize("p,tables", [([100, 120, 90], 3), ([2500, 30, 20], 1), ([5000, 30, 20], 1)])  # wide digit (10 / 12 bits) / two passes
 @pytest.mark.parametrize("nnz", [4096, 4097, 8191, 12288])
 @pytest.mark.parametrize("skew", [False, True])
@@ -328,11 +355,11 @@ def test_specialised_shapes_vs_oracle_and_generic(ranks, q):
         for mode in ("dense", "sgd", "adagrad"):
             got = run_case(c, mode, plan_shared=True)
             orc = oracle_case(c, mode)
-            E.lib().ttx_debug_skip(256)  # generic kernels (r = 64 with q1 = 8: a 128 KB core_1 slice, walked in blocks)
+            E.debug_skip(256)  # generic kernels (r = 64 with q1 = 8: a 128 KB core_1 slice, walked in blocks)
             try:
                 gen = run_case(c, mode, plan_shared=False)
             finally:
-                E.lib().ttx_debug_skip(0)
+                E.debug_skip(0)
             assert_close(got["out"], orc["out"], f"spec {ranks}{q} out vs oracle")
             assert_close(got["out"], gen["out"], f"spec {ranks}{q} out vs generic")
             gref = oracle_case(c, "dense")["grads"] if mode == "adagrad" else None
@@ -378,7 +405,7 @@ def test_block_walk_under_a_small_lds_budget(q, ranks, budget):
     r = [1] + ranks + [1]
     E_, D = int(np.prod(p)), int(np.prod(q))
     E.debug_lds_budget(budget * 1024)
-    E.lib().ttx_debug_skip(256)  # (some of these shapes would take a padded shape-specialised kernel: this is about the generic ones)
+    E.debug_skip(256)  # (some of these shapes would take a padded shape-specialised kernel: this is about the generic ones)
     try:
         tiles = E.debug_tiles(1, p, q, r)
         assert tiles["MC"] > 0 and tiles["ncp"] * tiles["nkb"] > 1 and tiles["bytes"] <= budget * 1024, tiles
@@ -389,7 +416,7 @@ def test_block_walk_under_a_small_lds_budget(q, ranks, budget):
             _check_modes(c, f"walk q={q} r={ranks} {tiles} tables={tables}")
     finally:
         E.debug_lds_budget(0)
-        E.lib().ttx_debug_skip(0)
+        E.debug_skip(0)
 
 
 @pytest.mark.parametrize("q,ranks", [([4, 4, 4], [128, 128]), ([4, 4, 4], [96, 96]), ([4, 4, 4], [80, 80]), ([2, 8, 8], [64, 64]),
@@ -405,13 +432,13 @@ def test_large_rank_shapes(q, ranks):
     p = [6, 5, 7, 3][:T]
     r = [1] + ranks + [1]
     E_, D = int(np.prod(p)), int(np.prod(q))
-    E.lib().ttx_debug_skip(256)  # (r = 64 with q = [2,8,8] also fits a padded specialised kernel: the generic walk is meant here)
+    E.debug_skip(256)  # (r = 64 with q = [2,8,8] also fits a padded specialised kernel: the generic walk is meant here)
     try:
         tiles = E.debug_tiles(1, p, q, r)
         assert tiles["MC"] > 0 and tiles["bytes"] <= 160 * 1024, tiles
         _large_rank_cases(E, T, p, q, r, ranks, E_, D, tiles)
     finally:
-        E.lib().ttx_debug_skip(0)
+        E.debug_skip(0)
 
 
 def _large_rank_cases(E, T, p, q, r, ranks, E_, D, tiles):
@@ -590,11 +617,11 @@ def test_padded_shapes_run_on_the_specialised_kernels(q, ranks):
         for mode in ("dense", "sgd", "adagrad"):
             got = run_case(c, mode, plan_shared=True)
             orc = oracle_case(c, mode)
-            E.lib().ttx_debug_skip(256)  # generic kernels
+            E.debug_skip(256)  # generic kernels
             try:
                 gen = run_case(c, mode, plan_shared=False)
             finally:
-                E.lib().ttx_debug_skip(0)
+                E.debug_skip(0)
             assert_close(got["out"], orc["out"], f"padded {ranks}{q} out vs oracle")
             assert_close(got["out"], gen["out"], f"padded {ranks}{q} out vs generic")
             gref = oracle_case(c, "dense")["grads"] if mode == "adagrad" else None
@@ -639,11 +666,11 @@ def test_four_cores_run_on_the_three_core_kernels(q, ranks):
         for mode in ("dense", "sgd", "adagrad"):
             got = run_case(c, mode, plan_shared=True)
             orc = oracle_case(c, mode)
-            E.lib().ttx_debug_skip(256)  # generic kernels
+            E.debug_skip(256)  # generic kernels
             try:
                 gen = run_case(c, mode, plan_shared=False)
             finally:
-                E.lib().ttx_debug_skip(0)
+                E.debug_skip(0)
             assert_close(got["out"], orc["out"], f"T=4 {ranks}{q} out vs oracle")
             assert_close(got["out"], gen["out"], f"T=4 {ranks}{q} out vs generic")
             gref = oracle_case(c, "dense")["grads"] if mode == "adagrad" else None
@@ -680,11 +707,11 @@ def test_two_cores_on_the_dedicated_kernels(q, ranks):
         for mode in ("dense", "sgd", "adagrad"):
             got = run_case(c, mode, plan_shared=True)
             orc = oracle_case(c, mode)
-            E.lib().ttx_debug_skip(256)  # generic kernels
+            E.debug_skip(256)  # generic kernels
             try:
                 gen = run_case(c, mode, plan_shared=False)
             finally:
-                E.lib().ttx_debug_skip(0)
+                E.debug_skip(0)
             assert_close(got["out"], orc["out"], f"T=2 {ranks}{q} out vs oracle")
             assert_close(got["out"], gen["out"], f"T=2 {ranks}{q} out vs generic")
             gref = oracle_case(c, "dense")["grads"] if mode == "adagrad" else None
