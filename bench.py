@@ -219,7 +219,7 @@ def secondary_record(workload="cfg5shard", steps=40, repeats=3):
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
         keep = ("metric", "value", "unit", "ms_per_step", "steps", "repeats", "timed_mode", "eager_ms_per_step", "us_per_nnz", "kernel_us",
-                "roofline", "spread")
+                "roofline", "spread", "no_prefetch", "cache_gather_roofline", "cache_hit_rate", "dtype")
         rec = {k: j[k] for k in keep if k in j}
         rec["workload"] = j["config"]["workload"]
         fl = j["config"]["flop_per_nnz_fwd_bwd"] * j["config"]["nnz_per_step_total"]
@@ -839,6 +839,8 @@ def main():
                                                       "frac_rocprof": round(g2 / (PEAK_HBM_TBS * 1e3), 4)})
             else:
                 line["cache_gather_roofline"]["rocprof_avg_us"] = None
+        if hit_rate is not None:
+            line["cache_hit_rate"] = round(hit_rate, 4)
         if not sharded and not args.no_cpu_baseline and ntab == 1:
             line["cpu_baseline"] = cpu_baseline(reqs_np, cores_np, d_out_np, Q_SHAPES, RANKS, B_GLOBAL)
         if args.run_baseline and not sharded and ntab == 1:
@@ -846,7 +848,20 @@ def main():
         if degraded:
             line["degraded"] = degraded
         if args.workload == "cfg2" and not sharded and not args.no_secondary:
-            line["secondary"] = secondary_record()
+            # (round 6) every BASELINE.json config under the driver's clock: besides the default line's configs[1], one rank's
+            # share of configs[4] (the regime where the contraction kernels are the bound), configs[3] (fused Adagrad at ranks 64,
+            # D = 128: its own roofline) and configs[2] (the row cache live on a Zipf stream: hit rate, cache_gather_roofline).
+            # A process each: a second module beside the first would perturb both.
+            line["secondary"] = [secondary_record("cfg5shard", 40, 3), secondary_record("cfg4", 100, 3),
+                                 secondary_record("cfg3", 100, 3)]
+            if "dense_embedding_bag" not in line and ntab == 1:
+                # the reference benchmark's --run-baseline leg (tt_embeddings_benchmark.py:195-211): the dense table the cores replace
+                try:
+                    line["dense_embedding_bag"] = dense_baseline(E_, D, reqs, grad, args.steps, args.warmup)
+                    line["dense_embedding_bag"]["tt_speedup"] = round(line["dense_embedding_bag"]["ms_per_step"] / line["eager_ms_per_step"], 3)
+                    line["dense_embedding_bag"]["tt_speedup_what"] = "dense eager ms/step over the TT module's eager ms/step (the same loop form)"
+                except Exception as ex:  # noqa: BLE001 -- a 2.8 GB table that does not fit must not take the line with it
+                    line["dense_embedding_bag"] = {"error": f"{type(ex).__name__}: {ex}"}
         if not (sharded and world > 1):
             print(json.dumps(line), flush=True)
     if sharded:

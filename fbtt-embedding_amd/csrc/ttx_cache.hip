@@ -1106,9 +1106,255 @@ int ttx_cache_backward_rowwise_adagrad_approx_n(int64_t nnz, const int32_t* skip
   return TTX_OK;
 }
 
+}  // extern "C"
+namespace ttx {
+// ---- the cache rows' update WITHOUT atomics (round 6): sorted, one writer per row, bit-identical from run to run ------------------
+// The reference adds every cached lookup's bag gradient to its cache row with float atomics (cu:1574-1657, 1659-1733) and lets the
+// row-wise Adagrad state race (cu:1735-1795); the kernels above do the same, so the order of additions -- and with it the last bits
+// of cache_weight -- changes from run to run.  Here the batch's cached lookups are first grouped by cache row: the duplicate map of
+// ttx_plan.hip (stable 64-bit radix sort + run heads: distinct rows ascending, a row's lookups in INDEX order) over the keys
+// `cache row` (lookups in front of the split point get the key cache_size and form a last run nobody applies).  Then
+//   SGD / dense:   Gu[u] = sum of the bag gradients of row u's lookups, in index order (gsum_slice / gsum_fold: every 16-lane group
+//                  the same amount of work whatever the skew, no atomics), and ONE thread group per distinct row applies it;
+//   row-wise Adagrad: the reference's per-lookup sequence old = state; state += g2; mult = lr / (sqrt(old + g2) + eps); w -= g mult,
+//                  taken in index order within a row -- the order of the sequential oracle, oracle/ttx_oracle.c:499: a segmented
+//                  inclusive scan of the lookups' g2 over the sorted order gives every lookup its multiplier, the same weighted sum
+//                  Gu[u] = sum mult_n g_n follows, the row's last lookup leaves the new state.
+// One pass over the gradient rows like the atomic kernels, plus the sort (16 B per lookup and 8-bit pass) and Gu (2 x 4 D per DISTINCT row).
+__global__ __launch_bounds__(kCT) void cs_keys_kernel(int N, const int* __restrict__ skip_dev, const int32_t* __restrict__ loc,
+                                                     long long cache_size, int64_t* __restrict__ keys, int64_t* __restrict__ vals) {
+  const int i = blockIdx.x * kCT + threadIdx.x;
+  if (i >= N) return;
+  const int skip = skip_dev ? max(0, min(N, *skip_dev)) : 0;
+  long long row = cache_size;  // (not a cached lookup: behind every real row)
+  if (i >= skip) { const long long c = loc[i]; if (c >= 0 && c < cache_size) row = c; }
+  keys[i] = cache_size - row;  // complemented: the descending sort leaves the rows ascending (all = cache_size + 1)
+  vals[i] = i;
+}
+
+// one 16-lane group per distinct row (float4 columns; D % 4 != 0: float columns): dst[row] = dst[row] + scale Gu[u] (SGD: scale = -lr,
+// Adagrad: -1 on the weighted sum) or dst[row] = Gu[u] (dense, onto the zeroed gradient)
+template <typename V>
+__global__ __launch_bounds__(kCT) void cs_apply_kernel(DedupMap M, int DV, long long cache_size, const V* __restrict__ Gu,
+                                                      float scale, int assign, V* __restrict__ dst) {
+  const int u = blockIdx.x * (kCT / 16) + threadIdx.x / 16, l = threadIdx.x & 15;
+  if (u >= M.nu[0]) return;
+  const long long row = M.uidx[u];
+  if (row >= cache_size) return;  // the run of the lookups that are not cached
+  const V* g = Gu + (size_t)u * DV;
+  V* w = dst + (size_t)row * DV;
+  for (int e = l; e < DV; e += 16) {
+    if (assign) w[e] = g[e];
+    else {
+      V x = w[e];
+      if constexpr (sizeof(V) == 16) { x.x += scale * g[e].x; x.y += scale * g[e].y; x.z += scale * g[e].z; x.w += scale * g[e].w; }
+      else x += scale * g[e];
+      w[e] = x;
+    }
+  }
+}
+
+// g2[b] = mean of the squares of bag gradient b (cu:1764-1772), a wave per bag, lanes striding the row, one butterfly
+__global__ __launch_bounds__(kCT) void cs_bag_g2_kernel(int B, int D, const float* __restrict__ grad, float* __restrict__ g2) {
+  const int b = blockIdx.x * (kCT / kWave) + threadIdx.x / kWave, lane = lane_id();
+  if (b >= B) return;
+  float s = 0.f;
+  for (int e = lane; e < D; e += kWave) { const float x = grad[(size_t)b * D + e]; s = fmaf(x, x, s); }
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
+  if (lane == 0) g2[b] = s / D;
+}
+
+// Segmented inclusive scan of v_i = g2[bag of the lookup at sorted position i] over the positions, segments = the map's runs, in
+// three steps over blocks of 1024 positions: (1) a block's TAIL = the sum of the positions behind its last run head (the whole
+// block if it holds none) and whether it holds a head; (2) one work-group walks the blocks: carry into block b = tail of b - 1
+// (+ the carry into b - 1 if that block held no head); (3) every position's prefix = carry (if no head lies in front of it in its
+// block) + the in-block segmented scan.  Fixed association, no atomics.
+constexpr int kCsBlock = 1024;
+struct CsScan { float incl; bool before_first_head; };
+__device__ __forceinline__ float cs_seg_scan(float v, bool head, float* wsum, int* whead, float* tail, int* has_head,
+                                             bool* no_head_before) {
+  // -> inclusive segmented scan of v within the 1024-position block; *tail / *has_head: see above; *no_head_before: no head at or in
+  // front of this position inside the block (the carry from the blocks before applies)
+  const int lane = lane_id(), w = threadIdx.x / kWave;
+  const unsigned long long hm = __ballot(head);
+  // in-wave: sum of the lanes from the last head at or below this lane (or lane 0) up to this lane
+  const unsigned long long below = hm & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+  const int start = below ? 63 - __clzll(below) : 0;  // first lane of this lane's run inside the wave
+  float x = v;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const float y = __shfl_up(x, o, kWave);
+    if (lane - o >= start) x += y;
+  }
+  // the wave's tail (sum from its last head, or the whole wave) and whether it holds a head
+  const int last_start = hm ? 63 - __clzll(hm) : 0;
+  const float wave_tail = __shfl(x, kWave - 1, kWave);  // lane 63's run starts at last_start: x[63] IS the tail
+  (void)last_start;
+  if (lane == 0) { wsum[w] = wave_tail; whead[w] = hm ? 1 : 0; }
+  __syncthreads();
+  // carry into this wave from the waves before it in the block: tails back to the nearest wave with a head
+  float carry = 0.f;
+  bool any = false;
+  for (int k = w - 1; k >= 0 && !any; --k) { carry += wsum[k]; any = whead[k] != 0; }
+  // NOTE the association: carry = wsum[w-1] + wsum[w-2] + ... (nearest first), fixed for a given batch
+  const bool mine_no_head = below == 0;  // no head at or in front of this lane inside its wave
+  if (mine_no_head) x += carry;
+  *no_head_before = mine_no_head && !any;
+  // the block's tail: from the last wave backwards to the nearest wave with a head
+  float t = 0.f;
+  bool h = false;
+  for (int k = kCsBlock / kWave - 1; k >= 0 && !h; --k) { t += wsum[k]; h = whead[k] != 0; }
+  *tail = t;
+  *has_head = h ? 1 : 0;
+  __syncthreads();
+  return x;
+}
+
+__device__ __forceinline__ float cs_position_value(const DedupMap& M, int N, int i, const int64_t* __restrict__ rowidx,
+                                                   const float* __restrict__ g2, bool* head, int* n_out) {
+  *head = false;
+  *n_out = -1;
+  if (i >= N) return 0.f;
+  const int n = M.occ[i];
+  *n_out = n;
+  *head = i == 0 || M.uid[M.occ[i - 1]] != M.uid[n];
+  return g2[rowidx[n]];
+}
+
+__global__ __launch_bounds__(kCsBlock) void cs_scan_tails_kernel(DedupMap M, int N, const int64_t* __restrict__ rowidx,
+                                                                const float* __restrict__ g2, float* __restrict__ blk_tail,
+                                                                int* __restrict__ blk_head) {
+  __shared__ float wsum[kCsBlock / kWave];
+  __shared__ int whead[kCsBlock / kWave];
+  bool head, nhb;
+  int n;
+  const float v = cs_position_value(M, N, blockIdx.x * kCsBlock + threadIdx.x, rowidx, g2, &head, &n);
+  float tail;
+  int hh;
+  cs_seg_scan(v, head, wsum, whead, &tail, &hh, &nhb);
+  if (threadIdx.x == 0) { blk_tail[blockIdx.x] = tail; blk_head[blockIdx.x] = hh; }
+}
+
+__global__ __launch_bounds__(64) void cs_scan_carry_kernel(int nblk, const float* __restrict__ blk_tail, const int* __restrict__ blk_head,
+                                                          float* __restrict__ blk_carry) {
+  if (threadIdx.x != 0) return;  // (a few thousand blocks at most: one lane, one fixed order)
+  float c = 0.f;
+  for (int b = 0; b < nblk; ++b) {
+    blk_carry[b] = c;
+    c = blk_head[b] ? blk_tail[b] : c + blk_tail[b];
+  }
+}
+
+// every cached lookup's multiplier (psw for the weighted sum) and, from a row's LAST lookup, the row's new state
+__global__ __launch_bounds__(kCsBlock) void cs_scan_emit_kernel(DedupMap M, int N, long long cache_size, const int64_t* __restrict__ rowidx,
+                                                               const float* __restrict__ g2, const float* __restrict__ blk_carry,
+                                                               float lr, float eps, float* __restrict__ state, float* __restrict__ mult) {
+  __shared__ float wsum[kCsBlock / kWave];
+  __shared__ int whead[kCsBlock / kWave];
+  const int i = blockIdx.x * kCsBlock + threadIdx.x;
+  bool head, nhb;
+  int n;
+  const float v = cs_position_value(M, N, i, rowidx, g2, &head, &n);
+  float tail;
+  int hh;
+  float incl = cs_seg_scan(v, head, wsum, whead, &tail, &hh, &nhb);
+  if (i >= N) return;
+  if (nhb) incl += blk_carry[blockIdx.x];
+  const int u = M.uid[n];
+  const long long row = M.uidx[u];
+  if (row >= cache_size) { mult[n] = 0.f; return; }  // not a cached lookup
+  const float s0 = state[row];  // (read by every lookup of the row, possibly in other blocks: the new state goes to a side array)
+  mult[n] = (float)(lr * (1.0 / (sqrtf(s0 + incl) + eps)));  // old + g2 = state + inclusive prefix (cu:1781-1782, double intermediate)
+  const bool last = i + 1 >= N || M.uid[M.occ[i + 1]] != u;
+  if (last) ((float*)M.iota)[u] = s0 + incl;  // (M.iota is unused by this map: the rows' new states, applied by cs_state_kernel)
+}
+__global__ __launch_bounds__(kCT) void cs_state_kernel(DedupMap M, long long cache_size, float* __restrict__ state) {
+  const int u = blockIdx.x * kCT + threadIdx.x;
+  if (u >= M.nu[0]) return;
+  const long long row = M.uidx[u];
+  if (row < cache_size) state[row] = ((const float*)M.iota)[u];
+}
+
+static size_t cs_scan_bytes(int64_t nnz, int64_t B) {
+  const size_t nblk = ((size_t)nnz + kCsBlock - 1) / kCsBlock;
+  return align_up((size_t)(B > 0 ? B : 1) * 4) + 3 * align_up(nblk * 4) + align_up((size_t)nnz * 4);
+}
+
+}  // namespace ttx
+extern "C" {
+
 // test hook: that sort on its own (tests/test_primref_gpu.py checks it against hipCUB's SortPairsDescending, the
 // library call the reference makes).  keys / vals are copied to keys_out / vals_out.
 size_t ttx_debug_sort_workspace_bytes(int64_t n) { return sort_pairs_ws_bytes(n); }
+
+size_t ttx_cache_backward_sorted_workspace_bytes(int64_t nnz, int64_t num_bags, int32_t D) {
+  if (nnz <= 0 || D <= 0 || num_bags < 0) return 0;
+  return align_up(dedup_bytes(nnz)) + align_up((size_t)(nnz + 1) * D * sizeof(float)) + gsum_scratch_bytes(D, nnz) +
+         cs_scan_bytes(nnz, num_bags);
+}
+
+int ttx_cache_backward_sorted(int32_t optim, int64_t nnz, const int32_t* skip_dev, int64_t num_bags, int32_t D, const float* grad,
+                              const int32_t* loc, const int64_t* rowidx, float lr, float eps, int64_t cache_size,
+                              float* cache_optimizer_state, float* dst, void* workspace, size_t workspace_bytes,
+                              ttx_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (optim != TTX_OPTIM_SGD && optim != TTX_OPTIM_ADAGRAD && optim != TTX_OPTIM_DENSE) TTX_FAIL(TTX_EINVAL, "unknown optimizer %d", optim);
+  if (D <= 0 || cache_size < 0 || cache_size >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "bad D / cache_size");
+  if (!dst) TTX_FAIL(TTX_EINVAL, "NULL output");
+  if (optim == TTX_OPTIM_DENSE && cache_size > 0)
+    TTX_HIP(hipMemsetAsync(dst, 0, (size_t)cache_size * D * sizeof(float), st));
+  if (nnz == 0 || cache_size == 0) return TTX_OK;
+  if (nnz >= (1ll << 31)) TTX_FAIL(TTX_EINVAL, "nnz=%lld out of range", (long long)nnz);
+  if (!grad || !loc || !rowidx) TTX_FAIL(TTX_EINVAL, "NULL input");
+  if (optim == TTX_OPTIM_ADAGRAD && (!cache_optimizer_state || num_bags <= 0))
+    TTX_FAIL(TTX_EINVAL, "row-wise Adagrad needs cache_optimizer_state and the number of bags");
+  if (!workspace || workspace_bytes < ttx_cache_backward_sorted_workspace_bytes(nnz, num_bags, D))
+    TTX_FAIL(TTX_EWORKSPACE, "sorted cache update: workspace too small");
+  char* ws = (char*)workspace;
+  const DedupMap M = carve_dedup(nnz, ws);
+  float* Gu = (float*)(ws + align_up(dedup_bytes(nnz)));
+  char* gscr = (char*)Gu + align_up((size_t)(nnz + 1) * D * sizeof(float));
+  char* sc = gscr + gsum_scratch_bytes(D, nnz);
+  const int N = (int)nnz;
+  int64_t *keys, *vals;
+  dedup_key_buffers(M, nnz, &keys, &vals);
+  hipLaunchKernelGGL(cs_keys_kernel, dim3((unsigned)((N + kCT - 1) / kCT)), dim3(kCT), 0, st, N, skip_dev, loc, (long long)cache_size,
+                     keys, vals);
+  int rc = dedup_build_from_keys(nnz, (unsigned long long)cache_size + 1ull, M, st);
+  if (rc) return rc;
+  const float* psw = nullptr;
+  if (optim == TTX_OPTIM_ADAGRAD) {
+    const int nblk = (N + kCsBlock - 1) / kCsBlock;
+    float* g2 = (float*)sc;
+    float* blk_tail = (float*)(sc + align_up((size_t)num_bags * 4));
+    int* blk_head = (int*)((char*)blk_tail + align_up((size_t)nblk * 4));
+    float* blk_carry = (float*)((char*)blk_head + align_up((size_t)nblk * 4));
+    float* mult = (float*)((char*)blk_carry + align_up((size_t)nblk * 4));
+    hipLaunchKernelGGL(cs_bag_g2_kernel, dim3((unsigned)((num_bags + kCT / kWave - 1) / (kCT / kWave))), dim3(kCT), 0, st, (int)num_bags,
+                       D, grad, g2);
+    hipLaunchKernelGGL(cs_scan_tails_kernel, dim3(nblk), dim3(kCsBlock), 0, st, M, N, rowidx, g2, blk_tail, blk_head);
+    hipLaunchKernelGGL(cs_scan_carry_kernel, dim3(1), dim3(64), 0, st, nblk, blk_tail, blk_head, blk_carry);
+    hipLaunchKernelGGL(cs_scan_emit_kernel, dim3(nblk), dim3(kCsBlock), 0, st, M, N, (long long)cache_size, rowidx, g2, blk_carry, lr, eps,
+                       cache_optimizer_state, mult);
+    hipLaunchKernelGGL(cs_state_kernel, dim3((unsigned)((N + kCT - 1) / kCT)), dim3(kCT), 0, st, M, (long long)cache_size,
+                       cache_optimizer_state);
+    TTX_HIP(hipGetLastError());
+    psw = mult;
+  }
+  rc = gsum_launch(M, nnz, 0, D, rowidx, nullptr, psw, grad, Gu, gscr, st);
+  if (rc) return rc;
+  const float scale = optim == TTX_OPTIM_SGD ? -lr : -1.0f;
+  const unsigned groups = (unsigned)((N + kCT / 16 - 1) / (kCT / 16));  // (nu <= N lives on the device: sized by N, surplus groups leave)
+  if (D % 4 == 0 && ((((uintptr_t)dst) | ((uintptr_t)Gu)) & 15) == 0)
+    hipLaunchKernelGGL(cs_apply_kernel<float4>, dim3(groups), dim3(kCT), 0, st, M, D / 4, (long long)cache_size, (const float4*)Gu, scale,
+                       optim == TTX_OPTIM_DENSE ? 1 : 0, (float4*)dst);
+  else
+    hipLaunchKernelGGL(cs_apply_kernel<float>, dim3(groups), dim3(kCT), 0, st, M, D, (long long)cache_size, (const float*)Gu, scale,
+                       optim == TTX_OPTIM_DENSE ? 1 : 0, dst);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
 
 int ttx_debug_sort_pairs_desc(int64_t n, const int64_t* keys, const int64_t* vals, int64_t* keys_out, int64_t* vals_out,
                               void* workspace, size_t workspace_bytes, ttx_stream_t stream) {

@@ -199,6 +199,14 @@ size_t dedup_bytes(long long nnz);
 DedupMap carve_dedup(long long nnz, void* base);
 int dedup_build(const Dims& d, long long nnz, const int64_t* indices, const int64_t* tableidx, const DedupMap& M,
                 hipStream_t stream);
+// the map over the caller's own 64-bit keys (ttx_plan.hip; used by the sorted cache-row update, ttx_cache.hip)
+void dedup_key_buffers(const DedupMap& M, long long nnz, int64_t** keys, int64_t** vals);
+int dedup_build_from_keys(long long nnz, unsigned long long all, const DedupMap& M, hipStream_t stream);
+// Gu[u, :] = sum over the occurrences n of distinct key u of (psw[n] *) d_output[(tableidx[n] * B +) rowidx[n], :], in index order,
+// no atomics (ttx_tt.hip gsum_slice_kernel / gsum_fold_kernel).  scratch: gsum_scratch_bytes(D, nnz) bytes.
+size_t gsum_scratch_bytes(int D, long long nnz);
+int gsum_launch(const DedupMap& M, long long nnz, int B, int D, const int64_t* rowidx, const int64_t* tableidx, const float* psw,
+                const float* d_output, float* Gu, void* scratch, hipStream_t st);
 
 // stable DESCENDING LSD radix sort of (int64 key, int64 value) pairs, 8 bits per pass, multi-work-group (ttx_cache.hip):
 // cache_populate's sort of (frequency, key) and the key sort of the duplicate map.  ws: sort_pairs_ws_bytes(n);

@@ -1877,6 +1877,35 @@ static int dedup_build_large(const Dims& d, long long nnz, const int64_t* indice
   return TTX_OK;
 }
 
+// The same map over 64-bit keys SOMEBODY ELSE wrote (round 6, ttx_cache.hip: the cached lookups of a batch keyed by their cache row,
+// for the atomic-free cache-row update): the caller fills dedup_key_buffers()'s keys[i] = all - 1 - key_i (complemented, like
+// dd_keys_kernel) and vals[i] = i for i < nnz, with every key_i < all; the map then lists the distinct keys ascending in uidx
+// (utab = 0), every key's occurrences in index order.  M must have been carved from dedup_bytes(nnz) bytes.
+void dedup_key_buffers(const DedupMap& M, long long nnz, int64_t** keys, int64_t** vals) {
+  char* extra = (char*)M.nu + dedup_map_bytes(nnz);
+  *keys = (int64_t*)extra;
+  *vals = (int64_t*)(extra + align_up((size_t)nnz * 8));
+}
+int dedup_build_from_keys(long long nnz, unsigned long long all, const DedupMap& M, hipStream_t stream) {
+  int bits = 1;
+  while (bits < 62 && (1ull << bits) < all) ++bits;
+  const int passes = (bits + 7) / 8;
+  const int N = (int)nnz;
+  int64_t *keys, *vals;
+  dedup_key_buffers(M, nnz, &keys, &vals);
+  char* sws = (char*)vals + align_up((size_t)nnz * 8);
+  int* blk = (int*)(sws + align_up(sort_pairs_ws_bytes(nnz)));
+  const int nblk = (int)dedup_blocks(nnz);
+  int64_t *sk = nullptr, *sv = nullptr;
+  const int rc = sort_pairs_desc(nnz, keys, vals, sws, &sk, &sv, stream, passes);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dd_count_kernel, dim3(nblk), dim3(kDdThreads), 0, stream, N, sk, blk);
+  hipLaunchKernelGGL(dd_scan_kernel, dim3(1), dim3(kDdThreads), 0, stream, nblk, N, blk, M);
+  hipLaunchKernelGGL(dd_emit_kernel, dim3(nblk), dim3(kDdThreads), 0, stream, N, all, all, sk, sv, blk, M);
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+
 int dedup_max_tables() { return kDedupMaxTables; }
 
 static int dedup_build_map(const Dims& d, long long nnz, const int64_t* indices, const int64_t* tableidx, const DedupMap& M,

@@ -386,6 +386,9 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     // bit 8 of `optim`: this batch's frequency update has been issued already (a planned-ahead prologue that was then
     // discarded, tt_embeddings_ops.py): look the indices up without counting them a second time
     const bool count_freq = (optim & 256) == 0;
+    // bits 9 / 10 of `optim`: the cache rows' update of the backward -- 9: sorted, atomic-free, bit-identical from run to run
+    // (ttx_cache_backward_sorted); 10: the one-launch float-atomic kernels; neither: sorted from kSortedAutoNnz lookups on
+    const int64_t det = (optim >> 9) & 3;
     optim &= 255;
     Geom G;
     make_geom(G, 1, p, q, r);
@@ -486,8 +489,8 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     // three saved entries (see TTLookupOp::forward): "m" = {optim, T, nstate, npre, weighted, psw_grad, has_copt, has_plan, p.., q.., r..},
     // "d" = {lr, eps}, "t" = cache_weight, then the six planned-ahead tensors or [buf], [copt], cores.., state.., [ppsw], [rows, porig]
     const bool has_copt = cache_opt_state.has_value() && cache_opt_state->defined();
-    std::vector<int64_t> meta = {optim, (int64_t)g.T, (int64_t)state.size(), (int64_t)pre.size(), weighted ? 1 : 0, psw_grad ? 1 : 0,
-                                 has_copt ? 1 : 0, nnz};
+    std::vector<int64_t> meta = {optim | (det << 9), (int64_t)g.T, (int64_t)state.size(), (int64_t)pre.size(), weighted ? 1 : 0,
+                                 psw_grad ? 1 : 0, has_copt ? 1 : 0, nnz};
     meta.insert(meta.end(), p.begin(), p.end());
     meta.insert(meta.end(), q.begin(), q.end());
     meta.insert(meta.end(), r.begin(), r.end());
@@ -510,7 +513,7 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     const auto meta = ctx->saved_data["m"].toIntVector();
     const auto lre = ctx->saved_data["d"].toDoubleVector();
     const auto keep = ctx->saved_data["t"].toTensorVector();
-    const int64_t optim = meta[0], T = meta[1], nstate_own = meta[2], nstate = meta[2] + meta[3];
+    const int64_t optim = meta[0] & 255, det = (meta[0] >> 9) & 3, T = meta[1], nstate_own = meta[2], nstate = meta[2] + meta[3];
     const bool weighted = meta[4] != 0, psw_grad = meta[5] != 0, has_copt = meta[6] != 0, planned = meta[3] == 6;
     const int64_t nnz = meta[7];
     const std::vector<int64_t> p(meta.begin() + 8, meta.begin() + 8 + T);
@@ -568,7 +571,9 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     const size_t wb = ttx_tt_backward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
     Tensor ws = bytes_on(cache_weight, wb);
     int32_t scatter_done = 0;  // the cache rows' SGD scatter rode in the optimizer's launch (ttx_tt_backward_wc)
-    if (optim == TTX_OPTIM_SGD && !ppsw.defined())
+    constexpr int64_t kSortedAutoNnz = 65536;  // (from here on the sorted update is also the faster one)
+    const bool sorted = det == 1 || (det == 0 && nnz >= kSortedAutoNnz);
+    if (optim == TTX_OPTIM_SGD && !ppsw.defined() && !sorted)
       check(ttx_tt_backward_wc(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz, pcol_p, prow_p, tableidx_p,
                                nullptr, go.data_ptr<float>(), cp, nullptr, nullptr, plan_p, ws.data_ptr(), wb, stream,
                                n_tt, ploc_p, go.data_ptr<float>(), -(float)lr, cache_weight.data_ptr<float>(), &scatter_done));
@@ -599,7 +604,24 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
       gcache = scaled.data_ptr<float>();
       rows = iota.data_ptr<int64_t>();
     }
-    if (optim == TTX_OPTIM_SGD) {
+    if (sorted) {  // atomic-free: the cached lookups grouped by cache row, one writer per row
+      const int64_t nbags = ppsw.defined() ? nnz : B;  // (weighted: every lookup brings its own scaled gradient row)
+      const size_t sb = ttx_cache_backward_sorted_workspace_bytes(nnz, nbags, (int32_t)D);
+      Tensor sws = bytes_on(cache_weight, sb);
+      Tensor gcw;
+      float* dst = cache_weight.data_ptr<float>();
+      if (optim == TTX_OPTIM_DENSE) {
+        for (int t = 0; t < T; ++t) grads[kHead + nstate + t] = dense[t];
+        gcw = at::empty_like(cache_weight);
+        dst = gcw.data_ptr<float>();
+        grads[12] = gcw;
+      } else if (optim == TTX_OPTIM_ADAGRAD) {
+        TORCH_CHECK(cache_opt_state.defined(), "tt_embeddings: Adagrad with a live cache needs cache_optimizer_state");
+      }
+      check(ttx_cache_backward_sorted((int32_t)optim, nnz, n_tt, nbags, (int32_t)D, gcache, loc, rows, (float)lr, (float)eps,
+                                      cache_weight.size(0), optim == TTX_OPTIM_ADAGRAD ? cache_opt_state.data_ptr<float>() : nullptr,
+                                      dst, sws.data_ptr(), sb, stream));
+    } else if (optim == TTX_OPTIM_SGD) {
       if (!scatter_done)
         check(ttx_cache_backward_sgd_n(nnz, n_tt, (int32_t)D, gcache, loc, rows, (float)lr,
                                        cache_weight.data_ptr<float>(), stream));

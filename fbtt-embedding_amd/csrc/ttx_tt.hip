@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kGsThreads) void gsum_slice_kernel(DedupMap M, int 
   for (int r = 0; r < kGsRounds; ++r) {
     off[r] = 0, w[r] = 1.f, up[r] = -1;
     if (n[r] >= 0) {
-      off[r] = (long long)tableidx[n[r]] * B + rowidx[n[r]];  // (64-bit: tables * B may exceed 2^31)
+      off[r] = (tableidx ? (long long)tableidx[n[r]] * B : 0ll) + rowidx[n[r]];  // (64-bit: tables * B may exceed 2^31)
       up[r] = M.uid[n[r]];
       if (psw) w[r] = psw[n[r]];
     }
@@ -2557,6 +2557,32 @@ static size_t gu_bytes(const Dims& d, long long nnz) {
   return gu_rows_bytes(d, nnz) + align_up(slices * 2 * d.D * sizeof(float));
 }
 
+}  // extern "C"
+namespace ttx {
+size_t gsum_scratch_bytes(int D, long long nnz) {
+  const size_t slices = ((size_t)nnz + kGsSlice - 1) / kGsSlice;
+  return align_up(slices * 2 * (size_t)D * sizeof(float));
+}
+int gsum_launch(const DedupMap& M, long long nnz, int B, int D, const int64_t* rowidx, const int64_t* tableidx, const float* psw,
+                const float* d_output, float* Gu, void* scratch, hipStream_t st) {
+  const int N = (int)nnz;
+  const int blocks = ((N + kGsSlice - 1) / kGsSlice + kGsThreads / 16 - 1) / (kGsThreads / 16);
+  float* Pp = (float*)scratch;
+  if (D % 4 == 0 && ((((uintptr_t)d_output) | ((uintptr_t)Gu)) & 15) == 0) {
+    hipLaunchKernelGGL(gsum_slice_kernel<float4>, dim3(blocks), dim3(kGsThreads), 0, st, M, N, B, D / 4, rowidx, tableidx, psw,
+                       (const float4*)d_output, (float4*)Gu, (float4*)Pp);
+    hipLaunchKernelGGL(gsum_fold_kernel<float4>, dim3(blocks), dim3(kGsThreads), 0, st, M, N, D / 4, (const float4*)Pp, (float4*)Gu);
+  } else {
+    hipLaunchKernelGGL(gsum_slice_kernel<float>, dim3(blocks), dim3(kGsThreads), 0, st, M, N, B, D, rowidx, tableidx, psw, d_output,
+                       Gu, Pp);
+    hipLaunchKernelGGL(gsum_fold_kernel<float>, dim3(blocks), dim3(kGsThreads), 0, st, M, N, D, (const float*)Pp, Gu);
+  }
+  TTX_HIP(hipGetLastError());
+  return TTX_OK;
+}
+}  // namespace ttx
+extern "C" {
+
 size_t ttx_tt_backward_dd_workspace_bytes(const ttx_geom* g, int32_t D, int64_t nnz) {
   Dims d;
   if (make_dims(g, &d) != TTX_OK || nnz < 0) return 0;
@@ -2582,19 +2608,8 @@ int ttx_tt_backward_dd(const ttx_geom* g, int32_t optim, int32_t B, int32_t D, f
   float* Gu = (float*)workspace;
   {
     ProfScope ps(TTX_PROF_POOL, st);
-    const int N = (int)nnz;
-    const int blocks = ((N + kGsSlice - 1) / kGsSlice + kGsThreads / 16 - 1) / (kGsThreads / 16);
-    float* Pp = (float*)((char*)workspace + gu_rows_bytes(d, nnz));
-    if (d.D % 4 == 0 && (((uintptr_t)d_output) & 15) == 0) {
-      hipLaunchKernelGGL(gsum_slice_kernel<float4>, dim3(blocks), dim3(kGsThreads), 0, st, M, N, B, d.D / 4, rowidx, tableidx, psw,
-                         (const float4*)d_output, (float4*)Gu, (float4*)Pp);
-      hipLaunchKernelGGL(gsum_fold_kernel<float4>, dim3(blocks), dim3(kGsThreads), 0, st, M, N, d.D / 4, (const float4*)Pp, (float4*)Gu);
-    } else {
-      hipLaunchKernelGGL(gsum_slice_kernel<float>, dim3(blocks), dim3(kGsThreads), 0, st, M, N, B, d.D, rowidx, tableidx, psw, d_output,
-                         Gu, Pp);
-      hipLaunchKernelGGL(gsum_fold_kernel<float>, dim3(blocks), dim3(kGsThreads), 0, st, M, N, d.D, (const float*)Pp, Gu);
-    }
-    TTX_HIP(hipGetLastError());
+    rc = gsum_launch(M, nnz, B, d.D, rowidx, tableidx, psw, d_output, Gu, (char*)workspace + gu_rows_bytes(d, nnz), st);
+    if (rc) return rc;
   }
   // the distinct pairs as a batch of their own: bag row of pair u is u, its bag gradient Gu[u] (B = 0: no table term)
   return ttx_tt_backward_w(g, optim, 0, D, lr, eps, nnz, M.uidx, M.iota, M.utab, nullptr, Gu, tt_cores, optimizer_state,

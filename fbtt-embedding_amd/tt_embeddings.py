@@ -140,6 +140,9 @@ def _load(path):
     L.ttx_has_test_hooks.argtypes = []
     L.ttx_debug_tiles.argtypes = [G, C.POINTER(i32)]
     L.ttx_cache_populate_f.argtypes = [G, vp, i64, vp, vp, vp, i64, i32, vp, i32, vp, sz, vp]
+    L.ttx_cache_backward_sorted_workspace_bytes.restype = C.c_size_t
+    L.ttx_cache_backward_sorted_workspace_bytes.argtypes = [i64, i64, i32]
+    L.ttx_cache_backward_sorted.argtypes = [i32, i64, vp, i64, i32, vp, vp, vp, f32, f32, i64, vp, vp, vp, sz, vp]
     for name in ("ttx_dedup_bytes", "ttx_tt_forward_dd_workspace_bytes", "ttx_tt_backward_dd_workspace_bytes"):
         getattr(L, name).restype = C.c_size_t
     L.ttx_dedup_bytes.argtypes = [G, i64]
@@ -623,8 +626,40 @@ def cache_forward(B: int, nnz: int, cache_locations: torch.Tensor, rowidx: torch
                                        cw.data_ptr(), output.data_ptr(), _stream(dev)))
 
 
+# The cache rows' update WITHOUT atomics (ttx_cache_backward_sorted: the cached lookups grouped by cache row with a stable sort, a
+# row's bag gradients added in index order, one writer per row -- bit-identical from run to run, and the sequential oracle's order
+# for row-wise Adagrad).  `deterministic` (trailing keyword of the three functions below, not in the reference): True = always,
+# False = the one-launch float-atomic kernels (the reference's own formulation; the last bits of cache_weight then depend on the
+# order the adds arrive in), None = "auto": sorted from DETERMINISTIC_AUTO_MIN_NNZ cached lookups on, where it is also the
+# faster of the two.  TTX_DETERMINISTIC=1 / 0 in the environment overrides None.
+DETERMINISTIC_AUTO_MIN_NNZ = int(os.environ.get("TTX_DETERMINISTIC_AUTO_MIN_NNZ", 65536))
+
+
+def _use_sorted(deterministic: Optional[bool], nnz: int) -> bool:
+    if deterministic is None and os.environ.get("TTX_DETERMINISTIC", "") != "":
+        deterministic = os.environ["TTX_DETERMINISTIC"] not in ("0", "")
+    return nnz >= DETERMINISTIC_AUTO_MIN_NNZ if deterministic is None else bool(deterministic)
+
+
+def _cache_backward_sorted(optim: int, nnz: int, go: torch.Tensor, cache_locations: torch.Tensor, rowidx: torch.Tensor, lr: float,
+                           eps: float, state: Optional[torch.Tensor], dst: torch.Tensor, skip_dev: Optional[torch.Tensor] = None) -> None:
+    dev = _dev(dst)
+    D, cs = dst.size(1), dst.size(0)
+    num_bags = go.numel() // D
+    lb = lib()
+    st = _stream(dev)
+    nb = lb.ttx_cache_backward_sorted_workspace_bytes(nnz, num_bags, D)
+    ws = _workspace(dev, st, nb)
+    with _guard(dev):
+        _check(lb.ttx_cache_backward_sorted(optim, nnz, None if skip_dev is None else skip_dev.data_ptr(), num_bags, D, go.data_ptr(),
+                                            cache_locations.data_ptr() if nnz else None,
+                                            _i64(rowidx, "rowidx").data_ptr() if nnz else None, lr, eps, cs,
+                                            None if state is None else state.data_ptr(), dst.data_ptr(),
+                                            ws.data_ptr() if nnz else None, ws.numel(), st))
+
+
 def cache_backward_sgd(nnz: int, grad_output: torch.Tensor, cache_locations: torch.Tensor, rowidx: torch.Tensor,
-                       learning_rate: float, cache_weight: torch.Tensor) -> None:
+                       learning_rate: float, cache_weight: torch.Tensor, deterministic: Optional[bool] = None) -> None:
     """tt_embeddings.cpp:105-111."""
     if nnz == 0:
         return
@@ -632,19 +667,24 @@ def cache_backward_sgd(nnz: int, grad_output: torch.Tensor, cache_locations: tor
     cw = cache_weight.detach()
     go = _f32(grad_output, "grad_output")
     _check_cached_args(nnz, cache_locations, rowidx)
+    if _use_sorted(deterministic, nnz):
+        return _cache_backward_sorted(OPTIM_SGD, nnz, go, cache_locations, rowidx, learning_rate, 0.0, None, cw)
     with _guard(dev):
         _check(lib().ttx_cache_backward_sgd(nnz, cw.size(1), go.data_ptr(), cache_locations.data_ptr(),
                                             _i64(rowidx, "rowidx").data_ptr(), learning_rate, cw.data_ptr(), _stream(dev)))
 
 
 def cache_backward_dense(nnz: int, grad_output: torch.Tensor, cache_locations: torch.Tensor, rowidx: torch.Tensor,
-                         learning_rate: float, cache_weight: torch.Tensor) -> torch.Tensor:
+                         learning_rate: float, cache_weight: torch.Tensor, deterministic: Optional[bool] = None) -> torch.Tensor:
     """tt_embeddings.cpp:113-119 (learning_rate unused, as in the reference)."""
     dev = _dev(cache_weight)
     cw = cache_weight.detach()
     out = torch.empty_like(cw)
     go = _f32(grad_output, "grad_output")
     _check_cached_args(nnz, cache_locations, rowidx)
+    if _use_sorted(deterministic, nnz):
+        _cache_backward_sorted(OPTIM_DENSE, nnz, go, cache_locations, rowidx, 0.0, 0.0, None, out)
+        return out
     with _guard(dev):
         _check(lib().ttx_cache_backward_dense(nnz, cw.size(1), go.data_ptr(),
                                               cache_locations.data_ptr() if nnz else None,
@@ -655,7 +695,8 @@ def cache_backward_dense(nnz: int, grad_output: torch.Tensor, cache_locations: t
 
 def cache_backward_rowwise_adagrad_approx(nnz: int, grad_output: torch.Tensor, cache_locations: torch.Tensor,
                                           rowidx: torch.Tensor, learning_rate: float, eps: float,
-                                          cache_optimizer_state: torch.Tensor, cache_weight: torch.Tensor) -> None:
+                                          cache_optimizer_state: torch.Tensor, cache_weight: torch.Tensor,
+                                          deterministic: Optional[bool] = None) -> None:
     """tt_embeddings.cpp:121-129."""
     if nnz == 0:
         return
@@ -664,6 +705,8 @@ def cache_backward_rowwise_adagrad_approx(nnz: int, grad_output: torch.Tensor, c
     go = _f32(grad_output, "grad_output")
     _dev(cache_optimizer_state)
     _check_cached_args(nnz, cache_locations, rowidx)
+    if _use_sorted(deterministic, nnz):
+        return _cache_backward_sorted(OPTIM_ADAGRAD, nnz, go, cache_locations, rowidx, learning_rate, eps, cache_optimizer_state, cw)
     with _guard(dev):
         _check(lib().ttx_cache_backward_rowwise_adagrad_approx(
             nnz, cw.size(1), go.data_ptr(), cache_locations.data_ptr(), _i64(rowidx, "rowidx").data_ptr(),

@@ -290,6 +290,7 @@ class TTLookupFunction(torch.autograd.Function):
         # one lookup plan serves forward and backward of this batch
         mk = getattr(_engine, "make_plan", None)
         ctx.plan = getattr(rowidx, "_ttx_plan", None)  # built by the module's lookup prologue
+        ctx.det = getattr(rowidx, "_ttx_det", None)    # the module's deterministic_cache_update (None: the engine's default)
         if ctx.plan is None and mk is not None:
             ctx.plan = mk(num_tables, tt_p_shapes, tt_q_shapes, tt_ranks, nnz_tt, indices, tableidx, rowidx)
         extra = {"plan": ctx.plan} if ctx.plan is not None else {}
@@ -305,6 +306,7 @@ class TTLookupFunction(torch.autograd.Function):
         p, q, ranks = ctx.geometry
         n_tt, n_c = ctx.nnz_tt, ctx.nnz_cached
         extra = {"plan": ctx.plan} if ctx.plan is not None else {}
+        det = {"deterministic": ctx.det} if ctx.det is not None else {}
         cores = list(ctx.tt_cores)
         d_output = d_output.contiguous()
         head: List[Optional[torch.Tensor]] = [None] * 19
@@ -314,20 +316,20 @@ class TTLookupFunction(torch.autograd.Function):
                                         d_output, cores, **extra)
                 if n_c > 0:
                     _engine.cache_backward_sgd(n_c, d_output, cache_locations[n_tt:], rowidx[n_tt:],
-                                               ctx.learning_rate, cache_weight)
+                                               ctx.learning_rate, cache_weight, **det)
             else:
                 _engine.tt_adagrad_backward(1000, ctx.D, ctx.learning_rate, ctx.eps, p, q, ranks, L, n_tt, indices,
                                             rowidx, tableidx, d_output, ctx.optimizer_state, cores, **extra)
                 if n_c > 0:
                     _engine.cache_backward_rowwise_adagrad_approx(n_c, d_output, cache_locations[n_tt:],
                                                                   rowidx[n_tt:], ctx.learning_rate, ctx.eps,
-                                                                  cache_optimizer_state, cache_weight)
+                                                                  cache_optimizer_state, cache_weight, **det)
             return tuple(head + [None] * len(cores))
         grads = _engine.tt_dense_backward(1000, ctx.D, p, q, ranks, L, n_tt, indices, rowidx, tableidx, d_output,
                                           cores, **extra)
         if n_c > 0:
             head[17] = _engine.cache_backward_dense(n_c, d_output, cache_locations[n_tt:], rowidx[n_tt:],
-                                                    ctx.learning_rate, cache_weight)
+                                                    ctx.learning_rate, cache_weight, **det)
         return tuple(head + list(grads))
 
 
@@ -414,8 +416,14 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                  sparse: bool = True, use_cache: bool = False, cache_size: int = 0, hashtbl_size: int = 0,
                  weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
                  device: Optional[torch.device] = None, include_last_offset: bool = True, dedup: bool = False,
-                 reference_exact_populate: bool = False) -> None:
+                 reference_exact_populate: bool = False, deterministic_cache_update: Optional[bool] = None) -> None:
         super().__init__()
+        # deterministic_cache_update (trailing keyword, not in the reference): how the backward updates the CACHE rows.  True: the
+        # cached lookups are grouped by cache row with a stable sort, a row's bag gradients added in index order, one writer per row --
+        # cache_weight (and the row-wise Adagrad state) bit-identical from run to run (ttx_cache_backward_sorted).  False: the
+        # reference's formulation, float atomics in one launch -- the last bits depend on arrival order.  None: sorted from 65,536
+        # lookups per batch on, where it is also the faster of the two.  The TT cores' update never uses atomics.
+        self.deterministic_cache_update = deterministic_cache_update
         # reference_exact_populate (trailing keyword, not in the reference): cache_populate() leaves the cache_state of evicted
         # slots untouched, bit for bit what the reference's mark_popular_colidx_kernel does (cu:1131-1133).  Default False: an
         # evicted slot drops its cache row (deviation 5).  Carried per call (TTX_POPULATE_REFERENCE_EXACT);
@@ -889,6 +897,13 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                            self.learning_rate, self.eps, None, None, list(self.optimizer_state) if use_state else [],
                            list(self.tt_cores), None, *pre)
 
+    def _det_bits(self) -> int:
+        """the C++ node's encoding of deterministic_cache_update (csrc/ttx_torch.cpp: bit 9 sorted, bit 10 atomics, neither auto)"""
+        det = self.__dict__.get("deterministic_cache_update")
+        if det is None and os.environ.get("TTX_DETERMINISTIC", "") != "":
+            det = os.environ["TTX_DETERMINISTIC"] not in ("0", "")
+        return 0 if det is None else (512 if det else 1024)
+
     def _dedup_may_share(self, nnz: int) -> bool:
         d = getattr(self, "dedup", False)
         return bool(d) and (d != "auto" or nnz >= _DEDUP_AUTO_MIN_NNZ)
@@ -1023,7 +1038,7 @@ class TableBatchedTTEmbeddingBag(nn.Module):
                                  self.cache_optimizer_state, self.cache_weight)
             out = fast.lookup_cached(indices if indices.is_contiguous() else indices.contiguous(),
                                      offsets if offsets.is_contiguous() else offsets.contiguous(), self.tt_p_shapes, self.tt_q_shapes,
-                                     self.tt_ranks, optim | (256 if self._pf_counted else 0), self.learning_rate, self.eps,
+                                     self.tt_ranks, optim | (256 if self._pf_counted else 0) | self._det_bits(), self.learning_rate, self.eps,
                                      fc[2], fc[3], fc[4], fc[5] if use_state else None,
                                      fc[6], fc[1] if use_state else [],
                                      fc[0], list(pre) if pre is not None else [], per_sample_weights)
@@ -1048,6 +1063,9 @@ class TableBatchedTTEmbeddingBag(nn.Module):
             indices, rowidx, tableidx, n_tt, cache_locations = _engine.preprocess_indices_sync(
                 indices, offsets, self.num_tables, self.warmup, self.hashtbl, self.cache_state)
         n_cached = indices.numel() - n_tt
+        det = self.__dict__.get("deterministic_cache_update")
+        if det is not None and n_cached > 0:
+            rowidx._ttx_det = bool(det)  # (picked up by TTLookupFunction.forward, like the plan: the reference's 19 arguments stay)
         return TTLookupFunction.apply(
             (offsets.numel() - 1) // self.num_tables, self.embedding_dim, self.tt_p_shapes, self.tt_q_shapes,
             self.tt_ranks, self.L, n_tt, n_cached, indices, rowidx, tableidx, self.optimizer, self.learning_rate,
@@ -1073,10 +1091,11 @@ class TTEmbeddingBag(TableBatchedTTEmbeddingBag):
                  sparse: bool = True, use_cache: bool = True, cache_size: int = 0, hashtbl_size: int = 0,
                  weight_dist: str = "approx-normal", enforce_embedding_dim: bool = False,
                  device: Optional[torch.device] = None, include_last_offset: bool = True, dedup: bool = False,
-                 reference_exact_populate: bool = False) -> None:
+                 reference_exact_populate: bool = False, deterministic_cache_update: Optional[bool] = None) -> None:
         super().__init__(1, num_embeddings, embedding_dim, tt_ranks, tt_p_shapes, tt_q_shapes, optimizer,
                          learning_rate, eps, sparse, use_cache, cache_size, hashtbl_size, weight_dist,
-                         enforce_embedding_dim, device, include_last_offset, dedup, reference_exact_populate)
+                         enforce_embedding_dim, device, include_last_offset, dedup, reference_exact_populate,
+                         deterministic_cache_update)
 
     def forward(self, indices: torch.Tensor, offsets: torch.Tensor, warmup: bool = True,
                 per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -506,6 +506,21 @@ int ttx_profile_mask(int mask);
 int ttx_profile_reset(void);
 int ttx_profile_read(int which, int64_t* launches, double* total_ms);
 
+/* The cache rows' update of one batch WITHOUT atomics: deterministic (bit-identical from run to run), one writer per cache row.
+ * Replaces cache_backward_sgd_cuda / cache_backward_dense_cuda / cache_backward_rowwise_adagrad_approx_cuda
+ * (tt_embeddings.cpp:105-129, tt_embeddings_cuda.cu:1574-1835) for callers that give it a workspace: the cached lookups
+ * [*skip_dev, nnz) (skip_dev NULL: all) are grouped by cache row with a stable sort, a row's bag gradients are added in INDEX
+ * order and applied once.  optim: TTX_OPTIM_SGD (dst = cache_weight, += -lr * sum), TTX_OPTIM_DENSE (dst = the cache_weight gradient
+ * [cache_size, D], zeroed here) or TTX_OPTIM_ADAGRAD (dst = cache_weight, cache_optimizer_state [cache_size]: the reference's
+ * per-lookup sequence old = state, state += g2, w -= g * lr / (sqrt(old + g2) + eps), taken in index order within a row -- the
+ * order of a sequential execution, where the reference's depends on which warp arrives first).  num_bags: rows of grad
+ * (row-wise Adagrad).  The atomic entry points above stay: one launch, faster below ~64k lookups. */
+size_t ttx_cache_backward_sorted_workspace_bytes(int64_t nnz, int64_t num_bags, int32_t D);
+int ttx_cache_backward_sorted(int32_t optim, int64_t nnz, const int32_t* skip_dev, int64_t num_bags, int32_t D,
+                              const float* grad_output, const int32_t* cache_locations, const int64_t* rowidx,
+                              float learning_rate, float eps, int64_t cache_size, float* cache_optimizer_state,
+                              float* dst, void* workspace, size_t workspace_bytes, ttx_stream_t stream);
+
 /* test entry: the stable descending 64-bit radix sort of (key, value) pairs behind ttx_cache_populate, on its own
  * (what the reference asks of cub::DeviceRadixSort::SortPairsDescending, tt_embeddings_cuda.cu:1280-1308).  Stateless. */
 size_t ttx_debug_sort_workspace_bytes(int64_t n);

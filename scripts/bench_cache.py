@@ -47,7 +47,17 @@ for nnz in (10240, 1 << 20):
         E.debug_cache_fwd(1)
         t_f_old = timed(lambda: E.cache_forward(B, nnz, loc, rowidx, w, outp))
         E.debug_cache_fwd(0)
-        t_b = timed(lambda: E.cache_backward_sgd(nnz, grad, loc, rowidx, 0.0, w))
+        t_b = timed(lambda: E.cache_backward_sgd(nnz, grad, loc, rowidx, 0.0, w, deterministic=False))
+        # (round 6) the atomic-free update: stable sort of the lookups by cache row + ordered sums + one writer per row, all launches
+        t_bs = timed(lambda: E.cache_backward_sgd(nnz, grad, loc, rowidx, 0.0, w, deterministic=True))
+        # ... and on a Zipf(1.2) stream over the rows (what a populated cache sees: row 0 takes a sixth of the lookups)
+        import numpy as np
+        zl = torch.from_numpy(((np.random.RandomState(3).zipf(1.2, size=nnz) - 1) % cache_rows).astype(np.int32)).to(dev)
+        t_bz = timed(lambda: E.cache_backward_sgd(nnz, grad, zl, rowidx, 0.0, w, deterministic=False))
+        t_bzs = timed(lambda: E.cache_backward_sgd(nnz, grad, zl, rowidx, 0.0, w, deterministic=True))
+        st_ = torch.zeros(cache_rows, device=dev)
+        t_az = timed(lambda: E.cache_backward_rowwise_adagrad_approx(nnz, grad, zl, rowidx, 0.0, 1e-4, st_, w, deterministic=False))
+        t_azs = timed(lambda: E.cache_backward_rowwise_adagrad_approx(nnz, grad, zl, rowidx, 0.0, 1e-4, st_, w, deterministic=True))
         H = 1 << 22
         idx = torch.randint(0, 11_000_000, (nnz,), generator=g, dtype=torch.int64).to(dev)
         ht = torch.full((H,), -1, dtype=torch.int64, device=dev)
@@ -60,6 +70,11 @@ for nnz in (10240, 1 << 20):
         for name, t, bytes_ in (("gather_fwd", t_f, nnz * (4 * D + 12) + B * 4 * D),
                                 ("gather_fwd_one_group_per_lookup", t_f_old, nnz * (4 * D + 12) + B * 4 * D),
                                 ("scatter_sgd_bwd", t_b, nnz * (2 * 4 * D + 12) + B * 4 * D),
+                                ("sorted_sgd_bwd_all_launches", t_bs, nnz * (2 * 4 * D + 12) + B * 4 * D),
+                                ("scatter_sgd_bwd_zipf", t_bz, nnz * (2 * 4 * D + 12) + B * 4 * D),
+                                ("sorted_sgd_bwd_zipf_all_launches", t_bzs, nnz * (2 * 4 * D + 12) + B * 4 * D),
+                                ("rowwise_adagrad_bwd_zipf", t_az, nnz * (2 * 4 * D + 12) + B * 4 * D),
+                                ("sorted_rowwise_adagrad_bwd_zipf_all_launches", t_azs, nnz * (2 * 4 * D + 12) + B * 4 * D),
                                 ("hash_update", t_u, nnz * 24), ("lookup_partition_sync", t_l, nnz * 25 + nnz * 3 * 20)):
             gbs = bytes_ / t / 1e9
             rec[name] = {"us": round(t * 1e6, 2), "GB/s": round(gbs, 1), "frac_of_8TB/s": round(gbs / PEAK, 4)}

@@ -31,4 +31,16 @@ for cfg in ("10240,262144", "1048576,262144", "1048576,4194304"):
                 us = float(r["AverageNs"]) / 1e3
                 gbs = byt[name] / us / 1e3
                 print(f"| {nnz} | {rows} ({rows * D * 4 >> 20}) | `{name}` | {r['Calls']} | {us:.2f} | {gbs:.0f} | {gbs / 80:.1f} % |")
+# (round 6) the atomic-free update is a chain of launches: every kernel of the run, so that the chain can be added up by hand
+# (bench_cache.py times each variant 23 times: calls / 23 = launches of that kernel per update, summed over the variants that use it)
+print("\n## every kernel of the runs (the sorted update = cs_keys + radix_* x passes + dd_* + gsum_* (+ cs_scan_* / cs_bag_g2 / cs_state for Adagrad) + cs_apply)\n")
+for cfg in ("10240,262144", "1048576,262144", "1048576,4194304"):
+    print(f"\n### {cfg}\n\n| kernel | calls | avg us | total us |\n|---|---|---|---|")
+    rowsx = []
+    for f in glob.glob(os.path.join(out, cfg, "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Name"].split("(")[0].replace("void ", "").replace("ttx::", "")
+            rowsx.append((float(r["TotalDurationNs"]) / 1e3, name, int(r["Calls"]), float(r["AverageNs"]) / 1e3))
+    for tot, name, calls, avg in sorted(rowsx, reverse=True)[:24]:
+        print(f"| `{name[:90]}` | {calls} | {avg:.2f} | {tot:.0f} |")
 PY

@@ -277,6 +277,109 @@ def test_cache_backward_rowwise_adagrad_hot_rows(n, D, cs):
         assert (moved[hit] > 0).all() and (moved[~hit] == 0).all()
 
 
+@pytest.mark.parametrize("n,D,cs,B", [(900, 64, 40, 256), (5000, 64, 1000, 512), (20000, 128, 1000, 512), (300000, 64, 4096, 4096),
+                                      (5000, 6, 300, 128), (70000, 60, 20000, 2048)])
+def test_sorted_cache_update_is_deterministic_and_matches_the_oracle(n, D, cs, B):
+    """Round 6: the cache rows' update WITHOUT atomics (ttx_cache_backward_sorted; the shim's `deterministic=True`): the cached
+    lookups grouped by cache row with a stable sort, a row's bag gradients added in INDEX order, one writer per row.  On a Zipf
+    stream over the cache rows (row 0 takes a sixth of the batch) for SGD, the dense gradient and row-wise Adagrad:
+      * two runs are BIT-identical (the atomic kernels are not: that is what this replaces);
+      * SGD / dense equal the float64 sum at the DEFAULT tolerance, hot rows included (the atomic path needs 10x for them);
+      * row-wise Adagrad equals the sequential oracle -- state AND weights, whatever the batch size: index order within a row IS
+        the oracle's order -- and the independent float64 restatement of the reference's kernel (util.rowwise_adagrad_segments_f64);
+      * a device-side split point (skip_dev) in front of the cached lookups, and lookups with no cache row (-1) are left alone."""
+    import tt_embeddings as E
+    from util import rowwise_adagrad_segments_f64
+
+    rs = np.random.RandomState(n + D)
+    loc = ((rs.zipf(1.2, size=n) - 1) % cs).astype(np.int32)
+    rowidx = np.sort(rs.randint(0, B, size=n)).astype(np.int64)
+    w = rs.randn(cs, D).astype(np.float32)
+    grad = ((rs.rand(B, D) - 0.3) * 0.1).astype(np.float32)
+    g64 = grad.astype(np.float64)
+    # float64 sums per cache row
+    delta = np.zeros((cs, D))
+    np.add.at(delta, loc, g64[rowidx])
+    dg, dl, dr = t(grad), t(loc), t(rowidx)
+    # SGD
+    runs = []
+    for _ in range(2):
+        dw = t(w)
+        E.cache_backward_sgd(n, dg, dl, dr, 0.1, dw, deterministic=True)
+        runs.append(dw.cpu().numpy())
+    assert np.array_equal(runs[0], runs[1]), "sorted SGD update differs from run to run"
+    # (a row's update is the fp32 sum of up to n / 6 gradient rows in a fixed tree of 32-position slices: against the float64 sum
+    #  its error grows like sqrt(terms) ulps of the running sum; atol is tied to the largest |delta|)
+    assert_close(runs[0], (w.astype(np.float64) - 0.1 * delta), "sorted cache_backward_sgd vs float64",
+                 **(dict(rtol=2e-5, atol_scale=4e-6) if n >= 100000 else {}))
+    # dense
+    gd = [E.cache_backward_dense(n, dg, dl, dr, 0.1, t(w), deterministic=True).cpu().numpy() for _ in range(2)]
+    assert np.array_equal(gd[0], gd[1])
+    assert_close(gd[0], delta, "sorted cache_backward_dense vs float64", **(dict(rtol=2e-5, atol_scale=4e-6) if n >= 100000 else {}))
+    assert not gd[0][np.bincount(loc, minlength=cs) == 0].any(), "rows nobody hit must stay zero"
+    # row-wise Adagrad: the sequential oracle and the float64 restatement of the reference's kernel
+    st0 = (rs.rand(cs) * 0.01).astype(np.float32)
+    st_o, w_o = st0.copy(), w.copy()
+    O.cache_backward_rowwise_adagrad_approx(grad, loc, rowidx, 0.1, 1e-4, st_o, w_o)
+    ada = []
+    for _ in range(2):
+        dst, dwa = t(st0), t(w)
+        E.cache_backward_rowwise_adagrad_approx(n, dg, dl, dr, 0.1, 1e-4, dst, dwa, deterministic=True)
+        ada.append((dst.cpu().numpy(), dwa.cpu().numpy()))
+    assert np.array_equal(ada[0][0], ada[1][0]) and np.array_equal(ada[0][1], ada[1][1]), "sorted Adagrad differs from run to run"
+    tol = dict(rtol=2e-5, atol_scale=4e-6)  # (state: a running fp32 sum of up to n / 6 terms, associated differently from the oracle's)
+    assert_close(ada[0][0], st_o, "sorted rowwise adagrad state vs oracle", **tol)
+    # (weights: the hottest row takes n / 6 sequential steps, each with its own rounding of the running state -- at 300k lookups the
+    #  50k updates of row 0 drift 4e-5 apart between the two associations of the state's prefix sum)
+    assert_close(ada[0][1], w_o, "sorted rowwise adagrad weights vs oracle", **(dict(rtol=1e-4, atol_scale=4e-6) if n >= 100000 else tol))
+    if n <= 20000:
+        st64, w64 = rowwise_adagrad_segments_f64(grad, loc, rowidx, 0.1, 1e-4, st0, w)
+        assert_close(st_o, st64, "oracle rowwise adagrad state vs the float64 restatement of cu:1735-1795", **tol)
+        assert_close(w_o, w64, "oracle rowwise adagrad weights vs the float64 restatement", **tol)
+        assert_close(ada[0][1], w64, "sorted rowwise adagrad weights vs the float64 restatement", **tol)
+    # behind a device-side split point, with uncached entries (-1) in front of it
+    import ctypes as C
+    k = 777
+    loc2 = t(np.concatenate([np.full(k, -1, dtype=np.int32), loc]))
+    row2 = t(np.concatenate([np.zeros(k, dtype=np.int64), rowidx]))
+    skip = torch.tensor([k], dtype=torch.int32, device=DEV)
+    dw2 = t(w)
+    E._cache_backward_sorted(E.OPTIM_SGD, n + k, dg, loc2, row2, 0.1, 0.0, None, dw2, skip_dev=skip)
+    assert np.array_equal(dw2.cpu().numpy(), runs[0]), "the split point must not change a bit"
+
+
+def test_rowwise_adagrad_where_the_reference_is_deterministic():
+    """Second checker for a12's row-wise Adagrad (round-5 verdict): where the reference's kernel has ONE possible result -- every
+    cache row hit from at most one segment (bag), possibly several times inside it -- the product's two kernels (atomic and
+    sorted), the oracle and the independent float64 restatement of cu:1735-1795 agree on state and weights."""
+    import tt_embeddings as E
+    from util import rowwise_adagrad_segments_f64
+
+    rs = np.random.RandomState(5)
+    cs, B, D = 3000, 256, 64
+    rows_of_bag = rs.permutation(cs)[:B * 6].reshape(B, 6)  # six cache rows per bag, no row in two bags ...
+    loc, rowidx = [], []
+    for b in range(B):
+        pick = rs.choice(6, size=rs.randint(0, 12))             # ... some of them hit several times inside the bag
+        loc += [int(rows_of_bag[b][j]) for j in pick]
+        rowidx += [b] * len(pick)
+    loc, rowidx = np.array(loc, dtype=np.int32), np.array(rowidx, dtype=np.int64)
+    n = loc.size
+    w = rs.randn(cs, D).astype(np.float32)
+    grad = ((rs.rand(B, D) - 0.5) * 0.2).astype(np.float32)
+    st0 = (rs.rand(cs) * 0.01).astype(np.float32)
+    st64, w64 = rowwise_adagrad_segments_f64(grad, loc, rowidx, 0.1, 1e-4, st0, w)
+    st_o, w_o = st0.copy(), w.copy()
+    O.cache_backward_rowwise_adagrad_approx(grad, loc, rowidx, 0.1, 1e-4, st_o, w_o)
+    assert_close(st_o, st64, "oracle state vs float64 restatement")
+    assert_close(w_o, w64, "oracle weights vs float64 restatement")
+    for det in (False, True):
+        dst, dw = t(st0), t(w)
+        E.cache_backward_rowwise_adagrad_approx(n, t(grad), t(loc), t(rowidx), 0.1, 1e-4, dst, dw, deterministic=det)
+        assert_close(dst.cpu().numpy(), st64, f"state (deterministic={det}) vs float64 restatement")
+        assert_close(dw.cpu().numpy(), w64, f"weights (deterministic={det}) vs float64 restatement")
+
+
 @pytest.mark.parametrize("tables,p,B,pf,std,H", [
     (1, [20, 22, 25], 300, 10, 3, 1 << 19),     # one launch: rows by binary search over the offsets, fused update
     (1, [20, 22, 25], 400, 8, 4, 0),            # one launch, no frequency table

@@ -1703,6 +1703,11 @@ _ROUTES = [
     # (a cache that holds every key of the three warm-up batches: nothing evicted, so no cached key behind an emptied slot whose
     #  re-insert could race a new key's insert -- the one decision the reference, too, leaves to hardware order)
     ("cache live (hits and misses)", dict(use_cache=True, cache_size=8192, hashtbl_size=1 << 15, live=3), [20, 22, 25], [4, 4, 4], [32, 32], 1),
+    # (round 6) ... with the atomic-free cache-row update: the cache rows are BIT-identical too, for SGD and row-wise Adagrad
+    ("cache live, sorted cache-row update", dict(use_cache=True, cache_size=8192, hashtbl_size=1 << 15, live=3,
+                                                 deterministic_cache_update=True), [20, 22, 25], [4, 4, 4], [32, 32], 1),
+    ("cache live, sorted cache-row update, Adagrad", dict(use_cache=True, cache_size=8192, hashtbl_size=1 << 15, live=3, optimizer="EXACT_ADAGRAD",
+                                                          deterministic_cache_update=True), [20, 22, 25], [4, 4, 4], [32, 32], 1),
 ]
 
 
@@ -1762,4 +1767,6 @@ def test_free_running_training_is_run_to_run_identical(node, route):
         #  hardware order; a hit / miss flip would be ~5e-3)
         assert np.array_equal(ca[0], cb[0]), "the same keys are cached"
         err = np.abs(ca[1] - cb[1]).max()
+        if extra.get("deterministic_cache_update"):
+            assert np.array_equal(ca[1], cb[1]), f"sorted cache-row update: cache rows by key differ between two runs (max {err:.3e})"
         assert err <= 2e-5, f"cache rows by key: max difference {err:.3e}"

@@ -188,3 +188,29 @@ def test_all_cores_baseline_equals_the_sequential_oracle(small_cases):
                     assert_close(cores[k], ref_cores[k], f"{name} omp sgd core{k}")
                 else:
                     assert_close(state[k], ref_state[k], f"{name} omp adagrad state{k}")
+
+
+def test_oracle_rowwise_adagrad_vs_float64_restatement_of_the_reference_kernel():
+    """a12 (round-5 verdict): oracle/ttx_oracle.c's cache_backward_rowwise_adagrad_approx against an INDEPENDENT float64
+    restatement of tt_embeddings_cuda.cu:1735-1795 written from the kernel's segment structure (util.rowwise_adagrad_segments_f64):
+    a stream where rows are hit from several bags (the oracle's sequential order = the restatement's segment order) and one where
+    the reference itself has a single possible result (no row in two bags)."""
+    import oracle_lib as O
+    from util import rowwise_adagrad_segments_f64
+
+    rs = np.random.RandomState(11)
+    for cs, B, D, n, zipf in ((200, 64, 64, 1500, True), (4000, 128, 60, 900, False)):
+        if zipf:
+            loc = ((rs.zipf(1.2, size=n) - 1) % cs).astype(np.int32)
+            rowidx = np.sort(rs.randint(0, B, size=n)).astype(np.int64)
+        else:
+            rowidx = np.sort(rs.randint(0, B, size=n)).astype(np.int64)
+            loc = (rowidx * 31 + rs.randint(0, 31, size=n)).astype(np.int32)  # bag b owns rows [31 b, 31 b + 31)
+        w = rs.randn(cs, D).astype(np.float32)
+        grad = ((rs.rand(B, D) - 0.5) * 0.2).astype(np.float32)
+        st0 = (rs.rand(cs) * 0.01).astype(np.float32)
+        st64, w64 = rowwise_adagrad_segments_f64(grad, loc, rowidx, 0.1, 1e-4, st0, w)
+        st_o, w_o = st0.copy(), w.copy()
+        O.cache_backward_rowwise_adagrad_approx(grad, loc, rowidx, 0.1, 1e-4, st_o, w_o)
+        assert_close(st_o, st64, "rowwise adagrad state", rtol=2e-5, atol_scale=4e-6)
+        assert_close(w_o, w64, "rowwise adagrad weights", rtol=2e-5, atol_scale=4e-6)

@@ -94,3 +94,33 @@ def assert_adagrad_close(got_w, ref_w, ref_g, what="", lr=LR, eps=EPS, state0=No
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError(f"{what}: {int(bad.sum())}/{bad.size} out of tolerance; worst at {i}: got {got_w[i]!r} "
                              f"ref {ref_w[i]!r} tol {tol[i]:.3e} |g| {g[i]:.3e}")
+
+
+def rowwise_adagrad_segments_f64(grad, loc, rowidx, lr, eps, state, weight):
+    """An INDEPENDENT float64 restatement of the reference's cache_backward_rowwise_adagrad_approx_kernel
+    (tt_embeddings_cuda.cu:1735-1795), written from the kernel's own structure -- not from oracle/ttx_oracle.c, which it checks
+    (round-5 verdict: the one hot-path kernel whose only pin was the restated oracle).  One "warp" per SEGMENT of equal rowidx
+    (cu:1751-1761: a run of cached lookups of one bag): g_avg_square = sum(g^2) / D of the bag's gradient row once per segment
+    (cu:1762-1771), then lookup after lookup of the segment (cu:1773-1793): old = state[idx]; state[idx] += g_avg_square;
+    multiplier = lr / (sqrt(old + g_avg_square) + eps); weight[idx] -= g * multiplier.  Segments are taken in index order here --
+    ONE of the orders the reference's concurrent warps can produce, the only one when no cache row is hit from two segments.
+    state [cache_size], weight [cache_size, D]: float64 copies are returned, the inputs are left alone."""
+    import numpy as np
+
+    g = np.asarray(grad, dtype=np.float64)
+    st, w = np.asarray(state, dtype=np.float64).copy(), np.asarray(weight, dtype=np.float64).copy()
+    n, D = len(loc), g.shape[1]
+    i = 0
+    while i < n:
+        row = int(rowidx[i])
+        sl = 1
+        while i + sl < n and int(rowidx[i + sl]) == row:
+            sl += 1
+        g_avg_square = float((g[row] * g[row]).sum()) / D
+        for k in range(sl):
+            idx = int(loc[i + k])
+            old = st[idx]
+            st[idx] = old + g_avg_square
+            w[idx] -= g[row] * (lr * (1.0 / (np.sqrt(old + g_avg_square) + eps)))
+        i += sl
+    return st, w
