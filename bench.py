@@ -226,9 +226,35 @@ def secondary_record(workload="cfg5shard", steps=40, repeats=3):
         rec["step_frac_of_fp32_peak"] = round(fl / (j["ms_per_step"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)
         if "fwd_contract_us" in j.get("kernel_us", {}):
             rec["fwd_frac_of_fp32_peak"] = round(fl / 3.0 / (j["kernel_us"]["fwd_contract_us"] * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4)
+        if workload == "cfg5shard":
+            rec["predicted_cfg5_on_8_gpus"] = predict_cfg5_8gpu(j["ms_per_step"])
         return rec
     except Exception as ex:  # noqa: BLE001 -- the secondary record must never take the headline line with it
         return {"error": f"{type(ex).__name__}: {ex}", "workload": workload}
+
+
+def predict_cfg5_8gpu(shard_ms, exchange_latency_us=20.0):
+    """A WRITTEN PREDICTION of BASELINE.json configs[4] on 8 x MI355X (no multi-GPU run has happened in any round: the first real
+    one has this to be compared with).  26 tables on 8 ranks = 4,4,3,3,3,3,3,3 per owner; the step is as long as
+    the slowest owner's: a 4-table owner's local step -- exactly the cfg5shard workload measured in this job, `shard_ms` -- plus
+    the three exchanges of a step (indices in: int32 since round 6; pooled rows out; their gradient back), each one a group of 7
+    concurrent point-to-point transfers over 7 links of 153 GB/s, priced at latency + bytes over the slowest link."""
+    W, NT, Bg, D, L = 8, 26, 4096, 64, POOL
+    b_local = Bg // W
+    own = 4                                                           # tables of the busiest owner
+    idx_link = NT * b_local * L * 4 / W                               # bytes a rank sends to ONE peer (its batch for that peer's ~NT/W tables)
+    pooled_link = own * b_local * D * 4                               # bytes the busiest owner returns to ONE peer
+    ex_us = [exchange_latency_us + idx_link / (XGMI_GBS * 1e3), exchange_latency_us + pooled_link / (XGMI_GBS * 1e3),
+             exchange_latency_us + pooled_link / (XGMI_GBS * 1e3)]
+    step_ms = shard_ms + sum(ex_us) * 1e-3
+    lookups = NT * Bg * L
+    fl = 3.0 * flop_per_nnz_fwd([4, 4, 4], [32, 32]) * lookups
+    return {"ms_per_step": round(step_ms, 4), "value_gflops": round(fl / (step_ms * 1e-3) / 1e9, 1),
+            "exchange_us": [round(x, 1) for x in ex_us], "bytes_per_link": {"indices_int32": int(idx_link), "pooled_rows": int(pooled_link)},
+            "assumes": f"{exchange_latency_us} us launch + rendezvous latency per exchange (one-rank RCCL calls measure ~5 us of issue "
+                       "time; the rest is a guess until two devices have talked), transfers at the 153 GB/s link rate, no overlap "
+                       "of an exchange with the local lookup, the busiest owner (4 of 26 tables) sets the pace",
+            "ideal_speedup_over_one_gpu": round(NT / own, 2)}
 
 
 def self_launch(n):

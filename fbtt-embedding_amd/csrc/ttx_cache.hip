@@ -1236,13 +1236,30 @@ __global__ __launch_bounds__(kCsBlock) void cs_scan_tails_kernel(DedupMap M, int
   if (threadIdx.x == 0) { blk_tail[blockIdx.x] = tail; blk_head[blockIdx.x] = hh; }
 }
 
-__global__ __launch_bounds__(64) void cs_scan_carry_kernel(int nblk, const float* __restrict__ blk_tail, const int* __restrict__ blk_head,
-                                                          float* __restrict__ blk_carry) {
-  if (threadIdx.x != 0) return;  // (a few thousand blocks at most: one lane, one fixed order)
-  float c = 0.f;
-  for (int b = 0; b < nblk; ++b) {
-    blk_carry[b] = c;
-    c = blk_head[b] ? blk_tail[b] : c + blk_tail[b];
+__global__ __launch_bounds__(1024) void cs_scan_carry_kernel(int nblk, const float* __restrict__ blk_tail, const int* __restrict__ blk_head,
+                                                            float* __restrict__ blk_carry) {
+  // one work-group: 1024 blocks at a time through LDS (coalesced in, coalesced out), ONE lane walks them in order -- a fixed
+  // association; the walk is a thousand LDS round trips per million lookups (first form: one lane on global memory, 72 us at 1 M)
+  __shared__ float tl[1024], cr[1024];
+  __shared__ int hd[1024];
+  __shared__ float c_run;
+  if (threadIdx.x == 0) c_run = 0.f;
+  for (int b0 = 0; b0 < nblk; b0 += 1024) {
+    const int b = b0 + threadIdx.x;
+    if (b < nblk) { tl[threadIdx.x] = blk_tail[b]; hd[threadIdx.x] = blk_head[b]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float c = c_run;
+      const int n = min(1024, nblk - b0);
+      for (int k = 0; k < n; ++k) {
+        cr[k] = c;
+        c = hd[k] ? tl[k] : c + tl[k];
+      }
+      c_run = c;
+    }
+    __syncthreads();
+    if (b < nblk) blk_carry[b] = cr[threadIdx.x];
+    __syncthreads();
   }
 }
 
@@ -1334,7 +1351,7 @@ int ttx_cache_backward_sorted(int32_t optim, int64_t nnz, const int32_t* skip_de
     hipLaunchKernelGGL(cs_bag_g2_kernel, dim3((unsigned)((num_bags + kCT / kWave - 1) / (kCT / kWave))), dim3(kCT), 0, st, (int)num_bags,
                        D, grad, g2);
     hipLaunchKernelGGL(cs_scan_tails_kernel, dim3(nblk), dim3(kCsBlock), 0, st, M, N, rowidx, g2, blk_tail, blk_head);
-    hipLaunchKernelGGL(cs_scan_carry_kernel, dim3(1), dim3(64), 0, st, nblk, blk_tail, blk_head, blk_carry);
+    hipLaunchKernelGGL(cs_scan_carry_kernel, dim3(1), dim3(1024), 0, st, nblk, blk_tail, blk_head, blk_carry);
     hipLaunchKernelGGL(cs_scan_emit_kernel, dim3(nblk), dim3(kCsBlock), 0, st, M, N, (long long)cache_size, rowidx, g2, blk_carry, lr, eps,
                        cache_optimizer_state, mult);
     hipLaunchKernelGGL(cs_state_kernel, dim3((unsigned)((N + kCT - 1) / kCT)), dim3(kCT), 0, st, M, (long long)cache_size,

@@ -571,7 +571,9 @@ struct TTCachedLookupOp : public torch::autograd::Function<TTCachedLookupOp> {
     const size_t wb = ttx_tt_backward_workspace_bytes(&g, (int32_t)B, (int32_t)D, nnz);
     Tensor ws = bytes_on(cache_weight, wb);
     int32_t scatter_done = 0;  // the cache rows' SGD scatter rode in the optimizer's launch (ttx_tt_backward_wc)
-    constexpr int64_t kSortedAutoNnz = 65536;  // (from here on the sorted update is also the faster one)
+    // (profiles/r06_cache_bandwidth.md: from here on the sorted update is also the faster one on a Zipf
+    //  stream -- near 300k lookups against the atomic SGD / dense scatter, near 60k against the atomic row-wise Adagrad)
+    const int64_t kSortedAutoNnz = optim == TTX_OPTIM_ADAGRAD ? 65536 : 262144;
     const bool sorted = det == 1 || (det == 0 && nnz >= kSortedAutoNnz);
     if (optim == TTX_OPTIM_SGD && !ppsw.defined() && !sorted)
       check(ttx_tt_backward_wc(&g, (int32_t)optim, (int32_t)B, (int32_t)D, (float)lr, (float)eps, nnz, pcol_p, prow_p, tableidx_p,

@@ -630,15 +630,21 @@ def cache_forward(B: int, nnz: int, cache_locations: torch.Tensor, rowidx: torch
 # row's bag gradients added in index order, one writer per row -- bit-identical from run to run, and the sequential oracle's order
 # for row-wise Adagrad).  `deterministic` (trailing keyword of the three functions below, not in the reference): True = always,
 # False = the one-launch float-atomic kernels (the reference's own formulation; the last bits of cache_weight then depend on the
-# order the adds arrive in), None = "auto": sorted from DETERMINISTIC_AUTO_MIN_NNZ cached lookups on, where it is also the
-# faster of the two.  TTX_DETERMINISTIC=1 / 0 in the environment overrides None.
-DETERMINISTIC_AUTO_MIN_NNZ = int(os.environ.get("TTX_DETERMINISTIC_AUTO_MIN_NNZ", 65536))
+# order the adds arrive in), None = "auto": sorted from DETERMINISTIC_AUTO_MIN_NNZ cached lookups on (row-wise Adagrad:
+# DETERMINISTIC_AUTO_MIN_NNZ_ADAGRAD), where it is also the faster of the two.  TTX_DETERMINISTIC=1 / 0 in the environment overrides None.
+# (measured, profiles/r06_cache_bandwidth.md: the sorted update is a chain of ~16 launches, ~65 us whatever the batch; on a Zipf
+#  stream it overtakes the atomic SGD / dense scatter near 300k cached lookups -- 232 against 343 us at 1 M -- and the atomic
+#  row-wise Adagrad, whose hot rows serialise, near 60k -- 330 against 1228 us at 1 M)
+DETERMINISTIC_AUTO_MIN_NNZ = int(os.environ.get("TTX_DETERMINISTIC_AUTO_MIN_NNZ", 262144))
+DETERMINISTIC_AUTO_MIN_NNZ_ADAGRAD = int(os.environ.get("TTX_DETERMINISTIC_AUTO_MIN_NNZ_ADAGRAD", 65536))
 
 
-def _use_sorted(deterministic: Optional[bool], nnz: int) -> bool:
+def _use_sorted(deterministic: Optional[bool], nnz: int, adagrad: bool = False) -> bool:
     if deterministic is None and os.environ.get("TTX_DETERMINISTIC", "") != "":
         deterministic = os.environ["TTX_DETERMINISTIC"] not in ("0", "")
-    return nnz >= DETERMINISTIC_AUTO_MIN_NNZ if deterministic is None else bool(deterministic)
+    if deterministic is None:
+        return nnz >= (DETERMINISTIC_AUTO_MIN_NNZ_ADAGRAD if adagrad else DETERMINISTIC_AUTO_MIN_NNZ)
+    return bool(deterministic)
 
 
 def _cache_backward_sorted(optim: int, nnz: int, go: torch.Tensor, cache_locations: torch.Tensor, rowidx: torch.Tensor, lr: float,
@@ -705,7 +711,7 @@ def cache_backward_rowwise_adagrad_approx(nnz: int, grad_output: torch.Tensor, c
     go = _f32(grad_output, "grad_output")
     _dev(cache_optimizer_state)
     _check_cached_args(nnz, cache_locations, rowidx)
-    if _use_sorted(deterministic, nnz):
+    if _use_sorted(deterministic, nnz, adagrad=True):
         return _cache_backward_sorted(OPTIM_ADAGRAD, nnz, go, cache_locations, rowidx, learning_rate, eps, cache_optimizer_state, cw)
     with _guard(dev):
         _check(lib().ttx_cache_backward_rowwise_adagrad_approx(

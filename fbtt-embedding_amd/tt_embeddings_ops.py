@@ -421,8 +421,9 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         # deterministic_cache_update (trailing keyword, not in the reference): how the backward updates the CACHE rows.  True: the
         # cached lookups are grouped by cache row with a stable sort, a row's bag gradients added in index order, one writer per row --
         # cache_weight (and the row-wise Adagrad state) bit-identical from run to run (ttx_cache_backward_sorted).  False: the
-        # reference's formulation, float atomics in one launch -- the last bits depend on arrival order.  None: sorted from 65,536
-        # lookups per batch on, where it is also the faster of the two.  The TT cores' update never uses atomics.
+        # reference's formulation, float atomics in one launch -- the last bits depend on arrival order.  None: sorted from 262,144
+        # lookups per batch on (row-wise Adagrad: 65,536), where it is also the faster of the two.  The TT
+        # cores' update never uses atomics.
         self.deterministic_cache_update = deterministic_cache_update
         # reference_exact_populate (trailing keyword, not in the reference): cache_populate() leaves the cache_state of evicted
         # slots untouched, bit for bit what the reference's mark_popular_colidx_kernel does (cu:1131-1133).  Default False: an

@@ -147,9 +147,18 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
     lookups, which removes the host read-back of split sizes."""
 
     def __init__(self, num_tables: int, num_embeddings: int, embedding_dim: int, tt_ranks: List[int],
-                 group: Optional["dist.ProcessGroup"] = None, **kw) -> None:
+                 group: Optional["dist.ProcessGroup"] = None, index_wire_dtype: Optional[torch.dtype] = None, **kw) -> None:
         super().__init__()
         self.group = group
+        # (round 6) what the "lookups in" exchange carries per index: int32 whenever the tables' row count allows it (every
+        # BASELINE config: E = 11M) -- half the bytes of the reference's int64 indices on the xGMI links (SURVEY.md section 8d:
+        # 8 B of the 8 + 4 D / L bytes a lookup costs on the wire at D = 64, L = 20 are the index).  The owner widens what it
+        # received on the device; lengths of ragged bags travel as int32 as well.  `index_wire_dtype=torch.int64` keeps round 5's wire.
+        if index_wire_dtype is None:
+            index_wire_dtype = torch.int32 if int(num_embeddings) < (1 << 31) else torch.int64
+        if index_wire_dtype not in (torch.int32, torch.int64) or (index_wire_dtype == torch.int32 and int(num_embeddings) >= (1 << 31)):
+            raise ValueError("index_wire_dtype: torch.int32 (tables of fewer than 2^31 rows) or torch.int64")
+        self.index_wire_dtype = index_wire_dtype
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.num_tables, self.embedding_dim = num_tables, embedding_dim
@@ -206,7 +215,7 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         n_me = n_own[self.rank]
         order = self._cached(("order", dev), lambda: torch.tensor(self._order, device=dev))
         # send: [table (owner-major)][batch][B * Lp] -- the block of destination d is its tables' rows, contiguous
-        stack = torch.stack([i.long().view(NT, B * Lp) for i, _ in batches], dim=1)   # [NT, K, B*Lp]
+        stack = torch.stack([i.to(self.index_wire_dtype).view(NT, B * Lp) for i, _ in batches], dim=1)   # [NT, K, B*Lp]
         send_idx = (stack if self._identity else stack[order]).contiguous().view(-1)
         in_splits = [k * K * B * Lp for k in n_own]
         out_splits = [n_me * K * B * Lp] * W
@@ -216,7 +225,7 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         else:
             self._a2a(recv_idx, send_idx, out_splits, in_splits)
         # wire order [src][k][batch][b][l] -> per batch table-major [k][src][b][l]
-        loc = recv_idx.view(W, n_me, K, B * Lp).permute(2, 1, 0, 3).contiguous().view(K, -1)
+        loc = recv_idx.view(W, n_me, K, B * Lp).permute(2, 1, 0, 3).long().contiguous().view(K, -1)  # (widened with the reorder)
         loc_off = self._cached(("off", dev, n_me * W * B, Lp), lambda: torch.arange(
             0, n_me * W * B * Lp + 1, Lp, device=dev, dtype=torch.int64))
         loc_idx = [loc[j] for j in range(K)]
@@ -286,16 +295,17 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
             loc_idx, loc_off = hit[5], hit[6]
         elif fixed_pooling is not None:
             Lp = int(fixed_pooling)
-            send_idx = indices if self._identity else indices.view(NT, B * Lp)[order].contiguous().view(-1)
+            wire = indices.to(self.index_wire_dtype)
+            send_idx = wire if self._identity else wire.view(NT, B * Lp)[order].contiguous().view(-1)
             in_splits = [k * B * Lp for k in n_own]
             out_splits = [n_me * B * Lp] * W
-            recv_idx = indices.new_empty(sum(out_splits))
+            recv_idx = wire.new_empty(sum(out_splits))
             if self.direct is not None:
                 self.direct.all_to_all(recv_idx, send_idx.contiguous(), out_splits, in_splits)
             else:
                 self._a2a(recv_idx, send_idx, out_splits, in_splits)
             # wire order [src][k][b][l] -> table-major [k][src][b][l]
-            loc_idx = recv_idx.view(W, n_me, B * Lp).permute(1, 0, 2).contiguous().view(-1)
+            loc_idx = recv_idx.view(W, n_me, B * Lp).permute(1, 0, 2).long().contiguous().view(-1)
             loc_off = self._cached(("off", dev, n_me * W * B, Lp), lambda: torch.arange(
                 0, n_me * W * B * Lp + 1, Lp, device=dev, dtype=torch.int64))
         else:
@@ -315,9 +325,10 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
             tbl_off = offsets[::B]                                         # [NT+1] start of each table's run
             seg_start = tbl_off[:-1][order]
             seg_len = tbl_cnt
-            send_idx = indices[_segment_gather(seg_start, seg_len, sum(in_splits))]
-            recv_idx = indices.new_empty(sum(out_splits))
+            send_idx = indices[_segment_gather(seg_start, seg_len, sum(in_splits))].to(self.index_wire_dtype)
+            recv_idx = send_idx.new_empty(sum(out_splits))
             self._a2a(recv_idx, send_idx, out_splits, in_splits)
+            recv_idx = recv_idx.long()
             # per-(src, k) segments -> table-major [k][src]
             seg_len_w = recv_len.sum(dim=2)                                # [W, n_me] wire order
             seg_start_w = (torch.cumsum(seg_len_w.view(-1), 0) - seg_len_w.view(-1)).view(W, n_me)
@@ -360,21 +371,23 @@ class ShardedTableBatchedTTEmbeddingBag(nn.Module):
         else:
             idx_pad = indices.new_zeros((NT * B, Lp))
         order = self._cached(("order", dev), lambda: torch.tensor(self._order, device=dev))
+        idx_pad = idx_pad.to(self.index_wire_dtype)
         send_idx = (idx_pad.view(NT, B * Lp) if self._identity else idx_pad.view(NT, B * Lp)[order]).contiguous().view(-1)
         lengths = lengths.clamp(max=Lp)  # (a bag longer than L is truncated: what travels is what the padded rows hold)
+        lengths = lengths.to(self.index_wire_dtype)
         send_len = (lengths.view(NT, B) if self._identity else lengths.view(NT, B)[order]).contiguous().view(-1)
         alone = W == 1 and not _FORCE_EXCHANGE  # one rank: nothing to exchange, the same padded lookup
         if alone:
             recv_idx, recv_len = send_idx, send_len
         else:
-            recv_idx = indices.new_empty(W * n_me * B * Lp)
+            recv_idx = send_idx.new_empty(W * n_me * B * Lp)
             recv_len = lengths.new_empty(W * n_me * B)
             ex = self.direct.all_to_all if self.direct is not None else self._a2a
             ex(recv_idx, send_idx, [n_me * B * Lp] * W, [k * B * Lp for k in n_own])
             ex(recv_len, send_len, [n_me * B] * W, [k * B for k in n_own])
         # wire order [src][k][b] -> table-major [k][src][b]
-        loc_idx = recv_idx.view(W, n_me, B * Lp).permute(1, 0, 2).contiguous().view(-1)
-        loc_len = recv_len.view(W, n_me, B).permute(1, 0, 2).reshape(-1)
+        loc_idx = recv_idx.view(W, n_me, B * Lp).permute(1, 0, 2).long().contiguous().view(-1)
+        loc_len = recv_len.view(W, n_me, B).permute(1, 0, 2).long().reshape(-1)
         if n_me and _COMPACT_RAGGED:
             # (round 5) the owner contracts the REAL lookups only: the padded rows are compacted on the device -- lookup l of bag b
             # goes to off[b] + l, the padding to a dump slot behind the buffer (fixed shapes: scatter, no boolean indexing) -- and

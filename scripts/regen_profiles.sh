@@ -13,7 +13,7 @@
 #   <tag>_cache_bandwidth.md    cache-path kernels: durations and GB/s on the algorithmic bytes
 #   <tag>_bench*.json           the bench lines (default line incl. its cfg5shard `secondary` record)
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=$(pwd); OUT=$REPO/gpurun_out/profiles_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 PMC_W=${PMC_WORKLOADS:-"cfg2 cfg5shard cfg4 r128 r256 t4"}
 KPROF_W=${KPROF_WORKLOADS:-"cfg3 cfg3warm cfg4 cfg5shard tb4 d32 d16 d256 r128 r13 d320 d512 d768 d1024 d1024r64 r256 t2 t4 t4d256 t2big"}

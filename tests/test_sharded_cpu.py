@@ -41,7 +41,7 @@ def _make_inputs(rank, fixed, NT=NT):
     return idx, off, grad
 
 
-def _worker(rank, world, port, fixed, q, NT=NT, direct=False):
+def _worker(rank, world, port, fixed, q, NT=NT, direct=False, wire=None):
     try:
         for p in (HERE, os.path.join(ROOT, "fbtt-embedding_amd")):
             sys.path.insert(0, p)
@@ -55,12 +55,29 @@ def _worker(rank, world, port, fixed, q, NT=NT, direct=False):
 
         ops._engine = oracle_engine  # CPU stand-in for the HIP engine (test only)
         cores_all = G.make_cores(5, NT, P, Q, R)
+        extra = {} if wire is None else {"index_wire_dtype": getattr(torch, wire)}
         m = ttx_sharded.ShardedTableBatchedTTEmbeddingBag(
             NT, int(np.prod(P)), D, R, tt_p_shapes=P, tt_q_shapes=Q, sparse=True, optimizer=ops.OptimType.SGD,
-            learning_rate=0.1, weight_dist="uniform", device="cpu")
+            learning_rate=0.1, weight_dist="uniform", device="cpu", **extra)
         mine = m.my_tables
         if direct:  # the direct route's bookkeeping (per-peer element counts), carried by gloo instead of RCCL
             m.enable_direct_exchange(ttx_sharded.CollectiveExchange(None))
+        # what integer dtype travels (round 6: int32 indices / lengths on the wire unless asked otherwise)
+        seen = set()
+        real_a2a = dist.all_to_all_single
+
+        def spy(out, inp, *a, **k):
+            if not inp.dtype.is_floating_point:
+                seen.add(str(inp.dtype))
+            return real_a2a(out, inp, *a, **k)
+        dist.all_to_all_single = spy
+        real_base = ttx_sharded._a2a
+
+        def spy_base(group, out, inp, out_splits, in_splits):
+            if not inp.dtype.is_floating_point:
+                seen.add(str(inp.dtype))
+            return real_base(group, out, inp, out_splits, in_splits)
+        ttx_sharded._a2a = spy_base
         if m.local is not None:
             with torch.no_grad():
                 for t, core in enumerate(m.local.tt_cores):
@@ -71,6 +88,10 @@ def _worker(rank, world, port, fixed, q, NT=NT, direct=False):
         else:
             out = m(torch.from_numpy(idx), torch.from_numpy(off), fixed_pooling=fixed or None)
         out.backward(torch.from_numpy(grad))
+        want = {"torch." + (wire or "int32")}
+        if fixed == 0:
+            want.add("torch.int64")  # (ragged bags with a host read-back: the lengths travel as they are; the indices as `wire`)
+        assert seen and seen <= want and ("torch." + (wire or "int32")) in seen, f"integer dtypes on the wire: {seen}, expected {want}"
         q.put((rank, out.detach().numpy(), mine, [c.detach().numpy() for c in m.local.tt_cores] if m.local is not None else []))
         dist.barrier()
         dist.destroy_process_group()
@@ -84,10 +105,13 @@ def _worker(rank, world, port, fixed, q, NT=NT, direct=False):
 # no table still has to take part in both exchanges, forward and backward; direct: DirectExchange's split lists
 # fixed < 0 (round 5): RAGGED bags with max_pooling = -fixed -- padded rows on the wire, compacted by the owner, the local lookup
 # told its live count (n_dev); -4 holds every bag (lengths 0..4), -3 truncates the bags of four
-@pytest.mark.parametrize("fixed,NT,direct", [(0, 5, False), (3, 5, False), (3, 2, False), (3, 5, True), (3, 2, True),
-                                             (3, 1, False), (0, 1, False), (3, 1, True), (2, 7, True),
-                                             (-4, 5, False), (-3, 5, True), (-4, 1, False), (-3, 2, False)])
-def test_two_rank_table_sharding_matches_single_process(fixed, NT, direct):
+@pytest.mark.parametrize("fixed,NT,direct,wire", [(0, 5, False, None), (3, 5, False, None), (3, 2, False, None), (3, 5, True, None),
+                                                  (3, 2, True, None), (3, 1, False, None), (0, 1, False, None), (3, 1, True, None),
+                                                  (2, 7, True, None), (-4, 5, False, None), (-3, 5, True, None), (-4, 1, False, None),
+                                                  (-3, 2, False, None),
+                                                  # round 6: int32 on the wire is the default above; the reference's int64 on request
+                                                  (3, 5, True, "int64"), (0, 5, False, "int64"), (-3, 5, False, "int64")])
+def test_two_rank_table_sharding_matches_single_process(fixed, NT, direct, wire):
     sys.path.insert(0, HERE)
     import gen_inputs as G
     import oracle_lib as O
@@ -96,7 +120,7 @@ def test_two_rank_table_sharding_matches_single_process(fixed, NT, direct):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, fixed, q, NT, direct)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fixed, q, NT, direct, wire)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
