@@ -1293,6 +1293,305 @@ __global__ __launch_bounds__(kCT) void cs_state_kernel(DedupMap M, long long cac
   if (row < cache_size) state[row] = ((const float*)M.iota)[u];
 }
 
+// ---- the same update for SMALL batches, one launch (round 6): every work-group OWNS the cache rows `row % G == g` -----------------
+// The sorted update above is a chain of ~16 launches (~65 us whatever the batch).  Up to kOwnMaxN lookups the grouping needs no
+// global sort: work-group g scans the batch's cached lookups for ITS rows (a stable compaction into LDS, index order), groups them
+// by row with a counting sort over its local row ids row / G (counts by LDS integer atomics -- order-free --, a scan, then ONE wave
+// places the entries batch after batch so that equal rows keep their index order), and sums every row's bag gradients in that order:
+// short runs by one 16-lane group each, long runs (a hot row: a sixth of a Zipf batch) by all 64 groups, strided, part sums folded
+// in group order.  One owner per row: plain read-modify-write, no atomics, the same bits every run.  Row-wise Adagrad walks a row's
+// lookups in index order (the sequential oracle's order); a long run gets its multipliers from a wave scan of the lookups' g2 first.
+// Rows are numbered by descending frequency (cache_populate), so `row % G` spreads the hot rows over the work-groups.
+constexpr int kOwnThreads = 1024, kOwnWaves = kOwnThreads / kWave, kOwnGroups = kOwnThreads / 16;
+constexpr int kOwnCap = 2048;      // list entries a work-group takes per round (more: further rounds, in index order)
+constexpr int kOwnLong = 48;       // a run beyond this many lookups is summed by the whole work-group
+constexpr int kOwnMaxLR = 4096;    // local row ids per work-group (cache_size / G rounded up)
+constexpr int kOwnMaxN = 32768;    // every work-group reads all N cache locations: beyond this the sorted update
+constexpr int kOwnMaxD4 = 64;      // D <= 256, D % 4 == 0
+struct OwnArgs {
+  int N, D4, optim, G, gshift, LR, B;  // G = 1 << gshift work-groups
+  float lr, eps;
+  long long cache_size;
+  const int* skip_dev;
+  const float4* grad;
+  const int32_t* loc;
+  const int64_t* rowidx;
+  float* state;
+  float4* dst;
+};
+__device__ __forceinline__ float own_group_sum16(float v) {  // sum over the 16 lanes of a group (all lanes get it)
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+  return v;
+}
+__device__ __forceinline__ float own_dot(const float4& a) { return fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, a.w * a.w))); }
+__device__ __forceinline__ void own_axpy(float4& acc, float m, const float4& v) {
+  acc.x = fmaf(m, v.x, acc.x); acc.y = fmaf(m, v.y, acc.y); acc.z = fmaf(m, v.z, acc.z); acc.w = fmaf(m, v.w, acc.w);
+}
+
+__global__ __launch_bounds__(kOwnThreads) void cache_update_owner_kernel(OwnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int own_lds[];
+  int* l_row = own_lds;                 // [cap] list: cache row, index order
+  int* l_bag = l_row + kOwnCap;         // [cap] its bag row
+  int* s_row = l_bag + kOwnCap;         // [cap] the same grouped by row
+  int* s_bag = s_row + kOwnCap;
+  int* seg = s_bag + kOwnCap;           // [cap + 2] run starts (+ end)
+  int* lng = seg + kOwnCap + 2;         // [cap / kOwnLong + 2] indices of the long runs
+  int* cnt = lng + kOwnCap / kOwnLong + 2;  // [LR] counts -> starts -> running positions
+  float* g2s = (float*)(cnt + a.LR);    // [cap] g2 of a long run's lookups, then their multipliers
+  float4* fold = (float4*)(((uintptr_t)(g2s + kOwnCap) + 15) & ~(uintptr_t)15);  // [groups][D4] part sums of a long run
+  __shared__ int wcnt[kOwnWaves];
+  __shared__ int s_scan[kOwnWaves + 1];
+  __shared__ int s_nseg, s_nlong;
+  __shared__ float s_run;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+  const int grp = tid >> 4, gl = tid & 15;
+  const int g = blockIdx.x, G = a.G, D4 = a.D4, N = a.N;
+  const int nv = (D4 + 15) / 16;  // float4 columns per lane (<= 4)
+  const int skip = a.skip_dev ? max(0, min(N, *a.skip_dev)) : 0;
+
+  auto process = [&](int n) {  // (every thread calls it with the same n: barriers inside)
+    // ---- group the list by row: counting sort over the local row ids, stable ----
+    for (int e = tid; e < a.LR; e += kOwnThreads) cnt[e] = 0;
+    for (int e = tid; e < n; e += kOwnThreads) l_bag[e] = (int)a.rowidx[l_bag[e]];  // position -> bag row
+    __syncthreads();
+    for (int e = tid; e < n; e += kOwnThreads) atomicAdd(&cnt[l_row[e] >> a.gshift], 1);
+    __syncthreads();
+    {  // exclusive scan of cnt[0, LR): a strip per thread
+      const int per = (a.LR + kOwnThreads - 1) / kOwnThreads;
+      const int b0 = tid * per, b1 = min(a.LR, b0 + per);
+      int sum = 0;
+      for (int e = b0; e < b1; ++e) sum += cnt[e];
+      const int inc = wave_incl_scan(sum);
+      if (lane == kWave - 1) s_scan[w] = inc;
+      __syncthreads();
+      int base = 0;
+      for (int k = 0; k < w; ++k) base += s_scan[k];
+      int run = base + inc - sum;
+      for (int e = b0; e < b1; ++e) { const int c = cnt[e]; cnt[e] = run; run += c; }
+    }
+    __syncthreads();
+    if (w == 0) {  // ONE wave places the entries, 64 at a time, in list order: equal rows keep their index order
+      for (int b0 = 0; b0 < n; b0 += kWave) {
+        const int e = b0 + lane;
+        const bool valid = e < n;
+        const int row = valid ? l_row[e] : -1, bag = valid ? l_bag[e] : 0;
+        const int key = valid ? (row >> a.gshift) : -1 - lane;  // (invalid lanes: keys of their own)
+        // rank among the batch's lanes with the same key, and how many there are: 64 lane broadcasts, no LDS, no serial turn per
+        // distinct key (the first version took a turn -- an LDS round trip -- per distinct key: 64 per batch on a uniform stream)
+        int before = 0, same = 0;
+#pragma unroll
+        for (int j = 0; j < kWave; ++j) {
+          const int kj = __builtin_amdgcn_readlane(key, j);
+          const int eq = kj == key ? 1 : 0;
+          same += eq;
+          before += (j < lane) ? eq : 0;
+        }
+        if (valid) {
+          const int basep = cnt[key];
+          const int dest = basep + before;
+          s_row[dest] = row;
+          s_bag[dest] = bag;
+          if (before == same - 1) cnt[key] = basep + same;  // (the key's last lane of the batch: one writer per key)
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    // ---- run heads -> seg[], long runs -> lng[] ----
+    if (tid == 0) { s_nseg = 0; s_nlong = 0; }
+    __syncthreads();
+    for (int b0 = 0; b0 < n; b0 += kOwnThreads) {  // (uniform)
+      const int j = b0 + tid;
+      const bool head = j < n && (j == 0 || s_row[j] != s_row[j - 1]);
+      const unsigned long long hm = __ballot(head);
+      if (lane == 0) wcnt[w] = __popcll(hm);
+      __syncthreads();
+      int off = 0, tot = 0;
+      for (int k = 0; k < kOwnWaves; ++k) { const int c = wcnt[k]; if (k < w) off += c; tot += c; }
+      const int base = s_nseg;
+      if (head) seg[base + off + __popcll(hm & lanemask_lt())] = j;
+      __syncthreads();
+      if (tid == 0) s_nseg = base + tot;
+      __syncthreads();
+    }
+    const int nseg = s_nseg;
+    if (tid == 0) seg[nseg] = n;
+    __syncthreads();
+    for (int s0 = tid; s0 < nseg; s0 += kOwnThreads)
+      if (seg[s0 + 1] - seg[s0] > kOwnLong) lng[atomicAdd(&s_nlong, 1)] = s0;  // (which long run first does not touch any value)
+    __syncthreads();
+    const int nlong = s_nlong;
+    // ---- short runs: one 16-lane group each, lookup after lookup in index order ----
+    for (int s0 = grp; s0 < nseg; s0 += kOwnGroups) {
+      const int b = seg[s0], e = seg[s0 + 1];
+      if (e - b > kOwnLong) continue;
+      const int row = s_row[b];
+      float4 acc[4], wv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (the row to update is requested now, with the first gradient rows -- not after the sums, one more trip to memory later)
+        wv[k] = (k < nv && gl + 16 * k < D4) ? a.dst[(size_t)row * D4 + gl + 16 * k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float run = a.optim == TTX_OPTIM_ADAGRAD ? a.state[row] : 0.f;
+      for (int j = b; j < e; j += 4) {
+        float4 v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int bag = j + u < e ? s_bag[j + u] : -1;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            v[u][k] = (bag >= 0 && k < nv && gl + 16 * k < D4) ? a.grad[(size_t)bag * D4 + gl + 16 * k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (j + u >= e) break;  // (group-uniform)
+          float m = 1.f;
+          if (a.optim == TTX_OPTIM_ADAGRAD) {
+            float sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sq += own_dot(v[u][k]);
+            const float g2 = own_group_sum16(sq) / (float)(4 * D4);
+            m = (float)(a.lr * (1.0 / (sqrtf(run + g2) + a.eps)));  // (cu:1781-1782: double intermediate)
+            run += g2;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) own_axpy(acc[k], m, v[u][k]);
+        }
+      }
+      const float scale = a.optim == TTX_OPTIM_SGD ? -a.lr : (a.optim == TTX_OPTIM_ADAGRAD ? -1.f : 1.f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < nv && gl + 16 * k < D4) {
+          // (dense: onto the zeroed gradient -- an add, not a store: a row whose lookups span two rounds of the list comes twice)
+          float4 x = wv[k];
+          own_axpy(x, scale, acc[k]);
+          a.dst[(size_t)row * D4 + gl + 16 * k] = x;
+        }
+      if (a.optim == TTX_OPTIM_ADAGRAD && gl == 0) a.state[row] = run;
+    }
+    // ---- long runs: the whole work-group, strided; part sums folded in group order ----
+    for (int h = 0; h < nlong; ++h) {  // (uniform)
+      const int s0 = lng[h];
+      const int b = seg[s0], e = seg[s0 + 1], len = e - b;
+      const int row = s_row[b];
+      if (a.optim == TTX_OPTIM_ADAGRAD) {
+        for (int j = grp; j < len; j += kOwnGroups) {  // g2 of every lookup of the run
+          const int bag = s_bag[b + j];
+          float sq = 0.f;
+          for (int k = 0; k < nv; ++k)
+            if (gl + 16 * k < D4) sq += own_dot(a.grad[(size_t)bag * D4 + gl + 16 * k]);
+          const float g2 = own_group_sum16(sq) / (float)(4 * D4);
+          if (gl == 0) g2s[j] = g2;
+        }
+        __syncthreads();
+        if (w == 0) {  // multipliers in index order: old + g2 = state + inclusive prefix
+          float run = a.state[row];
+          for (int j0 = 0; j0 < len; j0 += kWave) {
+            const float v = j0 + lane < len ? g2s[j0 + lane] : 0.f;
+            const float inc = wave_incl_scan_f(v);
+            if (j0 + lane < len) g2s[j0 + lane] = (float)(a.lr * (1.0 / (sqrtf(run + inc) + a.eps)));
+            run += __shfl(inc, kWave - 1, kWave);
+          }
+          if (lane == 0) s_run = run;
+        }
+        __syncthreads();
+      }
+      float4 acc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = grp; j < len; j += 4 * kOwnGroups) {
+        float4 v[4][4];
+        float m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int jj = j + u * kOwnGroups;
+          const int bag = jj < len ? s_bag[b + jj] : -1;
+          m[u] = (jj < len && a.optim == TTX_OPTIM_ADAGRAD) ? g2s[jj] : 1.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            v[u][k] = (bag >= 0 && k < nv && gl + 16 * k < D4) ? a.grad[(size_t)bag * D4 + gl + 16 * k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j + u * kOwnGroups < len) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) own_axpy(acc[k], m[u], v[u][k]);
+          }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < nv && gl + 16 * k < D4) fold[(size_t)grp * D4 + gl + 16 * k] = acc[k];
+      __syncthreads();
+      if (tid < D4) {
+        float4 t = fold[tid];
+        for (int q = 1; q < kOwnGroups; ++q) {
+          const float4 x = fold[(size_t)q * D4 + tid];
+          t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+        }
+        const float scale = a.optim == TTX_OPTIM_SGD ? -a.lr : (a.optim == TTX_OPTIM_ADAGRAD ? -1.f : 1.f);
+        float4* wp = a.dst + (size_t)row * D4 + tid;
+        float4 x = *wp;
+        own_axpy(x, scale, t);
+        *wp = x;
+        if (a.optim == TTX_OPTIM_ADAGRAD && tid == 0) a.state[row] = s_run;
+      }
+      __syncthreads();
+    }
+  };
+
+  // The scan: rounds of kOwnThreads positions; the cache location of the round after the next is requested before this round's
+  // barriers (a load per round in front of its barrier was 15 of the first version's 65 us at 10k lookups).  The list is
+  // processed when the next round might not fit -- ONE call site: the body is large, and a copy per round of an unrolled scan
+  // (second version) ran out of the instruction cache: 150 us.
+  const int nrounds = (N - skip + kOwnThreads - 1) / kOwnThreads;
+  auto fetch = [&](int r) -> int {
+    const int i = skip + r * kOwnThreads + tid;
+    return (r < nrounds && i < N) ? a.loc[i] : -1;
+  };
+  int c0 = fetch(0), c1 = fetch(1);
+  int r = 0;
+  while (r < nrounds) {  // (uniform)
+    int n = 0;
+    for (; r < nrounds; ++r) {
+      const int c2 = fetch(r + 2);
+      const int i = skip + r * kOwnThreads + tid;
+      const int c = c0;
+      const bool m = c >= 0 && (long long)c < a.cache_size && (c & (G - 1)) == g;
+      const unsigned long long bm = __ballot(m);
+      if (lane == 0) wcnt[w] = __popcll(bm);
+      __syncthreads();
+      int off = 0, tot = 0;
+      for (int k = 0; k < kOwnWaves; ++k) { const int cc = wcnt[k]; if (k < w) off += cc; tot += cc; }
+      __syncthreads();  // (wcnt is rewritten by the next round)
+      if (n + tot > kOwnCap) break;  // (uniform) the list is full: this round's rows are applied, the rest follows in a later turn
+      if (m) {
+        const int p = n + off + __popcll(bm & lanemask_lt());
+        l_row[p] = c;
+        l_bag[p] = i;  // (the lookup's position: process() turns it into the bag row, one round of loads for the whole list)
+      }
+      n += tot;
+      c0 = c1; c1 = c2;
+    }
+    __syncthreads();
+    if (n > 0) process(n);
+    __syncthreads();
+  }
+}
+
+static size_t own_lds_bytes(int LR, int D4) {
+  return (size_t)(5 * kOwnCap + 2 + kOwnCap / kOwnLong + 2 + LR) * 4 + (size_t)kOwnCap * 4 + 16 + (size_t)kOwnGroups * D4 * 16;
+}
+// G work-groups for this cache size, or 0: the batch / shape is not this kernel's
+static int own_groups(int64_t nnz, int64_t cache_size, int32_t D, const void* grad, const void* dst) {
+  if (nnz > kOwnMaxN || D % 4 != 0 || D / 4 > kOwnMaxD4 || ((((uintptr_t)grad) | ((uintptr_t)dst)) & 15) != 0) return 0;
+  int G = 128;
+  while ((cache_size + G - 1) / G > kOwnMaxLR && G < 4096) G *= 2;
+  if ((cache_size + G - 1) / G > kOwnMaxLR) return 0;
+  return G;
+}
+
 static size_t cs_scan_bytes(int64_t nnz, int64_t B) {
   const size_t nblk = ((size_t)nnz + kCsBlock - 1) / kCsBlock;
   return align_up((size_t)(B > 0 ? B : 1) * 4) + 3 * align_up(nblk * 4) + align_up((size_t)nnz * 4);
@@ -1326,6 +1625,20 @@ int ttx_cache_backward_sorted(int32_t optim, int64_t nnz, const int32_t* skip_de
   if (!grad || !loc || !rowidx) TTX_FAIL(TTX_EINVAL, "NULL input");
   if (optim == TTX_OPTIM_ADAGRAD && (!cache_optimizer_state || num_bags <= 0))
     TTX_FAIL(TTX_EINVAL, "row-wise Adagrad needs cache_optimizer_state and the number of bags");
+  if (const int G = own_groups(nnz, cache_size, D, grad, dst)) {  // small batch: one launch, every work-group owns its rows
+    OwnArgs A;
+    A.N = (int)nnz; A.D4 = D / 4; A.optim = optim; A.G = G; A.LR = (int)((cache_size + G - 1) / G); A.B = (int)num_bags;
+    A.gshift = 0;
+    while ((1 << A.gshift) < G) ++A.gshift;
+    A.lr = lr; A.eps = eps; A.cache_size = cache_size; A.skip_dev = skip_dev; A.grad = (const float4*)grad; A.loc = loc;
+    A.rowidx = rowidx; A.state = cache_optimizer_state; A.dst = (float4*)dst;
+    const size_t lds = own_lds_bytes(A.LR, A.D4);
+    const int rc_attr = allow_dynamic_lds((const void*)cache_update_owner_kernel, (int)lds);
+    if (rc_attr) return rc_attr;
+    hipLaunchKernelGGL(cache_update_owner_kernel, dim3((unsigned)G), dim3(kOwnThreads), lds, st, A);
+    TTX_HIP(hipGetLastError());
+    return TTX_OK;
+  }
   if (!workspace || workspace_bytes < ttx_cache_backward_sorted_workspace_bytes(nnz, num_bags, D))
     TTX_FAIL(TTX_EWORKSPACE, "sorted cache update: workspace too small");
   char* ws = (char*)workspace;

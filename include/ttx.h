@@ -514,8 +514,10 @@ int ttx_profile_read(int which, int64_t* launches, double* total_ms);
  * [cache_size, D], zeroed here) or TTX_OPTIM_ADAGRAD (dst = cache_weight, cache_optimizer_state [cache_size]: the reference's
  * per-lookup sequence old = state, state += g2, w -= g * lr / (sqrt(old + g2) + eps), taken in index order within a row -- the
  * order of a sequential execution, where the reference's depends on which warp arrives first).  num_bags: rows of grad
- * (row-wise Adagrad).  The atomic entry points above stay: one launch, faster below ~300k cached lookups (row-wise Adagrad: ~60k;
- * DESIGN.md section 4.6). */
+ * (row-wise Adagrad).  Up to 32,768 lookups (D % 4 == 0, D <= 256) it is ONE launch -- every work-group owns the rows
+ * row % G == g, finds and groups them in LDS -- and needs no workspace; beyond that a chain of ~16 launches (stable radix sort, run
+ * heads, ordered sums, apply).  The atomic entry points above stay: one launch, faster below ~300k cached lookups (row-wise
+ * Adagrad: ~60k). */
 size_t ttx_cache_backward_sorted_workspace_bytes(int64_t nnz, int64_t num_bags, int32_t D);
 int ttx_cache_backward_sorted(int32_t optim, int64_t nnz, const int32_t* skip_dev, int64_t num_bags, int32_t D,
                               const float* grad_output, const int32_t* cache_locations, const int64_t* rowidx,
