@@ -1171,7 +1171,6 @@ __global__ __launch_bounds__(kCT) void cs_bag_g2_kernel(int B, int D, const floa
 // (+ the carry into b - 1 if that block held no head); (3) every position's prefix = carry (if no head lies in front of it in its
 // block) + the in-block segmented scan.  Fixed association, no atomics.
 constexpr int kCsBlock = 1024;
-struct CsScan { float incl; bool before_first_head; };
 __device__ __forceinline__ float cs_seg_scan(float v, bool head, float* wsum, int* whead, float* tail, int* has_head,
                                              bool* no_head_before) {
   // -> inclusive segmented scan of v within the 1024-position block; *tail / *has_head: see above; *no_head_before: no head at or in
@@ -1188,9 +1187,7 @@ __device__ __forceinline__ float cs_seg_scan(float v, bool head, float* wsum, in
     if (lane - o >= start) x += y;
   }
   // the wave's tail (sum from its last head, or the whole wave) and whether it holds a head
-  const int last_start = hm ? 63 - __clzll(hm) : 0;
-  const float wave_tail = __shfl(x, kWave - 1, kWave);  // lane 63's run starts at last_start: x[63] IS the tail
-  (void)last_start;
+  const float wave_tail = __shfl(x, kWave - 1, kWave);  // (lane 63's run starts at the wave's last head: x[63] IS the tail)
   if (lane == 0) { wsum[w] = wave_tail; whead[w] = hm ? 1 : 0; }
   __syncthreads();
   // carry into this wave from the waves before it in the block: tails back to the nearest wave with a head
