@@ -634,7 +634,7 @@ def cache_forward(B: int, nnz: int, cache_locations: torch.Tensor, rowidx: torch
 # DETERMINISTIC_AUTO_MIN_NNZ_ADAGRAD), where it is also the faster of the two.  TTX_DETERMINISTIC=1 / 0 in the environment overrides None.
 # (measured, profiles/r06_cache_bandwidth.md: the sorted update is a chain of ~16 launches, ~65 us whatever the batch; on a Zipf
 #  stream it overtakes the atomic SGD / dense scatter near 300k cached lookups -- 232 against 343 us at 1 M -- and the atomic
-#  row-wise Adagrad, whose hot rows serialise, near 60k -- 330 against 1228 us at 1 M)
+#  row-wise Adagrad, whose hot rows serialise, near 60k -- 357 against 1228 us at 1 M)
 DETERMINISTIC_AUTO_MIN_NNZ = int(os.environ.get("TTX_DETERMINISTIC_AUTO_MIN_NNZ", 262144))
 DETERMINISTIC_AUTO_MIN_NNZ_ADAGRAD = int(os.environ.get("TTX_DETERMINISTIC_AUTO_MIN_NNZ_ADAGRAD", 65536))
 
