@@ -960,13 +960,17 @@ def test_cache_live_round_planned_ahead_equals_the_in_line_prologue(node, shape)
     assert hits > 0 and len(b._prefetched) == 0
 
 
+@pytest.mark.parametrize("det", [None, True])
 @pytest.mark.parametrize("optim", ["sgd", "adagrad"])
-def test_cache_live_training_round_planned_ahead_eager_and_captured(node, optim):
+def test_cache_live_training_round_planned_ahead_eager_and_captured(node, optim, det):
     """a round of cache-live training steps with the prologues planned ahead, eagerly and replayed from a hipGraph,
     against the plain sequence: first output bit-identical, the rest to rounding (the cache rows' fused SGD updates are
     float atomics whose order is not fixed, here as in the reference); the frequency table counts the same.  With
     Adagrad the cache rows' step sizes depend on which lookup of a row arrives first (cu:1735-1795, `old` of the
-    atomic) -- two plain runs differ in the second step already -- so only the first output and the table are held."""
+    atomic) -- two plain runs differ in the second step already -- so only the first output and the table are held.
+    det = True (round 6, `deterministic_cache_update`): the cache rows are updated without atomics, in index order within a row --
+    then EVERY output of the planned-ahead round and of the captured replay, the cores, the cache rows and (Adagrad) the cache's
+    optimizer state are BIT-identical to the plain sequence, for both optimizers."""
     import tt_embeddings_ops as ops
     import ttx_graph
 
@@ -975,9 +979,10 @@ def test_cache_live_training_round_planned_ahead_eager_and_captured(node, optim)
     p, q, r, E_, D, B, Lp = [200, 220, 250], [4, 4, 4], [32, 32], 11_000_000, 64, 512, 20
     optimizer = ops.OptimType.SGD if optim == "sgd" else ops.OptimType.EXACT_ADAGRAD
     a, b, reqs = _cache_live_pair(ops, p, q, r, E_, D, B, Lp, optimizer, n_req=4)
+    a.deterministic_cache_update = b.deterministic_cache_update = det
     c = ops.TTEmbeddingBag(num_embeddings=E_, embedding_dim=D, tt_ranks=r, tt_p_shapes=p, tt_q_shapes=q, weight_dist="uniform",
                            device=DEV, sparse=True, optimizer=optimizer, learning_rate=0.05, use_cache=True, cache_size=512,
-                           hashtbl_size=1 << 20)
+                           hashtbl_size=1 << 20, deterministic_cache_update=det)
     c.load_state_dict(a.state_dict())
     c.warmup = False
     grad = t(G.make_grad(72, 1, B, D)[0])
@@ -991,7 +996,9 @@ def test_cache_live_training_round_planned_ahead_eager_and_captured(node, optim)
         out = b(i, o)
         if k == 0:
             assert torch.equal(out.detach(), outs_a[0])
-        if optim == "sgd":
+        if det:
+            assert torch.equal(out.detach(), outs_a[k]), f"step {k}: the planned-ahead round must equal the plain sequence bit for bit"
+        elif optim == "sgd":
             assert torch.allclose(out.detach(), outs_a[k], rtol=2e-5, atol=2e-6), f"step {k}"
         assert bool(torch.isfinite(out).all())
         out.backward(grad)
@@ -1000,7 +1007,13 @@ def test_cache_live_training_round_planned_ahead_eager_and_captured(node, optim)
     torch.cuda.synchronize()
     rnd.replay()
     torch.cuda.synchronize()
-    if optim == "sgd":
+    if det:
+        for x, y, z in zip(a.tt_cores, b.tt_cores, c.tt_cores):
+            assert torch.equal(x, y) and torch.equal(x, z)
+        assert torch.equal(a.cache_weight, b.cache_weight) and torch.equal(a.cache_weight, c.cache_weight)
+        if optim != "sgd":
+            assert torch.equal(a.cache_optimizer_state, b.cache_optimizer_state) and torch.equal(a.cache_optimizer_state, c.cache_optimizer_state)
+    elif optim == "sgd":
         for x, y, z in zip(a.tt_cores, b.tt_cores, c.tt_cores):
             assert torch.allclose(x, y, rtol=2e-5, atol=2e-6) and torch.allclose(x, z, rtol=2e-5, atol=2e-6)
         assert torch.allclose(a.cache_weight, b.cache_weight, rtol=2e-5, atol=2e-6)
@@ -1055,8 +1068,9 @@ def test_more_batches_than_one_prologue_launch_holds(node, live):
     assert len(b._prefetched) == 0
 
 
+@pytest.mark.parametrize("det", [None, True])  # (round 6: True = the atomic-free cache-row update, every lookup its own scaled gradient row)
 @pytest.mark.parametrize("optim", ["dense", "sgd", "adagrad"])
-def test_per_sample_weights_with_a_live_cache(node, optim):
+def test_per_sample_weights_with_a_live_cache(node, optim, det):
     """nn.EmbeddingBag's per_sample_weights while the row cache is live (the part the reference has no
     counterpart for at all): against torch's embedding_bag + autograd on the table the module serves at that moment --
     the TT rows with the cached rows laid over them.  Forward, the weights' own gradient, the dense gradients of the cores
@@ -1069,6 +1083,7 @@ def test_per_sample_weights_with_a_live_cache(node, optim):
     p, q, r, E_, D, B, Lp = [20, 22, 25], [4, 4, 4], [16, 16], 11_000, 64, 96, 6
     optimizer = {"dense": None, "sgd": ops.OptimType.SGD, "adagrad": ops.OptimType.EXACT_ADAGRAD}[optim]
     a, _, reqs = _cache_live_pair(ops, p, q, r, E_, D, B, Lp, optimizer, n_req=1, cache_size=200)
+    a.deterministic_cache_update = det
     idx, off = reqs[0]
     rs = np.random.RandomState(4)
     psw = t((rs.rand(idx.numel()) * 2 - 0.5).astype(np.float32))
