@@ -879,7 +879,15 @@ def main():
             # D = 128: its own roofline) and configs[2] (the row cache live on a Zipf stream: hit rate, cache_gather_roofline).
             # A process each: a second module beside the first would perturb both.
             line["secondary"] = [secondary_record("cfg5shard", 40, 3), secondary_record("cfg4", 100, 3),
-                                 secondary_record("cfg3", 100, 3)]
+                                 secondary_record("cfg3", 100, 3), secondary_record("cfg5", 10, 3)]
+            # (configs[4] whole on ONE GPU -- 26 tables, 2.13 M lookups per step -- is the base of the predicted 8-GPU speed-up)
+            try:
+                pred = line["secondary"][0].get("predicted_cfg5_on_8_gpus")
+                if pred and "ms_per_step" in line["secondary"][3]:
+                    pred["one_gpu_ms_per_step"] = line["secondary"][3]["ms_per_step"]
+                    pred["predicted_speedup_over_one_gpu"] = round(line["secondary"][3]["ms_per_step"] / pred["ms_per_step"], 2)
+            except Exception:  # noqa: BLE001
+                pass
             if "dense_embedding_bag" not in line and ntab == 1:
                 # the reference benchmark's --run-baseline leg (tt_embeddings_benchmark.py:195-211): the dense table the cores replace
                 try:
