@@ -348,6 +348,74 @@ def test_sorted_cache_update_is_deterministic_and_matches_the_oracle(n, D, cs, B
     assert np.array_equal(dw2.cpu().numpy(), runs[0]), "the split point must not change a bit"
 
 
+@pytest.mark.parametrize("n,D,cs,what", [
+    (1, 64, 8, "one"), (700, 64, 1, "one_row"), (900, 64, 50, "none_cached"), (900, 64, 50, "skip_all"),
+    (40000, 64, 50, "none_cached"), (3000, 256, 30, "plain"), (3000, 260, 30, "plain"), (5000, 8, 3, "plain"),
+    (33000, 64, 5, "plain"), (2500, 128, 4_000_000, "plain"), (2500, 64, 9_000_000, "plain")])
+def test_sorted_cache_update_edge_cases(n, D, cs, what):
+    """the atomic-free update at the edges of its two routes (one launch up to 32,768 lookups with D % 4 == 0, D <= 256 and at most
+    4096 x 4096 cache rows; the sort chain otherwise): a single lookup, one cache row taking the whole batch (several rounds of the
+    owner's list), nothing cached (all -1 / the split point behind the batch: nothing may change), the widest row the one-launch
+    kernel takes and the first it does not, a row of two float4, a batch just beyond the one-launch limit, caches of millions of
+    rows (more work-groups / the chain).  SGD, dense and row-wise Adagrad against float64 / the oracle, twice, bit-identical."""
+    import tt_embeddings as E
+
+    rs = np.random.RandomState(n + D + cs % 1000)
+    B = 64
+    loc = ((rs.zipf(1.3, size=n) - 1) % cs).astype(np.int32) if cs > 1 else np.zeros(n, dtype=np.int32)
+    if cs > 1_000_000:
+        loc = rs.randint(0, cs, size=n).astype(np.int32)
+        loc[: n // 3] = loc[0]  # (one hot row among millions)
+    rowidx = np.sort(rs.randint(0, B, size=n)).astype(np.int64)
+    if what == "none_cached":
+        loc[:] = -1
+    grad = ((rs.rand(B, D) - 0.4) * 0.1).astype(np.float32)
+    rows = np.unique(loc[loc >= 0])
+    w0 = {int(r_): rs.randn(D).astype(np.float32) for r_ in rows}
+    dw = torch.zeros(cs, D, device=DEV)
+    if rows.size:
+        dw[torch.from_numpy(rows.astype(np.int64)).to(DEV)] = t(np.stack([w0[int(r_)] for r_ in rows]))
+    dst = torch.full((cs,), 0.01, device=DEV)
+    skip = torch.tensor([n if what == "skip_all" else 0], dtype=torch.int32, device=DEV)
+    live = (loc >= 0) & (what != "skip_all")
+    delta = {}
+    for i in np.nonzero(live)[0]:
+        delta.setdefault(int(loc[i]), np.zeros(D))
+        delta[int(loc[i])] += grad[rowidx[i]].astype(np.float64)
+    for optim in (E.OPTIM_SGD, E.OPTIM_DENSE, E.OPTIM_ADAGRAD):
+        outs = []
+        for _ in range(2):
+            w = dw.clone()
+            st = dst.clone()
+            target = torch.full((cs, D), 7.0, device=DEV) if optim == E.OPTIM_DENSE else w
+            E._cache_backward_sorted(optim, n, t(grad), t(loc), t(rowidx), 0.1, 1e-4, st if optim == E.OPTIM_ADAGRAD else None, target,
+                                     skip_dev=skip)
+            outs.append((target, st))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "two runs differ"
+        got = outs[0][0]
+        touched = torch.zeros(cs, dtype=torch.bool, device=DEV)
+        if delta:
+            touched[torch.tensor(sorted(delta), device=DEV)] = True
+        if optim == E.OPTIM_DENSE:
+            assert not got[~touched].any(), "dense gradient of rows nobody hit must be zero"
+        else:
+            assert torch.equal(got[~touched], dw[~touched]), "rows nobody hit must not change"
+        tol = dict(rtol=5e-5, atol_scale=1e-5) if n >= 30000 or cs == 1 else {}
+        for r_, dv in list(delta.items())[:200]:
+            if optim == E.OPTIM_SGD:
+                assert_close(got[r_].cpu().numpy(), w0[r_].astype(np.float64) - 0.1 * dv, f"sgd row {r_}", **tol)
+            elif optim == E.OPTIM_DENSE:
+                assert_close(got[r_].cpu().numpy(), dv, f"dense row {r_}", **tol)
+        if optim == E.OPTIM_ADAGRAD and delta:
+            st_o = np.full(cs if cs <= 100000 else 1, 0.01, dtype=np.float32)
+            if cs <= 100000:  # (the oracle takes dense arrays: small caches only)
+                w_o = dw.cpu().numpy().copy()
+                lo = np.where(live, loc, 0).astype(np.int32)[live]
+                O.cache_backward_rowwise_adagrad_approx(grad, lo, rowidx[live], 0.1, 1e-4, st_o, w_o)
+                assert_close(outs[0][1].cpu().numpy(), st_o, "adagrad state", rtol=5e-5, atol_scale=1e-5)
+                assert_close(got.cpu().numpy(), w_o, "adagrad rows", rtol=1e-4, atol_scale=1e-5)
+
+
 def test_rowwise_adagrad_where_the_reference_is_deterministic():
     """Second checker for a12's row-wise Adagrad (round-5 verdict): where the reference's kernel has ONE possible result -- every
     cache row hit from at most one segment (bag), possibly several times inside it -- the product's two kernels (atomic and
