@@ -883,6 +883,10 @@ class TableBatchedTTEmbeddingBag(nn.Module):
         plain = (fast is not None and self.warmup and indices.is_cuda and indices.numel() > 0 and not self.use_cache
                  and self.__dict__.get("_split0", 0) <= 1 and not self._dedup_may_share(indices.numel()))
         if not plain:  # (CPU tensors under the tests' oracle engine, a cache, part lookups, shared duplicates)
+            if indices.is_cuda and torch.cuda.is_current_stream_capturing():
+                # (round 6, advisor: this route reads the count back -- say so instead of failing inside the capture)
+                raise RuntimeError("TableBatchedTTEmbeddingBag.forward(n_dev=): with a cache, part lookups (q0 > 4) or shared duplicates "
+                                   "the live count is read back to the host -- not capturable in a hipGraph on this route")
             n = int(n_dev.item())
             return self.forward(indices[:n].contiguous(), offsets)
         indices = indices.long() if indices.dtype != torch.int64 else indices
