@@ -219,7 +219,7 @@ def secondary_record(workload="cfg5shard", steps=40, repeats=3):
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
         keep = ("metric", "value", "unit", "ms_per_step", "steps", "repeats", "timed_mode", "eager_ms_per_step", "us_per_nnz", "kernel_us",
-                "roofline", "spread", "no_prefetch", "cache_gather_roofline", "cache_hit_rate", "dtype")
+                "roofline", "spread", "no_prefetch", "cache_gather_roofline", "cache_hit_rate", "dtype", "kernel_rooflines")
         rec = {k: j[k] for k in keep if k in j}
         rec["workload"] = j["config"]["workload"]
         fl = j["config"]["flop_per_nnz_fwd_bwd"] * j["config"]["nnz_per_step_total"]
@@ -648,6 +648,35 @@ def main():
                                 "launches": n_bwd, "avg_us": round(bwd_us, 2), "timed_by": bwd_src, "bytes_per_launch": byt,
                                 "note": "core slices of 1 KB per lookup come from L2 / Infinity Cache, the partial rows go to HBM",
                                 "kernel_build": source_hash()}
+        # (round 6) every kernel of the step against ITS bound, from the rocprofv3 durations and PMC bytes of this build
+        # (profiles/pmc_bytes.json, scripts/measure_traffic.sh; absent or from another build: no entry): the contraction kernels
+        # against the fp32 MFMA peak on their algorithmic FLOP, everything else against 8 TB/s on the HBM bytes the counters saw
+        if os.path.exists(pmc_all) and not sharded and len(Q_SHAPES) == 3:
+            try:
+                j = json.load(open(pmc_all))
+                if j.get("source_hash") == source_hash():
+                    rows_ = []
+                    for kname, rec_ in j["workloads"].get(args.workload, {}).get("kernels", {}).items():
+                        us = rec_.get("rocprof_avg_us")
+                        if not us or int(rec_.get("rocprof_calls") or 0) < 10:  # (one-off launches -- cache_populate's -- are not the step's)
+                            continue
+                        ent = {"kernel": kname[:60], "avg_us": us, "hbm_bytes": rec_.get("hbm_bytes_per_launch")}
+                        if rec_.get("hbm_bytes_per_launch"):
+                            ent["hbm_GBps"] = round(rec_["hbm_bytes_per_launch"] / (us * 1e-6) / 1e9, 1)
+                            ent["hbm_frac"] = round(ent["hbm_GBps"] / (PEAK_HBM_TBS * 1e3), 4)
+                        if kname.startswith(("spec_fwd_kernel", "fwd_kernel")):
+                            ent["mfma_frac"] = round(bwd_flop_per_launch / 2.0 / (us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4)
+                            ent["bound"] = "mfma"
+                        elif kname.startswith(("spec_bwd_kernel", "bwd_kernel")):
+                            ent["mfma_frac"] = round(bwd_flop_per_launch / (us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4)
+                            ent["bound"] = "mfma"
+                        else:
+                            ent["bound"] = "latency (integer work)" if kname.startswith(("mb_", "mbw_", "plan_", "rowidx_", "partition_", "compute_rowidx")) else "hbm"
+                        rows_.append(ent)
+                    if rows_:
+                        line["kernel_rooflines"] = rows_
+            except Exception:  # noqa: BLE001
+                pass
         if a2a is not None:
             line["all_to_all"] = a2a
         line["debug_knobs"] = debug_state  # (ttx_debug_state(): 0 = every test / ablation knob of the library at its default)
