@@ -73,6 +73,18 @@ int allow_dynamic_lds(const void* kernel, int bytes) {
   return TTX_OK;
 }
 
+// compute units of the current device (persistent launches: two work-groups per CU); 256 if the runtime does not say
+int device_cus() {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  int& n = cus[dev];
+  if (n == 0 && (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)) n = 256;
+  return n;
+}
+
 int make_dims(const ttx_geom* g, Dims* d) {
   // every entry point starts here: whatever error an earlier, unrelated runtime call left behind on this thread
   // is not this call's (the launches below check hipGetLastError() after themselves)

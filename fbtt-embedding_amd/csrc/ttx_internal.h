@@ -37,6 +37,7 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // hipFuncAttributeMaxDynamicSharedMemorySize).  The attribute is per device: remembered per (kernel, device) under a
 // lock -- the forward and the autograd thread, and several devices of one process, all get here.  TTX_OK / TTX_EHIP.
 int allow_dynamic_lds(const void* kernel, int bytes);
+int device_cus();  // compute units of the current device
 
 // ------------------------------------------------------------- geometry ----
 // Derived per-stage GEMM shapes of the TT chain:
@@ -98,6 +99,8 @@ constexpr int kHotRowsPivot = TTX_HOT_PIVOT;  // chunk partials beyond which a p
 // backward's (which then skips its own), cleared by every plan build and by the fused optimizer's write to cores 2 / 3; [+5] = the
 // device-wide count of such writes (g_t4_epoch, ttx_tt.hip) when M was made: another plan's fused backward invalidates this M too.
 constexpr int kHdrT4Valid = 20;
+// hdr[kHdrGrab]: the chunk counter of bwd32_kernel's persistent work-groups (ttx_tt_spec.inc), zeroed in front of its launch
+constexpr int kHdrGrab = 32;
 struct Plan {
   int* hdr;  // [0] = number of chunks, [1] = MC, [2] = nnz, [3] = lrow valid, [8 + t] = hot slices of core t (-1: unknown), [20..25]: kHdrT4Valid
   int* sid[TTX_MAX_CORES];

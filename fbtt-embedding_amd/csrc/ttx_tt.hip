@@ -999,8 +999,10 @@ static bool spec_shape(const Dims& d) { return spec_match(d) != SPEC_NONE; }
 #endif
 static int spec_mc(const Dims& d, long long nnz) {
   const int ks = nnz >= TTX_SUBCHUNK_NNZ ? TTX_SUBCHUNKS : 1;
+  // (test build, ttx_debug_bwd32: the 32-lookup sub-chunks of bwd32_kernel want longer chunks)
+  const int b32_mc = g_bwd32_mc;
   switch (spec_match(d)) {
-    case SPEC_32_4_32_4: return S_32_4_32_4::MC * (S_32_4_32_4::SUB ? ks : 1);
+    case SPEC_32_4_32_4: return (b32_mc && ks > 1) ? b32_mc : S_32_4_32_4::MC * (S_32_4_32_4::SUB ? ks : 1);
     case SPEC_16_4_16_4: return S_16_4_16_4::MC * (S_16_4_16_4::SUB ? ks : 1);
     case SPEC_32_4_32_8: return S_32_4_32_8::MC * (S_32_4_32_8::SUB ? ks : 1);
     case SPEC_16_4_16_8: return S_16_4_16_8::MC * (S_16_4_16_8::SUB ? ks : 1);
@@ -1981,6 +1983,15 @@ int ttx_set_chunk(int32_t mc) {
   g_chunk_override = mc;
   return TTX_OK;
 }
+
+// experiment (round 6): the backward of the benchmark shape at large batches on bwd32_kernel -- eight lookups per wave on
+// v_mfma_f32_32x32x2, persistent work-groups -- with this many lookups per chunk (a multiple of 32); 0 = spec_bwd_kernel
+int ttx_debug_bwd32(int32_t lookups_per_chunk) {
+  if (lookups_per_chunk < 0 || lookups_per_chunk > 1024 || lookups_per_chunk % 32)
+    TTX_FAIL(TTX_EINVAL, "lookups per chunk %d: a multiple of 32 in 0..1024", lookups_per_chunk);
+  g_bwd32_mc = lookups_per_chunk;
+  return TTX_OK;
+}
 #endif  // TTX_TEST_HOOKS
 
 // test helper: how the generic kernels would walk this geometry's core_1 slice
@@ -2001,12 +2012,12 @@ int ttx_debug_tiles(const ttx_geom* g, int32_t* out) {
 }
 
 // Which of the TEST / ablation knobs are away from their defaults (0 = none): bit 0 ttx_debug_skip, 1 ttx_debug_lds_budget,
-// 2 ttx_set_chunk, 3 ttx_debug_stamps, 5 ttx_debug_cache_fwd.  The product build (libttx.so) has no knobs: this is the constant 0
+// 2 ttx_set_chunk, 3 ttx_debug_stamps, 5 ttx_debug_cache_fwd, 7 ttx_debug_bwd32.  The product build (libttx.so) has no knobs: this is the constant 0
 // there, and bench.py refuses to time a library where it is not.  In libttx_hooks.so the knobs are plain globals -- not per
 // stream, not thread-safe: tests and A/B timing only.
 int ttx_debug_state(void) {
   return ((g_debug_skip | g_skip_launch | g_disable_spec | g_disable_pad) ? 1 : 0) | (g_lds_budget != 160 * 1024 ? 2 : 0) |
-         (g_chunk_override ? 4 : 0) | (g_stamps ? 8 : 0) | (ttx_cache_debug_state() << 4);
+         (g_chunk_override ? 4 : 0) | (g_stamps ? 8 : 0) | (ttx_cache_debug_state() << 4) | (g_bwd32_mc ? 128 : 0);
 }
 
 /* 1 = this library was built with -DTTX_TEST_HOOKS (libttx_hooks.so), 0 = the product build */

@@ -83,10 +83,12 @@ __device__ __forceinline__ void zero_output(float* __restrict__ out, long long n
 extern int g_debug_skip;
 extern int g_disable_spec;
 extern long long* g_stamps;
+extern int g_bwd32_mc;  // ttx_debug_bwd32: lookups per chunk of bwd32_kernel (ttx_tt_spec.inc), 0 = spec_bwd_kernel as in the product
 #else
 constexpr int g_debug_skip = 0;
 constexpr int g_disable_spec = 0;
 constexpr long long* g_stamps = nullptr;
+constexpr int g_bwd32_mc = 0;
 #endif
 
 }  // namespace ttx

@@ -59,6 +59,8 @@ def lib():
     _lib = _product
     if os.environ.get("TTX_LDS_BUDGET"):  # experiments: LDS budget of the generic kernels' tile search (bytes)
         debug_lds_budget(int(os.environ["TTX_LDS_BUDGET"]))
+    if os.environ.get("TTX_BWD32"):  # experiment (A/B scripts): bwd32_kernel with this many lookups per chunk (1 = 128)
+        debug_bwd32(int(os.environ.get("TTX_BWD32_MC") or 128) if os.environ["TTX_BWD32"] == "1" else int(os.environ["TTX_BWD32"]))
     if os.environ.get("TTX_DEBUG_SKIP"):  # ablation runs (scripts/upper_bounds.py): results INVALID while set
         debug_skip(int(os.environ["TTX_DEBUG_SKIP"]))
     return _lib
@@ -79,6 +81,7 @@ def hooks_lib():
         _hooks.ttx_debug_skip.argtypes = [i32]
         _hooks.ttx_debug_cache_fwd.argtypes = [i32]
         _hooks.ttx_debug_stamps.argtypes = [C.c_void_p]
+        _hooks.ttx_debug_bwd32.argtypes = [i32]
     _lib = _hooks
     return _hooks
 
@@ -783,6 +786,13 @@ def debug_sort_pairs_desc(keys: torch.Tensor, vals: torch.Tensor) -> Tuple[torch
 def set_chunk(mc: int) -> None:
     """indices per work-group chunk (0 = heuristic)"""
     _check(hooks_lib().ttx_set_chunk(int(mc)))
+    _knobs_changed()
+
+
+def debug_bwd32(lookups_per_chunk: int) -> None:
+    """experiment (round 6): the backward of q = [4,4,4], ranks [32,32] at >= 131072 lookups on bwd32_kernel (v_mfma_f32_32x32x2,
+    persistent work-groups) with this many lookups per chunk (a multiple of 32); 0 = spec_bwd_kernel, the product's kernel"""
+    _check(hooks_lib().ttx_debug_bwd32(int(lookups_per_chunk)))
     _knobs_changed()
 
 

@@ -25,6 +25,9 @@ int ttx_debug_lds_budget(int32_t bytes);
 int ttx_debug_skip(int32_t mask);
 /* A/B knob (scripts/bench_cache.py): 1 = ttx_cache_forward uses the one-group-per-lookup kernel for every D */
 int ttx_debug_cache_fwd(int32_t lookup_groups);
+/* experiment (round 6): lookups per chunk (a multiple of 32, <= 1024) of bwd32_kernel -- the backward of q = [4,4,4], ranks [32,32] at
+ * >= 131072 lookups with eight lookups per wave on v_mfma_f32_32x32x2 and persistent work-groups; 0 = spec_bwd_kernel (the product's) */
+int ttx_debug_bwd32(int32_t lookups_per_chunk);
 /* (scripts/phase_times.py) device buffer receiving 16 int64 wall-clock stamps per backward work-group; NULL = off */
 int ttx_debug_stamps(void* device_buffer);
 

@@ -89,7 +89,7 @@ def test_product_library_has_no_test_knobs():
 
     hooks_hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ttx_test_hooks.h")).read(), flags=re.S)
     knobs = sorted(set(re.findall(r"\b(ttx_[a-z0-9_]+)\s*\(", hooks_hdr)))
-    assert set(knobs) == {"ttx_set_chunk", "ttx_debug_lds_budget", "ttx_debug_skip", "ttx_debug_cache_fwd", "ttx_debug_stamps"}
+    assert set(knobs) == {"ttx_set_chunk", "ttx_debug_lds_budget", "ttx_debug_skip", "ttx_debug_cache_fwd", "ttx_debug_stamps", "ttx_debug_bwd32"}
     so = os.path.join(ROOT, "fbtt-embedding_amd", "libttx.so")
     exported = [ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", so], text=True).splitlines()]
     assert exported and all(sym.startswith("ttx_") for sym in exported), [x for x in exported if not x.startswith("ttx_")]

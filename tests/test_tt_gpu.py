@@ -333,6 +333,36 @@ def test_benchmark_shape_large_batch_variant(q):
                 assert_close(got["cores"][k], orc["cores"][k], f"large-batch variant sgd core{k}")
 
 
+@pytest.mark.parametrize("mc,tables", [(128, 1), (64, 3), (256, 1)])
+def test_bwd32_experiment_vs_oracle(mc, tables):
+    """round 6's experimental backward of the benchmark shape at large batches (csrc/ttx_tt_spec.inc bwd32_kernel: eight lookups per
+    wave on v_mfma_f32_32x32x2, both register contractions on v_mfma_f32_4x4x1, persistent work-groups that take their chunks from
+    a counter; TEST BUILD only, ttx_debug_bwd32 -- measured slower than spec_bwd_kernel): dense gradients and fused
+    SGD against the oracle, bit-identical from run to run and to itself at another chunk length's ... thin cores (their sums do not
+    depend on the chunking); slices of 1 .. 3000 lookups: partial sub-chunks, waves without lookups, chunks of one sub-chunk"""
+    import tt_embeddings as E
+
+    p, q, r = [9, 8, 7], [4, 4, 4], [1, 32, 32, 1]
+    E_, D, B = int(np.prod(p)), int(np.prod(q)), 6800 // tables + 1
+    idx, off = G.make_bags(61 + tables, B, E_, 20, 2, tables)
+    assert idx.size > 131072
+    c = dict(tables=tables, T=3, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+             cores=G.make_cores(62, tables, p, q, r, "signed"), d_out=G.make_grad(63, tables, B, D))
+    plain = run_case(c, "dense", plan_shared=True)
+    E.debug_bwd32(mc)
+    try:
+        got, again = run_case(c, "dense", plan_shared=True), run_case(c, "dense", plan_shared=True)
+        sgd = run_case(c, "sgd", plan_shared=True)
+    finally:
+        E.debug_bwd32(0)
+    orc, orc_sgd = oracle_case(c, "dense"), oracle_case(c, "sgd")
+    for k in range(3):
+        assert_close(got["grads"][k], orc["grads"][k], f"bwd32 mc={mc} grad{k}")
+        assert np.array_equal(got["grads"][k], again["grads"][k]), "not deterministic"
+        assert_close(sgd["cores"][k], orc_sgd["cores"][k], f"bwd32 mc={mc} sgd core{k}")
+        assert_close(got["grads"][k], plain["grads"][k], f"bwd32 mc={mc} vs spec_bwd_kernel grad{k}")
+
+
 @pytest.mark.parametrize("ranks,q", [([32, 32], [4, 4, 4]), ([16, 16], [4, 4, 4]), ([32, 32], [4, 4, 8]), ([16, 16], [4, 4, 8]),
                                       ([64, 64], [4, 4, 8]), ([64, 64], [4, 4, 4]), ([32, 32], [2, 4, 4]), ([16, 16], [2, 4, 4]), ([64, 64], [2, 4, 4]),
                                       ([32, 32], [4, 8, 8]), ([64, 64], [4, 8, 8]), ([32, 32], [2, 2, 4]), ([64, 64], [2, 2, 4]), ([16, 16], [2, 2, 4]),
