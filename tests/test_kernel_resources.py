@@ -139,8 +139,9 @@ def test_contraction_tails_stay_off_the_lds_pipe():
             assert c.get("bpermute", 0) == 0, (name, c)
         padded = "ELb1EEEv" in name  # (the last template flag of both kernels)
         # a handful of address selects -- the padded variants pick an element's address or a valid dummy address per guarded
-        # float4 --; the butterfly was 126
-        assert c.get("cndmask", 0) <= (40 if padded else 16), (name, c)
+        # float4 --; the butterfly was 126.  (Round 6: + the selects that discard a record by its position in the sub-chunk: the
+        # record stage fetches unconditionally so that nothing reads a load it has just issued.)
+        assert c.get("cndmask", 0) <= (40 if padded else 24), (name, c)
         assert c.get("scratch", 0) == 0, (name, c)
         if fwd:
             assert c.get("permlane_swap", 0) >= 12, (name, c)
