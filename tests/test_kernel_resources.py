@@ -148,3 +148,64 @@ def test_contraction_tails_stay_off_the_lds_pipe():
         assert c.get("mfma", 0) >= 96, (name, c)  # (64 + 32 small per group forward, 192 + 64 backward)
         seen += 1
     assert seen >= 6, seen
+
+
+def _kernel_asm(asm_path, *needles):
+    """the instruction lines of the one kernel of the listing whose mangled name holds every needle"""
+    body, name, hits = [], None, {}
+    for raw in open(asm_path):
+        m = re.match(r"^(_Z\w+):", raw)
+        if m:
+            name, body = m.group(1), []
+            hits[name] = body
+            continue
+        if name is not None:
+            ln = raw.strip()
+            if ln.startswith("s_endpgm"):
+                name = None
+            elif ln and not ln.startswith((";", ".")):
+                body.append(ln)
+    sel = [v for k, v in hits.items() if all(n in k for n in needles)]
+    assert len(sel) == 1, (needles, len(sel))
+    return sel[0]
+
+
+def test_sub_chunk_prologues_request_without_reading():
+    """Round 6: `s_waitcnt vmcnt` counts loads, stores and scratch in one in-order counter, and with stores pending the
+    compiler waits for ZERO outstanding instructions at the first read of any loaded register -- a record fixed up behind its load, a
+    default merged with it, a bag row fetched under `rec.x >= 0`, made the wave wait for every load it had just issued for the NEXT
+    sub-chunk (three trips to memory in a row per sub-chunk of the backward, one of the forward).  In the large-batch kernels of the
+    benchmark shape, between the first and the last global load of the prefetch block inside the sub-chunk loop there is no wait for
+    vector memory on the path a plan with bag rows takes (the only wait sits in the branch of a plan without them, behind its
+    dependent rowidx[] load, and in the per_sample_weights branch)."""
+    asm = os.path.join(ROOT, "build", "asm", "spec32_test.s")
+    if not os.path.exists(asm):
+        os.makedirs(os.path.dirname(asm), exist_ok=True)
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Wno-pass-failed", "-S",
+                        "--cuda-device-only", "-o", asm, os.path.join(CSRC, "ttx_tt_spec32.hip")], check=True, timeout=900,
+                       capture_output=True)
+    big = "Shape3ILi32ELi4ELi32ELi4ELi2ELi16ELi4EEELb1"
+    for kern, flags, max_waits in (("spec_fwd_kernel", "ELb0ELb0E", 0), ("spec_bwd_kernel", "ELb0E", 2)):
+        body = _kernel_asm(asm, kern, big + flags)
+        # the prefetch block of the loop: the LAST run of global loads that is followed by a work-group barrier or the MFMAs of a
+        # sub-chunk -- found as the loads between the kernel's last `s_barrier`-free stretch that starts with a dword load of a
+        # record's row (ipos) ... simpler and robust: every maximal run of instructions between two MFMAs / barriers that holds
+        # at least six global loads is a request block; none of them may hold more vmcnt waits than the optional branches explain
+        runs, cur = [], []
+        for ln in body:
+            if ln.startswith(("v_mfma", "s_barrier")):
+                if cur:
+                    runs.append(cur)
+                cur = []
+            else:
+                cur.append(ln)
+        if cur:
+            runs.append(cur)
+        blocks = [r for r in runs if sum(x.startswith("global_load") for x in r) >= 6]
+        assert blocks, kern
+        assert len(blocks) >= 2, (kern, len(blocks))
+        for r in blocks[1:]:  # (the first block is the kernel's entry: chunk record -> records -> operands is a dependent chain)
+            first = next(i for i, x in enumerate(r) if x.startswith("global_load"))
+            waits = [x for x in r[first:] if x.startswith("s_waitcnt") and "vmcnt" in x]  # (up to the block's end: the next MFMA / barrier)
+            # (the kernels of round 5: one such wait in the forward, six in the backward)
+            assert len(waits) <= max_waits, (kern, waits)
