@@ -112,7 +112,19 @@ def test_contraction_and_reduce_kernels_budget(tt_res):
     assert pick(tt_res, "pool4_small_kernel")["ScratchSize"] == 0
 
 
-def test_contraction_tails_stay_off_the_lds_pipe():
+@pytest.fixture(scope="module")
+def spec32_asm():
+    """gfx950 assembly listing of the rank-32 translation unit, compiled once for the disassembly assertions below"""
+    out = os.path.join(ROOT, "build", "asm")
+    os.makedirs(out, exist_ok=True)
+    asm = os.path.join(out, "spec32_test.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Wno-pass-failed", "-S",
+                    "--cuda-device-only", "-o", asm, os.path.join(CSRC, "ttx_tt_spec32.hip")], check=True, timeout=900,
+                   capture_output=True)
+    return asm
+
+
+def test_contraction_tails_stay_off_the_lds_pipe(spec32_asm):
     """Round 4: the forward tail is a reduce-scatter over the four lane quarters on v_permlane{32,16}_swap, both tails contract on
     v_mfma_f32_4x4x1, lookup records are fetched by the lane that needs them.  No ds_bpermute (LDS pipe, shared with the MFMA
     operand reads) and no v_cndmask butterfly may come back: rounds 1-3 spent 66 ds_bpermute + 128 v_cndmask per 64 MFMA there."""
@@ -121,13 +133,7 @@ def test_contraction_tails_stay_off_the_lds_pipe():
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import asm_stats
 
-    out = os.path.join(ROOT, "build", "asm")
-    os.makedirs(out, exist_ok=True)
-    asm = os.path.join(out, "spec32_test.s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Wno-pass-failed", "-S",
-                    "--cuda-device-only", "-o", asm, os.path.join(CSRC, "ttx_tt_spec32.hip")], check=True, timeout=900,
-                   capture_output=True)
-    ks = asm_stats.parse_asm(asm)
+    ks = asm_stats.parse_asm(spec32_asm)
     cfg2 = "Shape3ILi32ELi4ELi32ELi4ELi2ELi16ELi4EEE"
     seen = 0
     for name, c in ks.items():
@@ -170,7 +176,7 @@ def _kernel_asm(asm_path, *needles):
     return sel[0]
 
 
-def test_sub_chunk_prologues_request_without_reading():
+def test_sub_chunk_prologues_request_without_reading(spec32_asm):
     """Round 6: `s_waitcnt vmcnt` counts loads, stores and scratch in one in-order counter, and with stores pending the
     compiler waits for ZERO outstanding instructions at the first read of any loaded register -- a record fixed up behind its load, a
     default merged with it, a bag row fetched under `rec.x >= 0`, made the wave wait for every load it had just issued for the NEXT
@@ -178,12 +184,7 @@ def test_sub_chunk_prologues_request_without_reading():
     benchmark shape, between the first and the last global load of the prefetch block inside the sub-chunk loop there is no wait for
     vector memory on the path a plan with bag rows takes (the only wait sits in the branch of a plan without them, behind its
     dependent rowidx[] load, and in the per_sample_weights branch)."""
-    asm = os.path.join(ROOT, "build", "asm", "spec32_test.s")
-    if not os.path.exists(asm):
-        os.makedirs(os.path.dirname(asm), exist_ok=True)
-        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Wno-pass-failed", "-S",
-                        "--cuda-device-only", "-o", asm, os.path.join(CSRC, "ttx_tt_spec32.hip")], check=True, timeout=900,
-                       capture_output=True)
+    asm = spec32_asm
     big = "Shape3ILi32ELi4ELi32ELi4ELi2ELi16ELi4EEELb1"
     for kern, flags, max_waits in (("spec_fwd_kernel", "ELb0ELb0E", 0), ("spec_bwd_kernel", "ELb0E", 2)):
         body = _kernel_asm(asm, kern, big + flags)
