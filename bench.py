@@ -42,6 +42,13 @@ for _p in (os.path.join(ROOT, "fbtt-embedding_amd"), os.path.join(ROOT, "tests")
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# Kernel arguments of eager launches in device memory (the HIP runtime reads this once, when it starts): on this stack the default
+# puts them in host memory and every kernel's first s_load crosses the bus -- the free-running eager loop (the reference
+# benchmark's form) measured 0.068 -> 0.052 ms/step at cfg2 (scripts/probes/r06_kernarg_ab.sh); a replayed hipGraph keeps its
+# arguments on the device either way (0.0417 / 0.0416).  A process setting of the runtime, not a library behaviour: the module
+# never touches the environment; the line reports what was in effect (`env`).
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -606,6 +613,7 @@ def main():
             "eager_what": ("the reference benchmark's loop form, `tt_emb(indices, offsets).backward(grad)` per request "
                            "(tt_embeddings_benchmark.py:94-108), free-running, no graph, no planning ahead, no event brackets, "
                            "backward() through autograd's engine (the module as imported)"),
+            "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
             "eager_with_event_brackets_ms_per_step": round(eager_profiled / args.steps * 1e3, 4),
             "eager_direct_backward": (None if eager_direct is None else {
                 "ms_per_step": round(eager_direct / args.steps * 1e3, 4),

@@ -7,6 +7,6 @@ NAME=$1; shift
 cd "$(dirname "$0")/.."
 mkdir -p fbtt-embedding_amd/variants
 OBJ=build/obj_$NAME; mkdir -p $OBJ
-ls fbtt-embedding_amd/csrc/*.hip | xargs -P 8 -I{} sh -c '/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -Iinclude "$@" -c {} -o '$OBJ'/$(basename {} .hip).o' _ "$@"
+ls fbtt-embedding_amd/csrc/*.hip | xargs -P 8 -I{} sh -c '/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -mllvm -amdgpu-kernarg-preload-count=16 -Iinclude "$@" -c {} -o '$OBJ'/$(basename {} .hip).o' _ "$@"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o fbtt-embedding_amd/variants/libttx_$NAME.so $OBJ/*.o
 echo built fbtt-embedding_amd/variants/libttx_$NAME.so

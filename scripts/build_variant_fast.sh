@@ -9,7 +9,7 @@ cd "$(dirname "$0")/.."
 mkdir -p fbtt-embedding_amd/variants build/obj_$NAME
 cp build/obj/*.o build/obj_$NAME/
 for u in $UNITS; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -Iinclude "$@" \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -mllvm -amdgpu-kernarg-preload-count=16 -Iinclude "$@" \
     -c fbtt-embedding_amd/csrc/$u.hip -o build/obj_$NAME/$u.o &
 done
 wait

@@ -11,11 +11,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "fbtt-embedding_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]  # as __graft_entry__.build() compiles the product
 
 
 def resources(src):
     """{mangled kernel name: {VGPRs, ScratchSize, Occupancy, ...}}"""
-    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-function",
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-function", *PRELOAD,
                           "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(CSRC, src)],
                          capture_output=True, text=True, timeout=900).stderr
     res, cur = {}, None
@@ -118,8 +119,8 @@ def spec32_asm():
     out = os.path.join(ROOT, "build", "asm")
     os.makedirs(out, exist_ok=True)
     asm = os.path.join(out, "spec32_test.s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Wno-pass-failed", "-S",
-                    "--cuda-device-only", "-o", asm, os.path.join(CSRC, "ttx_tt_spec32.hip")], check=True, timeout=900,
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Wno-pass-failed", *PRELOAD,
+                    "-S", "--cuda-device-only", "-o", asm, os.path.join(CSRC, "ttx_tt_spec32.hip")], check=True, timeout=900,
                    capture_output=True)
     return asm
 
@@ -210,3 +211,17 @@ def test_sub_chunk_prologues_request_without_reading(spec32_asm):
             waits = [x for x in r[first:] if x.startswith("s_waitcnt") and "vmcnt" in x]  # (up to the block's end: the next MFMA / barrier)
             # (the kernels of round 5: one such wait in the forward, six in the backward)
             assert len(waits) <= max_waits, (kern, waits)
+
+
+def test_contraction_kernels_get_their_first_pointers_with_the_wave(spec32_asm):
+    """Round 6 (kernarg preload, ttx_tt_spec.inc TTX_KHEAD): the seven pointers the first three trips to memory need -- chunk
+    records, lookup records, bag rows, plan header, the three cores -- lead the argument list as plain pointers, so the command
+    processor hands them over in SGPRs (14 dwords, the most gfx950 preloads) and the chunk record is requested without waiting
+    for an s_load of the argument segment."""
+    text = open(spec32_asm).read()
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S*spec_(?:fwd|bwd)_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S):
+        pl = re.search(r"\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", m.group(2))
+        assert pl and int(pl.group(1)) == 14, (m.group(1), pl and pl.group(1))
+        seen += 1
+    assert seen >= 4, seen
