@@ -166,28 +166,92 @@ __global__ __launch_bounds__(kThreads) void pool4_kernel(int Nmax, const int* __
 // wave-span kernel walk up to 16 heads per group one after the other: 12 us for 1200 lookups in 512
 // bags.)  Same sums in the same order.
 constexpr int kPoolSpanMin = 65536;
-__global__ __launch_bounds__(kThreads) void pool4_small_kernel(int Nmax, const int* __restrict__ hdr, int B, int D4,
-                                                              const int64_t* __restrict__ rowidx,
-                                                              const int64_t* __restrict__ tableidx,
-                                                              const float4* __restrict__ rows,
-                                                              const float* __restrict__ psw, float4* __restrict__ out) {
+// (Round 6: the chain of dependent trips to memory is what this kernel costs -- live count -> this lookup's bag -> the run
+//  scan -> the rows, 4.9 us for 2.6 MB at cfg2.  Everything whose ADDRESS does not depend on a loaded value is requested in one
+//  round: the live count, this lookup's bag and its predecessor's, the 32 candidates of the first two scan rounds (positions
+//  clamped to the arrays' last entry, compared under the real bound); then, the run length known, up to 32 rows of the run are in
+//  flight at once.  Longer runs go on as before.  Same sums in the same order.)
+constexpr int kPoolAhead = 24;  // rows in flight per round
+// N 64-bit (one 32-bit) values requested back to back and awaited together.  Written in assembly because the compiler sinks a load
+// whose value is first read behind a branch to behind that branch (a lookup that is not a run head leaves early): the requests
+// for this lookup's bag, its predecessor's and the scan candidates -- all at known addresses -- became three trips to memory.
+__device__ __forceinline__ void pool_ld_round(const int64_t* const (&p)[8], int64_t (&v)[8]) {
+  asm volatile(
+      "global_load_dwordx2 %0, %8, off\n\t"
+      "global_load_dwordx2 %1, %9, off\n\t"
+      "global_load_dwordx2 %2, %10, off\n\t"
+      "global_load_dwordx2 %3, %11, off\n\t"
+      "global_load_dwordx2 %4, %12, off\n\t"
+      "global_load_dwordx2 %5, %13, off\n\t"
+      "global_load_dwordx2 %6, %14, off\n\t"
+      "global_load_dwordx2 %7, %15, off\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+      : "memory");
+}
+__device__ __forceinline__ void pool_ld_round(const int64_t* const (&p)[4], const int32_t* q, int64_t (&v)[4], int32_t& w) {
+  asm volatile(
+      "global_load_dwordx2 %0, %5, off\n\t"
+      "global_load_dwordx2 %1, %6, off\n\t"
+      "global_load_dwordx2 %2, %7, off\n\t"
+      "global_load_dwordx2 %3, %8, off\n\t"
+      "global_load_dword %4, %9, off\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(w)
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(q)
+      : "memory");
+}
+// (rows through a buffer descriptor over the whole array: one 32-bit offset register per load instead of a 64-bit address, and a
+//  row behind the run's end is an offset behind the buffer's -- the hardware returns zeros, no branch around the load)
+typedef unsigned int pool_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 pool_ld4(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  const pool_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pool_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__global__ __launch_bounds__(kThreads, 3) void pool4_small_kernel(const int* __restrict__ hdr, const int64_t* __restrict__ rowidx,
+                                                                 const int64_t* __restrict__ tableidx,
+                                                                 const float4* __restrict__ rows, float4* __restrict__ out,
+                                                                 int Nmax, int B, int D4, const float* __restrict__ psw) {
+  // (argument order: the first 14 dwords arrive in SGPRs with the wave -- everything but the per_sample_weights)
   const int n = blockIdx.x * (kThreads / 16) + threadIdx.x / 16;
   const int l = threadIdx.x & 15;
-  const int N = min(Nmax, hdr[2]);
+  if (n >= Nmax) return;  // (the arrays hold Nmax entries: every position below is safe to request whatever the live count)
+  const int last = Nmax - 1;
+  const int c1 = n + 1 + l, c2 = n + 17 + l;
+  const int nlive = hdr[2];
+  const int np = n > 0 ? n - 1 : 0, k1 = min(c1, last), k2 = min(c2, last);
+  const int64_t* const pp[8] = {rowidx + n, tableidx + n, rowidx + np, tableidx + np, rowidx + k1, tableidx + k1, rowidx + k2, tableidx + k2};
+  int64_t vv[8];
+  pool_ld_round(pp, vv);
+  const int64_t r = vv[0], tb = vv[1], rp = vv[2], tp = vv[3], r1 = vv[4], t1 = vv[5], r2 = vv[6], t2 = vv[7];
+  const int N = min(Nmax, nlive);
   if (n >= N) return;
-  const int64_t r = rowidx[n], tb = tableidx[n];
-  if (n > 0 && rowidx[n - 1] == r && tableidx[n - 1] == tb) return;
+  if (n > 0 && rp == r && tp == tb) return;
   const int sh = threadIdx.x & 48;  // this group's 16 bits of the wave ballot
   int sl = 1;
-  for (;;) {
-    const int c = n + sl + l;
-    const bool same = c < N && rowidx[c] == r && tableidx[c] == tb;
-    const unsigned m = (unsigned)(__ballot(!same) >> sh) & 0xffffu;
-    if (m) { sl += __builtin_ctz(m); break; }
-    sl += 16;
+  {
+    const unsigned m1 = (unsigned)(__ballot(!(c1 < N && r1 == r && t1 == tb)) >> sh) & 0xffffu;
+    const unsigned m2 = (unsigned)(__ballot(!(c2 < N && r2 == r && t2 == tb)) >> sh) & 0xffffu;
+    if (m1) sl += __builtin_ctz(m1);
+    else if (m2) sl += 16 + __builtin_ctz(m2);
+    else {
+      sl += 32;
+      for (;;) {
+        const int c = n + sl + l;
+        const bool same = c < N && rowidx[c] == r && tableidx[c] == tb;
+        const unsigned m = (unsigned)(__ballot(!same) >> sh) & 0xffffu;
+        if (m) { sl += __builtin_ctz(m); break; }
+        sl += 16;
+      }
+    }
   }
   float4* o = out + ((size_t)tb * B + r) * D4;
   const float4* src = rows + (size_t)n * D4;
+  const __amdgpu_buffer_rsrc_t rrows = pool_rsrc(rows, (unsigned)Nmax * (unsigned)D4 * 16u);  // (< 2^32: the launcher's condition)
   for (int e = l; e < D4; e += 16) {
     float4 acc = o[e];
     if (psw) {
@@ -197,24 +261,14 @@ __global__ __launch_bounds__(kThreads) void pool4_small_kernel(int Nmax, const i
         acc.x = fmaf(wj, v.x, acc.x); acc.y = fmaf(wj, v.y, acc.y); acc.z = fmaf(wj, v.z, acc.z); acc.w = fmaf(wj, v.w, acc.w);
       }
     } else {
-      int j = 0;
-      for (; j + 8 <= sl; j += 8) {
-        float4 v[8];
+      for (int j0 = 0; j0 < sl; j0 += kPoolAhead) {
+        float4 v[kPoolAhead];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(j + u) * D4 + e];
+        for (int u = 0; u < kPoolAhead; ++u)
+          v[u] = pool_ld4(rrows, j0 + u < sl ? ((unsigned)(n + j0 + u) * (unsigned)D4 + (unsigned)e) * 16u : 0xfffffff0u);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-      }
-      for (; j + 4 <= sl; j += 4) {
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(j + u) * D4 + e];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-      }
-      for (; j < sl; ++j) {
-        const float4 v = src[(size_t)j * D4 + e];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        for (int u = 0; u < kPoolAhead; ++u)
+          if (j0 + u < sl) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
       }
     }
     o[e] = acc;
@@ -227,41 +281,71 @@ __global__ __launch_bounds__(kThreads) void pool4_small_kernel(int Nmax, const i
 // (pool4_small_kernel, then cache_forward4_kernel reading the output back).  Here every run head of either part adds ITS sum to
 // the zeroed output row with fp32 atomics: a row receives at most two terms, 0 + A + B is the same number in either order, so the
 // result does not depend on the order of arrival.  One launch less per step and the gather overlaps the pooling (cfg3).
-__global__ __launch_bounds__(kThreads) void pool4_small_cached_kernel(int nnz, const int* __restrict__ hdr, int D4,
-                                                                     const int64_t* __restrict__ rowidx,
+// (Round 6, as pool4_small_kernel: one round of requests for everything whose address is known up front -- here also the cache
+//  locations of the first 16 lookups of the run, handed round the 16-lane group by lane broadcasts -- 8.3 us at cfg3 before.)
+constexpr int kPoolAheadC = 16;
+__global__ __launch_bounds__(kThreads) void pool4_small_cached_kernel(const int* __restrict__ hdr, const int64_t* __restrict__ rowidx,
                                                                      const float4* __restrict__ rows,
                                                                      const int32_t* __restrict__ loc,
-                                                                     const float4* __restrict__ cw, float* __restrict__ out) {
+                                                                     const float4* __restrict__ cw, float* __restrict__ out,
+                                                                     int nnz, int D4) {
   const int n = blockIdx.x * (kThreads / 16) + threadIdx.x / 16;
   const int l = threadIdx.x & 15;
   if (n >= nnz) return;
-  const int ntt = min(nnz, hdr[2]);          // (the plan was built over the misses: its live count is the split point)
+  const int last = nnz - 1;
+  const int c1 = n + 1 + l, c2 = n + 17 + l;
+  const int nlive = hdr[2];
+  const int64_t* const pp[4] = {rowidx + n, rowidx + (n > 0 ? n - 1 : 0), rowidx + min(c1, last), rowidx + min(c2, last)};
+  int64_t vv[4];
+  int32_t la;  // cache location of lookup n + l
+  pool_ld_round(pp, loc + min(n + l, last), vv, la);
+  const int64_t r = vv[0], rp = vv[1], r1 = vv[2], r2 = vv[3];
+  const int ntt = min(nnz, nlive);           // (the plan was built over the misses: its live count is the split point)
   const bool hit = n >= ntt;
   const int lo = hit ? ntt : 0, hi = hit ? nnz : ntt;  // this lookup's part
-  const int64_t r = rowidx[n];
-  if (n > lo && rowidx[n - 1] == r) return;  // not a run head
+  if (n > lo && rp == r) return;             // not a run head
   const int sh = threadIdx.x & 48;           // this group's 16 bits of the wave ballot
   int sl = 1;
-  for (;;) {
-    const int c = n + sl + l;
-    const bool same = c < hi && rowidx[c] == r;
-    const unsigned m = (unsigned)(__ballot(!same) >> sh) & 0xffffu;
-    if (m) { sl += __builtin_ctz(m); break; }
-    sl += 16;
+  {
+    const unsigned m1 = (unsigned)(__ballot(!(c1 < hi && r1 == r)) >> sh) & 0xffffu;
+    const unsigned m2 = (unsigned)(__ballot(!(c2 < hi && r2 == r)) >> sh) & 0xffffu;
+    if (m1) sl += __builtin_ctz(m1);
+    else if (m2) sl += 16 + __builtin_ctz(m2);
+    else {
+      sl += 32;
+      for (;;) {
+        const int c = n + sl + l;
+        const bool same = c < hi && rowidx[c] == r;
+        const unsigned m = (unsigned)(__ballot(!same) >> sh) & 0xffffu;
+        if (m) { sl += __builtin_ctz(m); break; }
+        sl += 16;
+      }
+    }
   }
+  // the first 16 cache locations of the run, handed round the group while all of its 16 lanes are here
+  int lj[kPoolAheadC];
+#pragma unroll
+  for (int u = 0; u < kPoolAheadC; ++u) lj[u] = __shfl(la, sh + u, kWave);
   float* o = out + (size_t)r * D4 * 4;
   for (int e = l; e < D4; e += 16) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j0 = 0; j0 < sl; j0 += 8) {  // eight rows in flight, added in index order
-      float4 v[8];
+    for (int j0 = 0; j0 < sl; j0 += kPoolAheadC) {  // sixteen rows in flight, added in index order
+      float4 v[kPoolAheadC];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kPoolAheadC; ++u) {
         const int j = j0 + u;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < sl) v[u] = hit ? cw[(size_t)loc[n + j] * D4 + e] : rows[(size_t)(n + j) * D4 + e];
+        if (j < sl) {
+          if (hit) {
+            const int lc = j0 == 0 ? lj[u] : loc[n + j];
+            v[u] = cw[(size_t)lc * D4 + e];
+          } else {
+            v[u] = rows[(size_t)(n + j) * D4 + e];
+          }
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < kPoolAheadC; ++u)
         if (j0 + u < sl) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
     unsafeAtomicAdd(o + 4 * e, acc.x);
@@ -2158,14 +2242,14 @@ static int tt_forward_impl(const ttx_geom* g, int32_t B, int32_t D, int64_t nnz,
   if (cache_loc) {  // (ttx_tt_forward_cached: both parts of the batch in one launch)
     ProfScope ps(TTX_PROF_POOL, st);
     hipLaunchKernelGGL(pool4_small_cached_kernel, dim3(((int)nnz + kThreads / 16 - 1) / (kThreads / 16)), dim3(kThreads), 0, st,
-                       (int)nnz, P.hdr, d.D / 4, rowidx, (const float4*)rows, cache_loc, (const float4*)cache_weight, output);
+                       P.hdr, rowidx, (const float4*)rows, cache_loc, (const float4*)cache_weight, output, (int)nnz, d.D / 4);
     TTX_HIP(hipGetLastError());
   } else if (!(g_skip_launch & 1) && !fused) {
     ProfScope ps(TTX_PROF_POOL, st);
     if (d.D % 4 == 0 && (((uintptr_t)rows | (uintptr_t)output) & 15) == 0) {
-      if (nnz <= kPoolSpanMin)
+      if (nnz <= kPoolSpanMin && (unsigned long long)nnz * d.D * 4 < (1ull << 32) - 16)
         hipLaunchKernelGGL(pool4_small_kernel, dim3(((int)nnz + kThreads / 16 - 1) / (kThreads / 16)), dim3(kThreads), 0, st,
-                           (int)nnz, P.hdr, B, d.D / 4, rowidx, tableidx, (const float4*)rows, psw, (float4*)output);
+                           P.hdr, rowidx, tableidx, (const float4*)rows, (float4*)output, (int)nnz, B, d.D / 4, psw);
       else
         hipLaunchKernelGGL(pool4_kernel, dim3(((int)nnz + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
                            (int)nnz, P.hdr, B, d.D / 4, rowidx, tableidx, (const float4*)rows, psw, (float4*)output);
