@@ -1098,7 +1098,7 @@ int ttx_cache_backward_rowwise_adagrad_approx_n(int64_t nnz, const int32_t* skip
   if (D <= 0) TTX_FAIL(TTX_EINVAL, "D=%d must be > 0", D);
   if (!grad || !loc || !rowidx || !state || !cache_weight) TTX_FAIL(TTX_EINVAL, "NULL input");
   const int nmain = (int)((nnz + kCT / kWave - 1) / (kCT / kWave));
-  const int K = (((uintptr_t)grad & 15) == 0) ? hot_rows(nnz, D) : 0;
+  const int K = (((uintptr_t)grad & 15) == 0) ? hot_rows(nnz, D, true) : 0;
   const int nhot = K * (int)((nnz + kHotSeg - 1) / kHotSeg);
   hipLaunchKernelGGL(cache_rowwise_adagrad_kernel, dim3((unsigned)(nmain + nhot)), dim3(kCT), 0, (hipStream_t)stream,
                      (int)nnz, D, skip_dev, grad, loc, rowidx, lr, eps, state, cache_weight, nmain, K);
