@@ -225,3 +225,34 @@ def test_contraction_kernels_get_their_first_pointers_with_the_wave(spec32_asm):
         assert pl and int(pl.group(1)) == 14, (m.group(1), pl and pl.group(1))
         seen += 1
     assert seen >= 4, seen
+
+
+def _kernel_text(asm_path, *needles):
+    """every instruction line of the one kernel whose mangled name holds every needle, early exits (s_endpgm) included"""
+    text = open(asm_path).read()
+    names = [n for n in re.findall(r"^(_Z\w+):", text, re.M) if all(x in n for x in needles)]
+    assert len(names) == 1, (needles, len(names))
+    beg = text.index("\n" + names[0] + ":")
+    end = text.index(".Lfunc_end", beg)
+    return [ln.strip() for ln in text[beg:end].splitlines()[2:] if ln.strip() and not ln.strip().startswith((";", "."))]
+
+
+def test_single_sub_chunk_kernels_request_their_operands_in_one_round(spec32_asm):
+    """Round 6: at the benchmark batch a work-group is one chain of trips to memory -- chunk record -> lookup records -> operands.
+    The backward made five of them: the plan header word behind the chunk record, and two waits INSIDE the operand round (a
+    component of a core-0 slice load copied into the register of its zero default; the gradient row times per_sample_weights
+    meeting the plain row behind a branch).  Guard: between the records' request and the last operand request in front of the
+    first MFMA there are at most two waits for vector memory on the path of a plan with bag rows and no weights (the records'
+    own; the branch of a plan without bag rows holds a second), and the forward fetches its chunk record with ONE scalar load."""
+    small = "Shape3ILi32ELi4ELi32ELi4ELi2ELi16ELi4EEELb0"
+    for kern, flags in (("spec_bwd_kernel", "ELb0E"), ("spec_fwd_kernel", "ELb0ELb0E")):
+        body = _kernel_text(spec32_asm, kern, small + flags)
+        head = body[: next(i for i, x in enumerate(body) if x.startswith("v_mfma"))]
+        rec = next(i for i, x in enumerate(head) if x.startswith("global_load_dwordx3"))  # the lookup records (int4 without .w)
+        last = max(i for i, x in enumerate(head) if x.startswith("global_load"))
+        assert sum(x.startswith("global_load") for x in head[rec:last + 1]) >= 8, kern
+        waits = [x for x in head[rec:last] if x.startswith("s_waitcnt") and "vmcnt" in x]
+        assert len(waits) <= 2, (kern, waits)
+        if kern == "spec_fwd_kernel":
+            chunk_loads = [x for x in head[:rec] if re.match(r"s_load_dword(x\d)? s\[?\d+(:\d+)?\]?, s\[2:3\]", x)]
+            assert len(chunk_loads) == 1 and chunk_loads[0].startswith("s_load_dwordx4"), chunk_loads
