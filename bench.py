@@ -77,6 +77,9 @@ WORKLOADS = {
     "cfg5full": dict(q=[4, 4, 4], ranks=[32, 32], tables=26, B=4096, optimizer="sgd", alpha=1.0, populate=False),
     # one rank's share of cfg5 at 8 GPUs: 4 of the 26 tables, the whole 4096-bag batch
     "cfg5shard": dict(q=[4, 4, 4], ranks=[32, 32], tables=4, B=4096, optimizer="sgd", alpha=1.0, populate=False),
+    # ONE table of that share (81,920 lookups): what a launch set per table group would run (why the
+    # pooled exchange of one group is not hidden under the lookup of the next)
+    "cfg5shard1": dict(q=[4, 4, 4], ranks=[32, 32], tables=1, B=4096, optimizer="sgd", alpha=1.0, populate=False),
     # shapes outside the specialised family (reference-default q for D = 32 has q0 = 2): generic kernels
     "d32": dict(q=[2, 4, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
     "d16": dict(q=[2, 2, 4], ranks=[32, 32], tables=1, B=512, optimizer="sgd", alpha=1.0, populate=False),
