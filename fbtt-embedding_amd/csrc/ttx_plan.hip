@@ -941,12 +941,21 @@ __device__ __forceinline__ void finish_wide(const Dims& d, int t, const int (&to
   const int tid = threadIdx.x, lane = lane_id(), w = tid / kWave;
   const int S = d.S[t];
   if (t != 1) {
+    // (round 6) the number of hot slices of this core, as finish_single_pass leaves it: with "unknown" (-1) every segment
+    // work-group of reduce_apply copied the offset table and searched it to find that it has nothing to do -- the tail of the
+    // launch on a uniform stream (two cores, 10k lookups: 15 of reduce_apply's 20 us; an integer sum: order-free)
+    int nh = 0;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const int dg = tid * K + j;
       if (dg < S) P.off[t][dg] = dbase[j];
+      nh += (dg < S && tot[j] > 2 * kSegThin) ? 1 : 0;
     }
-    if (tid == 0) P.off[t][S] = N;
+    if (tid == 0) wt[0] = 0;
+    __syncthreads();
+    if (nh) atomicAdd(&wt[0], nh);
+    __syncthreads();
+    if (tid == 0) { P.off[t][S] = N; P.hdr[8 + t] = wt[0]; }
     return;
   }
   const int MC = P.MC;
@@ -981,6 +990,14 @@ __device__ __forceinline__ void finish_wide(const Dims& d, int t, const int (&to
     exq += packed[j];
   }
   for (int cc = ctot + tid; cc < P.max_chunks; cc += kWideThreads) P.chunk_rec[cc] = make_int4(0, 0, 0, 0);
+  int nh = 0;  // hot pivot slices (reduce_apply: more chunk partials than kHotRowsPivot); the thin cores' blocks write their own word
+#pragma unroll
+  for (int j = 0; j < K; ++j) nh += (tid * K + j < S && nf[j] + (pr[j] ? 1 : 0) > kHotRowsPivot) ? 1 : 0;
+  __syncthreads();  // (every thread is done with wt[])
+  if (tid == 0) wt[0] = 0;
+  __syncthreads();
+  if (nh) atomicAdd(&wt[0], nh);
+  __syncthreads();
   if (tid == 0) {
     P.chunk_off[S] = ctot;
     P.hdr[0] = ctot;
@@ -988,7 +1005,10 @@ __device__ __forceinline__ void finish_wide(const Dims& d, int t, const int (&to
     P.hdr[2] = N;
     P.hdr[3] = has_row ? 1 : 0;
     P.hdr[kHdrT4Valid] = 0;
-    for (int tt = 0; tt < TTX_MAX_CORES; ++tt) P.hdr[8 + tt] = -1;  // hot slices per core: unknown (reduce_apply looks)
+    // (the pivot: "none" or "some" -- with the COUNT known reduce_apply leaves more than kMaxHotPivot hot slices to their
+    //  owners, the right call for a few slices that are ALL hot (four cores, p_1 = 58) and the wrong one for the few dozen hot
+    //  slices of a skewed stream over 880: tb4z 218 -> 387 us, scripts/probes/r06_wide_hot_ab.sh; -1 keeps the column split)
+    P.hdr[8 + 1] = wt[0] ? -1 : 0;
   }
 }
 

@@ -879,10 +879,28 @@ struct CacheTail {
 #endif
 // (second launch bound = waves per SIMD the register allocation has to leave room for: the hot-slice paths pushed the
 //  kernel from 77 to 89-99 VGPRs, i.e. from three to two 512-thread work-groups per CU, +1.5 us at the benchmark batch)
+// element t of a small array that lives in the kernel arguments, as a chain of selects: a RUN-TIME subscript of a by-value
+// struct member sends the whole struct through scratch memory (44 bytes per lane here) -- a trip to memory in front of the first
+// real one (round 6: reduce_apply's slice owners read five such members before their offsets)
+template <class T>
+__device__ __forceinline__ T sel_core(const T (&a)[TTX_MAX_CORES], int t) {
+  T v = a[0];
+#pragma unroll
+  for (int c = 1; c < TTX_MAX_CORES; ++c) v = (t == c) ? a[c] : v;
+  return v;
+}
+// (slice number within the launch -> core t, slice within the core)
+__device__ __forceinline__ int core_of_slice(const Dims& d, int& b) {
+  int t = 0;
+#pragma unroll
+  for (int c = 0; c < TTX_MAX_CORES - 1; ++c)
+    if (t == c && c < d.T - 1 && b >= d.S[c]) { b -= d.S[c]; t = c + 1; }
+  return t;
+}
 __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply_kernel(Dims d, Plan P, Partials PC,
                                                                int optim, float lr, float eps,
                                                                CorePtrs W, CorePtrs St,
-                                                               CorePtrs DW, int nslices, int rows_max, CacheTail CT) {
+                                                               CorePtrs DW, int nslices, int rows_max, CacheTail CT, int pack) {
   if (CT.dst && (int)blockIdx.x >= CT.first) {  // (work-group-uniform) a work-group of the cache rows' scatter
     // (all threads: the body's hot-row path has work-group barriers; threads beyond kScatterThreads only wait at them)
     cache_scatter_add_body((int)blockIdx.x - CT.first, CT.N, CT.D, CT.scale, CT.skip_dev, CT.grad, CT.loc, CT.rowidx, CT.dst, CT.nmain, CT.K);
@@ -898,6 +916,58 @@ __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply
   int b = blockIdx.x;
   const bool skip_pivot = rows_max < 0;  // (ablation only)
   if (rows_max < 0) rows_max = -rows_max;
+  if (pack > 1) {
+    // ---------------- (round 6) small slices, many of them: ONE WAVE per slice, `pack` slices per work-group ----------------
+    // Two cores over 11 M rows are 2 x 3317 slices of 256 floats with ~3 partial rows each: a work-group per slice was 6634
+    // work-groups whose 64 float4 lanes of work sat behind a work-group barrier and an LDS fold.  A slice of at most 64 float4
+    // lanes is one wave's: lane v sums the slice's rows in index order (every request of a round of eight in flight), no
+    // barrier, no LDS, a quarter of the work-groups.  Hot slices stay with the segment work-groups, as below.
+    const int npk = (nslices + pack - 1) / pack;
+    if (b < npk) {
+      const int lane = tid & (kWave - 1);
+      int bs = b * pack + tid / kWave;
+      if (bs >= nslices) return;
+      const int t = core_of_slice(d, bs);
+      const int s = bs, sl = sel_core(d.slice, t), V = sl / 4;
+      if (skip_pivot && t == 1) return;
+      const int* offs = (t == 1) ? P.chunk_off : sel_core(P.off, t);
+      const int beg = offs[s], end = offs[s + 1];
+      float* const wt_ = sel_core(W.c, t);
+      float* const st_ = sel_core(St.c, t);
+      float* const dw_ = sel_core(DW.c, t);
+      const size_t base = (size_t)s * sl;
+      if (beg == end) {
+        if (optim == TTX_OPTIM_DENSE)
+          for (int e = lane; e < sl; e += kWave) dw_[base + e] = 0.f;
+        return;
+      }
+      if (end - beg > (t == 1 ? kHotRowsPivot : 2 * seg_len(t)) && PC.hot_cnt && !(t == 1 && P.hdr[8 + 1] > kMaxHotPivot)) return;
+      if (lane >= V) return;
+      const ApplyEmit ap{optim, lr, eps, wt_ + base, st_ ? st_ + base : nullptr, dw_ ? dw_ + base : nullptr};
+      const ApplyEmit::Pre pre = ap.prefetch(lane);
+      const float4* rows = (const float4*)(sel_core(PC.pc, t)) + lane;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int i = beg;
+      for (; i + 7 < end; i += 8) {
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = rows[(size_t)(i + u) * V];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+      }
+      if (i < end) {  // the last round: rows behind the end read the last row again and are not added
+        float4 x[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) x[u] = rows[(size_t)min(i + u, end - 1) * V];
+#pragma unroll
+        for (int u = 0; u < 7; ++u)
+          if (i + u < end) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+      }
+      ap(lane, acc, pre);
+      return;
+    }
+    b = b - npk + nslices;  // a segment work-group: numbered behind the slices, as without packing
+  }
   if (b >= nslices) {
     // ---------------- segment work-group (t, j): its share of the hot slice(s) it intersects ----------------
     b -= nslices;
@@ -962,41 +1032,41 @@ __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply
       }
       return;
     }
-    const int SEG = seg_len(t), sl = d.slice[t];
+    const int SEG = seg_len(t), sl = sel_core(d.slice, t), St_ = sel_core(d.S, t);  // (selects, not subscripts: sel_core)
     if ((sl & 3) != 0) return;  // (odd slice sizes stay with their single owner)
     const int total = (t == 1) ? P.hdr[0] : P.hdr[2];
     const int p0 = b * SEG, p1 = min(p0 + SEG, total);
     if (p0 >= total) return;
-    const int* off = (t == 1) ? P.chunk_off : P.off[t];
+    const int* off = (t == 1) ? P.chunk_off : sel_core(P.off, t);
     // the offset table goes to LDS in one coalesced round when it fits (a segment work-group of a
     // uniform stream has nothing to do and should find that out in one memory round trip, not ten)
     int* soff = (int*)red;
-    const bool in_lds = d.S[t] + 1 <= (int)(nthreads * sizeof(float4) / sizeof(int));
+    const bool in_lds = St_ + 1 <= (int)(nthreads * sizeof(float4) / sizeof(int));
     if (in_lds) {
-      for (int e = tid; e <= d.S[t]; e += nthreads) soff[e] = off[e];
+      for (int e = tid; e <= St_; e += nthreads) soff[e] = off[e];
       __syncthreads();
       off = soff;
     }
-    int lo = 0, hi = d.S[t];  // slice containing position p0: the last s with off[s] <= p0
+    int lo = 0, hi = St_;  // slice containing position p0: the last s with off[s] <= p0
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
       if (off[mid] <= p0) lo = mid; else hi = mid;
     }
     bool any_hot = false;  // (wave-uniform: every thread scans the same few slices)
-    for (int s = lo; s < d.S[t] && off[s] < p1; ++s) any_hot |= (off[s + 1] - off[s] > 2 * SEG);
+    for (int s = lo; s < St_ && off[s] < p1; ++s) any_hot |= (off[s + 1] - off[s] > 2 * SEG);
     if (!any_hot) return;
     if (in_lds) {  // `red` is about to be used by the reductions: back to the global table
       __syncthreads();
-      off = (t == 1) ? P.chunk_off : P.off[t];
+      off = (t == 1) ? P.chunk_off : sel_core(P.off, t);
     }
-    const float* __restrict__ pc = PC.pc[t];
-    for (int s = lo; s < d.S[t]; ++s) {  // at most two hot slices can touch one segment
+    const float* __restrict__ pc = sel_core(PC.pc, t);
+    for (int s = lo; s < St_; ++s) {  // at most two hot slices can touch one segment
       const int sbeg = off[s], send = off[s + 1];
       if (sbeg >= p1) break;
       if (send - sbeg <= 2 * SEG) continue;  // not hot: its owner does everything
       const int beg = max(sbeg, p0), end = min(send, p1);
       const int slot = (sbeg > p0) ? 1 : 0;
-      float* dst = PC.seg[t] + (size_t)(2 * b + slot) * sl;
+      float* dst = sel_core(PC.seg, t) + (size_t)(2 * b + slot) * sl;
       if (t == 1) sum_rows4(pc, sl, beg, end, red, IotaRow{}, StoreEmit{dst});
       else sum_rows4<IotaRow, StoreEmit, true>(pc, sl, beg, end, red, IotaRow{}, StoreEmit{dst});  // (partials lie in sorted order)
       // arrival (the "last block" pattern).  Producer: the work-group's plain stores are complete at the barrier
@@ -1008,7 +1078,8 @@ __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply
       __syncthreads();
       if (tid == 0) {
         int idx = s;
-        for (int tt = 0; tt < t; ++tt) idx += d.S[tt];
+        #pragma unroll
+        for (int tt = 0; tt < TTX_MAX_CORES - 1; ++tt) idx += tt < t ? d.S[tt] : 0;
         const int j_first = sbeg / SEG, j_last = (send - 1) / SEG;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const int old = __hip_atomic_fetch_add(&PC.hot_cnt[idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1019,34 +1090,33 @@ __global__ __launch_bounds__(kReduceThreads, TTX_REDUCE_WAVES) void reduce_apply
       if (s_last) {
         const int j_first = sbeg / SEG, j_last = (send - 1) / SEG;
         const size_t base = (size_t)s * sl;
-        const ApplyEmit ap{optim, lr, eps, W.c[t] + base, St.c[t] ? St.c[t] + base : nullptr,
-                           DW.c[t] ? DW.c[t] + base : nullptr};
-        sum_rows4(PC.seg[t], sl, 0, j_last - j_first + 1, red, SegRow{j_first, sbeg > j_first * SEG ? 1 : 0}, ap);
+        const ApplyEmit ap{optim, lr, eps, sel_core(W.c, t) + base, sel_core(St.c, t) ? sel_core(St.c, t) + base : nullptr,
+                           sel_core(DW.c, t) ? sel_core(DW.c, t) + base : nullptr};
+        sum_rows4(sel_core(PC.seg, t), sl, 0, j_last - j_first + 1, red, SegRow{j_first, sbeg > j_first * SEG ? 1 : 0}, ap);
       }
       __syncthreads();
     }
     return;
   }
   // ---------------- slice owner ----------------
-  int t = 0;
-  while (t < d.T - 1 && b >= d.S[t]) { b -= d.S[t]; ++t; }
+  const int t = core_of_slice(d, b);
   const int s = b;
-  const int sl = d.slice[t];
+  const int sl = sel_core(d.slice, t);
   if (skip_pivot && t == 1) return;
   int beg, end;
   const int* __restrict__ list;
   if (t == 1) { beg = P.chunk_off[s]; end = P.chunk_off[s + 1]; list = nullptr; }
-  else { beg = P.off[t][s]; end = P.off[t][s + 1]; list = nullptr; }  // partial rows = positions of the sorted order
+  else { const int* offs = sel_core(P.off, t); beg = offs[s]; end = offs[s + 1]; list = nullptr; }  // partial rows = positions of the sorted order
   const size_t base = (size_t)s * sl;
-  float* __restrict__ dw = DW.c[t];
-  float* __restrict__ wt = W.c[t];
-  float* __restrict__ stt = St.c[t];
+  float* __restrict__ dw = sel_core(DW.c, t);
+  float* __restrict__ wt = sel_core(W.c, t);
+  float* __restrict__ stt = sel_core(St.c, t);
   if (beg == end) {
     if (optim == TTX_OPTIM_DENSE)
       for (int e = tid; e < sl; e += nthreads) dw[base + e] = 0.f;
     return;
   }
-  const float* __restrict__ pc = PC.pc[t];
+  const float* __restrict__ pc = sel_core(PC.pc, t);
   if ((sl & 3) == 0) {
     if (end - beg > (t == 1 ? kHotRowsPivot : 2 * seg_len(t)) && PC.hot_cnt && !(t == 1 && P.hdr[8 + 1] > kMaxHotPivot))
       return;  // hot: the segment / column work-groups own it (unless the pivot has too many hot slices for the column split)
@@ -1952,6 +2022,7 @@ static int allow_lds(K kernel, int bytes) {
 static size_t rows_bytes(const Dims& d, long long nnz) { return align_up((size_t)nnz * d.D * 4); }
 
 static TTX_KNOB(int, g_skip_launch, 0);  // ablation (ttx_debug_skip bits 9..11): results invalid when != 0
+static TTX_KNOB(int, g_no_pack, 0);      // A/B (ttx_debug_skip bit 16): reduce_apply with a work-group per small slice, as before round 6
 
 // the family's translation unit takes it (ttx_tt_spec{16,32,64,128a,128b,128c}.hip)
 static int run_rows_spec(TTX_SPEC_FWD_ARGS) {
@@ -2048,6 +2119,7 @@ int ttx_debug_stamps(void* device_buffer) {
 int ttx_debug_skip(int32_t mask) {
   g_disable_spec = (mask & 256) ? 1 : 0;  // bit 8: force the generic kernels (A/B tests)
   g_disable_pad = (mask & 32768) ? 1 : 0;  // bit 15: shape-specialised kernels for exact shapes only (A/B tests)
+  g_no_pack = (mask >> 16) & 1;           // bit 16: no wave-per-slice packing in reduce_apply (results stay valid)
   g_skip_launch = (mask >> 9) & 63;       // bits 9..11: leave out the pooling launch / reduce_apply / reduce_apply's pivot slices (upper bounds); bit 12: no fused pooling (A/B)
   mask &= 255;
   g_debug_skip = mask;
@@ -2100,7 +2172,7 @@ int ttx_debug_tiles(const ttx_geom* g, int32_t* out) {
 // there, and bench.py refuses to time a library where it is not.  In libttx_hooks.so the knobs are plain globals -- not per
 // stream, not thread-safe: tests and A/B timing only.
 int ttx_debug_state(void) {
-  return ((g_debug_skip | g_skip_launch | g_disable_spec | g_disable_pad) ? 1 : 0) | (g_lds_budget != 160 * 1024 ? 2 : 0) |
+  return ((g_debug_skip | g_skip_launch | g_disable_spec | g_disable_pad | g_no_pack) ? 1 : 0) | (g_lds_budget != 160 * 1024 ? 2 : 0) |
          (g_chunk_override ? 4 : 0) | (g_stamps ? 8 : 0) | (ttx_cache_debug_state() << 4) | (g_bwd32_mc ? 128 : 0);
 }
 
@@ -2525,7 +2597,7 @@ static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t
     const int rthreads = smax <= 4096 ? TTX_RTHREADS_SMALL : kReduceThreads;
     ProfScope ps(TTX_PROF_APPLY, st);
     hipLaunchKernelGGL(reduce_apply_kernel, dim3(ns2 + nsg2), dim3(rthreads), reduce_lds_bytes(rthreads), st, d2, P, PC, optim, lr, eps, C, S, DW, ns2,
-                       (int)nnz, CacheTail{});
+                       (int)nnz, CacheTail{}, 1);
     TTX_HIP(hipGetLastError());
     hipLaunchKernelGGL(t4_apply23_kernel, dim3(d.S[2] * ((d.slice[2] + kT4ApplyBlock - 1) / kT4ApplyBlock) + d.S[3]), dim3(kT4Threads), 0, st, P, PC.pc[2], PC.pc[3], d.S[2],
                        d.slice[2], d.slice[3], t4_seg(nnz), optim, lr, eps, C.c[2], C.c[3], S.c[2], S.c[3], DW.c[2], DW.c[3]);
@@ -2533,7 +2605,6 @@ static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t
     return TTX_OK;
   }
   if (!(g_skip_launch & 2)) {
-    const int blocks = nslices + nsegs;  // slice owners, then the segment work-groups of hot slices
     int smax = 0;
     for (int t = 0; t < d.T; ++t) smax = d.slice[t] > smax ? d.slice[t] : smax;
     int rthreads = smax <= 4096 ? TTX_RTHREADS_SMALL : kReduceThreads;  // (measured: 512 is 1.7 us faster at r = 32, 1024 at r = 64)
@@ -2541,7 +2612,13 @@ static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t
     // threads for 64 float4 lanes of work each were 6.5 rounds of the chip's wave slots, 30 us -- get work-groups of their size
     if (smax <= 512) rthreads = 128;
     else if (smax <= 2048) rthreads = 256;
+    // (round 6) every slice at most 64 float4 lanes (two cores; three cores at tiny ranks): a wave per slice, four per work-group
+    int pack = 1, smin4 = 0;
+    for (int t = 0; t < d.T; ++t) smin4 |= d.slice[t] & 3;
+    if (smax <= 4 * kWave && smin4 == 0 && nslices >= 1024 && !g_no_pack) { pack = 4; rthreads = pack * kWave; }
     if (tail && tail->dst && rthreads < kScatterThreads) rthreads = kScatterThreads;  // (the cache rows' scatter needs its own threads)
+    if (pack > 1) pack = rthreads / kWave;
+    const int blocks = (pack > 1 ? (nslices + pack - 1) / pack : nslices) + nsegs;  // slice owners, then the hot slices' segment work-groups
     ProfScope ps(TTX_PROF_APPLY, st);
     CacheTail CT{};
     int tail_blocks = 0;
@@ -2554,7 +2631,7 @@ static int tt_backward_impl(const ttx_geom* g, int32_t optim, int32_t B, int32_t
       if (tail_done) *tail_done = 1;
     }
     hipLaunchKernelGGL(reduce_apply_kernel, dim3(blocks + tail_blocks), dim3(rthreads), reduce_lds_bytes(rthreads), st, d, P, PC, optim, lr,
-                       eps, C, S, DW, nslices, (g_skip_launch & 4) ? -(int)nnz : (int)nnz, CT);
+                       eps, C, S, DW, nslices, (g_skip_launch & 4) ? -(int)nnz : (int)nnz, CT, pack);
     TTX_HIP(hipGetLastError());
   }
   return TTX_OK;

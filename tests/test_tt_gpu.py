@@ -754,3 +754,47 @@ def test_two_cores_on_the_dedicated_kernels(q, ranks):
                 else:
                     assert_close(got["state"][k], orc["state"][k], f"T=2 {ranks}{q} state{k}")
                     assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], f"T=2 {ranks}{q} adagrad core{k}")
+
+
+@pytest.mark.parametrize("T,p,q,ranks", [(2, [600, 700], [8, 8], [32]), (2, [1100, 90], [4, 16], [16]), (3, [400, 500, 450], [4, 4, 4], [4, 4])])
+def test_reduce_apply_with_a_wave_per_small_slice(T, p, q, ranks):
+    """Round 6: when every slice is at most 64 float4 lanes and there are many of them (two cores over millions of rows; three at tiny
+    ranks), reduce_apply hands FOUR slices to a work-group, one per wave -- a slice's partial rows summed by its wave in index
+    order, no work-group barrier, no LDS fold -- and numbers the hot slices' segment work-groups behind the packed ones.  Against
+    the oracle for the dense gradient, SGD and Adagrad, on a uniform stream and on a skewed one (hot slices: segment work-groups in
+    the same launch), and against the launch with a work-group per slice (ttx_debug_skip bit 16): equal up to the order of
+    addition; two runs of the packed launch are bit-identical."""
+    import tt_embeddings as E
+
+    r = [1] + ranks + [1]
+    E_, D = int(np.prod(p)), int(np.prod(q))
+    for alpha, B, pf in ((1.0, 300, 20), (1.3, 400, 24)):
+        idx, off = G.make_bags(91 + B, B, E_, pf, 3, 1)
+        if alpha > 1.0:  # a skewed stream: a few rows take most of the lookups -> hot slices in every core
+            rs = np.random.RandomState(5)
+            idx = (rs.zipf(alpha, size=idx.size).astype(np.int64) * 7919) % E_
+        c = dict(tables=1, T=T, p=p, q=q, r=r, B=B, D=D, indices=idx, offsets=off,
+                 cores=G.make_cores(92 + B, 1, p, q, r, "signed"), d_out=G.make_grad(93, 1, B, D))
+        for mode in ("dense", "sgd", "adagrad"):
+            got = run_case(c, mode, plan_shared=True)
+            again = run_case(c, mode, plan_shared=True)
+            orc = oracle_case(c, mode)
+            E.debug_skip(1 << 16)  # a work-group per slice, as before round 6
+            try:
+                old = run_case(c, mode, plan_shared=True)
+            finally:
+                E.debug_skip(0)
+            gref = oracle_case(c, "dense")["grads"] if mode == "adagrad" else None
+            for k in range(T):
+                what = f"T={T} {p}{q}{ranks} alpha={alpha} {mode} core{k}"
+                if mode == "dense":
+                    assert np.array_equal(got["grads"][k], again["grads"][k]), what + ": run to run"
+                    assert_close(got["grads"][k], orc["grads"][k], what + " vs oracle")
+                    assert_close(got["grads"][k], old["grads"][k], what + " vs a work-group per slice")
+                elif mode == "sgd":
+                    assert np.array_equal(got["cores"][k], again["cores"][k]), what + ": run to run"
+                    assert_close(got["cores"][k], orc["cores"][k], what + " vs oracle")
+                    assert_close(got["cores"][k], old["cores"][k], what + " vs a work-group per slice")
+                else:
+                    assert_close(got["state"][k], orc["state"][k], what + " state")
+                    assert_adagrad_close(got["cores"][k], orc["cores"][k], gref[k], what)
