@@ -1359,6 +1359,40 @@ __global__ __launch_bounds__(1024) void mb_chunks_kernel(Dims d, int Nmax, const
     carry += total;
   }
   for (int c = carry + tid; c < P.max_chunks; c += 1024) P.chunk_rec[c] = make_int4(0, 0, 0, 0);
+  // (round 6) hot slices per core for reduce_apply, as the one-launch routes leave them (finish_single_pass / finish_wide): the
+  // thin cores' counts from their offset tables (complete: written by an earlier launch), the pivot's as none / some.  Every
+  // thread counts its own slices with eight offset pairs in flight, ONE work-group sum per core at the end (integer: order-free)
+  // -- a barrier-bounded round per 1024 slices was a trip to memory each: 21 -> 39 us for this kernel at 26 tables.
+  __shared__ int hs[TTX_MAX_CORES + 1];
+  if (tid <= TTX_MAX_CORES) hs[tid] = 0;
+  int loc[TTX_MAX_CORES], anyp = 0;
+#pragma unroll
+  for (int t = 0; t < TTX_MAX_CORES; ++t) {
+    loc[t] = 0;
+    if (t == 1 || t >= d.T) continue;
+    const int* offt = P.off[t];
+    const int St = d.S[t];
+    for (int s0 = tid; s0 < St; s0 += 8 * 1024) {
+      int len[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = min(s0 + u * 1024, St - 1);
+        len[u] = offt[s + 1] - offt[s];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) loc[t] += (s0 + u * 1024 < St && len[u] > 2 * kSegThin) ? 1 : 0;
+    }
+  }
+  for (int s = tid; s < S1; s += 1024) anyp |= ((off[s + 1] - off[s] + MC - 1) / MC > kHotRowsPivot) ? 1 : 0;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TTX_MAX_CORES; ++t)
+    if (loc[t]) atomicAdd(&hs[t], loc[t]);
+  if (anyp) atomicOr(&hs[TTX_MAX_CORES], 1);
+  __syncthreads();
+  int nhot[TTX_MAX_CORES];
+#pragma unroll
+  for (int t = 0; t < TTX_MAX_CORES; ++t) nhot[t] = (t == 1) ? (hs[TTX_MAX_CORES] ? -1 : 0) : (t < d.T ? hs[t] : -1);
   if (tid == 0) {
     P.chunk_off[S1] = carry;
     P.hdr[0] = carry;
@@ -1366,7 +1400,8 @@ __global__ __launch_bounds__(1024) void mb_chunks_kernel(Dims d, int Nmax, const
     P.hdr[2] = N;
     P.hdr[3] = has_row;
     P.hdr[kHdrT4Valid] = 0;
-    for (int tt = 0; tt < TTX_MAX_CORES; ++tt) P.hdr[8 + tt] = -1;  // hot slices per core: unknown (reduce_apply looks)
+#pragma unroll
+    for (int tt = 0; tt < TTX_MAX_CORES; ++tt) P.hdr[8 + tt] = nhot[tt];
   }
 }
 
