@@ -803,7 +803,8 @@ def debug_lds_budget(nbytes: int) -> None:
 
 
 def debug_skip(mask: int) -> None:
-    """bit 8: force the generic kernels; bit 15: exact-shape templates only; the other bits skip kernel phases / launches
+    """bit 8: force the generic kernels; bit 15: exact-shape templates only; bit 16: reduce_apply with a work-group (not a wave) per
+    small slice -- these three leave the results valid; the other bits skip kernel phases / launches
     (results INVALID).  0 = normal operation."""
     _check(hooks_lib().ttx_debug_skip(int(mask)))
     _knobs_changed()

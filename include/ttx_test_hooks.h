@@ -21,7 +21,8 @@ int ttx_set_chunk(int32_t indices_per_chunk);
  * shapes through the walk that ranks >= 80 need.  Set it before sizing workspaces / plans. */
 int ttx_debug_lds_budget(int32_t bytes);
 /* bit mask: bits 0..7 kernel phases to skip (results INVALID), bit 8 force the generic kernels, bits 9..12 leave out launches,
- * bit 15 shape-specialised kernels for exact shapes only.  0 = normal operation. */
+ * bit 15 shape-specialised kernels for exact shapes only; bit 16 reduce_apply with a work-group per small slice instead of a wave
+ * per slice (round 6; results stay valid up to the order of addition).  0 = normal operation. */
 int ttx_debug_skip(int32_t mask);
 /* A/B knob (scripts/bench_cache.py): 1 = ttx_cache_forward uses the one-group-per-lookup kernel for every D */
 int ttx_debug_cache_fwd(int32_t lookup_groups);
